@@ -1,0 +1,235 @@
+/* gbp_mi355x.h — C-ABI of the MI355X-native GBP bundle-adjustment engine.
+ *
+ * Drop-in boundary for ONE path of joeaortiz/gbp-poplar: the synchronous GBP sweep that the
+ * reference expresses as a Poplar program list + named host data streams
+ * (reference ba/ba.cpp:925-934 `progs = {WRITE, LINEARISE, GBP, WEAKEN_PRIORS, READ}`,
+ * ba/slam.cpp:937-948 adds READ_PRIORS and NEW_KEYFRAME).  The reference has no FFI; each
+ * entry point below replaces one `engine.run(<PROG>)` call (+ its connected streams) and cites it.
+ *
+ * Conventions: plain C, no exceptions across the ABI, every function returns 0 on success and a
+ * negative gbp_status otherwise (text via gbp_last_error).  All pointers are HOST memory owned by
+ * the caller unless the name ends in `_dev`.  A ctx is not thread-safe; calls are blocking unless
+ * stated.  All floating point is IEEE fp32, integers are 32-bit, layouts are the reference's
+ * row-major AoS host layouts (ba/ba.cpp:690-713,778-790).
+ */
+#ifndef GBP_MI355X_H
+#define GBP_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GBP_ABI_VERSION 1
+
+typedef enum {
+  GBP_OK = 0,
+  GBP_ERR_INVALID = -1,    /* bad argument / inconsistent sizes            */
+  GBP_ERR_NO_DEVICE = -2,  /* no gfx950 device (ref: ba.cpp:652-655 exit(-1)) */
+  GBP_ERR_HIP = -3,        /* a HIP runtime call failed                    */
+  GBP_ERR_STATE = -4,      /* call order violated (e.g. iterate before upload) */
+  GBP_ERR_IO = -5          /* file could not be read (ref: ba.cpp:484-487)  */
+} gbp_status;
+
+typedef struct gbp_ctx gbp_ctx;
+
+/* Graph structure: what ba.cpp:503-512 extracts from the BAL file and wires into vertices
+ * (ba.cpp:71-97,243-366).  Factor e joins camera cam_id[e] and landmark lmk_id[e]; the message
+ * slot order of a variable is the FILE order of its incident factors (ba.cpp:267-279). */
+typedef struct {
+  uint32_t n_cams;          /* C  */
+  uint32_t n_lmks;          /* L  */
+  uint32_t n_edges;         /* E  */
+  const uint32_t* cam_id;   /* [E] */
+  const uint32_t* lmk_id;   /* [E] */
+  float K[9];               /* row-major pin-hole {fx,0,cx,0,fy,cy,0,0,1}; the reference replicates
+                               this one matrix per edge (ba.cpp:494-501), we keep one copy        */
+} gbp_problem;
+
+/* Hyper-parameters: compile-time globals of the reference (gbp_codelets.cpp:11-16). */
+typedef struct {
+  float   maxeta_damping;      /* 0.4   */
+  int32_t num_undamped_iters;  /* 8     */
+  float   dmu_threshold;       /* 3e-3  */
+  int32_t min_linear_iters;    /* 10    */
+  float   nstds;               /* 2.5   */
+  int32_t relin_mode;          /* 0 = accumulate onto the old potential (faithful: matMul is `+=`
+                                  and PrepMessageVertex does not zero, gbp_codelets.cpp:285-336);
+                                  1 = reset (zero first)                                          */
+  int32_t graph_unroll;        /* GBP iterations captured per hipGraph (>=1); 0 = library default */
+  int32_t reserved[5];
+} gbp_params;
+
+/* Landmark shard of a multi-GPU run (one process per GPU).  The global problem is passed to
+ * gbp_create on every rank; a rank owns landmarks [lmk_begin, lmk_end) and every factor incident
+ * to them.  Cameras are replicated.  NULL shard == {0,1,0,L}.  Replaces `--ipus N`
+ * (ba.cpp:414-417,617-623). */
+typedef struct {
+  int32_t  rank, world;
+  uint32_t lmk_begin, lmk_end;
+} gbp_shard;
+
+/* WRITE_PROG streams (ba.cpp:868-886).  cams_dofs/lmk_dofs (always 6/3, ba.cpp:577-578) are not
+ * passed.  Any pointer may be NULL = "all zeros" (what the reference uploads for damping, mu,
+ * oldmu: ba.cpp:580-584), except priors/measurements/meas_variances/active_flag. */
+typedef struct {
+  const float*    damping;            /* [E]   */
+  const int32_t*  damping_count;      /* [E]   */
+  const float*    mu;                 /* [9E]  */
+  const float*    oldmu;              /* [9E]  */
+  const uint32_t* active_flag;        /* [E]   */
+  const float*    cam_scaling;        /* [C]   */
+  const float*    lmk_scaling;        /* [L]   */
+  const uint32_t* cam_weaken_flag;    /* [C]   */
+  const uint32_t* lmk_weaken_flag;    /* [L]   */
+  const float*    cam_priors_eta;     /* [6C]  */
+  const float*    cam_priors_lambda;  /* [36C] */
+  const float*    lmk_priors_eta;     /* [3L]  */
+  const float*    lmk_priors_lambda;  /* [9L]  */
+  const float*    measurements;       /* [2E]  */
+  const float*    meas_variances;     /* [E]   */
+} gbp_state_in;
+
+/* READ_PROG streams (ba.cpp:908-916).  NULL members are skipped.  In a sharded ctx only owned
+ * landmarks / factors are written, camera arrays are complete on every rank. */
+typedef struct {
+  float*    cam_beliefs_eta;     /* [6C]  */
+  float*    cam_beliefs_lambda;  /* [36C] */
+  float*    lmk_beliefs_eta;     /* [3L]  */
+  float*    lmk_beliefs_lambda;  /* [9L]  */
+  float*    damping;             /* [E]   */
+  int32_t*  damping_count;       /* [E]   */
+  uint32_t* robust_flag;         /* [E]   */
+} gbp_state_out;
+
+/* READ_PRIORS streams (slam.cpp:913-917): message slot 0 of every variable. */
+typedef struct {
+  float* cam_priors_eta;     /* [6C]  */
+  float* cam_priors_lambda;  /* [36C] */
+  float* lmk_priors_eta;     /* [3L]  */
+  float* lmk_priors_lambda;  /* [9L]  */
+} gbp_priors_out;
+
+/* NEW_KEYFRAME streams (slam.cpp:919-928). */
+typedef struct {
+  const int32_t*  damping_count;      /* [E]   */
+  const float*    cam_priors_eta;     /* [6C]  */
+  const float*    cam_priors_lambda;  /* [36C] */
+  const float*    lmk_priors_eta;     /* [3L]  */
+  const float*    lmk_priors_lambda;  /* [9L]  */
+  const uint32_t* active_flag;        /* [E]   */
+  const uint32_t* cam_weaken_flag;    /* [C]   */
+  const uint32_t* lmk_weaken_flag;    /* [L]   */
+} gbp_kf_update;
+
+/* Result of gbp_eval: util.cpp:74-144 + the two counters of ba.cpp:1011-1020.
+ * Sums are raw (not yet divided) so that shards can be added. */
+typedef struct {
+  double   sum_norm;     /* sum_e ||z - pi(x)||_2  over active edges  (reproj[0] * n_active)   */
+  double   sum_half_sq;  /* sum_e 0.5*||r||^2                         (reproj[1], "Cost")      */
+  uint64_t n_active;
+  uint64_t n_relin;      /* #(damping_count == -num_undamped_iters)   ba.cpp:1016-1020         */
+  uint64_t n_robust;     /* sum robust_flag                            ba.cpp:1013-1015        */
+  uint64_t n_nonfinite;  /* beliefs with a non-finite entry (replaces Poplar FP traps, ba.cpp:888-891) */
+} gbp_eval_out;
+
+typedef struct {
+  double   sweep_ms, belief_ms, total_ms;   /* accumulated hipEvent times of timed iterations */
+  uint64_t iterations;
+  uint64_t algorithmic_bytes_per_iter;      /* 1112*E + 336*C + 96*L               */
+  uint64_t device_bytes_allocated;
+} gbp_timing_out;
+
+/* ---- life cycle: graph build + Engine ctor/load (ba.cpp:659-937) -------------------------- */
+int  gbp_abi_version(void);
+void gbp_default_params(gbp_params* p);
+int  gbp_create(const gbp_problem* problem, const gbp_params* params /*NULL=defaults*/,
+                const gbp_shard* shard /*NULL=single GPU*/, gbp_ctx** out);
+void gbp_destroy(gbp_ctx* ctx);
+const char* gbp_last_error(const gbp_ctx* ctx /*NULL = last create error*/);
+
+/* ---- the program list ------------------------------------------------------------------- */
+int gbp_upload(gbp_ctx* ctx, const gbp_state_in* in);          /* WRITE_PROG      ba.cpp:868-886  */
+int gbp_linearise(gbp_ctx* ctx);                               /* LINEARISE_PROG  ba.cpp:890-893  */
+int gbp_iterate(gbp_ctx* ctx, int n_iters);                    /* GBP_PROG x n    ba.cpp:895-905  */
+int gbp_weaken_priors(gbp_ctx* ctx);                           /* WEAKEN_PRIORS   ba.cpp:863-865  */
+int gbp_read(gbp_ctx* ctx, gbp_state_out* out);                /* READ_PROG       ba.cpp:908-916  */
+int gbp_read_priors(gbp_ctx* ctx, gbp_priors_out* out);        /* READ_PRIORS     slam.cpp:913-917 */
+int gbp_new_keyframe(gbp_ctx* ctx, const gbp_kf_update* upd);  /* NEW_KEYFRAME    slam.cpp:919-928 */
+int gbp_eval(gbp_ctx* ctx, gbp_eval_out* out);                 /* util.cpp:74-144 on device (local shard) */
+int gbp_sync(gbp_ctx* ctx);                                    /* wait for queued device work     */
+int gbp_timing(gbp_ctx* ctx, gbp_timing_out* out, int reset);  /* ba.cpp:980,1056-1058            */
+
+/* ---- multi-GPU split-phase iteration (sharded ctx; exchange done by the caller, e.g.
+ *      torch.distributed all_gather over RCCL).  gbp_iterate == begin + (local copy) + end
+ *      when world == 1. -------------------------------------------------------------------- */
+int gbp_set_stream(gbp_ctx* ctx, void* hip_stream /* hipStream_t; NULL = ctx-owned stream */);
+/* send_dev: [C*42] fp32 this rank's camera partial sums; recv_dev: [world][C*42]. Caller-owned
+ * device memory (e.g. torch tensors).  Must be set before begin/end on a world>1 ctx. */
+int gbp_set_exchange_buffers(gbp_ctx* ctx, void* send_dev, void* recv_dev);
+int gbp_iterate_begin(gbp_ctx* ctx);   /* prep + messages + local camera partial -> send_dev     */
+int gbp_iterate_end(gbp_ctx* ctx);     /* camera beliefs = prior + sum_r recv_dev[r]; landmark beliefs */
+/* Re-derive beliefs after an exchange outside an iteration (LINEARISE / NEW_KEYFRAME on world>1):
+ * gbp_refresh_begin computes the local camera partials into send_dev, gbp_refresh_end combines. */
+int gbp_refresh_begin(gbp_ctx* ctx);
+int gbp_refresh_end(gbp_ctx* ctx);
+int gbp_linearise_factors(gbp_ctx* ctx);  /* the factor half of LINEARISE_PROG (after a refresh) */
+
+/* ---- host-side helpers of the path's callers (pure CPU, no device needed) ---------------- */
+/* BALProblem::LoadFile (dataio.cpp:17-57).  Two-call pattern: pass NULL arrays to get sizes. */
+typedef struct {
+  uint32_t n_cams, n_lmks, n_edges;
+  double   fx, fy, cx, cy;
+  uint32_t* cam_id;        /* [E]  caller-allocated */
+  uint32_t* lmk_id;        /* [E]  */
+  double*   observations;  /* [2E] */
+  double*   cameras;       /* [6C] */
+  double*   points;        /* [3L] */
+} gbp_bal;
+int gbp_bal_read_header(const char* path, gbp_bal* hdr);
+int gbp_bal_read(const char* path, gbp_bal* bal);
+int gbp_bal_write(const char* path, const gbp_bal* bal);
+
+/* set_prior_lambda (dataio.cpp:67-117 + util.cpp:48-72), O(E).  cam_file/lmk_file are the FILE
+ * values cast to float (the linearisation point of the prior strength), *_mean the (possibly
+ * noised) prior means. */
+int gbp_set_prior_lambda(const gbp_problem* problem, float reproj_meas_var,
+                         const float* cam_file /*[6C]*/, const float* lmk_file /*[3L]*/,
+                         const float* cam_mean /*[6C]*/, const float* lmk_mean /*[3L]*/,
+                         float* cam_priors_eta, float* cam_priors_lambda,
+                         float* lmk_priors_eta, float* lmk_priors_lambda);
+/* Prior-weakening scale factors (ba.cpp:561-572). */
+int gbp_prior_scalings(uint32_t n_cams, uint32_t n_lmks, const float* cam_priors_lambda,
+                       float steps, float prior_std_weaker_factor, float first_cam_prior_std,
+                       float* cam_scaling, float* lmk_scaling);
+/* SLAM flag bookkeeping (dataio.cpp:455-475, 477-508).  update returns n_new_lmks via out. */
+int gbp_slam_create_flags(const gbp_problem* problem, uint32_t steps, uint32_t* active_flag,
+                          uint32_t* cam_weaken_flag, uint32_t* lmk_weaken_flag,
+                          uint32_t* lmk_active_flag);
+int gbp_slam_update_flags(const gbp_problem* problem, uint32_t steps, uint32_t data_counter,
+                          uint32_t* active_flag, uint32_t* lmk_weaken_flag,
+                          uint32_t* cam_weaken_flag, uint32_t* lmk_active_flag,
+                          int32_t* n_new_lmks);
+/* initialise_new_kf (util.cpp:183-223): prior eta of camera data_counter+1 from the belief mean of
+ * camera data_counter.  The new-landmark branch is dead in the reference (out-of-bounds index,
+ * util.cpp:215) and is not reproduced. */
+int gbp_slam_initialise_new_kf(uint32_t data_counter, const float* cam_beliefs_eta,
+                               const float* cam_beliefs_lambda, const float* cam_priors_lambda,
+                               float* cam_priors_eta);
+/* Host metric (util.cpp:74-144) on read-back beliefs; same arithmetic as gbp_eval. */
+int gbp_eval_host(const gbp_problem* problem, const uint32_t* active_flag, const float* measurements,
+                  const float* cam_beliefs_eta, const float* cam_beliefs_lambda,
+                  const float* lmk_beliefs_eta, const float* lmk_beliefs_lambda,
+                  double* sum_norm, double* sum_half_sq, uint64_t* n_active);
+
+/* Synthetic BAL generator (SURVEY 8d spec; the reference has none).  Fills a caller-allocated
+ * gbp_bal with n_edges = n_lmks * obs_per_lmk, edges sorted by (camera, landmark). */
+int gbp_synth_generate(uint32_t n_cams, uint32_t n_lmks, uint32_t obs_per_lmk, uint64_t seed,
+                       gbp_bal* out, double* gt_cameras /*[6C] or NULL*/, double* gt_points /*[3L] or NULL*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GBP_MI355X_H */
