@@ -1,0 +1,75 @@
+"""Loader of the native library (HIP kernels + C-ABI).  There is no CPU fallback: if the HIP
+extension is missing or cannot be loaded, importing callers fail loudly."""
+import ctypes as C
+import os
+
+from . import _cabi as cabi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libgbp_mi355x.so")
+_lib = None
+
+# every symbol include/gbp_mi355x.h declares (tests/test_cabi_symbols.py parses the header and checks this list)
+_SIGS = {
+    "gbp_abi_version": (C.c_int, []),
+    "gbp_default_params": (None, [C.POINTER(cabi.GbpParams)]),
+    "gbp_create": (C.c_int, [C.POINTER(cabi.GbpProblem), C.POINTER(cabi.GbpParams), C.POINTER(cabi.GbpShard),
+                             C.POINTER(C.c_void_p)]),
+    "gbp_destroy": (None, [C.c_void_p]),
+    "gbp_last_error": (C.c_char_p, [C.c_void_p]),
+    "gbp_upload": (C.c_int, [C.c_void_p, C.POINTER(cabi.GbpStateIn)]),
+    "gbp_linearise": (C.c_int, [C.c_void_p]),
+    "gbp_iterate": (C.c_int, [C.c_void_p, C.c_int]),
+    "gbp_weaken_priors": (C.c_int, [C.c_void_p]),
+    "gbp_read": (C.c_int, [C.c_void_p, C.POINTER(cabi.GbpStateOut)]),
+    "gbp_read_priors": (C.c_int, [C.c_void_p, C.POINTER(cabi.GbpPriorsOut)]),
+    "gbp_new_keyframe": (C.c_int, [C.c_void_p, C.POINTER(cabi.GbpKfUpdate)]),
+    "gbp_eval": (C.c_int, [C.c_void_p, C.POINTER(cabi.GbpEvalOut)]),
+    "gbp_sync": (C.c_int, [C.c_void_p]),
+    "gbp_timing": (C.c_int, [C.c_void_p, C.POINTER(cabi.GbpTimingOut), C.c_int]),
+    "gbp_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "gbp_set_exchange_buffers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gbp_iterate_begin": (C.c_int, [C.c_void_p]),
+    "gbp_iterate_end": (C.c_int, [C.c_void_p]),
+    "gbp_refresh_begin": (C.c_int, [C.c_void_p]),
+    "gbp_refresh_end": (C.c_int, [C.c_void_p]),
+    "gbp_linearise_factors": (C.c_int, [C.c_void_p]),
+    "gbp_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "gbp_debug_get": (C.c_int, [C.c_void_p, C.c_int, cabi.c_f32p, cabi.c_f32p]),
+    "gbp_debug_set_factor_potentials": (C.c_int, [C.c_void_p, cabi.c_f32p, cabi.c_f32p]),
+    "gbp_bal_read_header": (C.c_int, [C.c_char_p, C.POINTER(cabi.GbpBal)]),
+    "gbp_bal_read": (C.c_int, [C.c_char_p, C.POINTER(cabi.GbpBal)]),
+    "gbp_bal_write": (C.c_int, [C.c_char_p, C.POINTER(cabi.GbpBal)]),
+    "gbp_set_prior_lambda": (C.c_int, [C.POINTER(cabi.GbpProblem), C.c_float] + [cabi.c_f32p] * 8),
+    "gbp_prior_scalings": (C.c_int, [C.c_uint32, C.c_uint32, cabi.c_f32p, C.c_float, C.c_float, C.c_float,
+                                     cabi.c_f32p, cabi.c_f32p]),
+    "gbp_slam_create_flags": (C.c_int, [C.POINTER(cabi.GbpProblem), C.c_uint32] + [cabi.c_u32p] * 4),
+    "gbp_slam_update_flags": (C.c_int, [C.POINTER(cabi.GbpProblem), C.c_uint32, C.c_uint32] + [cabi.c_u32p] * 4
+                              + [cabi.c_i32p]),
+    "gbp_slam_initialise_new_kf": (C.c_int, [C.c_uint32] + [cabi.c_f32p] * 4),
+    "gbp_eval_host": (C.c_int, [C.POINTER(cabi.GbpProblem), cabi.c_u32p] + [cabi.c_f32p] * 5
+                      + [cabi.c_f64p, cabi.c_f64p, C.POINTER(C.c_uint64)]),
+    "gbp_synth_generate": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(cabi.GbpBal),
+                                     cabi.c_f64p, cabi.c_f64p]),
+}
+
+
+def symbols():
+    return sorted(_SIGS)
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "native library %s is missing — build it with `python -m gbp_poplar_amd.build` "
+            "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

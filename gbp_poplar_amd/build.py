@@ -1,0 +1,58 @@
+"""Build recipe of the native library (in-tree, gfx950 only).
+
+    python -m gbp_poplar_amd.build        -> gbp_poplar_amd/libgbp_mi355x.so  (+ bin/ba, bin/slam when sources exist)
+
+hipcc cross-compiles for gfx950 without a GPU.  -ffp-contract=off: results are compared
+bit-for-bit with the CPU oracle, so no FMA contraction on either side.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libgbp_mi355x.so")
+BIN = os.path.join(HERE, "bin")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function"]
+LIB_SRCS = ["gbp_kernels.hip", "gbp_capi.cpp", "gbp_host.cpp"]
+CLI_SRCS = {"ba": "ba_main.cpp", "slam": "slam_main.cpp"}
+
+
+def hipcc():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the HIP extension cannot be built (there is no CPU fallback)")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    cc = hipcc()
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "gbp_mi355x.h")]
+    if force or _stale(LIB, deps):
+        cmd = [cc, "-shared", "-o", LIB] + FLAGS + ["-x", "hip"] + [os.path.join(CSRC, s) for s in LIB_SRCS]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    os.makedirs(BIN, exist_ok=True)
+    for name, src in CLI_SRCS.items():
+        path = os.path.join(CSRC, src)
+        exe = os.path.join(BIN, name)
+        if os.path.exists(path) and (force or _stale(exe, deps + [LIB])):
+            cmd = [cc, "-o", exe, "-O2", "-std=c++17", "-ffp-contract=off", path, LIB, "-Wl,-rpath,$ORIGIN/.."]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

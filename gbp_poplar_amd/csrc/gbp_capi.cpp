@@ -1,0 +1,675 @@
+// gbp_capi.cpp — C-ABI implementation (include/gbp_mi355x.h): context, HBM layout construction,
+// program list (WRITE / LINEARISE / GBP / WEAKEN_PRIORS / READ / READ_PRIORS / NEW_KEYFRAME),
+// hipGraph capture of the iteration, split-phase multi-GPU iteration.
+//
+// Replaces the Poplar graph/compute-set wiring of the reference (ba/ba.cpp:45-371, 659-937): where
+// the reference maps vertices to IPU tiles and connects tensor slices, this file sorts factors
+// into device order, builds the tile-coalesced arrays the kernels stream, and records the launch
+// sequence of one iteration as a hipGraph.
+#include "../../include/gbp_mi355x.h"
+#include "gbp_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace gbp;
+
+namespace {
+thread_local std::string g_create_error;
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+}  // namespace
+
+struct gbp_ctx {
+  uint32_t C = 0, L = 0, E = 0;       // global sizes
+  uint32_t lmk_begin = 0, lmk_end = 0, L_loc = 0, E_loc = 0;
+  int rank = 0, world = 1;
+  float K[9];
+  gbp_params prm;
+  // device-order maps (host)
+  std::vector<uint32_t> pos_edge;     // [Ep] device position -> global file edge index, ~0u = pad
+  std::vector<uint32_t> pos_cam, pos_lmk_loc, pos_lpos;
+  std::vector<uint32_t> cam_row_ptr;  // [C+1] rows of each camera
+  std::vector<uint32_t> lmk_ptr;      // [L_loc+1] records of each local landmark in LMSG
+  uint32_t Ep = 0, n_tiles = 0, n_rows = 0;
+  // device memory
+  std::vector<DevBuf*> all;
+  DevBuf idx, state, fac, cmsg, mu, lmsg, camb, camp, lmkb, lmkp, rowp, local, d_cam_row_ptr, d_lmk_ptr, cwf, lwf,
+      cscale, lscale, cam_mu, lmk_mu, dK, evalp, nonfinite;
+  void* send_dev = nullptr;
+  void* recv_dev = nullptr;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  int graph_iters = 0;
+  bool uploaded = false, beliefs_valid = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+  bool profile_stages = false;
+  double sweep_ms = 0, belief_ms = 0, total_ms = 0;
+  uint64_t timed_iters = 0, dev_bytes = 0;
+  std::string err;
+};
+
+namespace {
+
+int fail(gbp_ctx* c, int code, const std::string& msg) {
+  if (c) c->err = msg; else g_create_error = msg;
+  return code;
+}
+
+#define HIPCHK(ctx, expr)                                                                          \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess)                                                                          \
+      return fail(ctx, GBP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));           \
+  } while (0)
+
+int dev_alloc(gbp_ctx* c, DevBuf& b, size_t bytes) {
+  b.bytes = bytes ? bytes : 16;
+  HIPCHK(c, hipMalloc(&b.p, b.bytes));
+  HIPCHK(c, hipMemset(b.p, 0, b.bytes));
+  c->dev_bytes += b.bytes;
+  c->all.push_back(&b);
+  return GBP_OK;
+}
+
+template <class T> T* P(DevBuf& b) { return static_cast<T*>(b.p); }
+
+SweepArgs sweep_args(gbp_ctx* c) {
+  SweepArgs a;
+  a.idx = P<int4>(c->idx); a.state = P<float4>(c->state); a.fac = P<float4>(c->fac); a.cmsg = P<float4>(c->cmsg);
+  a.mu = P<float4>(c->mu); a.lmsg = P<float4>(c->lmsg); a.camb = P<float4>(c->camb); a.lmkb = P<float4>(c->lmkb);
+  a.rowp = P<float4>(c->rowp);
+  std::memcpy(a.K, c->K, sizeof(a.K));
+  a.hp.maxeta_damping = c->prm.maxeta_damping; a.hp.num_undamped_iters = c->prm.num_undamped_iters;
+  a.hp.dmu_threshold = c->prm.dmu_threshold; a.hp.min_linear_iters = c->prm.min_linear_iters;
+  a.hp.nstds = c->prm.nstds; a.hp.relin_mode = c->prm.relin_mode;
+  return a;
+}
+
+void drop_graph(gbp_ctx* c) {
+  if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+  if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
+  c->graph_iters = 0;
+}
+
+// camera beliefs from stored partials (single GPU: d_local; multi: recv_dev) + landmark beliefs re-summed
+int refresh_beliefs_from_partials(gbp_ctx* c) {
+  if (c->world == 1) {
+    launch_cam_combine(P<float4>(c->camp), P<float4>(c->local), 1, P<float4>(c->camb), c->C, c->stream);
+  } else {
+    if (!c->recv_dev) return fail(c, GBP_ERR_STATE, "exchange buffers not set");
+    launch_cam_combine(P<float4>(c->camp), static_cast<const float4*>(c->recv_dev), c->world, P<float4>(c->camb), c->C,
+                       c->stream);
+  }
+  launch_lmk_belief(P<float4>(c->lmkp), P<float4>(c->lmsg), P<uint32_t>(c->d_lmk_ptr), P<float4>(c->lmkb), c->L_loc,
+                    c->stream);
+  HIPCHK(c, hipGetLastError());
+  return GBP_OK;
+}
+
+void enqueue_iteration(gbp_ctx* c, const SweepArgs& a) {
+  launch_sweep(a, c->n_tiles, c->stream);
+  launch_cam_reduce(P<float4>(c->rowp), P<uint32_t>(c->d_cam_row_ptr), P<float4>(c->camp), P<float4>(c->local),
+                    P<float4>(c->camb), c->C, c->stream);
+  launch_lmk_belief(P<float4>(c->lmkp), P<float4>(c->lmsg), P<uint32_t>(c->d_lmk_ptr), P<float4>(c->lmkb), c->L_loc,
+                    c->stream);
+}
+
+void pack_cam(const float* eta, const float* lam, uint32_t C, std::vector<float>& out) {
+  out.assign((size_t)C * kCamRec, 0.f);
+  for (uint32_t c = 0; c < C; ++c) {
+    std::memcpy(&out[(size_t)c * kCamRec], eta + (size_t)c * 6, 6 * 4);
+    std::memcpy(&out[(size_t)c * kCamRec + 8], lam + (size_t)c * 36, 36 * 4);
+  }
+}
+void pack_lmk(const float* eta, const float* lam, uint32_t l0, uint32_t n, std::vector<float>& out) {
+  out.assign((size_t)n * 16, 0.f);
+  for (uint32_t i = 0; i < n; ++i) {
+    std::memcpy(&out[(size_t)i * 16], eta + (size_t)(l0 + i) * 3, 3 * 4);
+    std::memcpy(&out[(size_t)i * 16 + 4], lam + (size_t)(l0 + i) * 9, 9 * 4);
+  }
+}
+
+inline size_t tile_off(uint32_t p, int G, int f) {  // float offset of float f of position p in a G-group tiled array
+  return (((size_t)(p >> 6) * G + (f >> 2)) * 64 + (p & 63)) * 4 + (f & 3);
+}
+
+}  // namespace
+
+extern "C" {
+
+int gbp_abi_version(void) { return GBP_ABI_VERSION; }
+
+void gbp_default_params(gbp_params* p) {
+  if (!p) return;
+  std::memset(p, 0, sizeof(*p));
+  p->maxeta_damping = 0.4f; p->num_undamped_iters = 8; p->dmu_threshold = 3e-3f; p->min_linear_iters = 10;
+  p->nstds = 2.5f; p->relin_mode = 0; p->graph_unroll = 0;
+}
+
+const char* gbp_last_error(const gbp_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+void gbp_destroy(gbp_ctx* c) {
+  if (!c) return;
+  drop_graph(c);
+  for (DevBuf* b : c->all) if (b->p) (void)hipFree(b->p);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->ev2) (void)hipEventDestroy(c->ev2);
+  if (c->ev3) (void)hipEventDestroy(c->ev3);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+int gbp_create(const gbp_problem* pr, const gbp_params* prm, const gbp_shard* sh, gbp_ctx** out) {
+  if (!pr || !out || !pr->cam_id || !pr->lmk_id || pr->n_cams == 0 || pr->n_lmks == 0 || pr->n_edges == 0)
+    return fail(nullptr, GBP_ERR_INVALID, "gbp_create: null or empty problem");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(nullptr, GBP_ERR_NO_DEVICE, "gbp_create: no HIP device (the product has no CPU fallback)");
+  gbp_ctx* c = new gbp_ctx();
+  c->C = pr->n_cams; c->L = pr->n_lmks; c->E = pr->n_edges;
+  std::memcpy(c->K, pr->K, sizeof(c->K));
+  if (prm) c->prm = *prm; else gbp_default_params(&c->prm);
+  if (c->prm.graph_unroll <= 0) c->prm.graph_unroll = 10;
+  c->rank = sh ? sh->rank : 0;
+  c->world = sh ? sh->world : 1;
+  c->lmk_begin = sh ? sh->lmk_begin : 0;
+  c->lmk_end = sh ? sh->lmk_end : c->L;
+  if (c->world < 1 || c->rank < 0 || c->rank >= c->world || c->lmk_begin > c->lmk_end || c->lmk_end > c->L) {
+    delete c;
+    return fail(nullptr, GBP_ERR_INVALID, "gbp_create: bad shard");
+  }
+  c->L_loc = c->lmk_end - c->lmk_begin;
+
+  // ---- device order: camera-major, file order inside a camera, rows of 16, tiles of 64 ----
+  const uint32_t C = c->C, E = c->E;
+  std::vector<uint32_t> deg(C, 0), ldeg(c->L_loc, 0);
+  for (uint32_t e = 0; e < E; ++e) {
+    const uint32_t cam = pr->cam_id[e], l = pr->lmk_id[e];
+    if (cam >= C || l >= c->L) { delete c; return fail(nullptr, GBP_ERR_INVALID, "gbp_create: index out of range"); }
+    if (l >= c->lmk_begin && l < c->lmk_end) { deg[cam]++; ldeg[l - c->lmk_begin]++; c->E_loc++; }
+  }
+  c->cam_row_ptr.assign(C + 1, 0);
+  for (uint32_t k = 0; k < C; ++k) c->cam_row_ptr[k + 1] = c->cam_row_ptr[k] + (deg[k] + kRow - 1) / kRow;
+  c->n_rows = c->cam_row_ptr[C];
+  c->Ep = ((c->n_rows * kRow + 255) / 256) * 256;
+  if (c->Ep == 0) c->Ep = 256;
+  c->n_tiles = c->Ep / kTile;
+  c->lmk_ptr.assign(c->L_loc + 1, 0);
+  for (uint32_t l = 0; l < c->L_loc; ++l) c->lmk_ptr[l + 1] = c->lmk_ptr[l] + ldeg[l];
+  c->pos_edge.assign(c->Ep, ~0u);
+  c->pos_cam.assign(c->Ep, 0);
+  c->pos_lmk_loc.assign(c->Ep, 0);
+  c->pos_lpos.assign(c->Ep, c->E_loc);  // pads point at the dump record
+  for (uint32_t k = 0; k < C; ++k)
+    for (uint32_t r = c->cam_row_ptr[k]; r < c->cam_row_ptr[k + 1]; ++r)
+      for (int i = 0; i < kRow; ++i) c->pos_cam[(size_t)r * kRow + i] = k;
+  {
+    std::vector<uint32_t> cfill(C, 0), lfill(c->L_loc, 0);
+    for (uint32_t e = 0; e < E; ++e) {
+      const uint32_t cam = pr->cam_id[e], l = pr->lmk_id[e];
+      if (l < c->lmk_begin || l >= c->lmk_end) continue;
+      const uint32_t ll = l - c->lmk_begin;
+      const uint32_t p = c->cam_row_ptr[cam] * kRow + cfill[cam]++;
+      c->pos_edge[p] = e;
+      c->pos_lmk_loc[p] = ll;
+      c->pos_lpos[p] = c->lmk_ptr[ll] + lfill[ll]++;
+    }
+  }
+
+  // ---- device allocations ----
+  int rc = GBP_OK;
+  auto A = [&](DevBuf& b, size_t bytes) { if (rc == GBP_OK) rc = dev_alloc(c, b, bytes); };
+  const size_t Ep = c->Ep;
+  A(c->idx, Ep * 16); A(c->state, Ep * 16); A(c->fac, Ep * kFacG * 16); A(c->cmsg, Ep * kCmsgG * 16);
+  A(c->mu, Ep * kMuG * 16); A(c->lmsg, ((size_t)c->E_loc + 1) * 64);
+  A(c->camb, (size_t)C * kCamRec * 4); A(c->camp, (size_t)C * kCamRec * 4); A(c->local, (size_t)C * kCamRec * 4);
+  A(c->lmkb, (size_t)c->L_loc * 64); A(c->lmkp, (size_t)c->L_loc * 64);
+  A(c->rowp, (Ep / kRow) * kCamRec * 4);
+  A(c->d_cam_row_ptr, (size_t)(C + 1) * 4); A(c->d_lmk_ptr, (size_t)(c->L_loc + 1) * 4);
+  A(c->cwf, (size_t)C * 4); A(c->lwf, (size_t)c->L_loc * 4); A(c->cscale, (size_t)C * 4); A(c->lscale, (size_t)c->L_loc * 4);
+  A(c->cam_mu, (size_t)C * 6 * 4); A(c->lmk_mu, (size_t)c->L_loc * 3 * 4); A(c->dK, 16 * 4);
+  A(c->evalp, sizeof(DeviceEval) * 1024); A(c->nonfinite, 16);
+  if (rc != GBP_OK) { g_create_error = c->err; gbp_destroy(c); return rc; }
+  auto CK = [&](hipError_t e, const char* what) {
+    if (e != hipSuccess && rc == GBP_OK) { g_create_error = std::string(what) + ": " + hipGetErrorString(e); rc = GBP_ERR_HIP; }
+  };
+  CK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking), "hipStreamCreate");
+  c->stream = c->own_stream;
+  CK(hipEventCreate(&c->ev0), "hipEventCreate"); CK(hipEventCreate(&c->ev1), "hipEventCreate");
+  CK(hipEventCreate(&c->ev2), "hipEventCreate"); CK(hipEventCreate(&c->ev3), "hipEventCreate");
+  CK(hipMemcpy(c->d_cam_row_ptr.p, c->cam_row_ptr.data(), (size_t)(C + 1) * 4, hipMemcpyHostToDevice), "copy cam_row_ptr");
+  CK(hipMemcpy(c->d_lmk_ptr.p, c->lmk_ptr.data(), (size_t)(c->L_loc + 1) * 4, hipMemcpyHostToDevice), "copy lmk_ptr");
+  CK(hipMemcpy(c->dK.p, c->K, 9 * 4, hipMemcpyHostToDevice), "copy K");
+  {
+    std::vector<int32_t> idx(Ep * 4);
+    for (size_t p = 0; p < Ep; ++p) {
+      idx[4 * p] = (int32_t)c->pos_cam[p]; idx[4 * p + 1] = (int32_t)c->pos_lmk_loc[p];
+      idx[4 * p + 2] = (int32_t)c->pos_lpos[p]; idx[4 * p + 3] = (int32_t)c->pos_edge[p];
+    }
+    CK(hipMemcpy(c->idx.p, idx.data(), Ep * 16, hipMemcpyHostToDevice), "copy idx");
+  }
+  if (rc != GBP_OK) { gbp_destroy(c); return rc; }
+  *out = c;
+  return GBP_OK;
+}
+
+int gbp_set_stream(gbp_ctx* c, void* s) {
+  if (!c) return GBP_ERR_INVALID;
+  drop_graph(c);
+  c->stream = s ? static_cast<hipStream_t>(s) : c->own_stream;
+  return GBP_OK;
+}
+
+int gbp_set_exchange_buffers(gbp_ctx* c, void* send_dev, void* recv_dev) {
+  if (!c) return GBP_ERR_INVALID;
+  c->send_dev = send_dev; c->recv_dev = recv_dev;
+  return GBP_OK;
+}
+
+int gbp_sync(gbp_ctx* c) {
+  if (!c) return GBP_ERR_INVALID;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GBP_OK;
+}
+
+// WRITE_PROG (ba.cpp:868-886).  Also zeroes every tensor the reference leaves uninitialised
+// (messages, factor potentials, beliefs: ba.cpp:668-687,759-775).
+int gbp_upload(gbp_ctx* c, const gbp_state_in* in) {
+  if (!c || !in) return GBP_ERR_INVALID;
+  if (!in->cam_priors_eta || !in->cam_priors_lambda || !in->lmk_priors_eta || !in->lmk_priors_lambda ||
+      !in->measurements || !in->meas_variances || !in->active_flag)
+    return fail(c, GBP_ERR_INVALID, "gbp_upload: priors, measurements, meas_variances and active_flag are required");
+  if (in->mu && in->oldmu && std::memcmp(in->mu, in->oldmu, (size_t)c->E * 9 * 4) != 0)
+    return fail(c, GBP_ERR_INVALID, "gbp_upload: mu != oldmu is not supported (the reference uploads zeros for both, ba.cpp:582-583)");
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const size_t Ep = c->Ep;
+  std::vector<float> st(Ep * 4, 0.f), fac(Ep * kFacG * 4, 0.f), mu(Ep * kMuG * 4, 0.f);
+  for (size_t p = 0; p < Ep; ++p) {
+    const uint32_t e = c->pos_edge[p];
+    uint32_t flags;
+    if (e == ~0u) {
+      flags = kFlagPad;
+    } else {
+      flags = (in->active_flag[e] == 1) ? kFlagActive : 0u;
+      st[4 * p] = in->damping ? in->damping[e] : 0.f;
+      const int32_t cnt = in->damping_count ? in->damping_count[e] : 0;
+      std::memcpy(&st[4 * p + 1], &cnt, 4);
+      st[4 * p + 3] = in->meas_variances[e];
+      fac[tile_off((uint32_t)p, kFacG, 54)] = in->measurements[2 * (size_t)e];
+      fac[tile_off((uint32_t)p, kFacG, 55)] = in->measurements[2 * (size_t)e + 1];
+      const float* om = in->oldmu ? in->oldmu : in->mu;
+      if (om) for (int i = 0; i < 9; ++i) mu[tile_off((uint32_t)p, kMuG, i)] = om[(size_t)e * 9 + i];
+    }
+    std::memcpy(&st[4 * p + 2], &flags, 4);
+  }
+  HIPCHK(c, hipMemcpy(c->state.p, st.data(), Ep * 16, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->fac.p, fac.data(), fac.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->mu.p, mu.data(), mu.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemset(c->cmsg.p, 0, c->cmsg.bytes));
+  HIPCHK(c, hipMemset(c->lmsg.p, 0, c->lmsg.bytes));
+  HIPCHK(c, hipMemset(c->rowp.p, 0, c->rowp.bytes));
+  HIPCHK(c, hipMemset(c->local.p, 0, c->local.bytes));
+  HIPCHK(c, hipMemset(c->camb.p, 0, c->camb.bytes));
+  HIPCHK(c, hipMemset(c->lmkb.p, 0, c->lmkb.bytes));
+  std::vector<float> rec;
+  pack_cam(in->cam_priors_eta, in->cam_priors_lambda, c->C, rec);
+  HIPCHK(c, hipMemcpy(c->camp.p, rec.data(), rec.size() * 4, hipMemcpyHostToDevice));
+  pack_lmk(in->lmk_priors_eta, in->lmk_priors_lambda, c->lmk_begin, c->L_loc, rec);
+  if (c->L_loc) HIPCHK(c, hipMemcpy(c->lmkp.p, rec.data(), rec.size() * 4, hipMemcpyHostToDevice));
+  std::vector<float> zf(std::max(c->C, c->L), 0.f);
+  std::vector<uint32_t> zu(std::max(c->C, c->L), 0u);
+  HIPCHK(c, hipMemcpy(c->cscale.p, in->cam_scaling ? in->cam_scaling : zf.data(), (size_t)c->C * 4, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->cwf.p, in->cam_weaken_flag ? in->cam_weaken_flag : zu.data(), (size_t)c->C * 4, hipMemcpyHostToDevice));
+  if (c->L_loc) {
+    HIPCHK(c, hipMemcpy(c->lscale.p, in->lmk_scaling ? in->lmk_scaling + c->lmk_begin : zf.data(), (size_t)c->L_loc * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->lwf.p, in->lmk_weaken_flag ? in->lmk_weaken_flag + c->lmk_begin : zu.data(), (size_t)c->L_loc * 4, hipMemcpyHostToDevice));
+  }
+  if (c->world > 1 && c->recv_dev) HIPCHK(c, hipMemsetAsync(c->recv_dev, 0, (size_t)c->world * c->C * kCamRec * 4, c->stream));
+  c->uploaded = true;
+  c->beliefs_valid = false;
+  return GBP_OK;
+}
+
+int gbp_refresh_begin(gbp_ctx* c) {
+  if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "upload first");
+  float4* dst = c->world > 1 ? static_cast<float4*>(c->send_dev) : P<float4>(c->local);
+  if (!dst) return fail(c, GBP_ERR_STATE, "exchange buffers not set");
+  launch_cam_reduce(P<float4>(c->rowp), P<uint32_t>(c->d_cam_row_ptr), P<float4>(c->camp), dst, nullptr, c->C, c->stream);
+  HIPCHK(c, hipGetLastError());
+  return GBP_OK;
+}
+
+int gbp_refresh_end(gbp_ctx* c) {
+  if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "upload first");
+  const int rc = refresh_beliefs_from_partials(c);
+  if (rc == GBP_OK) c->beliefs_valid = true;
+  return rc;
+}
+
+int gbp_linearise_factors(gbp_ctx* c) {
+  if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "upload first");
+  launch_linearise(sweep_args(c), c->n_tiles, c->stream);
+  HIPCHK(c, hipGetLastError());
+  return GBP_OK;
+}
+
+// LINEARISE_PROG (ba.cpp:890-893): prog_ub, then RelineariseFactorVertex on every factor.
+int gbp_linearise(gbp_ctx* c) {
+  if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "gbp_linearise: upload first");
+  if (c->world > 1) return fail(c, GBP_ERR_STATE, "sharded ctx: use refresh_begin / exchange / refresh_end / linearise_factors");
+  int rc = gbp_refresh_begin(c);
+  if (rc == GBP_OK) rc = gbp_refresh_end(c);
+  if (rc == GBP_OK) rc = gbp_linearise_factors(c);
+  return rc;
+}
+
+int gbp_iterate_begin(gbp_ctx* c) {
+  if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "upload first");
+  float4* dst = c->world > 1 ? static_cast<float4*>(c->send_dev) : P<float4>(c->local);
+  if (!dst) return fail(c, GBP_ERR_STATE, "exchange buffers not set");
+  launch_sweep(sweep_args(c), c->n_tiles, c->stream);
+  launch_cam_reduce(P<float4>(c->rowp), P<uint32_t>(c->d_cam_row_ptr), P<float4>(c->camp), dst, nullptr, c->C, c->stream);
+  HIPCHK(c, hipGetLastError());
+  return GBP_OK;
+}
+
+int gbp_iterate_end(gbp_ctx* c) { return gbp_refresh_end(c); }
+
+// GBP_PROG x n (ba.cpp:895-905) on one GPU: replay of a captured hipGraph of `graph_unroll`
+// iterations, remainder launched directly.
+int gbp_iterate(gbp_ctx* c, int n) {
+  if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "gbp_iterate: upload first");
+  if (n <= 0) return GBP_OK;
+  if (c->world > 1) return fail(c, GBP_ERR_STATE, "sharded ctx: use gbp_iterate_begin / exchange / gbp_iterate_end");
+  const SweepArgs a = sweep_args(c);
+  HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+  if (c->profile_stages) {
+    for (int i = 0; i < n; ++i) {
+      HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+      launch_sweep(a, c->n_tiles, c->stream);
+      HIPCHK(c, hipEventRecord(c->ev2, c->stream));
+      launch_cam_reduce(P<float4>(c->rowp), P<uint32_t>(c->d_cam_row_ptr), P<float4>(c->camp), P<float4>(c->local),
+                        P<float4>(c->camb), c->C, c->stream);
+      launch_lmk_belief(P<float4>(c->lmkp), P<float4>(c->lmsg), P<uint32_t>(c->d_lmk_ptr), P<float4>(c->lmkb), c->L_loc,
+                        c->stream);
+      HIPCHK(c, hipEventRecord(c->ev3, c->stream));
+      HIPCHK(c, hipEventSynchronize(c->ev3));
+      float a_ms = 0, b_ms = 0;
+      HIPCHK(c, hipEventElapsedTime(&a_ms, c->ev1, c->ev2));
+      HIPCHK(c, hipEventElapsedTime(&b_ms, c->ev2, c->ev3));
+      c->sweep_ms += a_ms; c->belief_ms += b_ms;
+    }
+  } else {
+    int left = n;
+    const bool use_graph = (c->stream == c->own_stream) && c->prm.graph_unroll > 0 && n >= c->prm.graph_unroll;
+    if (use_graph) {
+      if (!c->graph_exec) {
+        HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        for (int i = 0; i < c->prm.graph_unroll; ++i) enqueue_iteration(c, a);
+        HIPCHK(c, hipStreamEndCapture(c->stream, &c->graph));
+        HIPCHK(c, hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0));
+        c->graph_iters = c->prm.graph_unroll;
+      }
+      while (left >= c->graph_iters) {
+        HIPCHK(c, hipGraphLaunch(c->graph_exec, c->stream));
+        left -= c->graph_iters;
+      }
+    }
+    for (; left > 0; --left) enqueue_iteration(c, a);
+  }
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipEventRecord(c->ev3, c->stream));
+  HIPCHK(c, hipEventSynchronize(c->ev3));
+  float ms = 0;
+  HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev3));
+  c->total_ms += ms;
+  c->timed_iters += (uint64_t)n;
+  c->beliefs_valid = true;
+  return GBP_OK;
+}
+
+// WEAKEN_PRIORS (ba.cpp:863-865): WeakenPriorVertex on every variable, then prog_ub.
+int gbp_weaken_priors(gbp_ctx* c) {
+  if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "gbp_weaken_priors: upload first");
+  launch_weaken(P<float4>(c->camp), P<float>(c->cscale), P<uint32_t>(c->cwf), c->C, kCamRec4, c->stream);
+  if (c->L_loc) launch_weaken(P<float4>(c->lmkp), P<float>(c->lscale), P<uint32_t>(c->lwf), c->L_loc, kLmkRec4, c->stream);
+  HIPCHK(c, hipGetLastError());
+  return refresh_beliefs_from_partials(c);
+}
+
+// READ_PROG (ba.cpp:908-916)
+int gbp_read(gbp_ctx* c, gbp_state_out* o) {
+  if (!c || !o) return GBP_ERR_INVALID;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (o->cam_beliefs_eta || o->cam_beliefs_lambda) {
+    std::vector<float> rec((size_t)c->C * kCamRec);
+    HIPCHK(c, hipMemcpy(rec.data(), c->camb.p, rec.size() * 4, hipMemcpyDeviceToHost));
+    for (uint32_t k = 0; k < c->C; ++k) {
+      if (o->cam_beliefs_eta) std::memcpy(o->cam_beliefs_eta + (size_t)k * 6, &rec[(size_t)k * kCamRec], 6 * 4);
+      if (o->cam_beliefs_lambda) std::memcpy(o->cam_beliefs_lambda + (size_t)k * 36, &rec[(size_t)k * kCamRec + 8], 36 * 4);
+    }
+  }
+  if ((o->lmk_beliefs_eta || o->lmk_beliefs_lambda) && c->L_loc) {
+    std::vector<float> rec((size_t)c->L_loc * 16);
+    HIPCHK(c, hipMemcpy(rec.data(), c->lmkb.p, rec.size() * 4, hipMemcpyDeviceToHost));
+    for (uint32_t l = 0; l < c->L_loc; ++l) {
+      if (o->lmk_beliefs_eta) std::memcpy(o->lmk_beliefs_eta + (size_t)(c->lmk_begin + l) * 3, &rec[(size_t)l * 16], 3 * 4);
+      if (o->lmk_beliefs_lambda) std::memcpy(o->lmk_beliefs_lambda + (size_t)(c->lmk_begin + l) * 9, &rec[(size_t)l * 16 + 4], 9 * 4);
+    }
+  }
+  if (o->damping || o->damping_count || o->robust_flag) {
+    std::vector<float> st((size_t)c->Ep * 4);
+    HIPCHK(c, hipMemcpy(st.data(), c->state.p, st.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t p = 0; p < c->Ep; ++p) {
+      const uint32_t e = c->pos_edge[p];
+      if (e == ~0u) continue;
+      uint32_t flags; int32_t cnt;
+      std::memcpy(&cnt, &st[4 * p + 1], 4); std::memcpy(&flags, &st[4 * p + 2], 4);
+      if (o->damping) o->damping[e] = st[4 * p];
+      if (o->damping_count) o->damping_count[e] = cnt;
+      if (o->robust_flag) o->robust_flag[e] = (flags & kFlagRobust) ? 1u : 0u;
+    }
+  }
+  return GBP_OK;
+}
+
+// READ_PRIORS (slam.cpp:913-917)
+int gbp_read_priors(gbp_ctx* c, gbp_priors_out* o) {
+  if (!c || !o) return GBP_ERR_INVALID;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::vector<float> rec((size_t)c->C * kCamRec);
+  HIPCHK(c, hipMemcpy(rec.data(), c->camp.p, rec.size() * 4, hipMemcpyDeviceToHost));
+  for (uint32_t k = 0; k < c->C; ++k) {
+    if (o->cam_priors_eta) std::memcpy(o->cam_priors_eta + (size_t)k * 6, &rec[(size_t)k * kCamRec], 6 * 4);
+    if (o->cam_priors_lambda) std::memcpy(o->cam_priors_lambda + (size_t)k * 36, &rec[(size_t)k * kCamRec + 8], 36 * 4);
+  }
+  if (c->L_loc) {
+    rec.resize((size_t)c->L_loc * 16);
+    HIPCHK(c, hipMemcpy(rec.data(), c->lmkp.p, rec.size() * 4, hipMemcpyDeviceToHost));
+    for (uint32_t l = 0; l < c->L_loc; ++l) {
+      if (o->lmk_priors_eta) std::memcpy(o->lmk_priors_eta + (size_t)(c->lmk_begin + l) * 3, &rec[(size_t)l * 16], 3 * 4);
+      if (o->lmk_priors_lambda) std::memcpy(o->lmk_priors_lambda + (size_t)(c->lmk_begin + l) * 9, &rec[(size_t)l * 16 + 4], 9 * 4);
+    }
+  }
+  return GBP_OK;
+}
+
+// NEW_KEYFRAME (slam.cpp:919-928): re-upload damping_count, priors, flags; then prog_ub.
+int gbp_new_keyframe(gbp_ctx* c, const gbp_kf_update* u) {
+  if (!c || !u || !c->uploaded) return fail(c, GBP_ERR_STATE, "gbp_new_keyframe: upload first");
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (u->damping_count || u->active_flag) {
+    std::vector<float> st((size_t)c->Ep * 4);
+    HIPCHK(c, hipMemcpy(st.data(), c->state.p, st.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t p = 0; p < c->Ep; ++p) {
+      const uint32_t e = c->pos_edge[p];
+      if (e == ~0u) continue;
+      if (u->damping_count) std::memcpy(&st[4 * p + 1], &u->damping_count[e], 4);
+      if (u->active_flag) {
+        uint32_t flags; std::memcpy(&flags, &st[4 * p + 2], 4);
+        flags = (u->active_flag[e] == 1) ? (flags | kFlagActive) : (flags & ~kFlagActive);
+        std::memcpy(&st[4 * p + 2], &flags, 4);
+      }
+    }
+    HIPCHK(c, hipMemcpy(c->state.p, st.data(), st.size() * 4, hipMemcpyHostToDevice));
+  }
+  if (u->cam_priors_eta && u->cam_priors_lambda) {
+    std::vector<float> rec;
+    pack_cam(u->cam_priors_eta, u->cam_priors_lambda, c->C, rec);
+    HIPCHK(c, hipMemcpy(c->camp.p, rec.data(), rec.size() * 4, hipMemcpyHostToDevice));
+  }
+  if (u->lmk_priors_eta && u->lmk_priors_lambda && c->L_loc) {
+    std::vector<float> rec;
+    pack_lmk(u->lmk_priors_eta, u->lmk_priors_lambda, c->lmk_begin, c->L_loc, rec);
+    HIPCHK(c, hipMemcpy(c->lmkp.p, rec.data(), rec.size() * 4, hipMemcpyHostToDevice));
+  }
+  if (u->cam_weaken_flag) HIPCHK(c, hipMemcpy(c->cwf.p, u->cam_weaken_flag, (size_t)c->C * 4, hipMemcpyHostToDevice));
+  if (u->lmk_weaken_flag && c->L_loc)
+    HIPCHK(c, hipMemcpy(c->lwf.p, u->lmk_weaken_flag + c->lmk_begin, (size_t)c->L_loc * 4, hipMemcpyHostToDevice));
+  return refresh_beliefs_from_partials(c);
+}
+
+// eval_reprojection_error (util.cpp:74-144) + counters (ba.cpp:1011-1020) over the local shard
+int gbp_eval(gbp_ctx* c, gbp_eval_out* o) {
+  if (!c || !o || !c->uploaded) return fail(c, GBP_ERR_STATE, "gbp_eval: upload first");
+  std::memset(o, 0, sizeof(*o));
+  launch_means(P<float4>(c->camb), P<float4>(c->lmkb), P<float>(c->cam_mu), P<float>(c->lmk_mu), c->C, c->L_loc, c->stream);
+  launch_eval(P<int4>(c->idx), P<float4>(c->state), P<float4>(c->fac), P<float>(c->cam_mu), P<float>(c->lmk_mu),
+              P<float>(c->dK), c->prm.num_undamped_iters, P<DeviceEval>(c->evalp), c->n_tiles, c->stream);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const uint32_t nb = eval_blocks(c->n_tiles);
+  std::vector<DeviceEval> part(nb);
+  HIPCHK(c, hipMemcpy(part.data(), c->evalp.p, sizeof(DeviceEval) * nb, hipMemcpyDeviceToHost));
+  for (uint32_t b = 0; b < nb; ++b) {
+    o->sum_norm += part[b].sum_norm; o->sum_half_sq += part[b].sum_half_sq;
+    o->n_active += part[b].n_active; o->n_relin += part[b].n_relin; o->n_robust += part[b].n_robust;
+  }
+  // non-finite guard (replaces the Poplar FP traps of ba.cpp:888-891): means of a broken belief are non-finite
+  {
+    std::vector<float> cm((size_t)c->C * 6), lm((size_t)c->L_loc * 3);
+    HIPCHK(c, hipMemcpy(cm.data(), c->cam_mu.p, cm.size() * 4, hipMemcpyDeviceToHost));
+    if (c->L_loc) HIPCHK(c, hipMemcpy(lm.data(), c->lmk_mu.p, lm.size() * 4, hipMemcpyDeviceToHost));
+    auto finite = [](float x) { return x == x && x - x == 0.f; };
+    if (c->rank == 0)
+      for (uint32_t k = 0; k < c->C; ++k) {
+        bool bad = false;
+        for (int i = 0; i < 6; ++i) bad |= !finite(cm[(size_t)k * 6 + i]);
+        o->n_nonfinite += bad;
+      }
+    for (uint32_t l = 0; l < c->L_loc; ++l) {
+      bool bad = false;
+      for (int i = 0; i < 3; ++i) bad |= !finite(lm[(size_t)l * 3 + i]);
+      o->n_nonfinite += bad;
+    }
+  }
+  return GBP_OK;
+}
+
+int gbp_timing(gbp_ctx* c, gbp_timing_out* t, int reset) {
+  if (!c || !t) return GBP_ERR_INVALID;
+  t->sweep_ms = c->sweep_ms; t->belief_ms = c->belief_ms; t->total_ms = c->total_ms; t->iterations = c->timed_iters;
+  t->algorithmic_bytes_per_iter = 1112ull * c->E_loc + 336ull * c->C + 96ull * c->L_loc;
+  t->device_bytes_allocated = c->dev_bytes;
+  if (reset) { c->sweep_ms = c->belief_ms = c->total_ms = 0; c->timed_iters = 0; }
+  return GBP_OK;
+}
+
+// ---- extras declared below the main program list -------------------------------------------------
+int gbp_set_profiling(gbp_ctx* c, int per_stage_events) {
+  if (!c) return GBP_ERR_INVALID;
+  c->profile_stages = per_stage_events != 0;
+  return GBP_OK;
+}
+
+// Raw internal state in the reference's tensor layouts, for stage-level parity tests.
+//   what = 0: factor_potentials_eta [9E] + factor_potentials_lambda [81E] = [cc36|cl18|lc18|ll9] (ba.cpp:93-96)
+//   what = 1: factor->camera messages as stored: eta [6E] + Lambda [36E] (lower triangle; upper = 0)
+//   what = 2: factor->landmark messages: eta [3E] + Lambda [9E]
+//   what = 3: mu [9E] + dmu [E]
+// Entries of factors outside the local shard are left untouched.
+int gbp_debug_get(gbp_ctx* c, int what, float* a, float* b) {
+  if (!c || !a || !b) return GBP_ERR_INVALID;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  auto tri = [](int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; };
+  if (what == 0) {
+    std::vector<float> f((size_t)c->Ep * kFacG * 4);
+    HIPCHK(c, hipMemcpy(f.data(), c->fac.p, f.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t p = 0; p < c->Ep; ++p) {
+      const uint32_t e = c->pos_edge[p];
+      if (e == ~0u) continue;
+      auto F = [&](int i) { return f[tile_off((uint32_t)p, kFacG, i)]; };
+      for (int i = 0; i < 9; ++i) a[(size_t)e * 9 + i] = F(i);
+      float* lam = b + (size_t)e * 81;
+      for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) lam[i * 6 + j] = F(9 + tri(i, j));
+      for (int i = 0; i < 6; ++i) for (int j = 0; j < 3; ++j) { lam[36 + i * 3 + j] = F(30 + i * 3 + j); lam[54 + j * 6 + i] = F(30 + i * 3 + j); }
+      for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) lam[72 + i * 3 + j] = F(48 + tri(i, j));
+    }
+  } else if (what == 1) {
+    std::vector<float> f((size_t)c->Ep * kCmsgG * 4);
+    HIPCHK(c, hipMemcpy(f.data(), c->cmsg.p, f.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t p = 0; p < c->Ep; ++p) {
+      const uint32_t e = c->pos_edge[p];
+      if (e == ~0u) continue;
+      for (int i = 0; i < 6; ++i) a[(size_t)e * 6 + i] = f[tile_off((uint32_t)p, kCmsgG, i)];
+      for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j)
+        b[(size_t)e * 36 + i * 6 + j] = (i >= j) ? f[tile_off((uint32_t)p, kCmsgG, 6 + tri(i, j))] : 0.f;
+    }
+  } else if (what == 2) {
+    std::vector<float> f(((size_t)c->E_loc + 1) * 16);
+    HIPCHK(c, hipMemcpy(f.data(), c->lmsg.p, f.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t p = 0; p < c->Ep; ++p) {
+      const uint32_t e = c->pos_edge[p];
+      if (e == ~0u) continue;
+      const float* r = &f[(size_t)c->pos_lpos[p] * 16];
+      for (int i = 0; i < 3; ++i) a[(size_t)e * 3 + i] = r[i];
+      for (int i = 0; i < 9; ++i) b[(size_t)e * 9 + i] = r[4 + i];
+    }
+  } else if (what == 3) {
+    std::vector<float> f((size_t)c->Ep * kMuG * 4);
+    HIPCHK(c, hipMemcpy(f.data(), c->mu.p, f.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t p = 0; p < c->Ep; ++p) {
+      const uint32_t e = c->pos_edge[p];
+      if (e == ~0u) continue;
+      for (int i = 0; i < 9; ++i) a[(size_t)e * 9 + i] = f[tile_off((uint32_t)p, kMuG, i)];
+      b[e] = f[tile_off((uint32_t)p, kMuG, 9)];
+    }
+  } else {
+    return fail(c, GBP_ERR_INVALID, "gbp_debug_get: unknown selector");
+  }
+  return GBP_OK;
+}
+
+// Inverse of gbp_debug_get(what = 0): overwrite the factor potentials (lower triangles of the
+// symmetric blocks and Lambda_cl are taken; Lambda_lc is implied).  Test hook only.
+int gbp_debug_set_factor_potentials(gbp_ctx* c, const float* eta9E, const float* lam81E) {
+  if (!c || !eta9E || !lam81E) return GBP_ERR_INVALID;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  auto tri = [](int i, int j) { return i * (i + 1) / 2 + j; };
+  std::vector<float> f((size_t)c->Ep * kFacG * 4);
+  HIPCHK(c, hipMemcpy(f.data(), c->fac.p, f.size() * 4, hipMemcpyDeviceToHost));
+  for (size_t p = 0; p < c->Ep; ++p) {
+    const uint32_t e = c->pos_edge[p];
+    if (e == ~0u) continue;
+    const float* lam = lam81E + (size_t)e * 81;
+    for (int i = 0; i < 9; ++i) f[tile_off((uint32_t)p, kFacG, i)] = eta9E[(size_t)e * 9 + i];
+    for (int i = 0; i < 6; ++i) for (int j = 0; j <= i; ++j) f[tile_off((uint32_t)p, kFacG, 9 + tri(i, j))] = lam[i * 6 + j];
+    for (int i = 0; i < 18; ++i) f[tile_off((uint32_t)p, kFacG, 30 + i)] = lam[36 + i];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j <= i; ++j) f[tile_off((uint32_t)p, kFacG, 48 + tri(i, j))] = lam[72 + i * 3 + j];
+  }
+  HIPCHK(c, hipMemcpy(c->fac.p, f.data(), f.size() * 4, hipMemcpyHostToDevice));
+  return GBP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,216 @@
+// gbp_device_math.hpp — register-resident small dense math for the GBP kernels (gfx950).
+//
+// Mapping: ONE LANE OWNS ONE FACTOR.  Every routine below is straight-line code over compile-time
+// indexed arrays (fully unrolled -> VGPRs, no scratch), evaluating fp32 operations in exactly the
+// order of the reference routine it cites, so that a sweep is bit-comparable with the CPU oracle
+// when compiled with -ffp-contract=off (no FMA) and IEEE division / sqrt (hipcc default).
+// Terms that are structurally zero in the reference's dense loops (triangular factors, hat
+// matrices) are skipped: adding a +-0 product to a partial sum does not change an fp32 value
+// (sign of an exact-zero result aside; non-finite inputs excepted).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace gbpdev {
+
+#define GBP_UNROLL _Pragma("unroll")
+#define GBP_DEV __device__ __forceinline__
+
+// packed lower-triangle index, i >= j
+GBP_DEV constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }
+GBP_DEV constexpr int trisym(int i, int j) { return i >= j ? tri(i, j) : tri(j, i); }
+
+// reference ba/matlib.cpp:143-161 — cofactor inverse, nine IEEE divisions by det.
+GBP_DEV void inv3x3(const float (&M)[9], float (&inv)[9]) {
+  const float det = M[0] * (M[4] * M[8] - M[7] * M[5]) - M[1] * (M[3] * M[8] - M[5] * M[6]) +
+                    M[2] * (M[3] * M[7] - M[4] * M[6]);
+  inv[0] = (M[4] * M[8] - M[7] * M[5]) / det;
+  inv[1] = (M[2] * M[7] - M[1] * M[8]) / det;
+  inv[2] = (M[1] * M[5] - M[2] * M[4]) / det;
+  inv[3] = (M[5] * M[6] - M[3] * M[8]) / det;
+  inv[4] = (M[0] * M[8] - M[2] * M[6]) / det;
+  inv[5] = (M[3] * M[2] - M[0] * M[5]) / det;
+  inv[6] = (M[3] * M[7] - M[6] * M[4]) / det;
+  inv[7] = (M[6] * M[1] - M[0] * M[7]) / det;
+  inv[8] = (M[0] * M[4] - M[3] * M[1]) / det;
+}
+
+// reference ba/matlib.cpp:180-222 — un-pivoted LDL^T of the LOWER triangle (packed, 21 entries),
+// D^-1, inverse of the unit upper factor (matlib.cpp:163-178), Ainv = (LT^-1 D^-1) LT^-T.
+// All 36 entries of Ainv are produced separately: (a*d)*b and (b*d)*a round differently, so the
+// reference's result is not bit-symmetric.
+GBP_DEV void inv6x6_lower(const float (&A)[21], float (&Ainv)[36]) {
+  float D[6], rD[6];
+  float U[6][6];   // U[j][i], i > j : LT(j,i)
+  float Ui[6][6];  // Ui[i][j], j > i : LTinv(i,j)
+  GBP_UNROLL
+  for (int j = 0; j < 6; ++j) {
+    float d = A[tri(j, j)];
+    GBP_UNROLL
+    for (int k = 0; k < j; ++k) d -= U[k][j] * U[k][j] * D[k];
+    D[j] = d;
+    rD[j] = 1 / d;
+    GBP_UNROLL
+    for (int i = j + 1; i < 6; ++i) {
+      float u = rD[j] * A[tri(i, j)];
+      GBP_UNROLL
+      for (int k = 0; k < j; ++k) u -= rD[j] * U[k][i] * U[k][j] * D[k];
+      U[j][i] = u;
+    }
+  }
+  GBP_UNROLL
+  for (int j = 1; j < 6; ++j) {
+    GBP_UNROLL
+    for (int i = 0; i < j; ++i) {
+      float acc = 0.f;
+      acc += U[i][j];  // k = i: LTinv(i,i) * LT(i,j) = 1 * LT(i,j)
+      GBP_UNROLL
+      for (int k = i + 1; k < j; ++k) acc += Ui[i][k] * U[k][j];
+      Ui[i][j] = acc / -1.f;
+    }
+  }
+  GBP_UNROLL
+  for (int i = 0; i < 6; ++i) {
+    GBP_UNROLL
+    for (int j = 0; j < 6; ++j) {
+      const int k0 = i > j ? i : j;
+      float acc = 0.f;
+      GBP_UNROLL
+      for (int k = k0; k < 6; ++k) {
+        const float w = (k == i) ? rD[k] : Ui[i][k] * rD[k];  // (LTinv Dinv)(i,k); LTinv(i,i) = 1
+        const float b = (k == j) ? 1.f : Ui[j][k];            // LTinv(j,k)
+        acc += (k == j) ? w : w * b;
+      }
+      Ainv[i * 6 + j] = acc;
+    }
+  }
+}
+
+// NB on the two shortcuts above: 1*x and x*1 are exact, so multiplying by the unit diagonal is
+// dropped; "0 + x" is kept (acc starts at 0.f) because 0 + (-0) = +0 in the reference too.
+
+// reference ba/bafuncs.cpp:31-55 — Rodrigues, identity if theta <= 1e-6.
+GBP_DEV void so3exp(const float (&v)[3], float (&R)[9]) {
+  const float theta = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  GBP_UNROLL
+  for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.f : 0.f;
+  if (theta > 1e-6f) {
+    // sin/cos are taken correctly rounded (fp64 evaluation rounded once to fp32): the reference's
+    // own std::sin/std::cos resolve to whatever libm its target ships (Poplar's on the IPU), so no
+    // libm is "the" reference; a correctly rounded value is the one every good libm approximates.
+    const float s = (float)sin((double)theta), c = (float)cos((double)theta);
+    const float H[9] = {0.f, -v[2], v[1], v[2], 0.f, -v[0], -v[1], v[0], 0.f};
+    const float a = s / theta;
+    const float b = (1 - c) / (theta * theta);
+    GBP_UNROLL
+    for (int i = 0; i < 3; ++i) {
+      GBP_UNROLL
+      for (int j = 0; j < 3; ++j) {
+        float h2 = 0.f;
+        GBP_UNROLL
+        for (int k = 0; k < 3; ++k)
+          if (k != i && k != j) h2 += H[i * 3 + k] * H[k * 3 + j];
+        float r = R[i * 3 + j];
+        if (i != j) r += a * H[i * 3 + j];
+        r += b * h2;
+        R[i * 3 + j] = r;
+      }
+    }
+  }
+}
+
+// Shared front end of hfunc (bafuncs.cpp:82-103) and Jac (bafuncs.cpp:106-213): both build the
+// same Tw2c and the same camera-frame point from the same inputs, so they are evaluated once.
+struct Lin {
+  float Jkf[12];  // 2x6
+  float Jl[6];    // 2x3
+  float hx[2];
+};
+
+GBP_DEV void jac_hfunc(const float (&cam)[6], const float (&lmk)[3], const float (&K)[9], Lin& o) {
+  float R[9];
+  const float v[3] = {cam[3], cam[4], cam[5]};
+  so3exp(v, R);
+  float yc[3];
+  GBP_UNROLL
+  for (int i = 0; i < 3; ++i) {
+    float acc = 0.f;
+    GBP_UNROLL
+    for (int k = 0; k < 3; ++k) acc += R[i * 3 + k] * lmk[k];
+    acc += cam[i];  // T(i,3) * 1.0
+    yc[i] = acc;
+  }
+  o.hx[0] = K[0] * (yc[0] / yc[2]) + K[2];
+  o.hx[1] = K[4] * (yc[1] / yc[2]) + K[5];
+
+  const float jp00 = K[0] / yc[2];
+  const float jp02 = -(K[0] * yc[0]) / (yc[2] * yc[2]);
+  const float jp11 = K[4] / yc[2];
+  const float jp12 = -(K[4] * yc[1]) / (yc[2] * yc[2]);
+  // Jlmk = J_proj * R  (J_proj has structural zeros at (0,1) and (1,0))
+  GBP_UNROLL
+  for (int j = 0; j < 3; ++j) {
+    float a0 = 0.f, a1 = 0.f;
+    a0 += jp00 * R[j];
+    a0 += jp02 * R[6 + j];
+    a1 += jp11 * R[3 + j];
+    a1 += jp12 * R[6 + j];
+    o.Jl[j] = a0;
+    o.Jl[3 + j] = a1;
+  }
+  o.Jkf[0] = jp00; o.Jkf[1] = 0.f;  o.Jkf[2] = jp02;
+  o.Jkf[6] = 0.f;  o.Jkf[7] = jp11; o.Jkf[8] = jp12;
+
+  // rotation block: dRy/dw = -R [y]x (w w^T + (R^T - I)[w]x) / |w|^2   (bafuncs.cpp:178-204)
+  const float vh[9] = {0.f, -v[2], v[1], v[2], 0.f, -v[0], -v[1], v[0], 0.f};
+  const float yh[9] = {0.f, -lmk[2], lmk[1], lmk[2], 0.f, -lmk[0], -lmk[1], lmk[0], 0.f};
+  float RtI[9], Ry[9], num[9], dR[9];
+  GBP_UNROLL
+  for (int i = 0; i < 3; ++i) {
+    GBP_UNROLL
+    for (int j = 0; j < 3; ++j) {
+      float t = (i == j) ? -1.f : 0.f;
+      t += R[j * 3 + i];
+      RtI[i * 3 + j] = t;
+    }
+  }
+  GBP_UNROLL
+  for (int i = 0; i < 3; ++i) {
+    GBP_UNROLL
+    for (int j = 0; j < 3; ++j) {
+      float a = 0.f, b = 0.f;
+      GBP_UNROLL
+      for (int k = 0; k < 3; ++k)
+        if (k != j) {  // hat matrices have a zero diagonal
+          a += R[i * 3 + k] * yh[k * 3 + j];
+          b += RtI[i * 3 + k] * vh[k * 3 + j];
+        }
+      Ry[i * 3 + j] = a;
+      num[i * 3 + j] = b + v[i] * v[j];
+    }
+  }
+  float den = 0.f;
+  GBP_UNROLL
+  for (int i = 0; i < 3; ++i) den += v[i] * v[i];
+  GBP_UNROLL
+  for (int i = 0; i < 3; ++i) {
+    GBP_UNROLL
+    for (int j = 0; j < 3; ++j) {
+      float a = 0.f;
+      GBP_UNROLL
+      for (int k = 0; k < 3; ++k) a += Ry[i * 3 + k] * num[k * 3 + j];
+      dR[i * 3 + j] = -a / den;
+    }
+  }
+  GBP_UNROLL
+  for (int j = 0; j < 3; ++j) {
+    float a0 = 0.f, a1 = 0.f;
+    a0 += jp00 * dR[j];
+    a0 += jp02 * dR[6 + j];
+    a1 += jp11 * dR[3 + j];
+    a1 += jp12 * dR[6 + j];
+    o.Jkf[3 + j] = a0;
+    o.Jkf[9 + j] = a1;
+  }
+}
+
+}  // namespace gbpdev

@@ -1,0 +1,385 @@
+// gbp_host.cpp — CPU-side helpers of the GBP path's callers (no device code, no HIP calls).
+//
+// These are the functions the reference's main() runs around the Poplar engine; they feed or
+// consume the hot path and are exported through the C-ABI (include/gbp_mi355x.h) so that the C++
+// CLIs, the Python bindings and a foreign host can share one implementation:
+//   gbp_bal_read / _write      BALProblem::LoadFile            reference ba/dataio.cpp:17-57
+//   gbp_set_prior_lambda       set_prior_lambda + reprojectionJacFn   dataio.cpp:67-117, util.cpp:48-72
+//   gbp_prior_scalings         prior-weakening scale factors   ba/ba.cpp:561-572
+//   gbp_slam_create_flags / gbp_slam_update_flags              dataio.cpp:455-475, 477-508
+//   gbp_slam_initialise_new_kf initialise_new_kf               util.cpp:183-197
+//   gbp_eval_host              eval_reprojection_error         util.cpp:74-144
+//   gbp_synth_generate         synthetic BAL graphs (the reference ships none)
+// The reference's O(E^2) / O((C+L)E) host loops (ba.cpp:267-279, dataio.cpp:76-116) are replaced by
+// single O(E) passes with identical results.  Eigen is not used; where the reference calls
+// Eigen's general inverse we solve in fp64 with partial pivoting.
+#include "../../include/gbp_mi355x.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+struct Rot3 { float m[9]; };
+
+// Rodrigues formula the way util.cpp:20-32 writes it (single expression, fp32).
+Rot3 rodrigues_host(const float* w) {
+  Rot3 R{{1, 0, 0, 0, 1, 0, 0, 0, 1}};
+  const float th = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+  if (th < 1e-6) return R;
+  const float W[9] = {0.f, -w[2], w[1], w[2], 0.f, -w[0], -w[1], w[0], 0.f};
+  const float a = std::sin(th) / th;
+  const float b = (1 - std::cos(th)) / (th * th);
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) {
+      float ww = 0.f;
+      for (int k = 0; k < 3; ++k) ww += W[r * 3 + k] * W[k * 3 + c];
+      R.m[r * 3 + c] = R.m[r * 3 + c] + (a * W[r * 3 + c] + b * ww);
+    }
+  return R;
+}
+
+inline float row_dot3(const float* row, const float* v) { return (row[0] * v[0] + row[1] * v[1]) + row[2] * v[2]; }
+
+// Largest |entry| of the 2x9 reprojection Jacobian of util.cpp:48-72 at (cam, lmk).
+float jacobian_peak(const float* cam, const float* lmk, const float* K) {
+  const Rot3 R = rodrigues_host(cam + 3);
+  float Ry[3], pc[3], p[3];
+  for (int i = 0; i < 3; ++i) Ry[i] = row_dot3(R.m + 3 * i, lmk);
+  for (int i = 0; i < 3; ++i) pc[i] = Ry[i] + cam[i];
+  for (int i = 0; i < 3; ++i) p[i] = row_dot3(K + 3 * i, pc);
+  const double z2 = static_cast<double>(p[2]) * static_cast<double>(p[2]);  // pow(p(2),2) is double
+  const float jp[6] = {1 / p[2], 0, static_cast<float>(-p[0] / z2), 0, 1 / p[2], static_cast<float>(-p[1] / z2)};
+  const float D[9] = {-0.f, Ry[2], -Ry[1], -Ry[2], -0.f, Ry[0], Ry[1], -Ry[0], -0.f};  // -hat(R*lmk)
+  float jK[6], peak = 0.f;
+  for (int r = 0; r < 2; ++r)
+    for (int c = 0; c < 3; ++c) {
+      float s = 0.f;
+      for (int k = 0; k < 3; ++k) s += jp[r * 3 + k] * K[k * 3 + c];
+      jK[r * 3 + c] = s;
+    }
+  for (int r = 0; r < 2; ++r)
+    for (int c = 0; c < 3; ++c) {
+      float s = 0.f, t = 0.f;
+      for (int k = 0; k < 3; ++k) {
+        s += jK[r * 3 + k] * D[k * 3 + c];
+        t += jK[r * 3 + k] * R.m[k * 3 + c];
+      }
+      peak = std::max(peak, std::max(std::fabs(jK[r * 3 + c]), std::max(std::fabs(s), std::fabs(t))));
+    }
+  return peak;
+}
+
+// x = A^-1 b, n <= 6: fp64 elimination with partial pivoting on fp32 inputs, result rounded to fp32.
+void solve_pivot(const float* A, const float* b, int n, float* x) {
+  double M[6][7];
+  for (int i = 0; i < n; ++i) {
+    for (int j = 0; j < n; ++j) M[i][j] = A[i * n + j];
+    M[i][n] = b[i];
+  }
+  for (int k = 0; k < n; ++k) {
+    int piv = k;
+    double best = std::fabs(M[k][k]);
+    for (int i = k + 1; i < n; ++i)
+      if (std::fabs(M[i][k]) > best) { best = std::fabs(M[i][k]); piv = i; }
+    if (piv != k)
+      for (int j = 0; j <= n; ++j) std::swap(M[k][j], M[piv][j]);
+    for (int i = k + 1; i < n; ++i) {
+      const double f = M[i][k] / M[k][k];
+      for (int j = k; j <= n; ++j) M[i][j] -= f * M[k][j];
+    }
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    double s = M[i][n];
+    for (int j = i + 1; j < n; ++j) s -= M[i][j] * static_cast<double>(x[j]);
+    x[i] = static_cast<float>(s / M[i][i]);
+  }
+}
+
+// ---- counter-based PRNG for the synthetic generator -------------------------------------------
+inline uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+struct Rng {
+  uint64_t seed;
+  uint64_t bits(uint64_t stream, uint64_t idx, uint64_t k) const {
+    return splitmix64(splitmix64(seed ^ (stream * 0xD1B54A32D192ED03ull)) ^ splitmix64(idx * 0x2545F4914F6CDD1Dull + k));
+  }
+  double uni(uint64_t stream, uint64_t idx, uint64_t k) const {  // (0,1)
+    return (static_cast<double>(bits(stream, idx, k) >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+  }
+  double normal(uint64_t stream, uint64_t idx, uint64_t k) const {  // Box-Muller on draws 2k, 2k+1
+    const double u1 = uni(stream, idx, 2 * k), u2 = uni(stream, idx, 2 * k + 1);
+    return std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586476925 * u2);
+  }
+};
+
+void rodrigues_f64(const double* w, double* R) {
+  const double th = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+  const double W[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+  const double a = th > 1e-12 ? std::sin(th) / th : 1.0, b = th > 1e-12 ? (1 - std::cos(th)) / (th * th) : 0.5;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) {
+      double ww = 0;
+      for (int k = 0; k < 3; ++k) ww += W[r * 3 + k] * W[k * 3 + c];
+      R[r * 3 + c] = (r == c ? 1.0 : 0.0) + a * W[r * 3 + c] + b * ww;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int gbp_bal_read_header(const char* path, gbp_bal* h) {
+  if (!path || !h) return GBP_ERR_INVALID;
+  FILE* f = std::fopen(path, "r");
+  if (!f) return GBP_ERR_IO;
+  int c = 0, l = 0, e = 0;
+  bool ok = std::fscanf(f, "%d %d %d", &c, &l, &e) == 3 &&
+            std::fscanf(f, "%lf %lf %lf %lf", &h->fx, &h->fy, &h->cx, &h->cy) == 4 && c > 0 && l > 0 && e > 0;
+  std::fclose(f);
+  if (!ok) return GBP_ERR_IO;
+  h->n_cams = static_cast<uint32_t>(c);
+  h->n_lmks = static_cast<uint32_t>(l);
+  h->n_edges = static_cast<uint32_t>(e);
+  return GBP_OK;
+}
+
+// Unlike the reference (FscanfOrDie only prints, dataio.cpp:59-65) a malformed file is an error.
+int gbp_bal_read(const char* path, gbp_bal* b) {
+  if (!path || !b || !b->cam_id || !b->lmk_id || !b->observations || !b->cameras || !b->points) return GBP_ERR_INVALID;
+  FILE* f = std::fopen(path, "r");
+  if (!f) return GBP_ERR_IO;
+  int c = 0, l = 0, e = 0;
+  bool ok = std::fscanf(f, "%d %d %d", &c, &l, &e) == 3 &&
+            std::fscanf(f, "%lf %lf %lf %lf", &b->fx, &b->fy, &b->cx, &b->cy) == 4;
+  ok = ok && static_cast<uint32_t>(c) == b->n_cams && static_cast<uint32_t>(l) == b->n_lmks &&
+       static_cast<uint32_t>(e) == b->n_edges;
+  for (int i = 0; ok && i < e; ++i) {
+    int ci, li;
+    ok = std::fscanf(f, "%d %d %lf %lf", &ci, &li, &b->observations[2 * i], &b->observations[2 * i + 1]) == 4 &&
+         ci >= 0 && ci < c && li >= 0 && li < l;
+    if (ok) { b->cam_id[i] = static_cast<uint32_t>(ci); b->lmk_id[i] = static_cast<uint32_t>(li); }
+  }
+  for (int i = 0; ok && i < 6 * c; ++i) ok = std::fscanf(f, "%lf", &b->cameras[i]) == 1;
+  for (int i = 0; ok && i < 3 * l; ++i) ok = std::fscanf(f, "%lf", &b->points[i]) == 1;
+  std::fclose(f);
+  return ok ? GBP_OK : GBP_ERR_IO;
+}
+
+int gbp_bal_write(const char* path, const gbp_bal* b) {
+  if (!path || !b) return GBP_ERR_INVALID;
+  FILE* f = std::fopen(path, "w");
+  if (!f) return GBP_ERR_IO;
+  std::fprintf(f, "%u %u %u\n%.16e %.16e %.16e %.16e\n", b->n_cams, b->n_lmks, b->n_edges, b->fx, b->fy, b->cx, b->cy);
+  for (uint32_t i = 0; i < b->n_edges; ++i)
+    std::fprintf(f, "%u %u %.16e %.16e\n", b->cam_id[i], b->lmk_id[i], b->observations[2 * i], b->observations[2 * i + 1]);
+  for (uint32_t i = 0; i < 6 * b->n_cams; ++i) std::fprintf(f, "%.16e\n", b->cameras[i]);
+  for (uint32_t i = 0; i < 3 * b->n_lmks; ++i) std::fprintf(f, "%.16e\n", b->points[i]);
+  return std::fclose(f) == 0 ? GBP_OK : GBP_ERR_IO;
+}
+
+int gbp_set_prior_lambda(const gbp_problem* p, float var, const float* cam_file, const float* lmk_file,
+                         const float* cam_mean, const float* lmk_mean, float* ce, float* cl, float* le, float* ll) {
+  if (!p || !cam_file || !lmk_file || !cam_mean || !lmk_mean || !ce || !cl || !le || !ll) return GBP_ERR_INVALID;
+  const uint32_t C = p->n_cams, L = p->n_lmks, E = p->n_edges;
+  std::vector<float> peak_c(C, 0.f), peak_l(L, 0.f);
+  for (uint32_t e = 0; e < E; ++e) {  // one pass: max over incident observations (dataio.cpp:78-87, 99-108)
+    const uint32_t c = p->cam_id[e], l = p->lmk_id[e];
+    if (c >= C || l >= L) return GBP_ERR_INVALID;
+    const float m = jacobian_peak(cam_file + 6ull * c, lmk_file + 3ull * l, p->K);
+    peak_c[c] = std::max(peak_c[c], m);
+    peak_l[l] = std::max(peak_l[l], m);
+  }
+  std::fill(cl, cl + 36ull * C, 0.f);
+  std::fill(ll, ll + 9ull * L, 0.f);
+  for (uint32_t c = 0; c < C; ++c) {  // lam = pow(max_jac,2)/var in double (dataio.cpp:88), eta = mean*lam
+    const float lam = static_cast<float>((static_cast<double>(peak_c[c]) * static_cast<double>(peak_c[c])) / static_cast<double>(var));
+    for (int i = 0; i < 6; ++i) { ce[6ull * c + i] = cam_mean[6ull * c + i] * lam; cl[36ull * c + 7 * i] = lam; }
+  }
+  for (uint32_t l = 0; l < L; ++l) {
+    const float lam = static_cast<float>((static_cast<double>(peak_l[l]) * static_cast<double>(peak_l[l])) / static_cast<double>(var));
+    for (int i = 0; i < 3; ++i) { le[3ull * l + i] = lmk_mean[3ull * l + i] * lam; ll[9ull * l + 4 * i] = lam; }
+  }
+  return GBP_OK;
+}
+
+int gbp_prior_scalings(uint32_t C, uint32_t L, const float* cpl, float steps, float weaker, float first_std,
+                       float* cs, float* ls) {
+  if (!cpl || !cs || !ls) return GBP_ERR_INVALID;
+  // ba.cpp:564: exp(-1/steps * log(lambda00 * pow(std,2))) — pow(float,int) promotes to double;
+  // ba.cpp:566,571: exp(-2/steps * log(weaker)) stays in fp32.
+  const float weak = std::exp(-2 / steps * std::log(weaker));
+  for (uint32_t c = 0; c < C; ++c)
+    cs[c] = (c < 2) ? static_cast<float>(std::exp(-1 / steps * std::log(cpl[36ull * c] * std::pow(static_cast<double>(first_std), 2))))
+                    : weak;
+  for (uint32_t l = 0; l < L; ++l) ls[l] = weak;
+  return GBP_OK;
+}
+
+int gbp_slam_create_flags(const gbp_problem* p, uint32_t steps, uint32_t* active, uint32_t* cwf, uint32_t* lwf,
+                          uint32_t* laf) {
+  if (!p || !active || !cwf || !lwf || !laf || p->n_cams < 2) return GBP_ERR_INVALID;
+  cwf[0] = cwf[1] = steps;
+  for (uint32_t e = 0; e < p->n_edges; ++e)
+    if (p->cam_id[e] <= 1) { active[e] = 1; lwf[p->lmk_id[e]] = steps; }
+  std::copy(lwf, lwf + p->n_lmks, laf);
+  return GBP_OK;
+}
+
+int gbp_slam_update_flags(const gbp_problem* p, uint32_t steps, uint32_t dc, uint32_t* active, uint32_t* lwf,
+                          uint32_t* cwf, uint32_t* laf, int32_t* n_new) {
+  if (!p || !active || !cwf || !lwf || !laf || dc + 1 >= p->n_cams || steps == 0) return GBP_ERR_INVALID;
+  for (uint32_t e = 0; e < p->n_edges; ++e) {
+    if (p->cam_id[e] == dc + 1) active[e] = 1;
+    if (p->cam_id[e] <= dc + 1) lwf[p->lmk_id[e]] = steps;
+  }
+  std::fill(cwf, cwf + p->n_cams, 0u);
+  cwf[dc + 1] = steps;
+  int total = 0;
+  for (uint32_t l = 0; l < p->n_lmks; ++l) {
+    lwf[l] -= laf[l];
+    laf[l] += lwf[l];
+    total += static_cast<int>(lwf[l]);
+  }
+  if (n_new) *n_new = total / static_cast<int>(steps);
+  return GBP_OK;
+}
+
+int gbp_slam_initialise_new_kf(uint32_t dc, const float* cbe, const float* cbl, const float* cpl, float* cpe) {
+  if (!cbe || !cbl || !cpl || !cpe) return GBP_ERR_INVALID;
+  float mu[6];
+  solve_pivot(cbl + 36ull * dc, cbe + 6ull * dc, 6, mu);
+  for (int i = 0; i < 6; ++i) {
+    float s = 0.f;
+    for (int k = 0; k < 6; ++k) s += cpl[36ull * (dc + 1) + 6 * i + k] * mu[k];
+    cpe[6ull * (dc + 1) + i] = s;
+  }
+  return GBP_OK;
+}
+
+int gbp_eval_host(const gbp_problem* p, const uint32_t* active, const float* meas, const float* cbe, const float* cbl,
+                  const float* lbe, const float* lbl, double* sum_norm, double* sum_half_sq, uint64_t* n_active) {
+  if (!p || !active || !meas || !cbe || !cbl || !lbe || !lbl || !sum_norm || !sum_half_sq || !n_active) return GBP_ERR_INVALID;
+  std::vector<float> cmu(6ull * p->n_cams), lmu(3ull * p->n_lmks);
+  for (uint32_t c = 0; c < p->n_cams; ++c) solve_pivot(cbl + 36ull * c, cbe + 6ull * c, 6, &cmu[6ull * c]);
+  for (uint32_t l = 0; l < p->n_lmks; ++l) solve_pivot(lbl + 9ull * l, lbe + 3ull * l, 3, &lmu[3ull * l]);
+  double a = 0, b = 0;
+  uint64_t n = 0;
+  for (uint32_t e = 0; e < p->n_edges; ++e) {
+    if (active[e] != 1) continue;
+    const float* cm = &cmu[6ull * p->cam_id[e]];
+    const float* lm = &lmu[3ull * p->lmk_id[e]];
+    const Rot3 R = rodrigues_host(cm + 3);
+    float pcf[3], pr[2];
+    for (int i = 0; i < 3; ++i) pcf[i] = row_dot3(R.m + 3 * i, lm);
+    for (int i = 0; i < 3; ++i) pcf[i] += cm[i];
+    for (int i = 0; i < 2; ++i) pr[i] = row_dot3(p->K + 3 * i, pcf) / pcf[2];
+    const float r0 = meas[2ull * e] - pr[0], r1 = meas[2ull * e + 1] - pr[1];
+    a += std::sqrt(r0 * r0 + r1 * r1);
+    b += static_cast<float>(0.5 * (r0 * r0 + r1 * r1));
+    ++n;
+  }
+  *sum_norm = a; *sum_half_sq = b; *n_active = n;
+  return GBP_OK;
+}
+
+int gbp_synth_generate(uint32_t C, uint32_t L, uint32_t obs_per_lmk, uint64_t seed, gbp_bal* out, double* gt_cams,
+                       double* gt_pts) {
+  if (!out || !out->cam_id || !out->lmk_id || !out->observations || !out->cameras || !out->points || C < 2 || L < 1)
+    return GBP_ERR_INVALID;
+  const uint32_t per = std::min(obs_per_lmk, C);
+  if (per == 0 || static_cast<uint64_t>(L) * per > 0xFFFFFFF0ull) return GBP_ERR_INVALID;
+  const Rng rng{seed};
+  enum { S_LMK = 1, S_CAMC = 2, S_CAMJ = 3, S_PICK = 4, S_PIX = 5, S_INITC = 6, S_INITL = 7 };
+  const double fx = 500, fy = 500, cx = 320, cy = 240;
+  out->n_cams = C; out->n_lmks = L; out->n_edges = L * per;
+  out->fx = fx; out->fy = fy; out->cx = cx; out->cy = cy;
+  std::vector<double> cam(6ull * C), pts(3ull * L);
+  for (uint32_t l = 0; l < L; ++l)
+    for (int k = 0; k < 3; ++k) pts[3ull * l + k] = -2.0 + 4.0 * rng.uni(S_LMK, l, k);
+  for (uint32_t c = 0; c < C; ++c) {
+    for (uint64_t attempt = 0;; ++attempt) {  // redraw until the axis-angle is well away from 0 and pi
+      const uint64_t id = c + attempt * 0x100000000ull;
+      double d[3];  // direction: normalised gaussian triple
+      for (int k = 0; k < 3; ++k) d[k] = rng.normal(S_CAMC, id, k);
+      const double n2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+      if (n2 < 1e-12) continue;
+      const double r = 8.0 + 4.0 * rng.uni(S_CAMC, id, 16), inv = 1.0 / std::sqrt(n2);
+      const double ctr[3] = {d[0] * inv * r, d[1] * inv * r, d[2] * inv * r};
+      double z[3] = {-ctr[0] / r, -ctr[1] / r, -ctr[2] / r};          // optical axis looks at the origin
+      double up[3] = {0, 0, 1};
+      if (std::fabs(z[2]) > 0.9) { up[0] = 1; up[2] = 0; }
+      double x[3] = {up[1] * z[2] - up[2] * z[1], up[2] * z[0] - up[0] * z[2], up[0] * z[1] - up[1] * z[0]};
+      const double xn = std::sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+      for (double& v : x) v /= xn;
+      const double y[3] = {z[1] * x[2] - z[2] * x[1], z[2] * x[0] - z[0] * x[2], z[0] * x[1] - z[1] * x[0]};
+      const double R0[9] = {x[0], x[1], x[2], y[0], y[1], y[2], z[0], z[1], z[2]};  // rows = camera axes in world
+      const double tr = R0[0] + R0[4] + R0[8];
+      const double th = std::acos(std::max(-1.0, std::min(1.0, 0.5 * (tr - 1.0))));
+      if (th < 0.05 || th > 3.0) continue;
+      const double s = th / (2.0 * std::sin(th));
+      double w[3] = {s * (R0[7] - R0[5]), s * (R0[2] - R0[6]), s * (R0[3] - R0[1])};
+      for (int k = 0; k < 3; ++k) w[k] += 0.05 * rng.normal(S_CAMJ, id, k);
+      if (w[0] * w[0] + w[1] * w[1] + w[2] * w[2] < 1e-3) continue;
+      double R[9];
+      rodrigues_f64(w, R);
+      for (int k = 0; k < 3; ++k) {
+        cam[6ull * c + k] = -(R[3 * k] * ctr[0] + R[3 * k + 1] * ctr[1] + R[3 * k + 2] * ctr[2]);
+        cam[6ull * c + 3 + k] = w[k];
+      }
+      break;
+    }
+  }
+  if (gt_cams) std::copy(cam.begin(), cam.end(), gt_cams);
+  if (gt_pts) std::copy(pts.begin(), pts.end(), gt_pts);
+
+  // choose `per` distinct cameras per landmark, bucket the edges by camera (landmarks ascend inside a bucket)
+  std::vector<uint32_t> pick(static_cast<size_t>(L) * per), deg(C + 1, 0);
+  for (uint32_t l = 0; l < L; ++l) {
+    uint32_t* mine = &pick[static_cast<size_t>(l) * per];
+    uint32_t got = 0;
+    for (uint64_t k = 0; got < per; ++k) {
+      const uint32_t c = static_cast<uint32_t>(rng.bits(S_PICK, l, k) % C);
+      if (std::find(mine, mine + got, c) == mine + got) mine[got++] = c;
+    }
+    for (uint32_t j = 0; j < per; ++j) deg[mine[j] + 1]++;
+  }
+  for (uint32_t c = 0; c < C; ++c) deg[c + 1] += deg[c];
+  std::vector<uint32_t> fill(deg.begin(), deg.end() - 1);
+  std::vector<double> Rc(9ull * C);
+  for (uint32_t c = 0; c < C; ++c) rodrigues_f64(&cam[6ull * c + 3], &Rc[9ull * c]);
+  for (uint32_t l = 0; l < L; ++l)
+    for (uint32_t j = 0; j < per; ++j) {
+      const uint32_t c = pick[static_cast<size_t>(l) * per + j];
+      const uint32_t e = fill[c]++;
+      const double* R = &Rc[9ull * c];
+      const double* t = &cam[6ull * c];
+      const double* y = &pts[3ull * l];
+      const double X = R[0] * y[0] + R[1] * y[1] + R[2] * y[2] + t[0];
+      const double Y = R[3] * y[0] + R[4] * y[1] + R[5] * y[2] + t[1];
+      const double Z = R[6] * y[0] + R[7] * y[1] + R[8] * y[2] + t[2];
+      out->cam_id[e] = c;
+      out->lmk_id[e] = l;
+      const uint64_t key = static_cast<uint64_t>(l) * per + j;
+      out->observations[2ull * e] = fx * X / Z + cx + rng.normal(S_PIX, key, 0);
+      out->observations[2ull * e + 1] = fy * Y / Z + cy + rng.normal(S_PIX, key, 1);
+    }
+  // initial values = ground truth + noise; cameras 0 and 1 are the gauge anchors and stay exact (ba.cpp:563-564)
+  for (uint32_t c = 0; c < C; ++c)
+    for (int k = 0; k < 6; ++k) {
+      const double sd = (c < 2) ? 0.0 : (k < 3 ? 0.05 : 0.01);
+      out->cameras[6ull * c + k] = cam[6ull * c + k] + sd * rng.normal(S_INITC, c, k);
+    }
+  for (uint32_t l = 0; l < L; ++l)
+    for (int k = 0; k < 3; ++k) out->points[3ull * l + k] = pts[3ull * l + k] + 0.1 * rng.normal(S_INITL, l, k);
+  return GBP_OK;
+}
+
+}  // extern "C"

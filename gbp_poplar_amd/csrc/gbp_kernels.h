@@ -1,0 +1,88 @@
+// gbp_kernels.h — device data layout + kernel launchers shared by gbp_kernels.hip and gbp_capi.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gbp {
+
+// ---- HBM layout ---------------------------------------------------------------------------------
+// Factors live in DEVICE ORDER: camera-major (a camera's local factors in file order), each camera
+// padded to whole ROWS of 16 lanes, the total padded to whole TILES of 64 lanes (= one wavefront).
+// Per-factor arrays are tile-coalesced AoSoA: float4 element (tile, group g, lane) sits at
+//   base4[(tile * G + g) * 64 + lane]
+// so that a wave's g-th access is one contiguous, 16-byte-per-lane, 1 KiB transaction.
+constexpr int kTile = 64;
+constexpr int kRow = 16;
+
+// FAC: factor potential, 56 floats / 14 groups (symmetric blocks packed; lossless because the
+// reference's Lambda_cc / Lambda_ll are bit-symmetric and Lambda_lc is a copy of Lambda_cl^T,
+// gbp_codelets.cpp:158-162,363-367):
+//   [0..8] eta (c0..5,l0..2)  [9..29] Lambda_cc lower  [30..47] Lambda_cl 6x3  [48..53] Lambda_ll lower
+//   [54,55] measurement z
+constexpr int kFacG = 14;
+// CMSG: factor->camera message as the sweep re-reads it, 28 floats / 7 groups:
+//   [0..5] eta  [6..26] Lambda lower triangle (only the lower triangle is ever read back:
+//   inv6x6 reads A(i,j), i>=j, matlib.cpp:195-201; the full 6x6 goes into the row partial sums)
+constexpr int kCmsgG = 7;
+// MU: [0..8] mu (== oldmu between sweeps, ba.cpp:898)  [9] dmu
+constexpr int kMuG = 3;
+// STATE (1 group): x = damping, y = damping_count (int bits), z = flags (uint bits), w = meas_variance
+constexpr uint32_t kFlagActive = 1u, kFlagRobust = 2u, kFlagPad = 4u;
+// IDX (1 int4): x = camera, y = landmark (local index), z = lpos (record in LMSG), w = file edge index
+//
+// Landmark-side records are landmark-major AoS of 16 floats (one 64-byte sector per factor):
+//   LMSG[lpos] / LMKB[l] / LMKP[l]:  [0..2] eta  [3] pad  [4..12] Lambda 3x3  [13..15] pad
+constexpr int kLmkRec4 = 4;
+// Camera-side records are 44 floats (11 float4):  [0..5] eta  [6,7] pad  [8..43] Lambda 6x6
+//   CAMB[c] beliefs, CAMP[c] priors, ROWP[row] row partial sums, exchange buffers [rank][c]
+constexpr int kCamRec4 = 11;
+constexpr int kCamRec = 44;
+
+struct Hyper {  // gbp_codelets.cpp:11-16
+  float maxeta_damping;
+  int num_undamped_iters;
+  float dmu_threshold;
+  int min_linear_iters;
+  float nstds;
+  int relin_mode;
+};
+
+struct SweepArgs {
+  const int4* idx;
+  float4* state;
+  float4* fac;
+  float4* cmsg;
+  float4* mu;
+  float4* lmsg;
+  const float4* camb;
+  const float4* lmkb;
+  float4* rowp;
+  float K[9];
+  Hyper hp;
+};
+
+struct DeviceEval {  // per-block partials, summed on the host in block order
+  double sum_norm, sum_half_sq;
+  unsigned long long n_active, n_relin, n_robust, pad;
+};
+
+void launch_sweep(const SweepArgs& a, uint32_t n_tiles, hipStream_t s);
+void launch_linearise(const SweepArgs& a, uint32_t n_tiles, hipStream_t s);
+// local[c] = sum of camera c's row partials (rows left to right); belief[c] = prior[c] + local[c]
+// when `belief` != nullptr (single GPU), else only `local` is written (multi-GPU send buffer).
+void launch_cam_reduce(const float4* rowp, const uint32_t* cam_row_ptr, const float4* prior, float4* local,
+                       float4* belief, uint32_t n_cams, hipStream_t s);
+// belief[c] = prior[c] + gathered[0][c] + ... + gathered[world-1][c]
+void launch_cam_combine(const float4* prior, const float4* gathered, int world, float4* belief, uint32_t n_cams,
+                        hipStream_t s);
+// belief[l] = prior[l] + msg[ptr[l]] + ... (slot order)
+void launch_lmk_belief(const float4* prior, const float4* lmsg, const uint32_t* lmk_ptr, float4* belief,
+                       uint32_t n_lmks, hipStream_t s);
+void launch_weaken(float4* prior, const float* scaling, uint32_t* flag, uint32_t n, int rec4, hipStream_t s);
+void launch_means(const float4* camb, const float4* lmkb, float* cam_mu, float* lmk_mu, uint32_t n_cams,
+                  uint32_t n_lmks, hipStream_t s);
+void launch_eval(const int4* idx, const float4* state, const float4* fac, const float* cam_mu, const float* lmk_mu,
+                 const float* K9_dev, int num_undamped_iters, DeviceEval* partials, uint32_t n_tiles, hipStream_t s);
+uint32_t eval_blocks(uint32_t n_tiles);
+
+}  // namespace gbp

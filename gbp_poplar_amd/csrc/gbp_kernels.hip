@@ -1,0 +1,621 @@
+// gbp_kernels.hip — CDNA4 (gfx950) kernels of one synchronous GBP iteration.
+//
+// Replaces the reference's per-iteration Poplar program (ba/ba.cpp:895-905):
+//   k_sweep        PrepMessageVertex + Copy(mu,oldmu) + the four Compute*Message*Vertex classes
+//                  (gbp_codelets.cpp:215-710) + the camera half of popops::reduceWithOutput
+//                  (ba.cpp:129-132) as per-row partial sums + Copy(msg,pmsg) (in-place messages)
+//   k_cam_reduce / k_cam_combine / k_lmk_belief    the rest of buildUpdateBeliefsProg (ba.cpp:104-139)
+//   k_linearise    RelineariseFactorVertex (gbp_codelets.cpp:20-172)
+//   k_weaken       WeakenPriorVertex (gbp_codelets.cpp:176-197)
+//   k_means/k_eval eval_reprojection_error (util.cpp:74-144) + counters (ba.cpp:1011-1020)
+//
+// Mapping: one LANE per factor, 64 factors per wavefront, all blocks in VGPRs.
+// The sweep is HBM-bound: every per-factor stream is a tile-coalesced 16-B-per-lane access, the
+// 6x6/3x3 algebra (no MFMA: the blocks are tiny and chains are serial) hides under the loads.
+// fp32 throughout, compiled with -ffp-contract=off so results are bit-comparable with the oracle.
+#include "gbp_kernels.h"
+#include "gbp_device_math.hpp"
+
+namespace gbp {
+using namespace gbpdev;
+
+namespace {
+
+template <int G>
+GBP_DEV void load_tile(const float4* base, uint32_t tile, uint32_t lane, float (&out)[G * 4]) {
+  const float4* p = base + (size_t)tile * G * 64 + lane;
+  GBP_UNROLL
+  for (int g = 0; g < G; ++g) {
+    const float4 v = p[g * 64];
+    out[4 * g] = v.x; out[4 * g + 1] = v.y; out[4 * g + 2] = v.z; out[4 * g + 3] = v.w;
+  }
+}
+template <int G>
+GBP_DEV void store_tile(float4* base, uint32_t tile, uint32_t lane, const float (&in)[G * 4]) {
+  float4* p = base + (size_t)tile * G * 64 + lane;
+  GBP_UNROLL
+  for (int g = 0; g < G; ++g) p[g * 64] = make_float4(in[4 * g], in[4 * g + 1], in[4 * g + 2], in[4 * g + 3]);
+}
+template <int G>
+GBP_DEV void load_rec(const float4* rec, float (&out)[G * 4]) {
+  GBP_UNROLL
+  for (int g = 0; g < G; ++g) {
+    const float4 v = rec[g];
+    out[4 * g] = v.x; out[4 * g + 1] = v.y; out[4 * g + 2] = v.z; out[4 * g + 3] = v.w;
+  }
+}
+
+// sum over the 16 lanes of a DPP row as a balanced binary tree in lane order:
+// ((x0+x1)+(x2+x3)) + ... ; every lane ends with the same bits (fp32 add is commutative).
+GBP_DEV float row16_sum(float x) {
+  int t;
+  t = __builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+  x = x + __int_as_float(t);
+  t = __builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+  x = x + __int_as_float(t);
+  t = __builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xF, 0xF, true);  // row_half_mirror
+  x = x + __int_as_float(t);
+  t = __builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x140, 0xF, 0xF, true);  // row_mirror
+  x = x + __int_as_float(t);
+  return x;
+}
+
+// belief means: inf2mean6x6 / inf2mean3x3 (bafuncs.cpp:2-15) on CAMB / LMKB records
+GBP_DEV void belief_means(const float (&cb)[44], const float (&lb)[16], float (&x0c)[6], float (&x0l)[3]) {
+  float Al[21], S6[36], B[9], S3[9];
+  GBP_UNROLL
+  for (int i = 0; i < 6; ++i) {
+    GBP_UNROLL
+    for (int j = 0; j <= i; ++j) Al[tri(i, j)] = cb[8 + i * 6 + j];
+  }
+  inv6x6_lower(Al, S6);
+  GBP_UNROLL
+  for (int i = 0; i < 6; ++i) {
+    float acc = 0.f;
+    GBP_UNROLL
+    for (int k = 0; k < 6; ++k) acc += S6[i * 6 + k] * cb[k];
+    x0c[i] = acc;
+  }
+  GBP_UNROLL
+  for (int i = 0; i < 9; ++i) B[i] = lb[4 + i];
+  inv3x3(B, S3);
+  GBP_UNROLL
+  for (int i = 0; i < 3; ++i) {
+    float acc = 0.f;
+    GBP_UNROLL
+    for (int k = 0; k < 3; ++k) acc += S3[i * 3 + k] * lb[k];
+    x0l[i] = acc;
+  }
+}
+
+// Shared body of gbp_codelets.cpp:90-168 and :294-373 on the packed FAC record: accumulate
+// J^T J / J^T (J x0 + z - h(x0)) onto the potential, Huber-rescale.  Returns the robust flag.
+GBP_DEV bool relin_core(float (&fac)[56], const float (&x0c)[6], const float (&x0l)[3], const float (&K)[9],
+                        float var, float nstds) {
+  Lin L;
+  jac_hfunc(x0c, x0l, K, L);
+  GBP_UNROLL
+  for (int i = 0; i < 6; ++i) {
+    GBP_UNROLL
+    for (int j = 0; j <= i; ++j) {
+      float acc = fac[9 + tri(i, j)];
+      GBP_UNROLL
+      for (int k = 0; k < 2; ++k) acc += L.Jkf[k * 6 + i] * L.Jkf[k * 6 + j];
+      fac[9 + tri(i, j)] = acc;
+    }
+  }
+  GBP_UNROLL
+  for (int i = 0; i < 3; ++i) {
+    GBP_UNROLL
+    for (int j = 0; j <= i; ++j) {
+      float acc = fac[48 + tri(i, j)];
+      GBP_UNROLL
+      for (int k = 0; k < 2; ++k) acc += L.Jl[k * 3 + i] * L.Jl[k * 3 + j];
+      fac[48 + tri(i, j)] = acc;
+    }
+  }
+  GBP_UNROLL
+  for (int i = 0; i < 6; ++i) {
+    GBP_UNROLL
+    for (int j = 0; j < 3; ++j) {
+      float acc = fac[30 + i * 3 + j];
+      GBP_UNROLL
+      for (int k = 0; k < 2; ++k) acc += L.Jkf[k * 6 + i] * L.Jl[k * 3 + j];
+      fac[30 + i * 3 + j] = acc;
+    }
+  }
+  const float z0 = fac[54], z1 = fac[55];
+  float buf[2];
+  GBP_UNROLL
+  for (int r = 0; r < 2; ++r) {
+    float acc = 0.f;
+    GBP_UNROLL
+    for (int k = 0; k < 6; ++k) acc += L.Jkf[r * 6 + k] * x0c[k];
+    GBP_UNROLL
+    for (int k = 0; k < 3; ++k) acc += L.Jl[r * 3 + k] * x0l[k];
+    acc = acc + (r == 0 ? z0 : z1);
+    acc = acc - L.hx[r];
+    buf[r] = acc;
+  }
+  GBP_UNROLL
+  for (int i = 0; i < 9; ++i) {
+    float acc = fac[i];
+    GBP_UNROLL
+    for (int k = 0; k < 2; ++k) acc += (i < 6 ? L.Jkf[k * 6 + i] : L.Jl[k * 3 + (i - 6)]) * buf[k];
+    fac[i] = acc;
+  }
+  // Huber (gbp_codelets.cpp:135-141): the 0.5 literal makes the denominator a double expression
+  const float err = sqrtf((L.hx[0] - z0) * (L.hx[0] - z0) + (L.hx[1] - z1) * (L.hx[1] - z1));
+  float mvar = var;
+  const bool robust = err > nstds * sqrtf(var);
+  if (robust) {
+    const double den = 2 * ((double)(nstds * sqrtf(var) * err) - 0.5 * (double)nstds * (double)nstds * (double)var);
+    mvar = (float)((double)(var * err * err) / den);
+  }
+  GBP_UNROLL
+  for (int i = 0; i < 54; ++i) fac[i] /= mvar;
+  return robust;
+}
+
+}  // namespace
+
+// =================================================================================================
+// k_sweep: one lane = one factor.
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
+  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t tile = p >> 6, lane = p & 63;
+
+  const int4 ix = a.idx[p];
+  float4 st = a.state[p];
+  float damping = st.x;
+  int count = __float_as_int(st.y);
+  uint32_t flags = __float_as_uint(st.z);
+  const float var = st.w;
+  const bool active = (flags & kFlagActive) != 0;
+  const bool is_pad = (flags & kFlagPad) != 0;
+
+  float fac[56], cm[28], mu[12], lm[16], cb[44], lb[16];
+  load_tile<kFacG>(a.fac, tile, lane, fac);
+  load_tile<kCmsgG>(a.cmsg, tile, lane, cm);
+  load_tile<kMuG>(a.mu, tile, lane, mu);
+  load_rec<kLmkRec4>(a.lmsg + (size_t)(uint32_t)ix.z * kLmkRec4, lm);
+  load_rec<kCamRec4>(a.camb + (size_t)(uint32_t)ix.x * kCamRec4, cb);
+  load_rec<kLmkRec4>(a.lmkb + (size_t)(uint32_t)ix.y * kLmkRec4, lb);
+
+  float K[9];
+  GBP_UNROLL
+  for (int i = 0; i < 9; ++i) K[i] = a.K[i];
+
+  float oc_eta[6], oc_lam[36], ol[16];
+  GBP_UNROLL
+  for (int i = 0; i < 6; ++i) oc_eta[i] = 0.f;
+  GBP_UNROLL
+  for (int i = 0; i < 36; ++i) oc_lam[i] = 0.f;
+  GBP_UNROLL
+  for (int i = 0; i < 16; ++i) ol[i] = 0.f;
+  bool relin = false;
+
+  if (active) {
+    // ---- PrepMessageVertex, gbp_codelets.cpp:241-378 ----
+    if (0 == count) damping = a.hp.maxeta_damping;
+    count += 1;
+    float x0c[6], x0l[3];
+    belief_means(cb, lb, x0c, x0l);
+    float d2 = 0.f;
+    GBP_UNROLL
+    for (int i = 0; i < 6; ++i) {
+      d2 += (mu[i] - x0c[i]) * (mu[i] - x0c[i]);
+      mu[i] = x0c[i];
+    }
+    GBP_UNROLL
+    for (int i = 0; i < 3; ++i) {
+      d2 += (mu[6 + i] - x0l[i]) * (mu[6 + i] - x0l[i]);
+      mu[6 + i] = x0l[i];
+    }
+    const float dmu = sqrtf(d2);
+    mu[9] = dmu;
+    relin = (dmu < a.hp.dmu_threshold) && (count > a.hp.min_linear_iters - a.hp.num_undamped_iters);
+    if (relin) {
+      damping = 0.f;
+      count = -a.hp.num_undamped_iters;
+      if (a.hp.relin_mode == 1) {
+        GBP_UNROLL
+        for (int i = 0; i < 54; ++i) fac[i] = 0.f;
+      }
+      const bool robust = relin_core(fac, x0c, x0l, K, var, a.hp.nstds);
+      flags = robust ? (flags | kFlagRobust) : (flags & ~kFlagRobust);
+    }
+
+    const float omd = 1 - damping;
+
+    // ---- Compute{Lmk}Message{Eta,Lambda}Vertex, gbp_codelets.cpp:503-562, 664-709 ----
+    {
+      float Ap[21], Ainv[36], G[18], ed[6];
+      GBP_UNROLL
+      for (int i = 0; i < 6; ++i) {
+        GBP_UNROLL
+        for (int j = 0; j <= i; ++j) {
+          float t = fac[9 + tri(i, j)] + cb[8 + i * 6 + j];
+          t = t - cm[6 + tri(i, j)];
+          Ap[tri(i, j)] = t;
+        }
+      }
+      inv6x6_lower(Ap, Ainv);
+      GBP_UNROLL
+      for (int i = 0; i < 3; ++i) {
+        GBP_UNROLL
+        for (int j = 0; j < 6; ++j) {
+          float acc = 0.f;
+          GBP_UNROLL
+          for (int k = 0; k < 6; ++k) acc += fac[30 + k * 3 + i] * Ainv[k * 6 + j];  // Lambda_lc(i,k) = Lambda_cl(k,i)
+          G[i * 6 + j] = acc;
+        }
+      }
+      GBP_UNROLL
+      for (int k = 0; k < 6; ++k) {
+        float t = fac[k] + cb[k];
+        ed[k] = t - cm[k];
+      }
+      GBP_UNROLL
+      for (int i = 0; i < 3; ++i) {
+        float s = 0.f;
+        GBP_UNROLL
+        for (int k = 0; k < 6; ++k) s += G[i * 6 + k] * ed[k];
+        const float h = fac[6 + i] - s;
+        ol[i] = h * omd + lm[i] * damping;
+      }
+      GBP_UNROLL
+      for (int i = 0; i < 3; ++i) {
+        GBP_UNROLL
+        for (int j = 0; j < 3; ++j) {
+          float t = 0.f;
+          GBP_UNROLL
+          for (int k = 0; k < 6; ++k) t += G[i * 6 + k] * fac[30 + k * 3 + j];
+          ol[4 + i * 3 + j] = fac[48 + trisym(i, j)] - t;
+        }
+      }
+    }
+    // ---- Compute{Cam}Message{Eta,Lambda}Vertex, gbp_codelets.cpp:411-471, 592-637 ----
+    {
+      float Bp[9], Bi[9], G2[18], el[3];
+      GBP_UNROLL
+      for (int i = 0; i < 3; ++i) {
+        GBP_UNROLL
+        for (int j = 0; j < 3; ++j) {
+          float t = fac[48 + trisym(i, j)] + lb[4 + i * 3 + j];
+          Bp[i * 3 + j] = t - lm[4 + i * 3 + j];
+        }
+      }
+      inv3x3(Bp, Bi);
+      GBP_UNROLL
+      for (int i = 0; i < 6; ++i) {
+        GBP_UNROLL
+        for (int j = 0; j < 3; ++j) {
+          float acc = 0.f;
+          GBP_UNROLL
+          for (int k = 0; k < 3; ++k) acc += fac[30 + i * 3 + k] * Bi[k * 3 + j];
+          G2[i * 3 + j] = acc;
+        }
+      }
+      GBP_UNROLL
+      for (int k = 0; k < 3; ++k) {
+        float t = fac[6 + k] + lb[k];
+        el[k] = t - lm[k];
+      }
+      GBP_UNROLL
+      for (int i = 0; i < 6; ++i) {
+        float s = 0.f;
+        GBP_UNROLL
+        for (int k = 0; k < 3; ++k) s += G2[i * 3 + k] * el[k];
+        const float h = fac[i] - s;
+        oc_eta[i] = h * omd + cm[i] * damping;
+      }
+      GBP_UNROLL
+      for (int i = 0; i < 6; ++i) {
+        GBP_UNROLL
+        for (int j = 0; j < 6; ++j) {
+          float t = 0.f;
+          GBP_UNROLL
+          for (int k = 0; k < 3; ++k) t += G2[i * 3 + k] * fac[30 + j * 3 + k];  // Lambda_lc(k,j) = Lambda_cl(j,k)
+          oc_lam[i * 6 + j] = fac[9 + trisym(i, j)] - t;
+        }
+      }
+    }
+  }
+
+  // ---- outputs --------------------------------------------------------------------------------
+  if (!is_pad) {
+    float4* rec = a.lmsg + (size_t)(uint32_t)ix.z * kLmkRec4;
+    GBP_UNROLL
+    for (int g = 0; g < 4; ++g) rec[g] = make_float4(ol[4 * g], ol[4 * g + 1], ol[4 * g + 2], ol[4 * g + 3]);
+  }
+  {
+    float cmo[28];
+    GBP_UNROLL
+    for (int i = 0; i < 6; ++i) cmo[i] = oc_eta[i];
+    GBP_UNROLL
+    for (int i = 0; i < 6; ++i) {
+      GBP_UNROLL
+      for (int j = 0; j <= i; ++j) cmo[6 + tri(i, j)] = oc_lam[i * 6 + j];
+    }
+    cmo[27] = 0.f;
+    store_tile<kCmsgG>(a.cmsg, tile, lane, cmo);
+  }
+  // camera half of the belief reduction: per-row (16 factors of one camera) tree sums
+  {
+    float rs[44];
+    GBP_UNROLL
+    for (int i = 0; i < 6; ++i) rs[i] = row16_sum(oc_eta[i]);
+    rs[6] = 0.f; rs[7] = 0.f;
+    GBP_UNROLL
+    for (int i = 0; i < 36; ++i) rs[8 + i] = row16_sum(oc_lam[i]);
+    if ((lane & 15) == 0) {
+      float4* rp = a.rowp + (size_t)(p >> 4) * kCamRec4;
+      GBP_UNROLL
+      for (int g = 0; g < kCamRec4; ++g) rp[g] = make_float4(rs[4 * g], rs[4 * g + 1], rs[4 * g + 2], rs[4 * g + 3]);
+    }
+  }
+  if (active) {
+    store_tile<kMuG>(a.mu, tile, lane, mu);
+    a.state[p] = make_float4(damping, __int_as_float(count), __uint_as_float(flags), var);
+    if (relin) store_tile<kFacG>(a.fac, tile, lane, fac);
+  }
+}
+
+// =================================================================================================
+// k_linearise: RelineariseFactorVertex on every factor (no active_flag test in the reference).
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_linearise(const SweepArgs a) {
+  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t tile = p >> 6, lane = p & 63;
+  const int4 ix = a.idx[p];
+  float4 st = a.state[p];
+  uint32_t flags = __float_as_uint(st.z);
+  if (flags & kFlagPad) return;
+  float fac[56], cb[44], lb[16], K[9], x0c[6], x0l[3];
+  load_tile<kFacG>(a.fac, tile, lane, fac);
+  load_rec<kCamRec4>(a.camb + (size_t)(uint32_t)ix.x * kCamRec4, cb);
+  load_rec<kLmkRec4>(a.lmkb + (size_t)(uint32_t)ix.y * kLmkRec4, lb);
+  GBP_UNROLL
+  for (int i = 0; i < 9; ++i) K[i] = a.K[i];
+  GBP_UNROLL
+  for (int i = 0; i < 54; ++i) fac[i] = 0.f;
+  belief_means(cb, lb, x0c, x0l);
+  const bool robust = relin_core(fac, x0c, x0l, K, st.w, a.hp.nstds);
+  flags = robust ? (flags | kFlagRobust) : (flags & ~kFlagRobust);
+  st.z = __uint_as_float(flags);
+  a.state[p] = st;
+  store_tile<kFacG>(a.fac, tile, lane, fac);
+}
+
+// =================================================================================================
+// Belief kernels
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_cam_reduce(const float* __restrict__ rowp, const uint32_t* __restrict__ cam_row_ptr,
+                                                    const float* __restrict__ prior, float* __restrict__ local,
+                                                    float* __restrict__ belief, uint32_t n_cams) {
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t c = t / kCamRec, j = t - c * kCamRec;
+  if (c >= n_cams) return;
+  const uint32_t r0 = cam_row_ptr[c], r1 = cam_row_ptr[c + 1];
+  float acc = 0.f;
+  if (r1 > r0) {
+    acc = rowp[(size_t)r0 * kCamRec + j];
+    for (uint32_t r = r0 + 1; r < r1; ++r) acc = acc + rowp[(size_t)r * kCamRec + j];
+  }
+  local[(size_t)c * kCamRec + j] = acc;
+  if (belief) belief[(size_t)c * kCamRec + j] = prior[(size_t)c * kCamRec + j] + acc;
+}
+
+__global__ __launch_bounds__(256) void k_cam_combine(const float* __restrict__ prior, const float* __restrict__ gathered,
+                                                     int world, float* __restrict__ belief, uint32_t n) {
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  float acc = prior[t];
+  for (int r = 0; r < world; ++r) acc = acc + gathered[(size_t)r * n + t];
+  belief[t] = acc;
+}
+
+// four lanes per landmark, lane q owns float4 #q of the 16-float record
+__global__ __launch_bounds__(256) void k_lmk_belief(const float4* __restrict__ prior, const float4* __restrict__ lmsg,
+                                                    const uint32_t* __restrict__ lmk_ptr, float4* __restrict__ belief,
+                                                    uint32_t n_lmks) {
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t l = t >> 2, q = t & 3;
+  if (l >= n_lmks) return;
+  float4 acc = prior[(size_t)l * 4 + q];
+  const uint32_t s0 = lmk_ptr[l], s1 = lmk_ptr[l + 1];
+  for (uint32_t s = s0; s < s1; ++s) {
+    const float4 m = lmsg[(size_t)s * 4 + q];
+    acc.x = acc.x + m.x; acc.y = acc.y + m.y; acc.z = acc.z + m.z; acc.w = acc.w + m.w;
+  }
+  belief[(size_t)l * 4 + q] = acc;
+}
+
+// WeakenPriorVertex: one lane per float4 of a prior record; lane q == 0 updates the flag
+__global__ __launch_bounds__(256) void k_weaken(float4* prior, const float* __restrict__ scaling, uint32_t* flag, uint32_t n,
+                                                int rec4) {
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t v = t / (uint32_t)rec4, q = t - v * (uint32_t)rec4;
+  if (v >= n) return;
+  const uint32_t f = flag[v];
+  if (f >= 1 && f <= 5) {
+    const float s = scaling[v];
+    float4 x = prior[(size_t)v * rec4 + q];
+    x.x *= s; x.y *= s; x.z *= s; x.w *= s;
+    prior[(size_t)v * rec4 + q] = x;
+  }
+}
+__global__ __launch_bounds__(256) void k_weaken_flags(uint32_t* flag, uint32_t n) {
+  const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= n) return;
+  const uint32_t f = flag[v];
+  if (f >= 1 && f <= 5) flag[v] = f - 1;
+}
+
+// =================================================================================================
+// Metric: util.cpp:74-144.  Variable means by an fp64 partial-pivot solve of the fp32 belief
+// (stands in for Eigen's general inverse), residuals in fp32, sums in fp64.
+// =================================================================================================
+template <int N>
+GBP_DEV void solve_pivot(const float* A, int lda, const float* b, float* x) {
+  double M[N][N + 1];
+  for (int i = 0; i < N; ++i) {
+    for (int j = 0; j < N; ++j) M[i][j] = A[i * lda + j];
+    M[i][N] = b[i];
+  }
+  for (int k = 0; k < N; ++k) {
+    int piv = k;
+    double best = fabs(M[k][k]);
+    for (int i = k + 1; i < N; ++i)
+      if (fabs(M[i][k]) > best) { best = fabs(M[i][k]); piv = i; }
+    if (piv != k)
+      for (int j = 0; j <= N; ++j) { const double t = M[k][j]; M[k][j] = M[piv][j]; M[piv][j] = t; }
+    for (int i = k + 1; i < N; ++i) {
+      const double f = M[i][k] / M[k][k];
+      for (int j = k; j <= N; ++j) M[i][j] -= f * M[k][j];
+    }
+  }
+  for (int i = N - 1; i >= 0; --i) {
+    double s = M[i][N];
+    for (int j = i + 1; j < N; ++j) s -= M[i][j] * (double)x[j];
+    x[i] = (float)(s / M[i][i]);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_means(const float* __restrict__ camb, const float* __restrict__ lmkb,
+                                               float* __restrict__ cam_mu, float* __restrict__ lmk_mu, uint32_t n_cams,
+                                               uint32_t n_lmks) {
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t < n_cams) {
+    float x[6];
+    solve_pivot<6>(camb + (size_t)t * kCamRec + 8, 6, camb + (size_t)t * kCamRec, x);
+    for (int i = 0; i < 6; ++i) cam_mu[(size_t)t * 6 + i] = x[i];
+  } else if (t - n_cams < n_lmks) {
+    const uint32_t l = t - n_cams;
+    float x[3];
+    solve_pivot<3>(lmkb + (size_t)l * 16 + 4, 3, lmkb + (size_t)l * 16, x);
+    for (int i = 0; i < 3; ++i) lmk_mu[(size_t)l * 3 + i] = x[i];
+  }
+}
+
+constexpr uint32_t kEvalBlocks = 1024;
+uint32_t eval_blocks(uint32_t n_tiles) {
+  const uint32_t want = (n_tiles + 3) / 4;
+  return want < kEvalBlocks ? (want ? want : 1) : kEvalBlocks;
+}
+
+__global__ __launch_bounds__(256) void k_eval(const int4* __restrict__ idx, const float4* __restrict__ state,
+                                              const float4* __restrict__ fac, const float* __restrict__ cam_mu,
+                                              const float* __restrict__ lmk_mu, const float* __restrict__ Kd,
+                                              int num_undamped, DeviceEval* partials, uint32_t n_tiles) {
+  double s_norm = 0, s_half = 0;
+  unsigned long long n_act = 0, n_rel = 0, n_rob = 0;
+  const uint32_t total = n_tiles * 64;
+  for (uint32_t p = blockIdx.x * 256 + threadIdx.x; p < total; p += gridDim.x * 256) {
+    const float4 st = state[p];
+    const uint32_t flags = __float_as_uint(st.z);
+    if (flags & kFlagPad) continue;
+    if (flags & kFlagRobust) ++n_rob;
+    if (__float_as_int(st.y) == -num_undamped) ++n_rel;
+    if (!(flags & kFlagActive)) continue;
+    const int4 ix = idx[p];
+    const uint32_t tile = p >> 6, lane = p & 63;
+    const float4 zg = fac[((size_t)tile * kFacG + 13) * 64 + lane];  // floats 52..55: z = .z, .w
+    float cm[6], lmu[3];
+    for (int i = 0; i < 6; ++i) cm[i] = cam_mu[(size_t)(uint32_t)ix.x * 6 + i];
+    for (int i = 0; i < 3; ++i) lmu[i] = lmk_mu[(size_t)(uint32_t)ix.y * 3 + i];
+    // eigenso3exp, util.cpp:20-32 (single expression)
+    const float th = sqrtf(cm[3] * cm[3] + cm[4] * cm[4] + cm[5] * cm[5]);
+    float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (!(th < 1e-6)) {
+      const float W[9] = {0.f, -cm[5], cm[4], cm[5], 0.f, -cm[3], -cm[4], cm[3], 0.f};
+      const float sa = sinf(th) / th, sb = (1 - cosf(th)) / (th * th);
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+          float ww = 0.f;
+          for (int k = 0; k < 3; ++k) ww += W[r * 3 + k] * W[k * 3 + c];
+          R[r * 3 + c] = R[r * 3 + c] + (sa * W[r * 3 + c] + sb * ww);
+        }
+    }
+    float pcf[3], pr[2];
+    for (int i = 0; i < 3; ++i) pcf[i] = (R[i * 3] * lmu[0] + R[i * 3 + 1] * lmu[1]) + R[i * 3 + 2] * lmu[2];
+    for (int i = 0; i < 3; ++i) pcf[i] += cm[i];
+    for (int i = 0; i < 2; ++i) pr[i] = ((Kd[i * 3] * pcf[0] + Kd[i * 3 + 1] * pcf[1]) + Kd[i * 3 + 2] * pcf[2]) / pcf[2];
+    const float r0 = zg.z - pr[0], r1 = zg.w - pr[1];
+    s_norm += (double)sqrtf(r0 * r0 + r1 * r1);
+    s_half += (double)(float)(0.5 * (double)(r0 * r0 + r1 * r1));
+    ++n_act;
+  }
+  // block reduction in a fixed order (deterministic): lane tree via shuffles, then wave 0 adds 4 wave sums
+  __shared__ double sh_d[2][4];
+  __shared__ unsigned long long sh_u[3][4];
+  for (int off = 32; off > 0; off >>= 1) {
+    s_norm += __shfl_down(s_norm, off);
+    s_half += __shfl_down(s_half, off);
+    n_act += __shfl_down(n_act, off);
+    n_rel += __shfl_down(n_rel, off);
+    n_rob += __shfl_down(n_rob, off);
+  }
+  const uint32_t w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    sh_d[0][w] = s_norm; sh_d[1][w] = s_half;
+    sh_u[0][w] = n_act; sh_u[1][w] = n_rel; sh_u[2][w] = n_rob;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    DeviceEval o;
+    o.sum_norm = ((sh_d[0][0] + sh_d[0][1]) + sh_d[0][2]) + sh_d[0][3];
+    o.sum_half_sq = ((sh_d[1][0] + sh_d[1][1]) + sh_d[1][2]) + sh_d[1][3];
+    o.n_active = sh_u[0][0] + sh_u[0][1] + sh_u[0][2] + sh_u[0][3];
+    o.n_relin = sh_u[1][0] + sh_u[1][1] + sh_u[1][2] + sh_u[1][3];
+    o.n_robust = sh_u[2][0] + sh_u[2][1] + sh_u[2][2] + sh_u[2][3];
+    o.pad = 0;
+    partials[blockIdx.x] = o;
+  }
+}
+
+// =================================================================================================
+// launchers
+// =================================================================================================
+static inline uint32_t blocks_for(uint64_t threads) { return (uint32_t)((threads + 255) / 256); }
+
+void launch_sweep(const SweepArgs& a, uint32_t n_tiles, hipStream_t s) {
+  hipLaunchKernelGGL(k_sweep, dim3(n_tiles / 4), dim3(256), 0, s, a);
+}
+void launch_linearise(const SweepArgs& a, uint32_t n_tiles, hipStream_t s) {
+  hipLaunchKernelGGL(k_linearise, dim3(n_tiles / 4), dim3(256), 0, s, a);
+}
+void launch_cam_reduce(const float4* rowp, const uint32_t* cam_row_ptr, const float4* prior, float4* local, float4* belief,
+                       uint32_t n_cams, hipStream_t s) {
+  hipLaunchKernelGGL(k_cam_reduce, dim3(blocks_for((uint64_t)n_cams * kCamRec)), dim3(256), 0, s, (const float*)rowp,
+                     cam_row_ptr, (const float*)prior, (float*)local, (float*)belief, n_cams);
+}
+void launch_cam_combine(const float4* prior, const float4* gathered, int world, float4* belief, uint32_t n_cams,
+                        hipStream_t s) {
+  const uint32_t n = n_cams * kCamRec;
+  hipLaunchKernelGGL(k_cam_combine, dim3(blocks_for(n)), dim3(256), 0, s, (const float*)prior, (const float*)gathered,
+                     world, (float*)belief, n);
+}
+void launch_lmk_belief(const float4* prior, const float4* lmsg, const uint32_t* lmk_ptr, float4* belief, uint32_t n_lmks,
+                       hipStream_t s) {
+  hipLaunchKernelGGL(k_lmk_belief, dim3(blocks_for((uint64_t)n_lmks * 4)), dim3(256), 0, s, prior, lmsg, lmk_ptr, belief,
+                     n_lmks);
+}
+void launch_weaken(float4* prior, const float* scaling, uint32_t* flag, uint32_t n, int rec4, hipStream_t s) {
+  hipLaunchKernelGGL(k_weaken, dim3(blocks_for((uint64_t)n * rec4)), dim3(256), 0, s, prior, scaling, flag, n, rec4);
+  hipLaunchKernelGGL(k_weaken_flags, dim3(blocks_for(n)), dim3(256), 0, s, flag, n);
+}
+void launch_means(const float4* camb, const float4* lmkb, float* cam_mu, float* lmk_mu, uint32_t n_cams, uint32_t n_lmks,
+                  hipStream_t s) {
+  hipLaunchKernelGGL(k_means, dim3(blocks_for((uint64_t)n_cams + n_lmks)), dim3(256), 0, s, (const float*)camb,
+                     (const float*)lmkb, cam_mu, lmk_mu, n_cams, n_lmks);
+}
+void launch_eval(const int4* idx, const float4* state, const float4* fac, const float* cam_mu, const float* lmk_mu,
+                 const float* K9_dev, int num_undamped_iters, DeviceEval* partials, uint32_t n_tiles, hipStream_t s) {
+  hipLaunchKernelGGL(k_eval, dim3(eval_blocks(n_tiles)), dim3(256), 0, s, idx, state, fac, cam_mu, lmk_mu, K9_dev,
+                     num_undamped_iters, partials, n_tiles);
+}
+
+}  // namespace gbp

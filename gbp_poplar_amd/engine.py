@@ -1,0 +1,151 @@
+"""GbpEngine — Python face of the device half of the C-ABI: the reference's Poplar program list
+(ba.cpp:925-934, slam.cpp:937-948) as methods.  Every call goes through libgbp_mi355x.so (HIP);
+construction raises if the library or a GPU is missing — there is no CPU path."""
+import ctypes as C
+
+import numpy as np
+
+from . import _cabi as cabi
+from ._lib import load
+
+
+class GbpError(RuntimeError):
+    pass
+
+
+class GbpEngine:
+    def __init__(self, cam_id, lmk_id, n_cams, n_lmks, K9, params=None, shard=None):
+        self.lib = load()
+        self._keep = []
+        self.problem = cabi.make_problem(cam_id, lmk_id, n_cams, n_lmks, K9, self._keep)
+        self.C, self.L, self.E = int(n_cams), int(n_lmks), int(self.problem.n_edges)
+        self.params = params if params is not None else cabi.GbpParams.defaults()
+        self.shard = None
+        if shard is not None:
+            self.shard = cabi.GbpShard(int(shard[0]), int(shard[1]), int(shard[2]), int(shard[3]))
+        h = C.c_void_p()
+        rc = self.lib.gbp_create(C.byref(self.problem), C.byref(self.params),
+                                 C.byref(self.shard) if self.shard is not None else None, C.byref(h))
+        if rc != 0:
+            raise GbpError("gbp_create: %s (status %d)" % (self.lib.gbp_last_error(None).decode(), rc))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gbp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise GbpError("%s: %s (status %d)" % (what, self.lib.gbp_last_error(self.h).decode(), rc))
+
+    # ---- program list ----
+    def upload(self, state):
+        keep = []
+        s = cabi.fill_struct(cabi.GbpStateIn(), state, keep)
+        self._chk(self.lib.gbp_upload(self.h, C.byref(s)), "gbp_upload")
+
+    def linearise(self):
+        self._chk(self.lib.gbp_linearise(self.h), "gbp_linearise")
+
+    def iterate(self, n=1):
+        self._chk(self.lib.gbp_iterate(self.h, int(n)), "gbp_iterate")
+
+    def weaken_priors(self):
+        self._chk(self.lib.gbp_weaken_priors(self.h), "gbp_weaken_priors")
+
+    def read(self):
+        out = {"cam_beliefs_eta": np.zeros(6 * self.C, np.float32),
+               "cam_beliefs_lambda": np.zeros(36 * self.C, np.float32),
+               "lmk_beliefs_eta": np.zeros(3 * self.L, np.float32),
+               "lmk_beliefs_lambda": np.zeros(9 * self.L, np.float32),
+               "damping": np.zeros(self.E, np.float32),
+               "damping_count": np.zeros(self.E, np.int32),
+               "robust_flag": np.zeros(self.E, np.uint32)}
+        keep = []
+        s = cabi.fill_struct(cabi.GbpStateOut(), out, keep)
+        self._chk(self.lib.gbp_read(self.h, C.byref(s)), "gbp_read")
+        return out
+
+    def read_priors(self):
+        out = {"cam_priors_eta": np.zeros(6 * self.C, np.float32),
+               "cam_priors_lambda": np.zeros(36 * self.C, np.float32),
+               "lmk_priors_eta": np.zeros(3 * self.L, np.float32),
+               "lmk_priors_lambda": np.zeros(9 * self.L, np.float32)}
+        keep = []
+        s = cabi.fill_struct(cabi.GbpPriorsOut(), out, keep)
+        self._chk(self.lib.gbp_read_priors(self.h, C.byref(s)), "gbp_read_priors")
+        return out
+
+    def new_keyframe(self, upd):
+        keep = []
+        s = cabi.fill_struct(cabi.GbpKfUpdate(), upd, keep)
+        self._chk(self.lib.gbp_new_keyframe(self.h, C.byref(s)), "gbp_new_keyframe")
+
+    def eval(self):
+        o = cabi.GbpEvalOut()
+        self._chk(self.lib.gbp_eval(self.h, C.byref(o)), "gbp_eval")
+        return {k: getattr(o, k) for k, _ in o._fields_}
+
+    def sync(self):
+        self._chk(self.lib.gbp_sync(self.h), "gbp_sync")
+
+    def timing(self, reset=False):
+        t = cabi.GbpTimingOut()
+        self._chk(self.lib.gbp_timing(self.h, C.byref(t), int(reset)), "gbp_timing")
+        return {k: getattr(t, k) for k, _ in t._fields_}
+
+    def set_profiling(self, on):
+        self._chk(self.lib.gbp_set_profiling(self.h, int(bool(on))), "gbp_set_profiling")
+
+    # ---- split-phase (sharded) ----
+    def set_stream(self, stream_handle):
+        self._chk(self.lib.gbp_set_stream(self.h, C.c_void_p(stream_handle)), "gbp_set_stream")
+
+    def set_exchange_buffers(self, send_ptr, recv_ptr):
+        self._chk(self.lib.gbp_set_exchange_buffers(self.h, C.c_void_p(send_ptr), C.c_void_p(recv_ptr)),
+                  "gbp_set_exchange_buffers")
+
+    def iterate_begin(self):
+        self._chk(self.lib.gbp_iterate_begin(self.h), "gbp_iterate_begin")
+
+    def iterate_end(self):
+        self._chk(self.lib.gbp_iterate_end(self.h), "gbp_iterate_end")
+
+    def refresh_begin(self):
+        self._chk(self.lib.gbp_refresh_begin(self.h), "gbp_refresh_begin")
+
+    def refresh_end(self):
+        self._chk(self.lib.gbp_refresh_end(self.h), "gbp_refresh_end")
+
+    def linearise_factors(self):
+        self._chk(self.lib.gbp_linearise_factors(self.h), "gbp_linearise_factors")
+
+    # ---- raw state for parity tests ----
+    def _debug(self, what, na, nb):
+        a, b = np.zeros(na, np.float32), np.zeros(nb, np.float32)
+        self._chk(self.lib.gbp_debug_get(self.h, what, cabi.ptr(a, cabi.c_f32p), cabi.ptr(b, cabi.c_f32p)),
+                  "gbp_debug_get")
+        return a, b
+
+    def factor_potentials(self):
+        return self._debug(0, 9 * self.E, 81 * self.E)
+
+    def set_factor_potentials(self, eta, lam):
+        eta, lam = np.ascontiguousarray(eta, np.float32), np.ascontiguousarray(lam, np.float32)
+        self._chk(self.lib.gbp_debug_set_factor_potentials(self.h, cabi.ptr(eta, cabi.c_f32p), cabi.ptr(lam, cabi.c_f32p)),
+                  "gbp_debug_set_factor_potentials")
+
+    def messages(self):
+        ce, cl = self._debug(1, 6 * self.E, 36 * self.E)
+        le, ll = self._debug(2, 3 * self.E, 9 * self.E)
+        return {"cam_eta": ce, "cam_lambda": cl, "lmk_eta": le, "lmk_lambda": ll}
+
+    def mu(self):
+        return self._debug(3, 9 * self.E, self.E)

@@ -1,0 +1,136 @@
+"""Python face of the CPU-side helper exports of the C-ABI (csrc/gbp_host.cpp): BAL loader, prior
+strength, weakening scales, SLAM flag bookkeeping, host metric, synthetic generator.  No device needed."""
+import ctypes as C
+
+import numpy as np
+
+from . import _cabi as cabi
+from ._lib import load
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed with status %d" % (what, rc))
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _alloc_bal(h):
+    out = {"cam_id": np.zeros(h.n_edges, np.uint32), "lmk_id": np.zeros(h.n_edges, np.uint32),
+           "observations": np.zeros(2 * h.n_edges, np.float64),
+           "cameras": np.zeros(6 * h.n_cams, np.float64), "points": np.zeros(3 * h.n_lmks, np.float64)}
+    h.cam_id, h.lmk_id = cabi.ptr(out["cam_id"], cabi.c_u32p), cabi.ptr(out["lmk_id"], cabi.c_u32p)
+    h.observations = cabi.ptr(out["observations"], cabi.c_f64p)
+    h.cameras, h.points = cabi.ptr(out["cameras"], cabi.c_f64p), cabi.ptr(out["points"], cabi.c_f64p)
+    return out
+
+
+def _finish_bal(h, out):
+    out.update(n_cams=int(h.n_cams), n_lmks=int(h.n_lmks), n_edges=int(h.n_edges),
+               fx=h.fx, fy=h.fy, cx=h.cx, cy=h.cy)
+    return out
+
+
+def bal_read(path):
+    """BALProblem::LoadFile (dataio.cpp:17-57); raises IOError like `./ba` returns 1 (ba.cpp:484-487)."""
+    lib = load()
+    h = cabi.GbpBal()
+    if lib.gbp_bal_read_header(path.encode(), C.byref(h)) != 0:
+        raise IOError("ERROR: unable to open file %s" % path)
+    out = _alloc_bal(h)
+    if lib.gbp_bal_read(path.encode(), C.byref(h)) != 0:
+        raise IOError("Invalid UW data file: %s" % path)
+    return _finish_bal(h, out)
+
+
+def bal_write(path, bal):
+    lib = load()
+    h = cabi.GbpBal()
+    h.n_cams, h.n_lmks, h.n_edges = bal["n_cams"], bal["n_lmks"], bal["n_edges"]
+    h.fx, h.fy, h.cx, h.cy = bal["fx"], bal["fy"], bal["cx"], bal["cy"]
+    keep = [np.ascontiguousarray(bal["cam_id"], np.uint32), np.ascontiguousarray(bal["lmk_id"], np.uint32),
+            np.ascontiguousarray(bal["observations"], np.float64), np.ascontiguousarray(bal["cameras"], np.float64),
+            np.ascontiguousarray(bal["points"], np.float64)]
+    h.cam_id, h.lmk_id = cabi.ptr(keep[0], cabi.c_u32p), cabi.ptr(keep[1], cabi.c_u32p)
+    h.observations, h.cameras, h.points = (cabi.ptr(keep[2], cabi.c_f64p), cabi.ptr(keep[3], cabi.c_f64p),
+                                           cabi.ptr(keep[4], cabi.c_f64p))
+    _chk(lib.gbp_bal_write(path.encode(), C.byref(h)), "gbp_bal_write")
+
+
+def synth_generate(n_cams, n_lmks, obs_per_lmk=10, seed=20200303, ground_truth=False):
+    """Synthetic BAL graph (SURVEY 8d spec)."""
+    lib = load()
+    h = cabi.GbpBal()
+    h.n_cams, h.n_lmks, h.n_edges = n_cams, n_lmks, n_lmks * min(obs_per_lmk, n_cams)
+    out = _alloc_bal(h)
+    gtc = np.zeros(6 * n_cams, np.float64) if ground_truth else None
+    gtp = np.zeros(3 * n_lmks, np.float64) if ground_truth else None
+    _chk(lib.gbp_synth_generate(n_cams, n_lmks, obs_per_lmk, seed, C.byref(h),
+                                cabi.ptr(gtc, cabi.c_f64p), cabi.ptr(gtp, cabi.c_f64p)), "gbp_synth_generate")
+    out = _finish_bal(h, out)
+    if ground_truth:
+        out["gt_cameras"], out["gt_points"] = gtc, gtp
+    return out
+
+
+def set_prior_lambda(cam_id, lmk_id, n_cams, n_lmks, K9, var, cam_file, lmk_file, cam_mean, lmk_mean):
+    lib = load()
+    keep = []
+    p = cabi.make_problem(cam_id, lmk_id, n_cams, n_lmks, K9, keep)
+    outs = [np.zeros(6 * n_cams, np.float32), np.zeros(36 * n_cams, np.float32),
+            np.zeros(3 * n_lmks, np.float32), np.zeros(9 * n_lmks, np.float32)]
+    ins = [_f32(cam_file), _f32(lmk_file), _f32(cam_mean), _f32(lmk_mean)]
+    _chk(lib.gbp_set_prior_lambda(C.byref(p), C.c_float(var), *[cabi.ptr(a, cabi.c_f32p) for a in ins + outs]),
+         "gbp_set_prior_lambda")
+    return outs
+
+
+def prior_scalings(n_cams, n_lmks, cam_priors_lambda, steps, weaker, first_std):
+    lib = load()
+    cs, ls = np.zeros(n_cams, np.float32), np.zeros(n_lmks, np.float32)
+    cpl = _f32(cam_priors_lambda)
+    _chk(lib.gbp_prior_scalings(n_cams, n_lmks, cabi.ptr(cpl, cabi.c_f32p), steps, weaker, first_std,
+                                cabi.ptr(cs, cabi.c_f32p), cabi.ptr(ls, cabi.c_f32p)), "gbp_prior_scalings")
+    return cs, ls
+
+
+def slam_create_flags(cam_id, lmk_id, n_cams, n_lmks, steps):
+    lib = load()
+    keep = []
+    p = cabi.make_problem(cam_id, lmk_id, n_cams, n_lmks, [0] * 9, keep)
+    active = np.zeros(p.n_edges, np.uint32)
+    cwf, lwf, laf = np.zeros(n_cams, np.uint32), np.zeros(n_lmks, np.uint32), np.zeros(n_lmks, np.uint32)
+    _chk(lib.gbp_slam_create_flags(C.byref(p), steps, *[cabi.ptr(x, cabi.c_u32p) for x in (active, cwf, lwf, laf)]),
+         "gbp_slam_create_flags")
+    return active, cwf, lwf, laf
+
+
+def slam_update_flags(cam_id, lmk_id, n_cams, n_lmks, steps, data_counter, active, lwf, cwf, laf):
+    lib = load()
+    keep = []
+    p = cabi.make_problem(cam_id, lmk_id, n_cams, n_lmks, [0] * 9, keep)
+    n_new = np.zeros(1, np.int32)
+    _chk(lib.gbp_slam_update_flags(C.byref(p), steps, data_counter,
+                                   *[cabi.ptr(x, cabi.c_u32p) for x in (active, lwf, cwf, laf)],
+                                   cabi.ptr(n_new, cabi.c_i32p)), "gbp_slam_update_flags")
+    return int(n_new[0])
+
+
+def slam_initialise_new_kf(data_counter, cbe, cbl, cpl, cpe):
+    lib = load()
+    _chk(lib.gbp_slam_initialise_new_kf(data_counter, *[cabi.ptr(x, cabi.c_f32p) for x in (cbe, cbl, cpl, cpe)]),
+         "gbp_slam_initialise_new_kf")
+
+
+def eval_host(cam_id, lmk_id, n_cams, n_lmks, K9, active, meas, cbe, cbl, lbe, lbl):
+    lib = load()
+    keep = []
+    p = cabi.make_problem(cam_id, lmk_id, n_cams, n_lmks, K9, keep)
+    a = np.ascontiguousarray(active, dtype=np.uint32)
+    arrs = [_f32(x) for x in (meas, cbe, cbl, lbe, lbl)]
+    sn, sh, na = C.c_double(), C.c_double(), C.c_uint64()
+    _chk(lib.gbp_eval_host(C.byref(p), cabi.ptr(a, cabi.c_u32p), *[cabi.ptr(x, cabi.c_f32p) for x in arrs],
+                           C.byref(sn), C.byref(sh), C.byref(na)), "gbp_eval_host")
+    return sn.value, sh.value, na.value

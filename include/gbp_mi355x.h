@@ -166,8 +166,10 @@ int gbp_timing(gbp_ctx* ctx, gbp_timing_out* out, int reset);  /* ba.cpp:980,105
  *      torch.distributed all_gather over RCCL).  gbp_iterate == begin + (local copy) + end
  *      when world == 1. -------------------------------------------------------------------- */
 int gbp_set_stream(gbp_ctx* ctx, void* hip_stream /* hipStream_t; NULL = ctx-owned stream */);
-/* send_dev: [C*42] fp32 this rank's camera partial sums; recv_dev: [world][C*42]. Caller-owned
- * device memory (e.g. torch tensors).  Must be set before begin/end on a world>1 ctx. */
+/* send_dev: [C*GBP_CAM_REC] fp32 this rank's camera partial sums; recv_dev: [world][C*GBP_CAM_REC]
+ * (camera record = 44 floats: eta 6, pad 2, Lambda 36).  Caller-owned device memory (e.g. torch
+ * tensors).  Must be set before begin/end on a world>1 ctx. */
+#define GBP_CAM_REC 44
 int gbp_set_exchange_buffers(gbp_ctx* ctx, void* send_dev, void* recv_dev);
 int gbp_iterate_begin(gbp_ctx* ctx);   /* prep + messages + local camera partial -> send_dev     */
 int gbp_iterate_end(gbp_ctx* ctx);     /* camera beliefs = prior + sum_r recv_dev[r]; landmark beliefs */
@@ -176,6 +178,19 @@ int gbp_iterate_end(gbp_ctx* ctx);     /* camera beliefs = prior + sum_r recv_de
 int gbp_refresh_begin(gbp_ctx* ctx);
 int gbp_refresh_end(gbp_ctx* ctx);
 int gbp_linearise_factors(gbp_ctx* ctx);  /* the factor half of LINEARISE_PROG (after a refresh) */
+
+/* ---- measurement / test hooks -------------------------------------------------------------- */
+/* per_stage_events != 0: gbp_iterate launches kernels directly with a hipEvent pair around the
+ * sweep and the belief kernels of every iteration (feeds gbp_timing.sweep_ms / belief_ms). */
+int gbp_set_profiling(gbp_ctx* ctx, int per_stage_events);
+/* Raw internal state in the reference's tensor layouts (ba.cpp:665-687,759-775):
+ *   what 0: a = factor_potentials_eta [9E],  b = factor_potentials_lambda [81E] = [cc36|cl18|lc18|ll9]
+ *   what 1: a = cam message eta [6E],        b = cam message Lambda [36E] (lower triangle as stored; upper 0)
+ *   what 2: a = lmk message eta [3E],        b = lmk message Lambda [9E]
+ *   what 3: a = mu [9E],                     b = dmu [E]                                          */
+int gbp_debug_get(gbp_ctx* ctx, int what, float* a, float* b);
+/* Overwrite the factor potentials from reference-layout arrays (inverse of what 0). Test hook. */
+int gbp_debug_set_factor_potentials(gbp_ctx* ctx, const float* eta9E, const float* lambda81E);
 
 /* ---- host-side helpers of the path's callers (pure CPU, no device needed) ---------------- */
 /* BALProblem::LoadFile (dataio.cpp:17-57).  Two-call pattern: pass NULL arrays to get sizes. */

@@ -90,12 +90,18 @@ def load(variant="restatement"):
         getattr(lib, name).argtypes = args
         getattr(lib, name).restype = None
     lib.om_impl_name.restype = C.c_char_p
+    lib.om_set_trig_mode.argtypes = [C.c_int]
     _LIBS[variant] = lib
     return lib
 
 
 def set_threads(n, variant="restatement"):
     load(variant).orc_set_threads(int(n))
+
+
+def set_trig_mode(mode, variant="restatement"):
+    """0 = host libm sinf/cosf (literal), 1 = correctly rounded (what the HIP kernels compute)."""
+    load(variant).om_set_trig_mode(int(mode))
 
 
 def _f32(a):

@@ -12,6 +12,14 @@
 
 const char* om_impl_name(void) { return "restatement"; }
 
+/* trig mode 0: sinf/cosf of the host libm (literal restatement of std::sin(float)).
+ * trig mode 1: correctly rounded (fp64 evaluation rounded once) — what the HIP kernels use; the
+ * reference's own target (IPU) has its own libm, so neither mode is more "reference" than the other. */
+static int g_trig_mode = 0;
+void om_set_trig_mode(int m) { g_trig_mode = m; }
+static float o_sin(float x) { return g_trig_mode ? (float)sin((double)x) : sinf(x); }
+static float o_cos(float x) { return g_trig_mode ? (float)cos((double)x) : cosf(x); }
+
 /* reference ba/matlib.cpp:47-89 — accumulate, k innermost, the three transpose modes in use. */
 void om_matmul(const float* A, int ar, int ac, const float* B, int br, int bc,
                float* P, int pc, int tA, int tB) {
@@ -98,7 +106,7 @@ void om_so3exp(const float* v, float* R) {
   R[0] = 1.f; R[4] = 1.f; R[8] = 1.f;
   theta = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
   if (theta > 1e-6f) {
-    float s = sinf(theta), c = cosf(theta);
+    float s = o_sin(theta), c = o_cos(theta);
     float H[9] = {0}, H2[9] = {0};
     int i;
     hat3(v, H);

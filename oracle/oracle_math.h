@@ -27,6 +27,7 @@ void om_hfunc(const float* cam6, const float* lmk3, const float* K9, float* hx2)
 void om_jac(const float* cam6, const float* lmk3, const float* K9,
             float* Jkf12_zeroed, float* Jlmk6_zeroed);   /* bafuncs.cpp:106-213 */
 const char* om_impl_name(void);
+void om_set_trig_mode(int mode);   /* restatement only: 0 = host libm sinf/cosf, 1 = correctly rounded */
 
 #ifdef __cplusplus
 }

@@ -14,6 +14,7 @@
 extern "C" {
 
 const char* om_impl_name(void) { return "reference"; }
+void om_set_trig_mode(int) {}  // the reference code calls std::sin/std::cos, nothing to select
 
 void om_matmul(const float* A, int ar, int ac, const float* B, int br, int bc,
                float* P, int pc, int tA, int tB) {
