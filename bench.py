@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py — GBP iterations/second on the synthetic 1M-factor BAL graph (BASELINE.json configs[3], "S1").
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" is one synchronous GBP iteration (GBP_PROG of the reference, ba/ba.cpp:895-905: prep ->
+messages -> beliefs) over the whole factor graph, inputs resident in HBM, no host read-back inside the
+timed region.  N = 1 runs S1 = 1 000 cameras x 100 000 landmarks x 1 000 000 factors.  N > 1 is WEAK
+scaling: N x S1 (1000 N cameras, 100k N landmarks, 1M N factors), landmark-sharded, one all-gather of
+camera partials per iteration.  `value` = iterations/s x (total factors / 1e6), i.e. "1M-factor-graph
+GBP iterations per second": at N = 1 it is exactly BASELINE.json's metric, and it aggregates over
+ranks like tokens/s does (raw iterations/s of the N x larger graph is in config.iters_per_sec).
+
+The warm-up runs the reference's start of a BA run (LINEARISE, prior weakening on iterations 1,3,5,7,9)
+so the timed iterations are steady-state sweeps of a converging problem.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+ALGO_BYTES_PER_FACTOR = 1112   # algorithmic bytes per factor-iteration of the sweep
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--cams", type=int, default=1000, help="cameras per GPU")
+    ap.add_argument("--lmks", type=int, default=100000, help="landmarks per GPU")
+    ap.add_argument("--obs", type=int, default=10, help="observations per landmark")
+    ap.add_argument("--seed", type=int, default=20200303)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--profile-steps", type=int, default=20, help="per-stage hipEvent-timed iterations for the roofline")
+    return ap.parse_args()
+
+
+def warm_start(eng, opts, warmup):
+    """ba.cpp:1001-1008 for `warmup` iterations (weaken priors on 1,3,5,7,9)."""
+    for it in range(warmup):
+        if ((it + 1) % 2 == 0) and (it < opts.steps * 2):
+            eng.weaken_priors()
+        eng.iterate(1)
+
+
+def cpu_baseline(bal, K, state, opts, budget_s):
+    """The CPU oracle (OpenMP over factors / variables) timed on this host on the SAME graph."""
+    from oracle import oracle as orc
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:  # honour a cgroup CPU quota (containers): "max 100000" or "<quota> <period>"
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = max(1, min(cores, int(float(q) / float(p) + 0.5)))
+    except Exception:
+        pass
+    orc.set_threads(cores)
+    o = orc.Oracle(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K)
+    o.upload(state)
+    o.linearise()
+    t0 = time.perf_counter()
+    o.iterate(1)
+    t1 = time.perf_counter() - t0
+    n = max(1, min(50, int((budget_s - t1) / max(t1, 1e-6))))
+    t0 = time.perf_counter()
+    o.iterate(n)
+    dt = time.perf_counter() - t0
+    ips = n / dt
+    o.close()
+    return {"value": ips * bal["n_edges"] / 1e6, "unit": "1M-factor GBP iters/s", "cores": cores, "kind": "port",
+            "sample": "%d full iterations of the same %d-factor graph after LINEARISE (oracle/, gcc -O2 -fopenmp, %d threads)"
+                      % (n, bal["n_edges"], cores)}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world != 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    if a.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with torch.distributed.run (one process per GPU)")
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from gbp_poplar_amd import driver, hostlib
+    from gbp_poplar_amd.distributed import ShardedGbp, landmark_partition
+    from gbp_poplar_amd.engine import GbpEngine
+
+    C, L = a.cams * world, a.lmks * world
+    bal = hostlib.synth_generate(C, L, a.obs, a.seed)      # every rank generates the same global graph
+    E = bal["n_edges"]
+    opts = driver.Options()
+    K, state, _ = driver.build_inputs(bal, opts, hostlib)
+
+    if world == 1:
+        eng = GbpEngine(bal["cam_id"], bal["lmk_id"], C, L, K)
+        run = eng
+        e_local = E
+    else:
+        bounds = landmark_partition(bal["lmk_id"], L, world)
+        eng = GbpEngine(bal["cam_id"], bal["lmk_id"], C, L, K, shard=(rank, world, int(bounds[rank]), int(bounds[rank + 1])))
+        run = ShardedGbp(eng, C, rank, world, dist=dist, device="cuda")
+        e_local = int(((bal["lmk_id"] >= bounds[rank]) & (bal["lmk_id"] < bounds[rank + 1])).sum())
+    run.upload(state)
+    run.linearise()
+    ev0 = run.eval()
+    warm_start(run, opts, a.warmup)
+
+    def fence():
+        run.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    run.iterate(a.steps)
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ev1 = run.eval()
+
+    # ---- roofline of the dominant kernel (k_sweep), measured live with hipEvents on its stream ----
+    roof = None
+    if world == 1 and a.profile_steps > 0:
+        eng.timing(reset=True)
+        eng.set_profiling(True)
+        eng.iterate(a.profile_steps)
+        eng.set_profiling(False)
+        tm = eng.timing(reset=True)
+        sweep_s = tm["sweep_ms"] / 1e3 / a.profile_steps
+        achieved = ALGO_BYTES_PER_FACTOR * e_local / sweep_s / 1e9
+        roof = {"bound": "hbm", "kernel": "k_sweep", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "algorithmic_bytes_per_launch": ALGO_BYTES_PER_FACTOR * e_local,
+                "avg_launch_us": round(sweep_s * 1e6, 2),
+                "belief_kernels_avg_us": round(tm["belief_ms"] * 1e3 / a.profile_steps, 2)}
+
+    cpu = None
+    if rank == 0 and world == 1 and a.cpu_seconds > 0:
+        cpu = cpu_baseline(bal, K, state, opts, a.cpu_seconds)
+
+    if rank == 0:
+        ips = a.steps / dt
+        m0, m1 = driver.metric(ev0), driver.metric(ev1)
+        out = {
+            "metric": "GBP iters/sec on the 1M-factor synthetic BAL graph (iterations/s x factors/1e6)",
+            "value": round(ips * E / 1e6, 2), "unit": "1M-factor GBP iters/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "S1 synthetic BAL graph x%d: %d cams x %d lmks x %d factors (seed %d), landmark-sharded"
+                                   % (world, C, L, E, a.seed),
+                       "cams": C, "lmks": L, "factors": E, "iters_per_sec": round(ips, 2),
+                       "parallelism": "1 GPU, hipGraph x10 iterations" if world == 1 else "landmark shards x%d + all_gather(cam partials)" % world,
+                       "reproj_rmse_px_initial": round(m0[2], 6), "reproj_rmse_px_final": round(m1[2], 6),
+                       "mean_reproj_px_final": round(m1[0], 6), "iterations_run": a.warmup + a.steps,
+                       "nonfinite_beliefs": int(ev1["n_nonfinite"])},
+        }
+        if roof:
+            out["roofline"] = roof
+        if cpu:
+            out["cpu_baseline"] = cpu
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
