@@ -49,6 +49,18 @@ int orc_read_priors(orc_ctx* o, gbp_priors_out* out);
 int orc_new_keyframe(orc_ctx* o, const gbp_kf_update* upd);
 int orc_eval(orc_ctx* o, gbp_eval_out* out);
 
+/* Rank-local split-phase view, mirroring gbp_iterate_begin/_end, gbp_refresh_begin/_end and
+ * gbp_linearise_factors of the C-ABI (camera records of 44 floats: eta 6, pad 2, Lambda 36), so the
+ * multi-process host logic can be tested on CPU (gloo).  Only factors whose landmark lies in
+ * [lmk_begin, lmk_end) are processed. */
+int orc_set_shard(orc_ctx* o, int rank, int world, uint32_t lmk_begin, uint32_t lmk_end);
+int orc_iterate_begin(orc_ctx* o, float* send);
+int orc_iterate_end(orc_ctx* o, const float* recv);
+int orc_refresh_begin(orc_ctx* o, float* send);
+int orc_refresh_end(orc_ctx* o, const float* recv);
+int orc_linearise_factors(orc_ctx* o);
+int orc_weaken_priors_sharded(orc_ctx* o, const float* recv);
+
 /* raw internal state for stage-level parity (reference tensor names, ba.cpp:665-687,759-775) */
 int orc_get_factor_potentials(orc_ctx* o, float* eta9E, float* lambda81E);
 int orc_get_messages(orc_ctx* o, float* cam_eta6E, float* cam_lam36E, float* lmk_eta3E, float* lmk_lam9E);

@@ -43,7 +43,13 @@ struct orc_ctx {
   int sum_mode, n_shards;
   uint32_t* bounds;
   int uploaded;
+  /* rank-local view for the multi-process tests (orc_set_shard): only factors whose landmark lies in
+   * [lb, le) are processed; camera beliefs come from gathered per-rank partials */
+  int sh_rank, sh_world;
+  uint32_t lb, le;
 };
+
+static int is_local(const orc_ctx* o, uint32_t e) { return o->lmk_id[e] >= o->lb && o->lmk_id[e] < o->le; }
 
 const char* orc_math_impl(void) { return om_impl_name(); }
 
@@ -106,6 +112,7 @@ orc_ctx* orc_create(const gbp_problem* p, const gbp_params* prm) {
   o->cscale = (float*)zalloc(C, 4); o->lscale = (float*)zalloc(L, 4);
   o->cwf = (uint32_t*)zalloc(C, 4); o->lwf = (uint32_t*)zalloc(L, 4);
   o->sum_mode = 0; o->n_shards = 1; o->bounds = NULL;
+  o->sh_rank = 0; o->sh_world = 1; o->lb = 0; o->le = L;
   return o;
 }
 
@@ -160,6 +167,26 @@ static float tree16(const float* x) {
   return c[0] + c[1];
 }
 
+/* element k (0..5 eta, 6..41 Lambda) of camera c's partial sum over the factors whose landmark lies
+ * in [lo, hi): rows of 16 in file order, each a balanced tree, rows added left to right */
+static float cam_partial(const orc_ctx* o, uint32_t c, int k, uint32_t lo, uint32_t hi) {
+  float local = 0.f, row[16];
+  int n = 0, have = 0;
+  uint32_t s;
+  for (s = o->cam_ptr[c]; s < o->cam_ptr[c + 1]; ++s) {
+    uint32_t e = o->cam_f[s];
+    if (o->lmk_id[e] < lo || o->lmk_id[e] >= hi) continue;
+    row[n++] = k < 6 ? o->mce[(size_t)e * 6 + k] : o->mcl[(size_t)e * 36 + (k - 6)];
+    if (n == 16) { float t = tree16(row); local = have ? local + t : t; have = 1; n = 0; }
+  }
+  if (n) {
+    float t;
+    while (n < 16) row[n++] = 0.f;
+    t = tree16(row); local = have ? local + t : t; have = 1;
+  }
+  return local;
+}
+
 static void cam_belief_device_order(const orc_ctx* o, uint32_t c) {
   int k, r;
   float* be = o->cbe + (size_t)c * 6;
@@ -168,21 +195,7 @@ static void cam_belief_device_order(const orc_ctx* o, uint32_t c) {
     float acc = k < 6 ? o->cpe[(size_t)c * 6 + k] : o->cpl[(size_t)c * 36 + (k - 6)];
     for (r = 0; r < o->n_shards; ++r) {
       uint32_t lo = o->bounds ? o->bounds[r] : 0, hi = o->bounds ? o->bounds[r + 1] : o->L;
-      float local = 0.f, row[16];
-      int n = 0, have = 0;
-      uint32_t s;
-      for (s = o->cam_ptr[c]; s < o->cam_ptr[c + 1]; ++s) {
-        uint32_t e = o->cam_f[s];
-        if (o->lmk_id[e] < lo || o->lmk_id[e] >= hi) continue;
-        row[n++] = k < 6 ? o->mce[(size_t)e * 6 + k] : o->mcl[(size_t)e * 36 + (k - 6)];
-        if (n == 16) { float t = tree16(row); local = have ? local + t : t; have = 1; n = 0; }
-      }
-      if (n) {
-        float t;
-        while (n < 16) row[n++] = 0.f;
-        t = tree16(row); local = have ? local + t : t; have = 1;
-      }
-      acc = acc + local;
+      acc = acc + cam_partial(o, c, k, lo, hi);
     }
     if (k < 6) be[k] = acc; else bl[k - 6] = acc;
   }
@@ -506,6 +519,98 @@ int orc_get_mu(orc_ctx* o, float* mu, float* dmu) {
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Rank-local split-phase view (mirrors gbp_iterate_begin/_end etc. of the C-ABI) so that the
+ * multi-process host logic (gbp_poplar_amd/distributed.py) can be exercised on CPU with gloo.
+ * Camera record layout of the exchange buffers: 44 floats = eta 6, pad 2, Lambda 36.
+ * ------------------------------------------------------------------------------------------ */
+int orc_set_shard(orc_ctx* o, int rank, int world, uint32_t lb, uint32_t le) {
+  if (rank < 0 || rank >= world || lb > le || le > o->L) return GBP_ERR_INVALID;
+  o->sh_rank = rank; o->sh_world = world; o->lb = lb; o->le = le;
+  return 0;
+}
+
+static void local_cam_partials(const orc_ctx* o, float* send) {
+  long c;
+#pragma omp parallel for schedule(static)
+  for (c = 0; c < (long)o->C; ++c) {
+    int k;
+    float* rec = send + c * 44;
+    rec[6] = 0.f; rec[7] = 0.f;
+    for (k = 0; k < 42; ++k) rec[k < 6 ? k : k + 2] = cam_partial(o, (uint32_t)c, k, o->lb, o->le);
+  }
+}
+
+static void beliefs_from_gathered(orc_ctx* o, const float* recv) {
+  long c, l;
+#pragma omp parallel for schedule(static)
+  for (c = 0; c < (long)o->C; ++c) {
+    int k, r;
+    for (k = 0; k < 42; ++k) {
+      float acc = k < 6 ? o->cpe[c * 6 + k] : o->cpl[c * 36 + (k - 6)];
+      for (r = 0; r < o->sh_world; ++r) acc = acc + recv[((size_t)r * o->C + c) * 44 + (k < 6 ? k : k + 2)];
+      if (k < 6) o->cbe[c * 6 + k] = acc; else o->cbl[c * 36 + (k - 6)] = acc;
+    }
+  }
+#pragma omp parallel for schedule(static)
+  for (l = (long)o->lb; l < (long)o->le; ++l) {
+    float* be = o->lbe + l * 3;
+    float* bl = o->lbl + l * 9;
+    uint32_t s;
+    int k;
+    for (k = 0; k < 3; ++k) be[k] = o->lpe[l * 3 + k];
+    for (k = 0; k < 9; ++k) bl[k] = o->lpl[l * 9 + k];
+    for (s = o->lmk_ptr[l]; s < o->lmk_ptr[l + 1]; ++s) {
+      uint32_t e = o->lmk_f[s];
+      for (k = 0; k < 3; ++k) be[k] += o->mle[(size_t)e * 3 + k];
+      for (k = 0; k < 9; ++k) bl[k] += o->mll[(size_t)e * 9 + k];
+    }
+  }
+}
+
+int orc_refresh_begin(orc_ctx* o, float* send) { local_cam_partials(o, send); return 0; }
+int orc_refresh_end(orc_ctx* o, const float* recv) { beliefs_from_gathered(o, recv); return 0; }
+
+int orc_linearise_factors(orc_ctx* o) {
+  long e;
+#pragma omp parallel for schedule(static)
+  for (e = 0; e < (long)o->E; ++e) if (is_local(o, (uint32_t)e)) relinearise_zero(o, (uint32_t)e);
+  return 0;
+}
+
+int orc_iterate_begin(orc_ctx* o, float* send) {
+  long e;
+  size_t E = o->E;
+#pragma omp parallel for schedule(static)
+  for (e = 0; e < (long)E; ++e) if (is_local(o, (uint32_t)e)) prep_factor(o, (uint32_t)e);
+  memcpy(o->oldmu, o->mu, E * 9 * 4);
+#pragma omp parallel for schedule(static)
+  for (e = 0; e < (long)E; ++e) {
+    if (!is_local(o, (uint32_t)e)) continue;
+    msg_cam_eta(o, (uint32_t)e); msg_lmk_eta(o, (uint32_t)e);
+    msg_cam_lambda(o, (uint32_t)e); msg_lmk_lambda(o, (uint32_t)e);
+  }
+  local_cam_partials(o, send);
+  return 0;
+}
+
+int orc_iterate_end(orc_ctx* o, const float* recv) {
+  size_t E = o->E;
+  beliefs_from_gathered(o, recv);
+  memcpy(o->pce, o->mce, E * 6 * 4);  memcpy(o->pcl, o->mcl, E * 36 * 4);
+  memcpy(o->ple, o->mle, E * 3 * 4);  memcpy(o->pll, o->mll, E * 9 * 4);
+  return 0;
+}
+
+/* weaken priors without a fresh exchange: partials are unchanged, only priors move (as the C-ABI does) */
+int orc_weaken_priors_sharded(orc_ctx* o, const float* recv) {
+  uint32_t v;
+  for (v = 0; v < o->C; ++v) weaken_var(o->cscale[v], &o->cwf[v], o->cpe + (size_t)v * 6, 6, o->cpl + (size_t)v * 36, 36);
+  for (v = 0; v < o->L; ++v) weaken_var(o->lscale[v], &o->lwf[v], o->lpe + (size_t)v * 3, 3, o->lpl + (size_t)v * 9, 9);
+  beliefs_from_gathered(o, recv);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
  * Host-side restatements (Eigen-free).
  * ------------------------------------------------------------------------------------------ */
 
@@ -718,8 +823,9 @@ static void var_means(uint32_t C, uint32_t L, const float* cbe, const float* cbl
 
 /* eval_reprojection_error, util.cpp:74-144, with fp64 accumulation; "active edges" instead of the
  * reference's "first n_active edges" (identical for camera-sorted files, util.cpp:95-99) */
-int orc_eval_host(const gbp_problem* p, const uint32_t* active, const float* meas, const float* cbe,
-                  const float* cbl, const float* lbe, const float* lbl, double* sn, double* sh, uint64_t* na) {
+static int eval_range(const gbp_problem* p, const uint32_t* active, const float* meas, const float* cbe,
+                      const float* cbl, const float* lbe, const float* lbl, uint32_t lmk_lo, uint32_t lmk_hi,
+                      double* sn, double* sh, uint64_t* na) {
   float* cmu = (float*)zalloc((size_t)p->n_cams * 6, 4);
   float* lmu = (float*)zalloc((size_t)p->n_lmks * 3, 4);
   double a = 0, b = 0;
@@ -729,12 +835,18 @@ int orc_eval_host(const gbp_problem* p, const uint32_t* active, const float* mea
   for (e = 0; e < p->n_edges; ++e) {
     float nr, hs;
     if (active[e] != 1) continue;
+    if (lmk_lo != lmk_hi && (p->lmk_id[e] < lmk_lo || p->lmk_id[e] >= lmk_hi)) continue;
     edge_residual(cmu + (size_t)p->cam_id[e] * 6, lmu + (size_t)p->lmk_id[e] * 3, p->K, meas + (size_t)e * 2, &nr, &hs);
     a += nr; b += hs; ++n;
   }
   *sn = a; *sh = b; *na = n;
   free(cmu); free(lmu);
   return 0;
+}
+
+int orc_eval_host(const gbp_problem* p, const uint32_t* active, const float* meas, const float* cbe,
+                  const float* cbl, const float* lbe, const float* lbl, double* sn, double* sh, uint64_t* na) {
+  return eval_range(p, active, meas, cbe, cbl, lbe, lbl, 0, 0, sn, sh, na);
 }
 
 int orc_eval_host_f32(const gbp_problem* p, const uint32_t* active, const float* meas, const float* cbe,
@@ -763,8 +875,10 @@ int orc_eval(orc_ctx* o, gbp_eval_out* out) {
   p.n_cams = o->C; p.n_lmks = o->L; p.n_edges = o->E; p.cam_id = o->cam_id; p.lmk_id = o->lmk_id;
   memcpy(p.K, o->K, sizeof(p.K));
   memset(out, 0, sizeof(*out));
-  orc_eval_host(&p, o->active, o->meas, o->cbe, o->cbl, o->lbe, o->lbl, &out->sum_norm, &out->sum_half_sq, &out->n_active);
+  eval_range(&p, o->active, o->meas, o->cbe, o->cbl, o->lbe, o->lbl, o->sh_world > 1 ? o->lb : 0,
+             o->sh_world > 1 ? o->le : 0, &out->sum_norm, &out->sum_half_sq, &out->n_active);
   for (e = 0; e < o->E; ++e) {
+    if (!is_local(o, e)) continue;
     out->n_robust += o->robust[e];
     if (o->count[e] == -o->prm.num_undamped_iters) out->n_relin++;
   }

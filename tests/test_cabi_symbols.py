@@ -1,0 +1,66 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/gbp_mi355x.h declares
+(no device compute is called here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "gbp_mi355x.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"^\s*(?:const\s+char\s*\*|int|void)\s+(gbp_\w+)\s*\(", src, flags=re.M)
+    return sorted(set(names))
+
+
+def test_header_declares_the_program_list():
+    names = declared_functions()
+    for must in ("gbp_create", "gbp_destroy", "gbp_last_error", "gbp_upload", "gbp_linearise", "gbp_iterate",
+                 "gbp_weaken_priors", "gbp_read", "gbp_read_priors", "gbp_new_keyframe", "gbp_eval", "gbp_timing",
+                 "gbp_iterate_begin", "gbp_iterate_end", "gbp_bal_read", "gbp_set_prior_lambda", "gbp_synth_generate"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    from gbp_poplar_amd import _lib
+    lib = _lib.load()
+    names = declared_functions()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), "libgbp_mi355x.so does not export %s" % n
+    assert sorted(_lib.symbols()) == names, set(names) ^ set(_lib.symbols())
+    assert lib.gbp_abi_version() == 1
+
+
+def test_struct_sizes_match_the_header():
+    from gbp_poplar_amd import _cabi as cabi
+    assert ctypes.sizeof(cabi.GbpParams) == 4 * 12
+    assert ctypes.sizeof(cabi.GbpShard) == 16
+    assert ctypes.sizeof(cabi.GbpProblem) == 16 + 16 + 36 + 4   # 3 x u32 (+pad), 2 pointers, K[9] (+pad)
+    assert ctypes.sizeof(cabi.GbpEvalOut) == 48
+    assert ctypes.sizeof(cabi.GbpStateIn) == 15 * 8 and ctypes.sizeof(cabi.GbpStateOut) == 7 * 8
+
+
+def test_no_cpu_fallback_without_a_gpu():
+    """gbp_create must fail loudly (GBP_ERR_NO_DEVICE) instead of falling back to host code."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from gbp_poplar_amd import hostlib
+    from gbp_poplar_amd.engine import GbpEngine, GbpError
+    bal = hostlib.synth_generate(4, 24, 3, 1)
+    with pytest.raises(GbpError, match="no HIP device"):
+        GbpEngine(bal["cam_id"], bal["lmk_id"], 4, 24, [1] * 9)
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "gbp_poplar_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+                assert "oracle/" not in txt.replace("oracle/oracle.py, test", "").replace("under oracle/", "") or f in ("_cabi.py", "__init__.py", "distributed.py"), f

@@ -268,3 +268,82 @@ def test_graph_replay_equals_direct_launches(oracle_mod):
     ra, rb = a.read(), b.read()
     for k in ra:
         assert np.array_equal(ra[k], rb[k]), k
+
+
+# ---- committed golden fixtures (tests/golden/*.npz, produced with the REFERENCE's math layer) ----------------
+
+def _golden(name):
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", name))
+
+
+def _gpu_snapshot(eng):
+    r, m = eng.read(), eng.messages()
+    fe, fl = eng.factor_potentials()
+    d = dict(r)
+    d.update({"msg_" + k: v for k, v in m.items()})
+    d.update(fac_eta=fe, fac_lambda=fl)
+    return d
+
+
+def test_golden_tiny_state():
+    """4 cams x 24 lmks: every tensor after LINEARISE and 4 sweeps.  `dev_` golden (device conventions):
+    bit for bit.  `ref_` golden (reference math, libm trig, slot-order sums): 1e-5 after LINEARISE /
+    1 sweep, 1e-4 up to 4 sweeps (north_star tolerance)."""
+    from gbp_poplar_amd.engine import GbpEngine
+    g = _golden("state_tiny.npz")
+    bal = {k[4:]: g[k] for k in g.files if k.startswith("bal_")}
+    state = {k[6:]: g[k] for k in g.files if k.startswith("state_")}
+    eng = GbpEngine(bal["cam_id"], bal["lmk_id"], int(bal["n_cams"]), int(bal["n_lmks"]), g["K"])
+    eng.upload(state)
+    eng.linearise()
+    snaps = {"lin": _gpu_snapshot(eng)}
+    for it in range(4):
+        if (it + 1) % 2 == 0:
+            eng.weaken_priors()
+        eng.iterate(1)
+        snaps["it%d" % it] = _gpu_snapshot(eng)
+    width = {"cam_beliefs_eta": 6, "cam_beliefs_lambda": 36, "lmk_beliefs_eta": 3, "lmk_beliefs_lambda": 9,
+             "msg_cam_eta": 6, "msg_cam_lambda": 36, "msg_lmk_eta": 3, "msg_lmk_lambda": 9, "fac_eta": 9, "fac_lambda": 81}
+    low = np.tile(np.tril(np.ones((6, 6), bool)).ravel(), eng.E)
+    for tag, d in snaps.items():
+        for k, v in d.items():
+            dev, ref = g["dev_%s_%s" % (tag, k)], g["ref_%s_%s" % (tag, k)]
+            if k == "msg_cam_lambda":        # only the lower triangle of a camera message is stored per factor
+                v, dev, ref = v[low], dev[low], ref[low]
+            assert np.array_equal(v, dev), ("dev", tag, k)
+            if k in width:
+                w = 21 if k == "msg_cam_lambda" else width[k]
+                tol = 1e-5 if tag in ("lin", "it0") else 1e-4
+                assert per_var_rel(v, ref, w) <= tol, ("ref", tag, k, per_var_rel(v, ref, w))
+            else:
+                assert np.array_equal(v, ref), ("ref", tag, k)
+
+
+def test_golden_sequence_snapshots():
+    """fr2robot2 belief snapshots at LINEARISE and sweeps 0,1,2,5 from the reference-math oracle."""
+    from gbp_poplar_amd import driver, hostlib
+    from gbp_poplar_amd.engine import GbpEngine
+    g = _golden("sequence_snapshots.npz")
+    bal = _bal("fr2robot2")
+    opts = driver.Options()
+    K, state, _ = driver.build_inputs(bal, opts, hostlib)
+    eng = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K)
+    eng.upload(state)
+    eng.linearise()
+    w = {"cam_beliefs_eta": 6, "cam_beliefs_lambda": 36, "lmk_beliefs_eta": 3, "lmk_beliefs_lambda": 9}
+    r = eng.read()
+    for k in w:
+        assert np.array_equal(r[k], g["lin_" + k]), k
+    for it in range(6):
+        if (it + 1) % 2 == 0:
+            eng.weaken_priors()
+        eng.iterate(1)
+        if it in (0, 1, 2, 5):
+            r = eng.read()
+            for k in w:
+                err = per_var_rel(r[k], g["it%d_%s" % (it, k)], w[k])
+                assert err <= (1e-4 if it <= 2 else 1e-3), (it, k, err)
+        ev = eng.eval()
+        m = ev["sum_norm"] / ev["n_active"]
+        assert abs(m - g["traj_fr2robot2"][it + 1, 1]) <= 1e-4 * m, (it, m)

@@ -1,0 +1,138 @@
+"""Pins of the oracle's vertex programs + schedule.
+
+gbp_codelets.cpp / ba.cpp need the Poplar SDK (absent) and cannot be built here, so this level is
+pinned (a) against the reference-run known answers recorded in BASELINE.md (the survey drove the
+reference's own vertex code in ba.cpp program order), (b) against committed golden state produced with
+the REFERENCE's math layer (tests/golden/*.npz), and (c) by running the restatement against the
+reference-math build over long chaotic trajectories (bit-for-bit)."""
+import os
+
+import numpy as np
+import pytest
+
+from gbp_poplar_amd import driver
+from oracle import oracle as orc
+from tests.conftest import seq_path
+from tests.oracle_host import OracleHost
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+# iter -> (mean reprojection error px, cost)
+KNOWN = {
+    "fr1xyz": {-1: (199.109661, 316403624.6), 0: (146.078941, 174728834.0), 1: (112.179332, 108629835.3),
+               2: (100.597049, 89917522.8), 3: (64.809624, 38371264.1), 4: (54.835361, 29072130.5),
+               5: (40.599969, 15475871.9), 6: (35.914498, 12635729.7)},
+    "fr2robot2": {-1: (39.863837, 4242224.19), 0: (28.488358, 2182828.51), 1: (17.600413, 879065.88),
+                  2: (16.256836, 751254.21), 3: (7.911513, 185321.27), 4: (6.586535, 127320.88),
+                  5: (4.774667, 65125.34), 6: (3.693480, 35898.19)},
+}
+ROBUST_AFTER_LINEARISE = {"fr1xyz": 12903, "fr2robot2": 3478}
+# ulp-level differences (Eigen-dependent prior code, metric accumulation) amplify ~x3-5 per sweep
+TOL = {-1: 1e-7, 0: 1e-7, 1: 5e-7, 2: 5e-7, 3: 5e-6, 4: 1e-5, 5: 5e-5, 6: 1e-4}
+
+
+def _run(name, n, variant="restatement", host_variant="restatement", **kw):
+    host = OracleHost(host_variant)
+    bal = host.bal_read(seq_path(name))
+    opts = driver.Options()
+    K, state, _ = driver.build_inputs(bal, opts, host)
+    o = orc.Oracle(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K, variant=variant)
+    return o, driver.run_ba(o, state, opts, n_iters=n, **kw), bal
+
+
+@pytest.mark.parametrize("name", ["fr2robot2", "fr1xyz"])
+def test_first_sweeps_match_reference_run(name):
+    o, traj, bal = _run(name, 7)
+    for i, mean, cost, n_relin, n_robust in traj:
+        km, kc = KNOWN[name][i]
+        assert abs(mean - km) <= max(TOL[i], 2e-8) * km + 6e-7, (i, mean, km)   # printed to 6 decimals
+        assert abs(cost - kc) <= max(TOL[i] * 3, 2e-8) * kc, (i, cost, kc)
+        if i < 6:
+            assert n_robust == ROBUST_AFTER_LINEARISE[name]
+        assert n_relin == (bal["n_edges"] if i == 6 else 0)      # countdown passes -8 at sweep 6
+
+
+def test_restatement_equals_golden_state_bit_for_bit():
+    """tiny synthetic graph: LINEARISE + 4 sweeps, every tensor, against the reference-math golden state."""
+    g = np.load(os.path.join(GOLD, "state_tiny.npz"))
+    bal = {k[4:]: g[k] for k in g.files if k.startswith("bal_")}
+    state = {k[6:]: g[k] for k in g.files if k.startswith("state_")}
+    for prefix, trig, so in (("ref", 0, 0), ("dev", 1, 1)):
+        orc.set_trig_mode(trig)
+        try:
+            o = orc.Oracle(bal["cam_id"], bal["lmk_id"], int(bal["n_cams"]), int(bal["n_lmks"]), g["K"])
+            o.set_sum_order(so)
+            o.upload(state)
+            o.linearise()
+            stages = ["lin"]
+            snaps = {}
+
+            def snap(tag):
+                r, m = o.read(), o.messages()
+                fe, fl = o.factor_potentials()
+                d = dict(r)
+                d.update({"msg_" + k: v for k, v in m.items()})
+                d.update(fac_eta=fe, fac_lambda=fl)
+                snaps[tag] = d
+            snap("lin")
+            for it in range(4):
+                if (it + 1) % 2 == 0:
+                    o.weaken_priors()
+                o.iterate(1)
+                snap("it%d" % it)
+        finally:
+            orc.set_trig_mode(0)
+        for tag, d in snaps.items():
+            for k, v in d.items():
+                assert np.array_equal(v, g["%s_%s_%s" % (prefix, tag, k)]), (prefix, tag, k)
+
+
+def test_sequence_snapshots_and_trajectories():
+    g = np.load(os.path.join(GOLD, "sequence_snapshots.npz"))
+    o, traj, _ = _run("fr2robot2", 6)
+    t = np.array([(i, m, c, r, b) for i, m, c, r, b in traj])
+    assert np.allclose(t[:, 1:3], g["traj_fr2robot2"][:7, 1:3], rtol=1e-12)
+    assert np.array_equal(t[:, 3:], g["traj_fr2robot2"][:7, 3:])
+    r = o.read()
+    for k in ("cam_beliefs_eta", "cam_beliefs_lambda", "lmk_beliefs_eta", "lmk_beliefs_lambda"):
+        assert np.array_equal(r[k], g["it5_" + k]), k
+    # the committed trajectory agrees with BASELINE.md's reference-run numbers too
+    for name in ("fr2robot2", "fr1xyz"):
+        for row in g["traj_" + name][:8]:
+            km, _ = KNOWN[name][int(row[0])]
+            assert abs(row[1] - km) <= max(TOL[int(row[0])], 2e-8) * km + 6e-7
+
+
+@pytest.mark.skipif(not orc.have("ref"), reason="oracle/_ref not built (needs /root/reference)")
+def test_long_chaotic_trajectory_equals_reference_math_build():
+    """fr1xyz is chaotic in fp32 (ulp differences blow up within ~25 sweeps): 200 sweeps with
+    relinearisations staying bit-identical means the restated math layer IS the reference's."""
+    a, ta, _ = _run("fr1xyz", 200, "restatement", eval_every=50)
+    b, tb, _ = _run("fr1xyz", 200, "ref", "ref", eval_every=50)
+    assert ta == tb
+    ra, rb = a.read(), b.read()
+    for k in ra:
+        assert np.array_equal(ra[k], rb[k]), k
+    assert 1.0 < ta[-1][1] < 4.0      # converging band at 200 sweeps
+
+
+def test_converged_band_fr2robot2():
+    _, traj, _ = _run("fr2robot2", 400, eval_every=50)
+    assert 0.85 < traj[-1][1] < 0.92, traj[-1]     # 0.8741 after 1500 sweeps, ~0.875 from 400 on
+
+
+def test_reset_relin_mode_differs_from_faithful_accumulate():
+    """quirk C-1: PrepMessageVertex accumulates onto the old potential; relin_mode=1 zeroes first."""
+    from gbp_poplar_amd import _cabi as cabi
+    host = OracleHost()
+    bal = host.bal_read(seq_path("fr2robot2"))
+    opts = driver.Options()
+    K, state, _ = driver.build_inputs(bal, opts, host)
+    res = []
+    for mode in (0, 1):
+        o = orc.Oracle(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K,
+                       params=cabi.GbpParams.defaults(relin_mode=mode))
+        driver.run_ba(o, state, opts, n_iters=19, eval_every=0)
+        res.append(o.factor_potentials()[1])
+    relinearised = np.any(res[0].reshape(-1, 81) != res[1].reshape(-1, 81), axis=1)
+    assert 100 < relinearised.sum() < len(relinearised)
