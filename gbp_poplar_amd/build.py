@@ -47,7 +47,9 @@ def build(force=False, verbose=False):
         path = os.path.join(CSRC, src)
         exe = os.path.join(BIN, name)
         if os.path.exists(path) and (force or _stale(exe, deps + [LIB])):
-            cmd = [cc, "-o", exe, "-O2", "-std=c++17", "-ffp-contract=off", path, LIB, "-Wl,-rpath,$ORIGIN/.."]
+            # the CLIs are plain C++ on top of the C-ABI: host compiler, linked against the in-tree library
+            cmd = [shutil.which("g++") or "g++", "-o", exe, "-O2", "-std=c++17", "-ffp-contract=off", path,
+                   "-L" + HERE, "-lgbp_mi355x", "-Wl,-rpath,$ORIGIN/.."]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

@@ -1,0 +1,72 @@
+// ba_main.cpp — `./ba --bal_file F`: batch bundle adjustment by synchronous GBP on one MI355X.
+// Same flow, flags and stdout lines as the reference's ba/ba.cpp main() (479-1085), with the Poplar
+// engine replaced by the C-ABI: WRITE -> LINEARISE -> READ -> loop {WEAKEN_PRIORS?, GBP, READ, eval}.
+#include "cli_common.hpp"
+
+int main(int argc, char** argv) {
+  cli::Options o;
+  const int pr = cli::parse(argc, argv, /*slam=*/false, o);
+  if (pr) return pr == 1 ? 0 : 1;
+  cli::Problem P;
+  if (cli::load_problem(o, P)) return 1;
+  const uint32_t C = P.bal.n_cams, L = P.bal.n_lmks, E = P.bal.n_edges;
+
+  std::cout << "\nBundle Adjustment\n";                       // ba.cpp:587-590
+  P.active.assign(E, 1u);
+  P.cwf.assign(C, (uint32_t)o.steps);
+  P.lwf.assign(L, (uint32_t)o.steps);
+  std::cout << "\nNumber of keyframe nodes in the graph: " << C << '\n';
+  std::cout << "Number of landmark nodes in the graph: " << L << '\n';
+  std::cout << "Number of edges in the graph: " << E << '\n';
+  if (o.gpus > 1) std::cout << "note: --gpus/--ipus > 1 runs one process per GPU (see bench.py / gbp_poplar_amd.distributed); this binary uses 1 GPU\n";
+  std::cout << "\nNumber of GPUs: 1\n\nAttaching to GPU device..." << std::endl;
+
+  gbp_ctx* ctx = nullptr;
+  if (gbp_create(&P.prob, nullptr, nullptr, &ctx) != GBP_OK) {
+    std::cout << "Could not find a device\n" << gbp_last_error(nullptr) << "\n";  // ba.cpp:652-655
+    return 255;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  std::cout << "Running program to stream initial data to GPU\n";
+  const gbp_state_in in = cli::state_in(P);
+  CLI_CHECK(ctx, gbp_upload(ctx, &in));
+  std::cout << "Initial data streaming complete\n\n";
+  std::cout << "Sending priors and computing factor potentials.\n";
+  CLI_CHECK(ctx, gbp_linearise(ctx));
+
+  cli::Readback rb(C, L);
+  gbp_eval_out ev{};
+  CLI_CHECK(ctx, gbp_eval(ctx, &ev));
+  std::cout << "Initial Reprojection error: " << (float)(ev.sum_norm / (double)ev.n_active) << " Cost " << (float)ev.sum_half_sq << "\n";
+  std::cout << "Number of iterations: " << o.n_iters << "\n";
+
+  unsigned iter = 0;
+  for (int i = 0; i < o.n_iters; ++i) {
+    if (((iter + 1) % 2 == 0) && (iter < o.steps * 2)) {       // ba.cpp:1003-1006
+      std::cout << "Weakening priors \n";
+      CLI_CHECK(ctx, gbp_weaken_priors(ctx));
+    }
+    CLI_CHECK(ctx, gbp_iterate(ctx, 1));
+    if ((i + 1) % o.eval_every == 0 || i + 1 == o.n_iters) {
+      CLI_CHECK(ctx, gbp_eval(ctx, &ev));
+      std::cout << "Iter " << iter << " // Reprojection error " << (float)(ev.sum_norm / (double)ev.n_active);
+      std::cout << " // Cost " << (float)ev.sum_half_sq << " // n relins: " << ev.n_relin;
+      std::cout << " // n robust edges " << ev.n_robust << "\n";
+      if (ev.n_nonfinite) std::cout << "warning: " << ev.n_nonfinite << " beliefs are non-finite\n";
+      if (o.verbose) {
+        CLI_CHECK(ctx, gbp_read(ctx, &rb.out));
+        cli::print_verbose(rb);
+      }
+    }
+    iter += 1;
+  }
+  std::cout << "\n Finished GBP.\n";
+  const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  gbp_timing_out tm{};
+  gbp_timing(ctx, &tm, 0);
+  std::cout << "Total time: " << wall << " s; device time in GBP iterations: " << tm.total_ms << " ms over " << tm.iterations
+            << " iterations (" << (tm.total_ms > 0 ? 1e3 * (double)tm.iterations / tm.total_ms : 0.0) << " iters/s)\n";
+  if (o.profile) cli::write_profile(ctx, "ba", wall, o.n_iters);
+  gbp_destroy(ctx);
+  return 0;
+}

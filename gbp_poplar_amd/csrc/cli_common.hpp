@@ -1,0 +1,328 @@
+// cli_common.hpp — shared host driver code of the `ba` and `slam` executables.
+//
+// Keeps the command-line contract of the reference's two programs (flag names and defaults of
+// ba/ba.cpp:394-476 and ba/slam.cpp:394-476, stdout lines of ba.cpp:996,1004,1026-1028 and
+// slam.cpp:1073-1076) on top of the C-ABI instead of a Poplar engine.  Boost.Program_options is
+// replaced by a small `--name value` / `--name=value` parser.  Differences, all deliberate:
+//   * `--help` prints the options and exits 0 (the reference throws an uncaught exception, ba.cpp:469-472);
+//   * a malformed data file is an error (the reference only prints "Invalid UW data file.");
+//   * `--ipus N` is kept as an alias of `--gpus N`; `--camspertile` is accepted and ignored;
+//   * `--seed S` makes the initialisation-noise flags reproducible (the reference seeds from the clock,
+//     dataio.cpp:334,349,406); `--eval_every K` thins the per-iteration read-back + metric (default 1).
+#pragma once
+#include "../../include/gbp_mi355x.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace cli {
+
+struct Options {
+  std::string bal_file;
+  int n_iters = 1500;           // ba only
+  int iters_between_kfs = 700;  // slam only
+  bool profile = false;
+  int gpus = 1;
+  int cams_per_tile = 1;
+  float transnoise = 0.f, rotnoise = 0.f, lmktrans_noise = 0.f;
+  bool av_depth_on = false;
+  float av_depth = 1.f;
+  float reproj_meas_var = 4.f;
+  float prior_std_weaker_factor = 100.f;
+  float first_cam_prior_std = 0.01f;
+  float steps = 5.f;
+  int iters_before_damping = 15;
+  bool verbose = false;
+  unsigned long long seed = 0;
+  int eval_every = 1;
+};
+
+inline void usage(bool slam) {
+  std::cout << "Options:\n"
+               "  --help                         Show command help\n"
+               "  --bal_file arg                 Set the bal file\n";
+  if (slam) std::cout << "  --iters_between_kfs arg (=700) Number of iterations of GBP between new keyframes\n";
+  else std::cout << "  --n_iters arg (=1500)          Number of iterations of synchronous GBP\n";
+  std::cout << "  --profile arg (=0)             Save profile report after execution\n"
+               "  --gpus arg (=1)                Number of GPUs (alias: --ipus)\n"
+               "  --camspertile arg (=1)         accepted for compatibility, ignored\n"
+               "  --tn arg (=0)                  Set keyframe translation noise value\n"
+               "  --rn arg (=0)                  Set keyframe rotation noise value\n"
+               "  --ltn arg (=0)                 Set landmark translation noise noise value\n"
+               "  --avdepth_on arg (=0)          initialise landmarks at a depth in front of the first observing keyframe\n"
+               "  --avdepth arg (=1)             Average depth\n"
+               "  --reproj_meas_var arg (=4)     Variance of the reprojection measurement model\n"
+               "  --prior_std_weaker_factor arg (=100)\n"
+               "  --first_cam_prior_std arg (=0.01)\n"
+               "  --steps arg (=5)               The priors are gradually weakened over this many steps\n"
+               "  --undamped_start arg (=15)     Number of undamped iterations before damping GBP\n"
+               "  --v arg (=0)                   Verbose: print beliefs\n"
+               "  --seed arg (=0)                seed of the initialisation noise (0 = from the clock)\n"
+               "  --eval_every arg (=1)          read back + evaluate every K iterations\n";
+}
+
+// returns 0 = run, 1 = exit with code 0 (help), 2 = exit with code 1 (error)
+inline int parse(int argc, char** argv, bool slam, Options& o) {
+  std::map<std::string, std::string> kv;
+  for (int i = 1; i < argc; ++i) {
+    std::string a = argv[i];
+    if (a.rfind("--", 0) != 0) { std::cerr << "unrecognised argument '" << a << "'\n"; return 2; }
+    a = a.substr(2);
+    if (a == "help") { usage(slam); return 1; }
+    std::string val;
+    const size_t eq = a.find('=');
+    if (eq != std::string::npos) { val = a.substr(eq + 1); a = a.substr(0, eq); }
+    else if (i + 1 < argc) val = argv[++i];
+    else { std::cerr << "the required argument for option '--" << a << "' is missing\n"; return 2; }
+    kv[a] = val;
+  }
+  auto B = [](const std::string& s) { return s == "1" || s == "true" || s == "on" || s == "yes"; };
+  try {
+    for (auto& p : kv) {
+      const std::string &k = p.first, &v = p.second;
+      if (k == "bal_file") o.bal_file = v;
+      else if (k == "n_iters" && !slam) o.n_iters = std::stoi(v);
+      else if (k == "iters_between_kfs" && slam) o.iters_between_kfs = std::stoi(v);
+      else if (k == "profile") o.profile = B(v);
+      else if (k == "ipus" || k == "gpus") o.gpus = std::stoi(v);
+      else if (k == "camspertile") o.cams_per_tile = std::stoi(v);
+      else if (k == "tn") o.transnoise = std::stof(v);
+      else if (k == "rn") o.rotnoise = std::stof(v);
+      else if (k == "ltn") o.lmktrans_noise = std::stof(v);
+      else if (k == "avdepth_on") o.av_depth_on = B(v);
+      else if (k == "avdepth") o.av_depth = std::stof(v);
+      else if (k == "reproj_meas_var") o.reproj_meas_var = std::stof(v);
+      else if (k == "prior_std_weaker_factor") o.prior_std_weaker_factor = std::stof(v);
+      else if (k == "first_cam_prior_std") o.first_cam_prior_std = std::stof(v);
+      else if (k == "steps") o.steps = std::stof(v);
+      else if (k == "undamped_start") o.iters_before_damping = std::stoi(v);
+      else if (k == "v") o.verbose = B(v);
+      else if (k == "seed") o.seed = std::stoull(v);
+      else if (k == "eval_every") o.eval_every = std::max(1, std::stoi(v));
+      else { std::cerr << "unrecognised option '--" << k << "'\n"; return 2; }
+    }
+  } catch (const std::exception&) {
+    std::cerr << "invalid option value\n";
+    return 2;
+  }
+  if (o.bal_file.empty()) { std::cerr << "the option '--bal_file' is required but missing\n"; return 2; }
+  return 0;
+}
+
+// ---- problem data (what ba.cpp:489-604 builds on the host) -----------------------------------------
+struct Problem {
+  gbp_bal bal{};
+  std::vector<uint32_t> cam_id, lmk_id;
+  std::vector<double> obs, cams, pts;
+  std::vector<float> K, meas, var, cam_file, lmk_file, cam_mean, lmk_mean;
+  std::vector<float> cpe, cpl, lpe, lpl, cscale, lscale, damping, mu;
+  std::vector<int32_t> count;
+  std::vector<uint32_t> active, cwf, lwf;
+  gbp_problem prob{};
+};
+
+// tiny deterministic normal generator for the optional initialisation noise
+struct Noise {
+  unsigned long long s;
+  explicit Noise(unsigned long long seed) : s(seed ? seed : (unsigned long long)std::chrono::system_clock::now().time_since_epoch().count()) {}
+  unsigned long long next() {
+    s += 0x9E3779B97F4A7C15ull;
+    unsigned long long x = s;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+  }
+  double uni() { return ((double)(next() >> 11) + 0.5) / 9007199254740992.0; }
+  float normal(float sd) { return sd * (float)(std::sqrt(-2.0 * std::log(uni())) * std::cos(6.283185307179586 * uni())); }
+};
+
+inline void rodrigues(const float* w, float* R) {
+  const float th = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+  const float W[9] = {0.f, -w[2], w[1], w[2], 0.f, -w[0], -w[1], w[0], 0.f};
+  for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.f : 0.f;
+  if (th < 1e-6) return;
+  const float a = std::sin(th) / th, b = (1 - std::cos(th)) / (th * th);
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) {
+      float ww = 0.f;
+      for (int k = 0; k < 3; ++k) ww += W[r * 3 + k] * W[k * 3 + c];
+      R[r * 3 + c] += a * W[r * 3 + c] + b * ww;
+    }
+}
+
+// add_cam_rot_noise, dataio.cpp:345-400: rotate the camera-to-world orientation about a random axis
+inline void add_rot_noise(std::vector<float>& cam, uint32_t C, float sd_deg, Noise& rng) {
+  for (uint32_t c = 2; c < C; ++c) {
+    const float ang = rng.normal(sd_deg) * (float)M_PI / 180.f;
+    const int axis = (int)(rng.next() % 3);
+    float Rn[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    const float cs = std::cos(ang), sn = std::sin(ang);
+    if (axis == 0) { Rn[4] = cs; Rn[5] = -sn; Rn[7] = sn; Rn[8] = cs; }
+    else if (axis == 1) { Rn[0] = cs; Rn[2] = sn; Rn[6] = -sn; Rn[8] = cs; }
+    else { Rn[0] = cs; Rn[1] = -sn; Rn[3] = sn; Rn[4] = cs; }
+    float Rw2c[9];
+    rodrigues(&cam[6 * c + 3], Rw2c);
+    // Tc2w = [R^T, -R^T t]; rotate its rotation block: Rc2w' = Rn * R^T, translation (camera centre) kept
+    float Rc2w[9], ctr[3], Rnew[9];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) Rc2w[i * 3 + j] = Rw2c[j * 3 + i];
+    for (int i = 0; i < 3; ++i) ctr[i] = -(Rc2w[i * 3] * cam[6 * c] + Rc2w[i * 3 + 1] * cam[6 * c + 1] + Rc2w[i * 3 + 2] * cam[6 * c + 2]);
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        float s = 0.f;
+        for (int k = 0; k < 3; ++k) s += Rn[i * 3 + k] * Rc2w[k * 3 + j];
+        Rnew[i * 3 + j] = s;
+      }
+    // back to world->camera: R' = Rnew^T, t' = -R' ctr
+    float Rp[9];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) Rp[i * 3 + j] = Rnew[j * 3 + i];
+    for (int i = 0; i < 3; ++i) cam[6 * c + i] = -(Rp[i * 3] * ctr[0] + Rp[i * 3 + 1] * ctr[1] + Rp[i * 3 + 2] * ctr[2]);
+    // so3log, util.cpp:34-46
+    const float d = 0.5f * (Rp[0] + Rp[4] + Rp[8] - 1);
+    const float f = std::acos(d) / (2 * std::sqrt(1 - d * d));
+    cam[6 * c + 3] = f * (Rp[7] - Rp[5]);
+    cam[6 * c + 4] = f * (Rp[2] - Rp[6]);
+    cam[6 * c + 5] = f * (Rp[3] - Rp[1]);
+  }
+}
+
+// av_depth_init, dataio.cpp:417-453: landmarks start one unit in front of the first keyframe observing them
+// (the reference uses the literal depth 1.0, not --avdepth, dataio.cpp:437)
+inline void av_depth_init(const Problem& P, std::vector<float>& lmk_mean) {
+  const uint32_t C = P.bal.n_cams, E = P.bal.n_edges;
+  std::vector<char> done(P.bal.n_lmks, 0);
+  std::vector<float> spot(3 * (size_t)C);
+  for (uint32_t c = 0; c < C; ++c) {
+    float R[9];
+    rodrigues(&P.cam_mean[6 * c + 3], R);
+    const float v[3] = {0.f - P.cam_mean[6 * c], 0.f - P.cam_mean[6 * c + 1], 1.f - P.cam_mean[6 * c + 2]};
+    for (int i = 0; i < 3; ++i) spot[3 * c + i] = R[i] * v[0] + R[3 + i] * v[1] + R[6 + i] * v[2];  // R^T (p - t)
+  }
+  for (uint32_t c = 0; c < C; ++c)  // camera-major visiting order of the reference (O(E) because files are camera-sorted)
+    for (uint32_t e = 0; e < E; ++e)
+      if (P.cam_id[e] == c && !done[P.lmk_id[e]]) {
+        for (int i = 0; i < 3; ++i) lmk_mean[3 * (size_t)P.lmk_id[e] + i] = spot[3 * c + i];
+        done[P.lmk_id[e]] = 1;
+      }
+}
+
+inline int load_problem(const Options& o, Problem& P) {
+  if (gbp_bal_read_header(o.bal_file.c_str(), &P.bal) != GBP_OK) {
+    std::cerr << "ERROR: unable to open file " << o.bal_file << "\n";  // ba.cpp:484-487
+    return 1;
+  }
+  const uint32_t C = P.bal.n_cams, L = P.bal.n_lmks, E = P.bal.n_edges;
+  P.cam_id.resize(E); P.lmk_id.resize(E); P.obs.resize(2 * (size_t)E); P.cams.resize(6 * (size_t)C); P.pts.resize(3 * (size_t)L);
+  P.bal.cam_id = P.cam_id.data(); P.bal.lmk_id = P.lmk_id.data(); P.bal.observations = P.obs.data();
+  P.bal.cameras = P.cams.data(); P.bal.points = P.pts.data();
+  if (gbp_bal_read(o.bal_file.c_str(), &P.bal) != GBP_OK) {
+    std::cerr << "Invalid UW data file.\nERROR: unable to read file " << o.bal_file << "\n";
+    return 1;
+  }
+  P.K = {(float)P.bal.fx, 0.f, (float)P.bal.cx, 0.f, (float)P.bal.fy, (float)P.bal.cy, 0.f, 0.f, 1.f};  // ba.cpp:494-495
+  P.meas.resize(2 * (size_t)E);
+  for (size_t i = 0; i < 2 * (size_t)E; ++i) P.meas[i] = (float)P.obs[i];
+  P.var.assign(E, o.reproj_meas_var);
+  P.cam_file.resize(6 * (size_t)C); P.lmk_file.resize(3 * (size_t)L);
+  for (size_t i = 0; i < P.cam_file.size(); ++i) P.cam_file[i] = (float)P.cams[i];
+  for (size_t i = 0; i < P.lmk_file.size(); ++i) P.lmk_file[i] = (float)P.pts[i];
+  P.cam_mean = P.cam_file; P.lmk_mean = P.lmk_file;
+  P.prob.n_cams = C; P.prob.n_lmks = L; P.prob.n_edges = E; P.prob.cam_id = P.cam_id.data(); P.prob.lmk_id = P.lmk_id.data();
+  std::memcpy(P.prob.K, P.K.data(), 9 * sizeof(float));
+
+  Noise rng(o.seed);  // ba.cpp:536-548
+  if (o.transnoise != 0.f) {
+    std::cout << "\nAdding Gaussian noise with std: " << o.transnoise << "m to the keyframe translaton intialisations\n";
+    for (uint32_t c = 2; c < C; ++c) for (int i = 0; i < 3; ++i) P.cam_mean[6 * (size_t)c + i] += rng.normal(o.transnoise);
+  }
+  if (o.rotnoise != 0.f) {
+    std::cout << "Adding Gaussian noise with std: " << o.rotnoise << " to the keyframe rotation intialisations\n";
+    add_rot_noise(P.cam_mean, C, o.rotnoise, rng);
+  }
+  if (o.lmktrans_noise != 0.f && !o.av_depth_on) {
+    std::cout << "Adding Gaussian noise with std: " << o.lmktrans_noise << "m to the landmark intialisations\n";
+    for (float& x : P.lmk_mean) x += rng.normal(o.lmktrans_noise);
+  } else if (o.av_depth_on) {
+    std::cout << "Initialising all landmarks at an average depth of: " << o.av_depth << "\n";
+    av_depth_init(P, P.lmk_mean);
+  }
+
+  P.cpe.resize(6 * (size_t)C); P.cpl.resize(36 * (size_t)C); P.lpe.resize(3 * (size_t)L); P.lpl.resize(9 * (size_t)L);
+  gbp_set_prior_lambda(&P.prob, o.reproj_meas_var, P.cam_file.data(), P.lmk_file.data(), P.cam_mean.data(), P.lmk_mean.data(),
+                       P.cpe.data(), P.cpl.data(), P.lpe.data(), P.lpl.data());
+  P.cscale.resize(C); P.lscale.resize(L);
+  gbp_prior_scalings(C, L, P.cpl.data(), o.steps, o.prior_std_weaker_factor, o.first_cam_prior_std, P.cscale.data(), P.lscale.data());
+  std::cout << "Completed loading data!\n";
+  P.damping.assign(E, 0.f);
+  P.count.assign(E, -o.iters_before_damping);  // ba.cpp:581
+  P.mu.assign(9 * (size_t)E, 0.f);
+  return 0;
+}
+
+inline gbp_state_in state_in(const Problem& P) {
+  gbp_state_in s{};
+  s.damping = P.damping.data(); s.damping_count = P.count.data(); s.mu = P.mu.data(); s.oldmu = P.mu.data();
+  s.active_flag = P.active.data(); s.cam_scaling = P.cscale.data(); s.lmk_scaling = P.lscale.data();
+  s.cam_weaken_flag = P.cwf.data(); s.lmk_weaken_flag = P.lwf.data();
+  s.cam_priors_eta = P.cpe.data(); s.cam_priors_lambda = P.cpl.data(); s.lmk_priors_eta = P.lpe.data();
+  s.lmk_priors_lambda = P.lpl.data(); s.measurements = P.meas.data(); s.meas_variances = P.var.data();
+  return s;
+}
+
+struct Readback {
+  std::vector<float> cbe, cbl, lbe, lbl;
+  gbp_state_out out{};
+  Readback(uint32_t C, uint32_t L) : cbe(6 * (size_t)C), cbl(36 * (size_t)C), lbe(3 * (size_t)L), lbl(9 * (size_t)L) {
+    out.cam_beliefs_eta = cbe.data(); out.cam_beliefs_lambda = cbl.data();
+    out.lmk_beliefs_eta = lbe.data(); out.lmk_beliefs_lambda = lbl.data();
+  }
+};
+
+inline void print_verbose(const Readback& r) {  // ba.cpp:1030-1051
+  std::cout << "\nKeyframe Eta beliefs: \n";
+  for (unsigned i = 0; i < 6; ++i) std::printf("%.12f  ", r.cbe[6 + i]);
+  std::cout << "\nKeyframe Lambda beliefs: \n";
+  for (unsigned i = 0; i < 36; ++i) std::printf("%.12f  ", r.cbl[36 + i]);
+  std::cout << '\n';
+  std::cout << "\nLandmark Eta beliefs: \n";
+  for (unsigned i = 0; i < 12; ++i) std::printf("%.12f  ", r.lbe[i]);
+  std::cout << "\nLandmark Lambda beliefs: \n";
+  for (unsigned i = 0; i < 18; ++i) std::printf("%.12f  ", r.lbl[i]);
+  std::cout << '\n';
+  std::fflush(stdout);
+}
+
+#define CLI_CHECK(ctx, call)                                                              \
+  do {                                                                                    \
+    const int rc_ = (call);                                                               \
+    if (rc_ != GBP_OK) {                                                                  \
+      std::cerr << #call << " failed (" << rc_ << "): " << gbp_last_error(ctx) << "\n";  \
+      return 1;                                                                           \
+    }                                                                                     \
+  } while (0)
+
+inline void write_profile(gbp_ctx* ctx, const char* tool, double wall_s, long iters) {  // ba.cpp:1060-1082
+  const char* dir = std::getenv("GC_PROFILE_LOG_DIR");
+  const std::string path = std::string(dir ? dir : ".") + "/gbp_profile.json";
+  gbp_timing_out t{};
+  gbp_timing(ctx, &t, 0);
+  if (FILE* f = std::fopen(path.c_str(), "w")) {
+    std::fprintf(f, "{\"tool\": \"%s\", \"iterations\": %ld, \"wall_s\": %.6f, \"device_ms\": %.3f, \"iters_per_s_device\": %.3f, "
+                    "\"algorithmic_bytes_per_iter\": %llu, \"device_bytes_allocated\": %llu}\n",
+                 tool, iters, wall_s, t.total_ms, t.total_ms > 0 ? 1e3 * (double)t.iterations / t.total_ms : 0.0,
+                 (unsigned long long)t.algorithmic_bytes_per_iter, (unsigned long long)t.device_bytes_allocated);
+    std::fclose(f);
+    std::cout << "Profile written to " << path << "\n";
+  }
+}
+
+}  // namespace cli

@@ -1,0 +1,97 @@
+// slam_main.cpp — `./slam --bal_file F`: incremental SLAM, one new keyframe every --iters_between_kfs
+// GBP iterations.  Same flow as the reference's ba/slam.cpp main() (479-1135): factors of cameras 0,1
+// start active, then per keyframe update_flags -> READ_PRIORS -> initialise_new_kf -> re-arm
+// damping_count to -15 -> NEW_KEYFRAME, with the usual {WEAKEN_PRIORS?, GBP, READ, eval} body.
+#include "cli_common.hpp"
+
+int main(int argc, char** argv) {
+  cli::Options o;
+  const int pr = cli::parse(argc, argv, /*slam=*/true, o);
+  if (pr) return pr == 1 ? 0 : 1;
+  cli::Problem P;
+  if (cli::load_problem(o, P)) return 1;
+  const uint32_t C = P.bal.n_cams, L = P.bal.n_lmks, E = P.bal.n_edges;
+  if (C < 2) { std::cerr << "slam needs at least two keyframes\n"; return 1; }
+
+  std::cout << "SLAM\n";                                        // slam.cpp:586-595
+  const unsigned steps = static_cast<unsigned>(o.steps);
+  P.active.assign(E, 0u); P.cwf.assign(C, 0u); P.lwf.assign(L, 0u);
+  std::vector<uint32_t> lmk_active(L, 0u);
+  gbp_slam_create_flags(&P.prob, steps, P.active.data(), P.cwf.data(), P.lwf.data(), lmk_active.data());
+  std::cout << "\nNumber of keyframe nodes in the graph: " << C << '\n';
+  std::cout << "Number of landmark nodes in the graph: " << L << '\n';
+  std::cout << "Number of edges in the graph: " << E << '\n';
+  std::cout << "\nNumber of GPUs: 1\n\nAttaching to GPU device..." << std::endl;
+
+  gbp_ctx* ctx = nullptr;
+  if (gbp_create(&P.prob, nullptr, nullptr, &ctx) != GBP_OK) {
+    std::cout << "Could not find a device\n" << gbp_last_error(nullptr) << "\n";
+    return 255;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  const gbp_state_in in = cli::state_in(P);
+  CLI_CHECK(ctx, gbp_upload(ctx, &in));
+  std::cout << "Sending priors and computing factor potentials.\n";
+  CLI_CHECK(ctx, gbp_linearise(ctx));
+
+  cli::Readback rb(C, L);
+  gbp_priors_out po{};
+  po.cam_priors_eta = P.cpe.data(); po.cam_priors_lambda = P.cpl.data();
+  po.lmk_priors_eta = P.lpe.data(); po.lmk_priors_lambda = P.lpl.data();
+  gbp_eval_out ev{};
+  CLI_CHECK(ctx, gbp_eval(ctx, &ev));
+  std::cout << "Initial Reprojection error: " << (float)(ev.sum_norm / (double)ev.n_active) << " Cost " << (float)ev.sum_half_sq << "\n";
+
+  const unsigned niters = (C - 1) * (unsigned)o.iters_between_kfs - 1;   // slam.cpp:1013
+  unsigned iter = 0, data_counter = 0;
+  std::cout << "Total number of GBP iterations: " << niters << "\n";
+  std::cout << "GBP iterations between sucessive keyframes: " << o.iters_between_kfs << "\n";
+  for (unsigned i = 0; i < niters; ++i) {
+    if ((i + 1) % (unsigned)o.iters_between_kfs == 0) {         // slam.cpp:1020-1046
+      iter = 0;
+      data_counter += 1;
+      int32_t n_new = 0;
+      gbp_slam_update_flags(&P.prob, steps, data_counter, P.active.data(), P.lwf.data(), P.cwf.data(), lmk_active.data(), &n_new);
+      std::cout << "\n**********************************************************";
+      std::cout << "\n Adding keyframe " << data_counter + 1;
+      std::cout << "\n Adding " << n_new << " new landmarks";
+      std::cout << "\n**********************************************************\n\n";
+      CLI_CHECK(ctx, gbp_read_priors(ctx, &po));
+      CLI_CHECK(ctx, gbp_read(ctx, &rb.out));
+      gbp_slam_initialise_new_kf(data_counter, rb.cbe.data(), rb.cbl.data(), P.cpl.data(), P.cpe.data());
+      std::fill(P.count.begin(), P.count.end(), -15);           // literal, slam.cpp:1039-1041
+      gbp_kf_update up{};
+      up.damping_count = P.count.data();
+      up.cam_priors_eta = P.cpe.data(); up.cam_priors_lambda = P.cpl.data();
+      up.lmk_priors_eta = P.lpe.data(); up.lmk_priors_lambda = P.lpl.data();
+      up.active_flag = P.active.data(); up.cam_weaken_flag = P.cwf.data(); up.lmk_weaken_flag = P.lwf.data();
+      CLI_CHECK(ctx, gbp_new_keyframe(ctx, &up));
+    }
+    if (((iter + 1) % 2 == 0) && (iter < o.steps * 2)) {
+      std::cout << "Weakening priors \n";
+      CLI_CHECK(ctx, gbp_weaken_priors(ctx));
+    }
+    CLI_CHECK(ctx, gbp_iterate(ctx, 1));
+    if ((i + 1) % (unsigned)o.eval_every == 0 || i + 1 == niters) {
+      CLI_CHECK(ctx, gbp_eval(ctx, &ev));
+      std::cout << "Iters " << (unsigned)o.iters_between_kfs * data_counter + iter;
+      std::cout << " (since last kf " << iter << ") // Reprojection error " << (float)(ev.sum_norm / (double)ev.n_active);
+      std::cout << " // Cost " << (float)ev.sum_half_sq << " // n relins: " << ev.n_relin;
+      std::cout << " // n robust edges " << ev.n_robust << "\n";
+      if (o.verbose) {
+        CLI_CHECK(ctx, gbp_read(ctx, &rb.out));
+        cli::print_verbose(rb);
+      }
+    }
+    iter += 1;
+  }
+  std::cout << "\n Finished GBP.\n";
+  const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  gbp_timing_out tm{};
+  gbp_timing(ctx, &tm, 0);
+  std::cout << "Total time: " << wall << " s; device time in GBP iterations: " << tm.total_ms << " ms over " << tm.iterations
+            << " iterations (" << (tm.total_ms > 0 ? 1e3 * (double)tm.iterations / tm.total_ms : 0.0) << " iters/s)\n";
+  if (o.profile) cli::write_profile(ctx, "slam", wall, niters);
+  gbp_destroy(ctx);
+  return 0;
+}

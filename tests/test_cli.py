@@ -1,0 +1,100 @@
+"""The `ba` / `slam` executables (csrc/ba_main.cpp, slam_main.cpp): flag contract and error behaviour on CPU,
+full runs against the oracle on the GPU."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests.conftest import seq_path
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BA = os.path.join(ROOT, "gbp_poplar_amd", "bin", "ba")
+SLAM = os.path.join(ROOT, "gbp_poplar_amd", "bin", "slam")
+
+
+def run(cmd):
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    return p.returncode, p.stdout, p.stderr
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    if not (os.path.exists(BA) and os.path.exists(SLAM)):
+        from gbp_poplar_amd import build
+        build.build()
+
+
+def test_help_lists_the_reference_flags():
+    rc, out, _ = run([BA, "--help"])
+    assert rc == 0                                   # the reference aborts via an uncaught exception (ba.cpp:469-472)
+    for flag in ("bal_file", "n_iters", "profile", "camspertile", "tn", "rn", "ltn", "avdepth_on", "avdepth",
+                 "reproj_meas_var", "prior_std_weaker_factor", "first_cam_prior_std", "steps", "undamped_start", "v"):
+        assert "--" + flag in out, flag
+    assert "(=1500)" in out and "(=0.01)" in out and "(=15)" in out
+    rc, out, _ = run([SLAM, "--help"])
+    assert rc == 0 and "--iters_between_kfs arg (=700)" in out and "--n_iters" not in out
+
+
+def test_argument_errors():
+    rc, _, err = run([BA])
+    assert rc == 1 and "--bal_file" in err
+    rc, _, err = run([BA, "--bal_file", "/nonexistent/file.txt"])
+    assert rc == 1 and "ERROR: unable to open file /nonexistent/file.txt" in err      # ba.cpp:484-487
+    rc, _, err = run([BA, "--bal_file", seq_path("fr2robot2"), "--bogus", "1"])
+    assert rc == 1 and "bogus" in err
+    rc, _, err = run([BA, "--bal_file", seq_path("fr2robot2"), "--n_iters", "abc"])
+    assert rc == 1
+
+
+def test_no_device_is_a_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    rc, out, _ = run([BA, "--bal_file", seq_path("fr2robot2"), "--n_iters", "2"])
+    assert rc != 0 and "Could not find a device" in out                               # ba.cpp:652-655
+
+
+LINE = re.compile(r"Iter (\d+) // Reprojection error (\S+) // Cost (\S+) // n relins: (\d+) // n robust edges (\d+)")
+
+
+@pytest.mark.gpu
+def test_ba_run_matches_oracle(oracle_mod, oracle_host):
+    from gbp_poplar_amd import driver
+    rc, out, err = run([BA, "--bal_file", seq_path("fr2robot2"), "--n_iters", "12"])
+    assert rc == 0, err
+    init = re.search(r"Initial Reprojection error: (\S+) Cost (\S+)", out)
+    rows = [m.groups() for m in LINE.finditer(out)]
+    assert init and len(rows) == 12 and out.count("Weakening priors") == 5 and " Finished GBP." in out
+    bal = oracle_host.bal_read(seq_path("fr2robot2"))
+    opts = driver.Options()
+    K, state, _ = driver.build_inputs(bal, opts, oracle_host)
+    o = oracle_mod.Oracle(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K)
+    traj = driver.run_ba(o, state, opts, n_iters=12)
+    assert abs(float(init.group(1)) - traj[0][1]) <= 2e-5 * traj[0][1]               # printed with 6 significant digits
+    for (it, m, c, nr, nb), (i, mean, cost, n_relin, n_robust) in zip(rows, traj[1:]):
+        assert int(it) == i
+        assert abs(float(m) - mean) <= (2e-5 if i < 6 else 1e-3) * mean, (i, m, mean)
+        assert int(nr) == n_relin and abs(int(nb) - n_robust) <= (0 if i < 6 else 3)
+
+
+@pytest.mark.gpu
+def test_slam_run_matches_oracle(oracle_mod, oracle_host):
+    """./slam with 8 iterations per keyframe on fr2robot2 (20 keyframes -> 151 iterations)."""
+    from gbp_poplar_amd import driver
+    rc, out, err = run([SLAM, "--bal_file", seq_path("fr2robot2"), "--iters_between_kfs", "8"])
+    assert rc == 0, err
+    rows = re.findall(r"Iters (\d+) \(since last kf (\d+)\) // Reprojection error (\S+) // Cost (\S+)", out)
+    assert len(rows) == 19 * 8 - 1 and out.count("Adding keyframe") == 18
+    bal = oracle_host.bal_read(seq_path("fr2robot2"))
+    opts = driver.Options()
+    K, state, extra = driver.build_inputs(bal, opts, oracle_host, slam=True)
+    o = oracle_mod.Oracle(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K)
+    traj = driver.run_slam(o, oracle_host, bal, state, extra, opts, iters_between_kfs=8)
+    init = re.search(r"Initial Reprojection error: (\S+) Cost (\S+)", out)
+    assert abs(float(init.group(1)) - traj[0][1]) <= 2e-5 * traj[0][1]
+    assert abs(traj[0][1] - 32.752624) < 1e-4                                         # SLAM initial, 2 keyframes
+    for k, ((tot, since, m, c), (i, mean, *_)) in enumerate(zip(rows, traj[1:])):
+        assert int(since) == i % 8 if i >= 7 else int(since) == i
+        assert abs(float(m) - mean) <= 5e-3 * mean + 1e-4, (i, m, mean)              # no relinearisation in 8-iteration windows
