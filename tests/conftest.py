@@ -4,6 +4,20 @@ import sys
 import numpy as np
 import pytest
 
+def _effective_cores():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p) + 0.5)))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+# the oracle's OpenMP loops: never oversubscribe a CPU-quota'd container (the GPU box shows 256 CPUs, quota 16)
+os.environ.setdefault("OMP_NUM_THREADS", str(_effective_cores()))
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 SEQ = os.path.join(ROOT, "data", "sequences")
