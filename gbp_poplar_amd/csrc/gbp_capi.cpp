@@ -43,7 +43,8 @@ struct gbp_ctx {
   // device memory
   std::vector<DevBuf*> all;
   DevBuf idx, state, fac, cmsg, mu, lmsg, camb, camp, lmkb, lmkp, rowp, local, d_cam_row_ptr, d_lmk_ptr, cwf, lwf,
-      cscale, lscale, cam_mu, lmk_mu, dK, evalp, nonfinite;
+      cscale, lscale, cam_mu, lmk_mu, dK, evalp, hmu_c, hmu_l;
+  bool hoist = true;  // per-variable belief means (k_sweep<true>); false = literal per-factor mu/oldmu tensors
   void* send_dev = nullptr;
   void* recv_dev = nullptr;
   hipStream_t own_stream = nullptr, stream = nullptr;
@@ -88,6 +89,7 @@ SweepArgs sweep_args(gbp_ctx* c) {
   a.idx = P<int4>(c->idx); a.state = P<float4>(c->state); a.fac = P<float4>(c->fac); a.cmsg = P<float4>(c->cmsg);
   a.mu = P<float4>(c->mu); a.lmsg = P<float4>(c->lmsg); a.camb = P<float4>(c->camb); a.lmkb = P<float4>(c->lmkb);
   a.rowp = P<float4>(c->rowp);
+  a.cam_mu = P<float4>(c->hmu_c); a.lmk_mu = P<float4>(c->hmu_l);
   std::memcpy(a.K, c->K, sizeof(a.K));
   a.hp.maxeta_damping = c->prm.maxeta_damping; a.hp.num_undamped_iters = c->prm.num_undamped_iters;
   a.hp.dmu_threshold = c->prm.dmu_threshold; a.hp.min_linear_iters = c->prm.min_linear_iters;
@@ -101,27 +103,46 @@ void drop_graph(gbp_ctx* c) {
   c->graph_iters = 0;
 }
 
-// camera beliefs from stored partials (single GPU: d_local; multi: recv_dev) + landmark beliefs re-summed
-int refresh_beliefs_from_partials(gbp_ctx* c) {
+BeliefArgs belief_args(gbp_ctx* c) {
+  BeliefArgs b{};
+  b.rowp = P<float>(c->rowp); b.cam_row_ptr = P<uint32_t>(c->d_cam_row_ptr); b.cam_prior = P<float>(c->camp);
+  b.cam_local = P<float>(c->local); b.gathered = nullptr; b.world = c->world;
+  b.camb = P<float>(c->camb); b.cam_mu = P<float4>(c->hmu_c); b.n_cams = c->C;
+  b.lmk_prior = P<float4>(c->lmkp); b.lmsg = P<float4>(c->lmsg); b.lmk_ptr = P<uint32_t>(c->d_lmk_ptr);
+  b.lmkb = P<float4>(c->lmkb); b.lmk_mu = P<float4>(c->hmu_l); b.n_lmks = c->L_loc;
+  b.partial_only = 0; b.hoist = c->hoist ? 1 : 0; b.roll = 0;
+  return b;
+}
+
+// camera beliefs from stored partials (single GPU: d_local; multi: recv_dev) + landmark beliefs re-summed.
+// roll = true at the end of an iteration (the sweep has consumed the current means), false for
+// prior-only refreshes (WEAKEN_PRIORS, NEW_KEYFRAME, LINEARISE).
+int refresh_beliefs_from_partials(gbp_ctx* c, bool roll) {
+  BeliefArgs b = belief_args(c);
   if (c->world == 1) {
-    launch_cam_combine(P<float4>(c->camp), P<float4>(c->local), 1, P<float4>(c->camb), c->C, c->stream);
+    b.gathered = P<float>(c->local); b.world = 1;
   } else {
     if (!c->recv_dev) return fail(c, GBP_ERR_STATE, "exchange buffers not set");
-    launch_cam_combine(P<float4>(c->camp), static_cast<const float4*>(c->recv_dev), c->world, P<float4>(c->camb), c->C,
-                       c->stream);
+    b.gathered = static_cast<const float*>(c->recv_dev);
   }
-  launch_lmk_belief(P<float4>(c->lmkp), P<float4>(c->lmsg), P<uint32_t>(c->d_lmk_ptr), P<float4>(c->lmkb), c->L_loc,
-                    c->stream);
+  b.roll = roll ? 1 : 0;
+  launch_beliefs(b, true, true, c->stream);
   HIPCHK(c, hipGetLastError());
   return GBP_OK;
 }
 
 void enqueue_iteration(gbp_ctx* c, const SweepArgs& a) {
-  launch_sweep(a, c->n_tiles, c->stream);
-  launch_cam_reduce(P<float4>(c->rowp), P<uint32_t>(c->d_cam_row_ptr), P<float4>(c->camp), P<float4>(c->local),
-                    P<float4>(c->camb), c->C, c->stream);
-  launch_lmk_belief(P<float4>(c->lmkp), P<float4>(c->lmsg), P<uint32_t>(c->d_lmk_ptr), P<float4>(c->lmkb), c->L_loc,
-                    c->stream);
+  launch_sweep(a, c->n_tiles, c->hoist, c->stream);
+  BeliefArgs b = belief_args(c);
+  b.roll = 1;
+  launch_beliefs(b, true, true, c->stream);
+}
+
+// local camera partials only (before an exchange / before a prior-only refresh)
+void enqueue_cam_partials(gbp_ctx* c, float* dst) {
+  BeliefArgs b = belief_args(c);
+  b.cam_local = dst; b.partial_only = 1;
+  launch_beliefs(b, true, false, c->stream);
 }
 
 void pack_cam(const float* eta, const float* lam, uint32_t C, std::vector<float>& out) {
@@ -181,6 +202,7 @@ int gbp_create(const gbp_problem* pr, const gbp_params* prm, const gbp_shard* sh
   std::memcpy(c->K, pr->K, sizeof(c->K));
   if (prm) c->prm = *prm; else gbp_default_params(&c->prm);
   if (c->prm.graph_unroll <= 0) c->prm.graph_unroll = 10;
+  c->hoist = c->prm.per_factor_mu == 0;
   c->rank = sh ? sh->rank : 0;
   c->world = sh ? sh->world : 1;
   c->lmk_begin = sh ? sh->lmk_begin : 0;
@@ -239,7 +261,8 @@ int gbp_create(const gbp_problem* pr, const gbp_params* prm, const gbp_shard* sh
   A(c->d_cam_row_ptr, (size_t)(C + 1) * 4); A(c->d_lmk_ptr, (size_t)(c->L_loc + 1) * 4);
   A(c->cwf, (size_t)C * 4); A(c->lwf, (size_t)c->L_loc * 4); A(c->cscale, (size_t)C * 4); A(c->lscale, (size_t)c->L_loc * 4);
   A(c->cam_mu, (size_t)C * 6 * 4); A(c->lmk_mu, (size_t)c->L_loc * 3 * 4); A(c->dK, 16 * 4);
-  A(c->evalp, sizeof(DeviceEval) * 1024); A(c->nonfinite, 16);
+  A(c->evalp, sizeof(DeviceEval) * 1024);
+  A(c->hmu_c, (size_t)C * 4 * 16); A(c->hmu_l, (size_t)c->L_loc * 2 * 16);
   if (rc != GBP_OK) { g_create_error = c->err; gbp_destroy(c); return rc; }
   auto CK = [&](hipError_t e, const char* what) {
     if (e != hipSuccess && rc == GBP_OK) { g_create_error = std::string(what) + ": " + hipGetErrorString(e); rc = GBP_ERR_HIP; }
@@ -292,6 +315,13 @@ int gbp_upload(gbp_ctx* c, const gbp_state_in* in) {
     return fail(c, GBP_ERR_INVALID, "gbp_upload: priors, measurements, meas_variances and active_flag are required");
   if (in->mu && in->oldmu && std::memcmp(in->mu, in->oldmu, (size_t)c->E * 9 * 4) != 0)
     return fail(c, GBP_ERR_INVALID, "gbp_upload: mu != oldmu is not supported (the reference uploads zeros for both, ba.cpp:582-583)");
+  if (c->hoist) {
+    const float* om = in->oldmu ? in->oldmu : in->mu;
+    if (om)
+      for (size_t i = 0; i < (size_t)c->E * 9; ++i)
+        if (om[i] != 0.f)
+          return fail(c, GBP_ERR_INVALID, "gbp_upload: non-zero oldmu needs gbp_params.per_factor_mu = 1 (the reference uploads zeros, ba.cpp:582-583)");
+  }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const size_t Ep = c->Ep;
   std::vector<float> st(Ep * 4, 0.f), fac(Ep * kFacG * 4, 0.f), mu(Ep * kMuG * 4, 0.f);
@@ -322,6 +352,8 @@ int gbp_upload(gbp_ctx* c, const gbp_state_in* in) {
   HIPCHK(c, hipMemset(c->local.p, 0, c->local.bytes));
   HIPCHK(c, hipMemset(c->camb.p, 0, c->camb.bytes));
   HIPCHK(c, hipMemset(c->lmkb.p, 0, c->lmkb.bytes));
+  HIPCHK(c, hipMemset(c->hmu_c.p, 0, c->hmu_c.bytes));
+  HIPCHK(c, hipMemset(c->hmu_l.p, 0, c->hmu_l.bytes));
   std::vector<float> rec;
   pack_cam(in->cam_priors_eta, in->cam_priors_lambda, c->C, rec);
   HIPCHK(c, hipMemcpy(c->camp.p, rec.data(), rec.size() * 4, hipMemcpyHostToDevice));
@@ -345,14 +377,14 @@ int gbp_refresh_begin(gbp_ctx* c) {
   if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "upload first");
   float4* dst = c->world > 1 ? static_cast<float4*>(c->send_dev) : P<float4>(c->local);
   if (!dst) return fail(c, GBP_ERR_STATE, "exchange buffers not set");
-  launch_cam_reduce(P<float4>(c->rowp), P<uint32_t>(c->d_cam_row_ptr), P<float4>(c->camp), dst, nullptr, c->C, c->stream);
+  enqueue_cam_partials(c, reinterpret_cast<float*>(dst));
   HIPCHK(c, hipGetLastError());
   return GBP_OK;
 }
 
 int gbp_refresh_end(gbp_ctx* c) {
   if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "upload first");
-  const int rc = refresh_beliefs_from_partials(c);
+  const int rc = refresh_beliefs_from_partials(c, false);
   if (rc == GBP_OK) c->beliefs_valid = true;
   return rc;
 }
@@ -378,13 +410,18 @@ int gbp_iterate_begin(gbp_ctx* c) {
   if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "upload first");
   float4* dst = c->world > 1 ? static_cast<float4*>(c->send_dev) : P<float4>(c->local);
   if (!dst) return fail(c, GBP_ERR_STATE, "exchange buffers not set");
-  launch_sweep(sweep_args(c), c->n_tiles, c->stream);
-  launch_cam_reduce(P<float4>(c->rowp), P<uint32_t>(c->d_cam_row_ptr), P<float4>(c->camp), dst, nullptr, c->C, c->stream);
+  launch_sweep(sweep_args(c), c->n_tiles, c->hoist, c->stream);
+  enqueue_cam_partials(c, reinterpret_cast<float*>(dst));
   HIPCHK(c, hipGetLastError());
   return GBP_OK;
 }
 
-int gbp_iterate_end(gbp_ctx* c) { return gbp_refresh_end(c); }
+int gbp_iterate_end(gbp_ctx* c) {
+  if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "upload first");
+  const int rc = refresh_beliefs_from_partials(c, true);
+  if (rc == GBP_OK) c->beliefs_valid = true;
+  return rc;
+}
 
 // GBP_PROG x n (ba.cpp:895-905) on one GPU: replay of a captured hipGraph of `graph_unroll`
 // iterations, remainder launched directly.
@@ -397,12 +434,13 @@ int gbp_iterate(gbp_ctx* c, int n) {
   if (c->profile_stages) {
     for (int i = 0; i < n; ++i) {
       HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-      launch_sweep(a, c->n_tiles, c->stream);
+      launch_sweep(a, c->n_tiles, c->hoist, c->stream);
       HIPCHK(c, hipEventRecord(c->ev2, c->stream));
-      launch_cam_reduce(P<float4>(c->rowp), P<uint32_t>(c->d_cam_row_ptr), P<float4>(c->camp), P<float4>(c->local),
-                        P<float4>(c->camb), c->C, c->stream);
-      launch_lmk_belief(P<float4>(c->lmkp), P<float4>(c->lmsg), P<uint32_t>(c->d_lmk_ptr), P<float4>(c->lmkb), c->L_loc,
-                        c->stream);
+      {
+        BeliefArgs b = belief_args(c);
+        b.roll = 1;
+        launch_beliefs(b, true, true, c->stream);
+      }
       HIPCHK(c, hipEventRecord(c->ev3, c->stream));
       HIPCHK(c, hipEventSynchronize(c->ev3));
       float a_ms = 0, b_ms = 0;
@@ -445,7 +483,7 @@ int gbp_weaken_priors(gbp_ctx* c) {
   launch_weaken(P<float4>(c->camp), P<float>(c->cscale), P<uint32_t>(c->cwf), c->C, kCamRec4, c->stream);
   if (c->L_loc) launch_weaken(P<float4>(c->lmkp), P<float>(c->lscale), P<uint32_t>(c->lwf), c->L_loc, kLmkRec4, c->stream);
   HIPCHK(c, hipGetLastError());
-  return refresh_beliefs_from_partials(c);
+  return refresh_beliefs_from_partials(c, false);
 }
 
 // READ_PROG (ba.cpp:908-916)
@@ -537,7 +575,7 @@ int gbp_new_keyframe(gbp_ctx* c, const gbp_kf_update* u) {
   if (u->cam_weaken_flag) HIPCHK(c, hipMemcpy(c->cwf.p, u->cam_weaken_flag, (size_t)c->C * 4, hipMemcpyHostToDevice));
   if (u->lmk_weaken_flag && c->L_loc)
     HIPCHK(c, hipMemcpy(c->lwf.p, u->lmk_weaken_flag + c->lmk_begin, (size_t)c->L_loc * 4, hipMemcpyHostToDevice));
-  return refresh_beliefs_from_partials(c);
+  return refresh_beliefs_from_partials(c, false);
 }
 
 // eval_reprojection_error (util.cpp:74-144) + counters (ba.cpp:1011-1020) over the local shard
@@ -635,6 +673,22 @@ int gbp_debug_get(gbp_ctx* c, int what, float* a, float* b) {
       const float* r = &f[(size_t)c->pos_lpos[p] * 16];
       for (int i = 0; i < 3; ++i) a[(size_t)e * 3 + i] = r[i];
       for (int i = 0; i < 9; ++i) b[(size_t)e * 9 + i] = r[4 + i];
+    }
+  } else if (what == 3 && c->hoist) {
+    // hoisted mode: mu of a factor = the per-variable means its last sweep used; dmu is not kept per factor
+    std::vector<float> mc((size_t)c->C * 16), ml((size_t)c->L_loc * 8);
+    HIPCHK(c, hipMemcpy(mc.data(), c->hmu_c.p, mc.size() * 4, hipMemcpyDeviceToHost));
+    if (c->L_loc) HIPCHK(c, hipMemcpy(ml.data(), c->hmu_l.p, ml.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<float> st((size_t)c->Ep * 4);
+    HIPCHK(c, hipMemcpy(st.data(), c->state.p, st.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t p = 0; p < c->Ep; ++p) {
+      const uint32_t e = c->pos_edge[p];
+      if (e == ~0u) continue;
+      uint32_t flags; std::memcpy(&flags, &st[4 * p + 2], 4);
+      if (!(flags & kFlagActive)) continue;  // inactive factors never update mu (gbp_codelets.cpp:242)
+      for (int i = 0; i < 6; ++i) a[(size_t)e * 9 + i] = mc[(size_t)c->pos_cam[p] * 16 + 8 + i];
+      for (int i = 0; i < 3; ++i) a[(size_t)e * 9 + 6 + i] = ml[(size_t)c->pos_lmk_loc[p] * 8 + 4 + i];
+      b[e] = 0.f;
     }
   } else if (what == 3) {
     std::vector<float> f((size_t)c->Ep * kMuG * 4);

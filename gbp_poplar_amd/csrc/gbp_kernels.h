@@ -57,8 +57,26 @@ struct SweepArgs {
   const float4* camb;
   const float4* lmkb;
   float4* rowp;
+  const float4* cam_mu;   // [C][4]: hoisted camera means (current x2 float4, used-by-last-sweep x2)
+  const float4* lmk_mu;   // [L][2]
   float K[9];
   Hyper hp;
+};
+
+struct BeliefArgs {
+  // camera part
+  const float* rowp; const uint32_t* cam_row_ptr; const float* cam_prior;
+  float* cam_local;          // [C][44] local row sums (kept for prior-only refreshes / the exchange buffer)
+  const float* gathered;     // != nullptr: belief = prior + sum_r gathered[r] instead of the row sums
+  int world;
+  float* camb; float4* cam_mu; uint32_t n_cams;
+  // landmark part
+  const float4* lmk_prior; const float4* lmsg; const uint32_t* lmk_ptr; float4* lmkb; float4* lmk_mu; uint32_t n_lmks;
+  // control
+  uint32_t cam_blocks;
+  int partial_only;          // camera part writes cam_local only (multi-GPU: before the exchange)
+  int hoist;                 // compute per-variable means + dmu^2 pieces
+  int roll;                  // end of an iteration: "means used by the last sweep" := current means, then recompute
 };
 
 struct DeviceEval {  // per-block partials, summed on the host in block order
@@ -66,18 +84,9 @@ struct DeviceEval {  // per-block partials, summed on the host in block order
   unsigned long long n_active, n_relin, n_robust, pad;
 };
 
-void launch_sweep(const SweepArgs& a, uint32_t n_tiles, hipStream_t s);
+void launch_sweep(const SweepArgs& a, uint32_t n_tiles, bool hoist, hipStream_t s);
 void launch_linearise(const SweepArgs& a, uint32_t n_tiles, hipStream_t s);
-// local[c] = sum of camera c's row partials (rows left to right); belief[c] = prior[c] + local[c]
-// when `belief` != nullptr (single GPU), else only `local` is written (multi-GPU send buffer).
-void launch_cam_reduce(const float4* rowp, const uint32_t* cam_row_ptr, const float4* prior, float4* local,
-                       float4* belief, uint32_t n_cams, hipStream_t s);
-// belief[c] = prior[c] + gathered[0][c] + ... + gathered[world-1][c]
-void launch_cam_combine(const float4* prior, const float4* gathered, int world, float4* belief, uint32_t n_cams,
-                        hipStream_t s);
-// belief[l] = prior[l] + msg[ptr[l]] + ... (slot order)
-void launch_lmk_belief(const float4* prior, const float4* lmsg, const uint32_t* lmk_ptr, float4* belief,
-                       uint32_t n_lmks, hipStream_t s);
+void launch_beliefs(BeliefArgs b, bool do_cam, bool do_lmk, hipStream_t s);
 void launch_weaken(float4* prior, const float* scaling, uint32_t* flag, uint32_t n, int rec4, hipStream_t s);
 void launch_means(const float4* camb, const float4* lmkb, float* cam_mu, float* lmk_mu, uint32_t n_cams,
                   uint32_t n_lmks, hipStream_t s);

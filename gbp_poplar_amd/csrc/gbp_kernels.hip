@@ -162,6 +162,14 @@ GBP_DEV bool relin_core(float (&fac)[56], const float (&x0c)[6], const float (&x
 // =================================================================================================
 // k_sweep: one lane = one factor.
 // =================================================================================================
+// HOIST = true: the belief means are per-VARIABLE quantities (inf2mean of the camera / landmark belief,
+// gbp_codelets.cpp:264-265) that the reference recomputes in every incident factor.  The belief kernels
+// compute them once per variable; dmu^2 = ((((((0+t0)+..+t5) + u0) + u1) + u2) splits into a per-camera
+// prefix S_c (CAMB slot 6) and three per-landmark terms u (LMKB slots 3,13,14), evaluated with the same
+// fp32 operations in the same order, so the result is bit-identical while the per-factor MU stream and
+// two of the five small inverses disappear from the sweep.  HOIST = false keeps the literal per-factor
+// mu/oldmu tensors (needed only if a caller uploads non-zero oldmu).
+template <bool HOIST>
 __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
   const uint32_t p = blockIdx.x * 256 + threadIdx.x;
   const uint32_t tile = p >> 6, lane = p & 63;
@@ -178,7 +186,7 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
   float fac[56], cm[28], mu[12], lm[16], cb[44], lb[16];
   load_tile<kFacG>(a.fac, tile, lane, fac);
   load_tile<kCmsgG>(a.cmsg, tile, lane, cm);
-  load_tile<kMuG>(a.mu, tile, lane, mu);
+  if (!HOIST) load_tile<kMuG>(a.mu, tile, lane, mu);
   load_rec<kLmkRec4>(a.lmsg + (size_t)(uint32_t)ix.z * kLmkRec4, lm);
   load_rec<kCamRec4>(a.camb + (size_t)(uint32_t)ix.x * kCamRec4, cb);
   load_rec<kLmkRec4>(a.lmkb + (size_t)(uint32_t)ix.y * kLmkRec4, lb);
@@ -201,22 +209,36 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
     if (0 == count) damping = a.hp.maxeta_damping;
     count += 1;
     float x0c[6], x0l[3];
-    belief_means(cb, lb, x0c, x0l);
-    float d2 = 0.f;
-    GBP_UNROLL
-    for (int i = 0; i < 6; ++i) {
-      d2 += (mu[i] - x0c[i]) * (mu[i] - x0c[i]);
-      mu[i] = x0c[i];
-    }
-    GBP_UNROLL
-    for (int i = 0; i < 3; ++i) {
-      d2 += (mu[6 + i] - x0l[i]) * (mu[6 + i] - x0l[i]);
-      mu[6 + i] = x0l[i];
+    float d2;
+    if (HOIST) {
+      d2 = cb[6];
+      d2 += lb[3];
+      d2 += lb[13];
+      d2 += lb[14];
+    } else {
+      belief_means(cb, lb, x0c, x0l);
+      d2 = 0.f;
+      GBP_UNROLL
+      for (int i = 0; i < 6; ++i) {
+        d2 += (mu[i] - x0c[i]) * (mu[i] - x0c[i]);
+        mu[i] = x0c[i];
+      }
+      GBP_UNROLL
+      for (int i = 0; i < 3; ++i) {
+        d2 += (mu[6 + i] - x0l[i]) * (mu[6 + i] - x0l[i]);
+        mu[6 + i] = x0l[i];
+      }
     }
     const float dmu = sqrtf(d2);
     mu[9] = dmu;
     relin = (dmu < a.hp.dmu_threshold) && (count > a.hp.min_linear_iters - a.hp.num_undamped_iters);
     if (relin) {
+      if (HOIST) {  // linearisation point = the hoisted means (rare path: loaded only here)
+        const float4 m0 = a.cam_mu[(size_t)(uint32_t)ix.x * 4], m1 = a.cam_mu[(size_t)(uint32_t)ix.x * 4 + 1];
+        const float4 l0 = a.lmk_mu[(size_t)(uint32_t)ix.y * 2];
+        x0c[0] = m0.x; x0c[1] = m0.y; x0c[2] = m0.z; x0c[3] = m0.w; x0c[4] = m1.x; x0c[5] = m1.y;
+        x0l[0] = l0.x; x0l[1] = l0.y; x0l[2] = l0.z;
+      }
       damping = 0.f;
       count = -a.hp.num_undamped_iters;
       if (a.hp.relin_mode == 1) {
@@ -357,7 +379,7 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
     }
   }
   if (active) {
-    store_tile<kMuG>(a.mu, tile, lane, mu);
+    if (!HOIST) store_tile<kMuG>(a.mu, tile, lane, mu);
     a.state[p] = make_float4(damping, __int_as_float(count), __uint_as_float(flags), var);
     if (relin) store_tile<kFacG>(a.fac, tile, lane, fac);
   }
@@ -390,47 +412,143 @@ __global__ __launch_bounds__(256) void k_linearise(const SweepArgs a) {
 }
 
 // =================================================================================================
-// Belief kernels
+// k_beliefs: buildUpdateBeliefsProg (ba.cpp:104-139) in ONE launch.
+//   blocks [0, cam_blocks): camera part, one wavefront per camera (lanes 0..43 = the 44-float record);
+//   remaining blocks:       landmark part, four lanes per landmark (lane q = float4 #q of the record).
+// Camera beliefs: local = rows of this camera left to right (rows were tree-summed by k_sweep), then
+// belief = prior + local (single GPU) or prior + sum_r gathered[r] (after the all-gather, rank order).
+// Landmark beliefs: prior + messages in slot order.  With `hoist` the belief means (inf2mean, bafuncs.cpp:2-15)
+// and the dmu^2 pieces of the next sweep are computed here once per variable (see k_sweep<HOIST>).
 // =================================================================================================
-__global__ __launch_bounds__(256) void k_cam_reduce(const float* __restrict__ rowp, const uint32_t* __restrict__ cam_row_ptr,
-                                                    const float* __restrict__ prior, float* __restrict__ local,
-                                                    float* __restrict__ belief, uint32_t n_cams) {
-  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-  const uint32_t c = t / kCamRec, j = t - c * kCamRec;
-  if (c >= n_cams) return;
-  const uint32_t r0 = cam_row_ptr[c], r1 = cam_row_ptr[c + 1];
-  float acc = 0.f;
-  if (r1 > r0) {
-    acc = rowp[(size_t)r0 * kCamRec + j];
-    for (uint32_t r = r0 + 1; r < r1; ++r) acc = acc + rowp[(size_t)r * kCamRec + j];
+GBP_DEV void cam_mean(const float (&cb)[44], float (&x0c)[6]) {
+  float Al[21], S6[36];
+  GBP_UNROLL
+  for (int i = 0; i < 6; ++i) {
+    GBP_UNROLL
+    for (int j = 0; j <= i; ++j) Al[tri(i, j)] = cb[8 + i * 6 + j];
   }
-  local[(size_t)c * kCamRec + j] = acc;
-  if (belief) belief[(size_t)c * kCamRec + j] = prior[(size_t)c * kCamRec + j] + acc;
+  inv6x6_lower(Al, S6);
+  GBP_UNROLL
+  for (int i = 0; i < 6; ++i) {
+    float acc = 0.f;
+    GBP_UNROLL
+    for (int k = 0; k < 6; ++k) acc += S6[i * 6 + k] * cb[k];
+    x0c[i] = acc;
+  }
 }
 
-__global__ __launch_bounds__(256) void k_cam_combine(const float* __restrict__ prior, const float* __restrict__ gathered,
-                                                     int world, float* __restrict__ belief, uint32_t n) {
-  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= n) return;
-  float acc = prior[t];
-  for (int r = 0; r < world; ++r) acc = acc + gathered[(size_t)r * n + t];
-  belief[t] = acc;
-}
-
-// four lanes per landmark, lane q owns float4 #q of the 16-float record
-__global__ __launch_bounds__(256) void k_lmk_belief(const float4* __restrict__ prior, const float4* __restrict__ lmsg,
-                                                    const uint32_t* __restrict__ lmk_ptr, float4* __restrict__ belief,
-                                                    uint32_t n_lmks) {
-  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void k_beliefs(const BeliefArgs b) {
+  __shared__ float sh[4][48];
+  if (blockIdx.x < b.cam_blocks) {
+    const uint32_t w = threadIdx.x >> 6, j = threadIdx.x & 63;
+    const uint32_t c = blockIdx.x * 4 + w;
+    const bool live = c < b.n_cams && j < (uint32_t)kCamRec;
+    float bel = 0.f;
+    if (live) {
+      if (b.gathered) {
+        float acc = b.cam_prior[(size_t)c * kCamRec + j];
+        const size_t n = (size_t)b.n_cams * kCamRec;
+        for (int r = 0; r < b.world; ++r) acc = acc + b.gathered[(size_t)r * n + (size_t)c * kCamRec + j];
+        bel = acc;
+      } else {
+        const uint32_t r0 = b.cam_row_ptr[c], r1 = b.cam_row_ptr[c + 1];
+        float acc = 0.f;
+        if (r1 > r0) {
+          const float* row = b.rowp + (size_t)r0 * kCamRec + j;
+          acc = row[0];
+          uint32_t r = 1;
+          const uint32_t n = r1 - r0;
+          for (; r + 8 <= n; r += 8) {  // loads of 8 rows in flight, adds in row order
+            float v[8];
+            GBP_UNROLL
+            for (int k = 0; k < 8; ++k) v[k] = row[(size_t)(r + k) * kCamRec];
+            GBP_UNROLL
+            for (int k = 0; k < 8; ++k) acc = acc + v[k];
+          }
+          for (; r < n; ++r) acc = acc + row[(size_t)r * kCamRec];
+        }
+        b.cam_local[(size_t)c * kCamRec + j] = acc;
+        bel = b.cam_prior[(size_t)c * kCamRec + j] + acc;
+      }
+      sh[w][j] = bel;
+    }
+    if (b.partial_only) return;
+    __syncthreads();
+    if (b.hoist && live && j == 0) {
+      float cb[44], x0c[6];
+      GBP_UNROLL
+      for (int i = 0; i < 44; ++i) cb[i] = sh[w][i];
+      cam_mean(cb, x0c);
+      float4* mu = b.cam_mu + (size_t)c * 4;  // [0,1] = means of the current belief, [2,3] = means the last sweep used
+      float4 u0 = mu[2], u1 = mu[3];
+      if (b.roll) { u0 = mu[0]; u1 = mu[1]; mu[2] = u0; mu[3] = u1; }
+      const float used[6] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y};
+      float S = 0.f;
+      GBP_UNROLL
+      for (int i = 0; i < 6; ++i) S += (used[i] - x0c[i]) * (used[i] - x0c[i]);
+      mu[0] = make_float4(x0c[0], x0c[1], x0c[2], x0c[3]);
+      mu[1] = make_float4(x0c[4], x0c[5], 0.f, 0.f);
+      sh[w][6] = S;
+    }
+    __syncthreads();
+    if (live) b.camb[(size_t)c * kCamRec + j] = sh[w][j];
+    return;
+  }
+  // ---- landmark part ----
+  const uint32_t t = (blockIdx.x - b.cam_blocks) * 256 + threadIdx.x;
   const uint32_t l = t >> 2, q = t & 3;
-  if (l >= n_lmks) return;
-  float4 acc = prior[(size_t)l * 4 + q];
-  const uint32_t s0 = lmk_ptr[l], s1 = lmk_ptr[l + 1];
-  for (uint32_t s = s0; s < s1; ++s) {
-    const float4 m = lmsg[(size_t)s * 4 + q];
-    acc.x = acc.x + m.x; acc.y = acc.y + m.y; acc.z = acc.z + m.z; acc.w = acc.w + m.w;
+  const bool live = l < b.n_lmks;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (live) {
+    acc = b.lmk_prior[(size_t)l * 4 + q];
+    const uint32_t s0 = b.lmk_ptr[l], s1 = b.lmk_ptr[l + 1];
+    uint32_t s = s0;
+    for (; s + 4 <= s1; s += 4) {
+      float4 m[4];
+      GBP_UNROLL
+      for (int k = 0; k < 4; ++k) m[k] = b.lmsg[(size_t)(s + k) * 4 + q];
+      GBP_UNROLL
+      for (int k = 0; k < 4; ++k) { acc.x = acc.x + m[k].x; acc.y = acc.y + m[k].y; acc.z = acc.z + m[k].z; acc.w = acc.w + m[k].w; }
+    }
+    for (; s < s1; ++s) {
+      const float4 m = b.lmsg[(size_t)s * 4 + q];
+      acc.x = acc.x + m.x; acc.y = acc.y + m.y; acc.z = acc.z + m.z; acc.w = acc.w + m.w;
+    }
   }
-  belief[(size_t)l * 4 + q] = acc;
+  if (b.hoist) {
+    // gather the 16-float record of the quad into its lane 0 (all lanes execute the shuffles)
+    float rec[16];
+    GBP_UNROLL
+    for (int k = 0; k < 4; ++k) {
+      rec[4 * k] = __shfl(acc.x, k, 4); rec[4 * k + 1] = __shfl(acc.y, k, 4);
+      rec[4 * k + 2] = __shfl(acc.z, k, 4); rec[4 * k + 3] = __shfl(acc.w, k, 4);
+    }
+    float u[3] = {0.f, 0.f, 0.f};
+    if (live && q == 0) {
+      float B[9], S3[9], x0l[3];
+      GBP_UNROLL
+      for (int i = 0; i < 9; ++i) B[i] = rec[4 + i];
+      inv3x3(B, S3);
+      GBP_UNROLL
+      for (int i = 0; i < 3; ++i) {
+        float a2 = 0.f;
+        GBP_UNROLL
+        for (int k = 0; k < 3; ++k) a2 += S3[i * 3 + k] * rec[k];
+        x0l[i] = a2;
+      }
+      float4* mu = b.lmk_mu + (size_t)l * 2;  // [0] = mean of the current belief, [1] = mean the last sweep used
+      float4 used = mu[1];
+      if (b.roll) { used = mu[0]; mu[1] = used; }
+      u[0] = (used.x - x0l[0]) * (used.x - x0l[0]);
+      u[1] = (used.y - x0l[1]) * (used.y - x0l[1]);
+      u[2] = (used.z - x0l[2]) * (used.z - x0l[2]);
+      mu[0] = make_float4(x0l[0], x0l[1], x0l[2], 0.f);
+    }
+    const float u0 = __shfl(u[0], 0, 4), u1 = __shfl(u[1], 0, 4), u2 = __shfl(u[2], 0, 4);
+    if (q == 0) acc.w = u0;                       // record slot 3
+    if (q == 3) { acc.y = u1; acc.z = u2; }       // record slots 13, 14
+  }
+  if (live) b.lmkb[(size_t)l * 4 + q] = acc;
 }
 
 // WeakenPriorVertex: one lane per float4 of a prior record; lane q == 0 updates the flag
@@ -581,27 +699,18 @@ __global__ __launch_bounds__(256) void k_eval(const int4* __restrict__ idx, cons
 // =================================================================================================
 static inline uint32_t blocks_for(uint64_t threads) { return (uint32_t)((threads + 255) / 256); }
 
-void launch_sweep(const SweepArgs& a, uint32_t n_tiles, hipStream_t s) {
-  hipLaunchKernelGGL(k_sweep, dim3(n_tiles / 4), dim3(256), 0, s, a);
+void launch_sweep(const SweepArgs& a, uint32_t n_tiles, bool hoist, hipStream_t s) {
+  if (hoist) hipLaunchKernelGGL(k_sweep<true>, dim3(n_tiles / 4), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(k_sweep<false>, dim3(n_tiles / 4), dim3(256), 0, s, a);
 }
 void launch_linearise(const SweepArgs& a, uint32_t n_tiles, hipStream_t s) {
   hipLaunchKernelGGL(k_linearise, dim3(n_tiles / 4), dim3(256), 0, s, a);
 }
-void launch_cam_reduce(const float4* rowp, const uint32_t* cam_row_ptr, const float4* prior, float4* local, float4* belief,
-                       uint32_t n_cams, hipStream_t s) {
-  hipLaunchKernelGGL(k_cam_reduce, dim3(blocks_for((uint64_t)n_cams * kCamRec)), dim3(256), 0, s, (const float*)rowp,
-                     cam_row_ptr, (const float*)prior, (float*)local, (float*)belief, n_cams);
-}
-void launch_cam_combine(const float4* prior, const float4* gathered, int world, float4* belief, uint32_t n_cams,
-                        hipStream_t s) {
-  const uint32_t n = n_cams * kCamRec;
-  hipLaunchKernelGGL(k_cam_combine, dim3(blocks_for(n)), dim3(256), 0, s, (const float*)prior, (const float*)gathered,
-                     world, (float*)belief, n);
-}
-void launch_lmk_belief(const float4* prior, const float4* lmsg, const uint32_t* lmk_ptr, float4* belief, uint32_t n_lmks,
-                       hipStream_t s) {
-  hipLaunchKernelGGL(k_lmk_belief, dim3(blocks_for((uint64_t)n_lmks * 4)), dim3(256), 0, s, prior, lmsg, lmk_ptr, belief,
-                     n_lmks);
+void launch_beliefs(BeliefArgs b, bool do_cam, bool do_lmk, hipStream_t s) {
+  b.cam_blocks = do_cam ? (b.n_cams + 3) / 4 : 0;
+  const uint32_t lmk_blocks = do_lmk ? blocks_for((uint64_t)b.n_lmks * 4) : 0;
+  if (b.cam_blocks + lmk_blocks == 0) return;
+  hipLaunchKernelGGL(k_beliefs, dim3(b.cam_blocks + lmk_blocks), dim3(256), 0, s, b);
 }
 void launch_weaken(float4* prior, const float* scaling, uint32_t* flag, uint32_t n, int rec4, hipStream_t s) {
   hipLaunchKernelGGL(k_weaken, dim3(blocks_for((uint64_t)n * rec4)), dim3(256), 0, s, prior, scaling, flag, n, rec4);

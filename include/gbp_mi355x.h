@@ -59,7 +59,11 @@ typedef struct {
                                   and PrepMessageVertex does not zero, gbp_codelets.cpp:285-336);
                                   1 = reset (zero first)                                          */
   int32_t graph_unroll;        /* GBP iterations captured per hipGraph (>=1); 0 = library default */
-  int32_t reserved[5];
+  int32_t per_factor_mu;       /* 0 (default): belief means are computed once per variable (bit-identical
+                                  to the per-factor recomputation of gbp_codelets.cpp:264-277, requires the
+                                  uploaded mu/oldmu to be zero as in ba.cpp:582-583); 1: keep the literal
+                                  per-factor mu/oldmu tensors                                            */
+  int32_t reserved[4];
 } gbp_params;
 
 /* Landmark shard of a multi-GPU run (one process per GPU).  The global problem is passed to

@@ -15,12 +15,13 @@ from tests.conftest import per_var_rel, rel_err, seq_path, small_synth
 pytestmark = pytest.mark.gpu
 
 
-def _setup(bal, oracle_mod, slam=False, sum_order=1):
-    from gbp_poplar_amd import driver, hostlib
+def _setup(bal, oracle_mod, slam=False, sum_order=1, per_factor_mu=0):
+    from gbp_poplar_amd import _cabi, driver, hostlib
     from gbp_poplar_amd.engine import GbpEngine
     opts = driver.Options()
     K, state, extra = driver.build_inputs(bal, opts, hostlib, slam=slam)
-    eng = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K)
+    eng = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K,
+                    params=_cabi.GbpParams.defaults(per_factor_mu=per_factor_mu))
     orc = oracle_mod.Oracle(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K)
     orc.set_sum_order(sum_order)
     eng.upload(state)
@@ -74,10 +75,12 @@ def test_linearise_parity(name, oracle_mod):
     assert per_var_rel(gl, ol, 81) <= 1e-5
 
 
+@pytest.mark.parametrize("per_factor_mu", [0, 1])
 @pytest.mark.parametrize("name", ["fr2robot2", "fr1xyz"])
-def test_sweep_bit_exact_from_identical_state(name, oracle_mod):
-    """Prep + messages + beliefs: three sweeps with prior weakening, bit-for-bit (no relinearisation yet)."""
-    eng, orc, opts, *_ = _setup(_bal(name), oracle_mod, sum_order=1)
+def test_sweep_bit_exact_from_identical_state(name, per_factor_mu, oracle_mod):
+    """Prep + messages + beliefs: three sweeps with prior weakening, bit-for-bit (no relinearisation yet),
+    with the belief means hoisted per variable (default) and with the literal per-factor mu tensors."""
+    eng, orc, opts, *_ = _setup(_bal(name), oracle_mod, sum_order=1, per_factor_mu=per_factor_mu)
     eng.linearise()
     orc.linearise()
     _sync_potentials(eng, orc)
@@ -90,7 +93,9 @@ def test_sweep_bit_exact_from_identical_state(name, oracle_mod):
         _assert_state_equal(eng, orc, exact=True)
     gmu, gd = eng.mu()
     omu, od = orc.mu()
-    assert np.array_equal(gmu, omu) and np.array_equal(gd, od)
+    assert np.array_equal(gmu, omu)
+    if per_factor_mu:
+        assert np.array_equal(gd, od)          # dmu is kept per factor only in the literal mode
 
 
 def test_sweep_vs_slot_order_oracle(oracle_mod):
@@ -116,12 +121,13 @@ def _run_to_relin(eng, orc):
         orc.iterate(1)
 
 
-def test_relinearising_sweeps_bit_exact(oracle_mod):
+@pytest.mark.parametrize("per_factor_mu", [0, 1])
+def test_relinearising_sweeps_bit_exact(per_factor_mu, oracle_mod):
     """Sweeps 17..24 relinearise (count -15 -> 3).  With the oracle's trig in correctly-rounded mode
     (what the kernels compute) the whole state stays bit-for-bit equal through relinearisation."""
     oracle_mod.set_trig_mode(1)
     try:
-        eng, orc, opts, *_ = _setup(_bal("fr2robot2"), oracle_mod, sum_order=1)
+        eng, orc, opts, *_ = _setup(_bal("fr2robot2"), oracle_mod, sum_order=1, per_factor_mu=per_factor_mu)
         _run_to_relin(eng, orc)
         _assert_state_equal(eng, orc, exact=True)
         n_relin = 0
@@ -237,6 +243,50 @@ def test_synthetic_end_to_end(oracle_mod):
     o2 = orc2.read()
     for k in g:
         assert np.array_equal(g[k], o2[k]), k
+
+
+def test_slam_flow_bit_exact(oracle_mod):
+    """./slam flow (keyframe insertion every 25 sweeps, NEW_KEYFRAME / READ_PRIORS, activation of factors,
+    relinearisations after 18 active sweeps) against the oracle, bit for bit, in both mu modes."""
+    from gbp_poplar_amd import driver, hostlib
+    bal = _bal("fr2robot2")
+    oracle_mod.set_trig_mode(1)
+    try:
+        reads = []
+        for per_factor_mu in (0, 1):
+            eng, orc, opts, state, extra = _setup(bal, oracle_mod, slam=True, sum_order=1, per_factor_mu=per_factor_mu)
+            tg = driver.run_slam(eng, hostlib, bal, state, extra, opts, iters_between_kfs=25, max_iters=110, eval_every=10)
+            if per_factor_mu == 0:
+                to = driver.run_slam(orc, hostlib, bal, state, extra, opts, iters_between_kfs=25, max_iters=110, eval_every=10)
+                ro = orc.read()
+            reads.append(eng.read())
+            for (i, mg, cg, rg, bg), (_, mo, co, ro_, bo) in zip(tg, to):
+                assert abs(mg - mo) <= 1e-5 * mo and rg == ro_ and bg == bo, (i, mg, mo)
+        for k in ro:
+            assert np.array_equal(reads[0][k], ro[k]) and np.array_equal(reads[1][k], ro[k]), k
+        assert np.sum(ro["damping_count"] == -8) + np.sum(ro["robust_flag"]) > 0
+    finally:
+        oracle_mod.set_trig_mode(0)
+
+
+def test_nonzero_oldmu_needs_per_factor_mode():
+    from gbp_poplar_amd import _cabi, driver, hostlib
+    from gbp_poplar_amd.engine import GbpEngine, GbpError
+    bal = small_synth(n_cams=5, n_lmks=30, obs=3, seed=2)
+    opts = driver.Options()
+    K, state, _ = driver.build_inputs(bal, opts, hostlib)
+    state = dict(state)
+    state["mu"] = np.full(9 * bal["n_edges"], 0.25, np.float32)
+    state["oldmu"] = state["mu"].copy()
+    eng = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K)
+    with pytest.raises(GbpError, match="per_factor_mu"):
+        eng.upload(state)
+    eng2 = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K,
+                     params=_cabi.GbpParams.defaults(per_factor_mu=1))
+    eng2.upload(state)
+    eng2.linearise()
+    eng2.iterate(1)
+    assert np.all(eng2.mu()[1] > 0)       # dmu measured against the uploaded oldmu
 
 
 def test_inactive_factors_and_ragged_degrees(oracle_mod):
