@@ -43,7 +43,7 @@ struct gbp_ctx {
   // device memory
   std::vector<DevBuf*> all;
   DevBuf idx, state, fac, cmsg, mu, lmsg, camb, camp, lmkb, lmkp, rowp, local, d_cam_row_ptr, d_lmk_ptr, cwf, lwf,
-      cscale, lscale, cam_mu, lmk_mu, dK, evalp, hmu_c, hmu_l;
+      cscale, lscale, cam_mu, lmk_mu, dK, evalp, hmu_c, hmu_l, d_lmk_fpos;
   bool hoist = true;  // per-variable belief means (k_sweep<true>); false = literal per-factor mu/oldmu tensors
   void* send_dev = nullptr;
   void* recv_dev = nullptr;
@@ -109,6 +109,7 @@ BeliefArgs belief_args(gbp_ctx* c) {
   b.cam_local = P<float>(c->local); b.gathered = nullptr; b.world = c->world;
   b.camb = P<float>(c->camb); b.cam_mu = P<float4>(c->hmu_c); b.n_cams = c->C;
   b.lmk_prior = P<float4>(c->lmkp); b.lmsg = P<float4>(c->lmsg); b.lmk_ptr = P<uint32_t>(c->d_lmk_ptr);
+  b.lmk_fpos = P<uint32_t>(c->d_lmk_fpos);
   b.lmkb = P<float4>(c->lmkb); b.lmk_mu = P<float4>(c->hmu_l); b.n_lmks = c->L_loc;
   b.partial_only = 0; b.hoist = c->hoist ? 1 : 0; b.roll = 0;
   return b;
@@ -254,7 +255,7 @@ int gbp_create(const gbp_problem* pr, const gbp_params* prm, const gbp_shard* sh
   auto A = [&](DevBuf& b, size_t bytes) { if (rc == GBP_OK) rc = dev_alloc(c, b, bytes); };
   const size_t Ep = c->Ep;
   A(c->idx, Ep * 16); A(c->state, Ep * 16); A(c->fac, Ep * kFacG * 16); A(c->cmsg, Ep * kCmsgG * 16);
-  A(c->mu, Ep * kMuG * 16); A(c->lmsg, ((size_t)c->E_loc + 1) * 64);
+  A(c->mu, Ep * kMuG * 16); A(c->lmsg, Ep * 64); A(c->d_lmk_fpos, (size_t)c->E_loc * 4);
   A(c->camb, (size_t)C * kCamRec * 4); A(c->camp, (size_t)C * kCamRec * 4); A(c->local, (size_t)C * kCamRec * 4);
   A(c->lmkb, (size_t)c->L_loc * 64); A(c->lmkp, (size_t)c->L_loc * 64);
   A(c->rowp, (Ep / kRow) * kCamRec * 4);
@@ -274,6 +275,12 @@ int gbp_create(const gbp_problem* pr, const gbp_params* prm, const gbp_shard* sh
   CK(hipMemcpy(c->d_cam_row_ptr.p, c->cam_row_ptr.data(), (size_t)(C + 1) * 4, hipMemcpyHostToDevice), "copy cam_row_ptr");
   CK(hipMemcpy(c->d_lmk_ptr.p, c->lmk_ptr.data(), (size_t)(c->L_loc + 1) * 4, hipMemcpyHostToDevice), "copy lmk_ptr");
   CK(hipMemcpy(c->dK.p, c->K, 9 * 4, hipMemcpyHostToDevice), "copy K");
+  {
+    std::vector<uint32_t> fpos(c->E_loc ? c->E_loc : 1, 0u);  // landmark-major slot list -> device position
+    for (size_t p = 0; p < Ep; ++p)
+      if (c->pos_edge[p] != ~0u) fpos[c->pos_lpos[p]] = (uint32_t)p;
+    CK(hipMemcpy(c->d_lmk_fpos.p, fpos.data(), (size_t)c->E_loc * 4, hipMemcpyHostToDevice), "copy lmk_fpos");
+  }
   {
     std::vector<int32_t> idx(Ep * 4);
     for (size_t p = 0; p < Ep; ++p) {
@@ -665,12 +672,12 @@ int gbp_debug_get(gbp_ctx* c, int what, float* a, float* b) {
         b[(size_t)e * 36 + i * 6 + j] = (i >= j) ? f[tile_off((uint32_t)p, kCmsgG, 6 + tri(i, j))] : 0.f;
     }
   } else if (what == 2) {
-    std::vector<float> f(((size_t)c->E_loc + 1) * 16);
+    std::vector<float> f((size_t)c->Ep * 16);
     HIPCHK(c, hipMemcpy(f.data(), c->lmsg.p, f.size() * 4, hipMemcpyDeviceToHost));
     for (size_t p = 0; p < c->Ep; ++p) {
       const uint32_t e = c->pos_edge[p];
       if (e == ~0u) continue;
-      const float* r = &f[(size_t)c->pos_lpos[p] * 16];
+      const float* r = &f[p * 16];
       for (int i = 0; i < 3; ++i) a[(size_t)e * 3 + i] = r[i];
       for (int i = 0; i < 9; ++i) b[(size_t)e * 9 + i] = r[4 + i];
     }
@@ -702,6 +709,22 @@ int gbp_debug_get(gbp_ctx* c, int what, float* a, float* b) {
   } else {
     return fail(c, GBP_ERR_INVALID, "gbp_debug_get: unknown selector");
   }
+  return GBP_OK;
+}
+
+// Timing experiment: average duration (us) of `reps` launches of an ablated k_sweep (see gbp_kernels.hip).
+// The ctx state is garbage afterwards; upload again before using it.
+int gbp_debug_time_sweep(gbp_ctx* c, int ablation, int reps, double* avg_us) {
+  if (!c || !avg_us || reps <= 0 || !c->uploaded) return GBP_ERR_INVALID;
+  const SweepArgs a = sweep_args(c);
+  launch_sweep_ablated(a, c->n_tiles, ablation, c->stream);
+  HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+  for (int i = 0; i < reps; ++i) launch_sweep_ablated(a, c->n_tiles, ablation, c->stream);
+  HIPCHK(c, hipEventRecord(c->ev2, c->stream));
+  HIPCHK(c, hipEventSynchronize(c->ev2));
+  float ms = 0;
+  HIPCHK(c, hipEventElapsedTime(&ms, c->ev1, c->ev2));
+  *avg_us = 1e3 * ms / reps;
   return GBP_OK;
 }
 

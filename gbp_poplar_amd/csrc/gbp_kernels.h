@@ -28,10 +28,12 @@ constexpr int kCmsgG = 7;
 constexpr int kMuG = 3;
 // STATE (1 group): x = damping, y = damping_count (int bits), z = flags (uint bits), w = meas_variance
 constexpr uint32_t kFlagActive = 1u, kFlagRobust = 2u, kFlagPad = 4u;
-// IDX (1 int4): x = camera, y = landmark (local index), z = lpos (record in LMSG), w = file edge index
+// IDX (1 int4): x = camera, y = landmark (local index), z = slot record (landmark-major rank), w = file edge index
 //
-// Landmark-side records are landmark-major AoS of 16 floats (one 64-byte sector per factor):
-//   LMSG[lpos] / LMKB[l] / LMKP[l]:  [0..2] eta  [3] pad  [4..12] Lambda 3x3  [13..15] pad
+// Landmark-side records are AoS of 16 floats (one 64-byte sector each):
+//   LMSG[p] (factor->landmark message of the factor at DEVICE position p; a landmark's records are found
+//   through LMK_FPOS[lmk_ptr[l] .. lmk_ptr[l+1]) in slot order), LMKB[l] / LMKP[l] beliefs / priors:
+//   [0..2] eta  [3] pad  [4..12] Lambda 3x3  [13..15] pad   (LMKB pads carry the hoisted dmu^2 pieces)
 constexpr int kLmkRec4 = 4;
 // Camera-side records are 44 floats (11 float4):  [0..5] eta  [6,7] pad  [8..43] Lambda 6x6
 //   CAMB[c] beliefs, CAMP[c] priors, ROWP[row] row partial sums, exchange buffers [rank][c]
@@ -71,7 +73,8 @@ struct BeliefArgs {
   int world;
   float* camb; float4* cam_mu; uint32_t n_cams;
   // landmark part
-  const float4* lmk_prior; const float4* lmsg; const uint32_t* lmk_ptr; float4* lmkb; float4* lmk_mu; uint32_t n_lmks;
+  const float4* lmk_prior; const float4* lmsg; const uint32_t* lmk_ptr; const uint32_t* lmk_fpos;
+  float4* lmkb; float4* lmk_mu; uint32_t n_lmks;
   // control
   uint32_t cam_blocks;
   int partial_only;          // camera part writes cam_local only (multi-GPU: before the exchange)
@@ -85,6 +88,7 @@ struct DeviceEval {  // per-block partials, summed on the host in block order
 };
 
 void launch_sweep(const SweepArgs& a, uint32_t n_tiles, bool hoist, hipStream_t s);
+void launch_sweep_ablated(const SweepArgs& a, uint32_t n_tiles, int abl, hipStream_t s);  // timing experiments only
 void launch_linearise(const SweepArgs& a, uint32_t n_tiles, hipStream_t s);
 void launch_beliefs(BeliefArgs b, bool do_cam, bool do_lmk, hipStream_t s);
 void launch_weaken(float4* prior, const float* scaling, uint32_t* flag, uint32_t n, int rec4, hipStream_t s);

@@ -21,20 +21,27 @@ using namespace gbpdev;
 
 namespace {
 
-template <int G>
+// The per-factor tiles are touched exactly once per sweep: stream them with the non-temporal hint so that
+// they do not displace the gathered tables (landmark messages / beliefs, camera beliefs: ~70 MB for S1)
+// from L2 and the 256 MiB Infinity Cache.
+typedef float v4f __attribute__((ext_vector_type(4)));
+template <int G, bool NT = true>
 GBP_DEV void load_tile(const float4* base, uint32_t tile, uint32_t lane, float (&out)[G * 4]) {
-  const float4* p = base + (size_t)tile * G * 64 + lane;
+  const v4f* p = reinterpret_cast<const v4f*>(base) + (size_t)tile * G * 64 + lane;
   GBP_UNROLL
   for (int g = 0; g < G; ++g) {
-    const float4 v = p[g * 64];
+    const v4f v = NT ? __builtin_nontemporal_load(p + g * 64) : p[g * 64];
     out[4 * g] = v.x; out[4 * g + 1] = v.y; out[4 * g + 2] = v.z; out[4 * g + 3] = v.w;
   }
 }
-template <int G>
+template <int G, bool NT = true>
 GBP_DEV void store_tile(float4* base, uint32_t tile, uint32_t lane, const float (&in)[G * 4]) {
-  float4* p = base + (size_t)tile * G * 64 + lane;
+  v4f* p = reinterpret_cast<v4f*>(base) + (size_t)tile * G * 64 + lane;
   GBP_UNROLL
-  for (int g = 0; g < G; ++g) p[g * 64] = make_float4(in[4 * g], in[4 * g + 1], in[4 * g + 2], in[4 * g + 3]);
+  for (int g = 0; g < G; ++g) {
+    const v4f v = {in[4 * g], in[4 * g + 1], in[4 * g + 2], in[4 * g + 3]};
+    if (NT) __builtin_nontemporal_store(v, p + g * 64); else p[g * 64] = v;
+  }
 }
 template <int G>
 GBP_DEV void load_rec(const float4* rec, float (&out)[G * 4]) {
@@ -169,7 +176,10 @@ GBP_DEV bool relin_core(float (&fac)[56], const float (&x0c)[6], const float (&x
 // fp32 operations in the same order, so the result is bit-identical while the per-factor MU stream and
 // two of the five small inverses disappear from the sweep.  HOIST = false keeps the literal per-factor
 // mu/oldmu tensors (needed only if a caller uploads non-zero oldmu).
-template <bool HOIST>
+// ABL != 0 builds timing-only ablations of the same instruction stream (gbp_debug_time_sweep; results are
+// garbage): 1 = no landmark-message stream, 2 = no landmark-belief gather, 4 = no arithmetic (pass-through),
+// 16 / 32 = no landmark-message load / store.
+template <bool HOIST, int ABL = 0>
 __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
   const uint32_t p = blockIdx.x * 256 + threadIdx.x;
   const uint32_t tile = p >> 6, lane = p & 63;
@@ -187,9 +197,39 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
   load_tile<kFacG>(a.fac, tile, lane, fac);
   load_tile<kCmsgG>(a.cmsg, tile, lane, cm);
   if (!HOIST) load_tile<kMuG>(a.mu, tile, lane, mu);
-  load_rec<kLmkRec4>(a.lmsg + (size_t)(uint32_t)ix.z * kLmkRec4, lm);
+  // Landmark messages live as 64-byte records in DEVICE (camera-major) order: the wave's 64 records are one
+  // contiguous 4 KiB block, moved with four coalesced 1 KiB accesses and transposed through a wave-private
+  // LDS staging area (records padded to 80 B => conflict-free ds_read/ds_write_b128).  k_beliefs gathers
+  // the records of a landmark by position (random 64-B READS are ~2.3x cheaper than random 64-B writes,
+  // profiles/ablate_sweep.py).
+  __shared__ float4 lm_stage[4][64 * 5];
+  float4* stage = lm_stage[threadIdx.x >> 6];
+  float4* lm_tile = a.lmsg + (size_t)tile * 256;
+  if (ABL & (1 | 16)) {  // 16 = no LMSG load (store stays), 32 = no LMSG store (load stays)
+    GBP_UNROLL
+    for (int i = 0; i < 16; ++i) lm[i] = 0.f;
+  } else {
+    GBP_UNROLL
+    for (int k = 0; k < 4; ++k) {
+      const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(lm_tile) + k * 64 + lane);
+      stage[(k * 16 + (lane >> 2)) * 5 + (lane & 3)] = make_float4(v.x, v.y, v.z, v.w);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    GBP_UNROLL
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = stage[lane * 5 + q];
+      lm[4 * q] = v.x; lm[4 * q + 1] = v.y; lm[4 * q + 2] = v.z; lm[4 * q + 3] = v.w;
+    }
+  }
   load_rec<kCamRec4>(a.camb + (size_t)(uint32_t)ix.x * kCamRec4, cb);
-  load_rec<kLmkRec4>(a.lmkb + (size_t)(uint32_t)ix.y * kLmkRec4, lb);
+  if (ABL & 2) {
+    GBP_UNROLL
+    for (int i = 0; i < 16; ++i) lb[i] = (i == 4 || i == 8 || i == 12) ? 1.f : 0.f;
+  } else {
+    load_rec<kLmkRec4>(a.lmkb + (size_t)(uint32_t)ix.y * kLmkRec4, lb);
+  }
 
   float K[9];
   GBP_UNROLL
@@ -204,7 +244,15 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
   for (int i = 0; i < 16; ++i) ol[i] = 0.f;
   bool relin = false;
 
-  if (active) {
+  if (ABL & 4) {  // keep every load alive, no algebra
+    GBP_UNROLL
+    for (int i = 0; i < 16; ++i) ol[i] = lm[i] + lb[i];
+    GBP_UNROLL
+    for (int i = 0; i < 6; ++i) oc_eta[i] = cm[i] + fac[i];
+    GBP_UNROLL
+    for (int i = 0; i < 36; ++i) oc_lam[i] = fac[9 + i] + cb[8 + i] + cm[6 + (i % 21)];
+  }
+  if (active && !(ABL & 4)) {
     // ---- PrepMessageVertex, gbp_codelets.cpp:241-378 ----
     if (0 == count) damping = a.hp.maxeta_damping;
     count += 1;
@@ -347,10 +395,16 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
   }
 
   // ---- outputs --------------------------------------------------------------------------------
-  if (!is_pad) {
-    float4* rec = a.lmsg + (size_t)(uint32_t)ix.z * kLmkRec4;
+  if (!(ABL & (1 | 32))) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     GBP_UNROLL
-    for (int g = 0; g < 4; ++g) rec[g] = make_float4(ol[4 * g], ol[4 * g + 1], ol[4 * g + 2], ol[4 * g + 3]);
+    for (int q = 0; q < 4; ++q) stage[lane * 5 + q] = make_float4(ol[4 * q], ol[4 * q + 1], ol[4 * q + 2], ol[4 * q + 3]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    GBP_UNROLL
+    for (int k = 0; k < 4; ++k) lm_tile[k * 64 + lane] = stage[(k * 16 + (lane >> 2)) * 5 + (lane & 3)];
   }
   {
     float cmo[28];
@@ -503,16 +557,27 @@ __global__ __launch_bounds__(256) void k_beliefs(const BeliefArgs b) {
     acc = b.lmk_prior[(size_t)l * 4 + q];
     const uint32_t s0 = b.lmk_ptr[l], s1 = b.lmk_ptr[l + 1];
     uint32_t s = s0;
-    for (; s + 4 <= s1; s += 4) {
-      float4 m[4];
+    for (; s + 8 <= s1; s += 8) {  // 8 record gathers in flight, adds in slot order
+      uint32_t pos[8];
+      float4 m[8];
       GBP_UNROLL
-      for (int k = 0; k < 4; ++k) m[k] = b.lmsg[(size_t)(s + k) * 4 + q];
+      for (int k = 0; k < 8; ++k) pos[k] = b.lmk_fpos[s + k];
       GBP_UNROLL
-      for (int k = 0; k < 4; ++k) { acc.x = acc.x + m[k].x; acc.y = acc.y + m[k].y; acc.z = acc.z + m[k].z; acc.w = acc.w + m[k].w; }
+      for (int k = 0; k < 8; ++k) m[k] = b.lmsg[(size_t)pos[k] * 4 + q];
+      GBP_UNROLL
+      for (int k = 0; k < 8; ++k) { acc.x = acc.x + m[k].x; acc.y = acc.y + m[k].y; acc.z = acc.z + m[k].z; acc.w = acc.w + m[k].w; }
     }
-    for (; s < s1; ++s) {
-      const float4 m = b.lmsg[(size_t)s * 4 + q];
-      acc.x = acc.x + m.x; acc.y = acc.y + m.y; acc.z = acc.z + m.z; acc.w = acc.w + m.w;
+    {
+      uint32_t pos[8];
+      float4 m[8];
+      const uint32_t n = s1 - s;  // < 8
+      GBP_UNROLL
+      for (int k = 0; k < 8; ++k) pos[k] = (uint32_t)k < n ? b.lmk_fpos[s + k] : 0u;
+      GBP_UNROLL
+      for (int k = 0; k < 8; ++k) m[k] = (uint32_t)k < n ? b.lmsg[(size_t)pos[k] * 4 + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+      GBP_UNROLL
+      for (int k = 0; k < 8; ++k)
+        if ((uint32_t)k < n) { acc.x = acc.x + m[k].x; acc.y = acc.y + m[k].y; acc.z = acc.z + m[k].z; acc.w = acc.w + m[k].w; }
     }
   }
   if (b.hoist) {
@@ -702,6 +767,19 @@ static inline uint32_t blocks_for(uint64_t threads) { return (uint32_t)((threads
 void launch_sweep(const SweepArgs& a, uint32_t n_tiles, bool hoist, hipStream_t s) {
   if (hoist) hipLaunchKernelGGL(k_sweep<true>, dim3(n_tiles / 4), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(k_sweep<false>, dim3(n_tiles / 4), dim3(256), 0, s, a);
+}
+void launch_sweep_ablated(const SweepArgs& a, uint32_t n_tiles, int abl, hipStream_t s) {
+  const dim3 g(n_tiles / 4), b(256);
+  switch (abl) {
+    case 1: hipLaunchKernelGGL((k_sweep<true, 1>), g, b, 0, s, a); break;
+    case 2: hipLaunchKernelGGL((k_sweep<true, 2>), g, b, 0, s, a); break;
+    case 3: hipLaunchKernelGGL((k_sweep<true, 3>), g, b, 0, s, a); break;
+    case 4: hipLaunchKernelGGL((k_sweep<true, 4>), g, b, 0, s, a); break;
+    case 7: hipLaunchKernelGGL((k_sweep<true, 7>), g, b, 0, s, a); break;
+    case 16: hipLaunchKernelGGL((k_sweep<true, 16>), g, b, 0, s, a); break;
+    case 32: hipLaunchKernelGGL((k_sweep<true, 32>), g, b, 0, s, a); break;
+    default: hipLaunchKernelGGL((k_sweep<true, 0>), g, b, 0, s, a); break;
+  }
 }
 void launch_linearise(const SweepArgs& a, uint32_t n_tiles, hipStream_t s) {
   hipLaunchKernelGGL(k_linearise, dim3(n_tiles / 4), dim3(256), 0, s, a);

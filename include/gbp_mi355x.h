@@ -193,6 +193,10 @@ int gbp_set_profiling(gbp_ctx* ctx, int per_stage_events);
  *   what 2: a = lmk message eta [3E],        b = lmk message Lambda [9E]
  *   what 3: a = mu [9E],                     b = dmu [E]                                          */
 int gbp_debug_get(gbp_ctx* ctx, int what, float* a, float* b);
+/* Timing experiment: average us per launch of an ablated sweep kernel (1 = no landmark-message
+ * gather/scatter, 2 = no landmark-belief gather, 4 = no arithmetic, 8 = streaming landmark messages;
+ * bits combine).  Leaves garbage in the ctx. */
+int gbp_debug_time_sweep(gbp_ctx* ctx, int ablation, int reps, double* avg_us);
 /* Overwrite the factor potentials from reference-layout arrays (inverse of what 0). Test hook. */
 int gbp_debug_set_factor_potentials(gbp_ctx* ctx, const float* eta9E, const float* lambda81E);
 
