@@ -46,7 +46,15 @@ int main(int argc, char** argv) {
       std::cout << "Weakening priors \n";
       CLI_CHECK(ctx, gbp_weaken_priors(ctx));
     }
-    CLI_CHECK(ctx, gbp_iterate(ctx, 1));
+    // run up to the next host event (prior weakening or read-back) in one call: gbp_iterate(k) replays
+    // the captured hipGraph, so with --eval_every > 1 the loop never leaves the device in between
+    int burst = 1;
+    while (i + burst < o.n_iters && (i + burst) % o.eval_every != 0 &&
+           !(((iter + burst + 1) % 2 == 0) && (iter + burst < o.steps * 2)))
+      ++burst;
+    CLI_CHECK(ctx, gbp_iterate(ctx, burst));
+    i += burst - 1;
+    iter += burst - 1;
     if ((i + 1) % o.eval_every == 0 || i + 1 == o.n_iters) {
       CLI_CHECK(ctx, gbp_eval(ctx, &ev));
       std::cout << "Iter " << iter << " // Reprojection error " << (float)(ev.sum_norm / (double)ev.n_active);

@@ -43,15 +43,25 @@ class ShardedGbp:
         self.dist = dist
         self.send = torch.zeros(self.C * CAM_REC, dtype=torch.float32, device=device)
         self.recv = torch.zeros(self.world * self.C * CAM_REC, dtype=torch.float32, device=device)
+        self.stream = None
         if device != "cpu":
-            engine.set_stream(torch.cuda.current_stream().cuda_stream)
+            # One dedicated (non-default) stream carries BOTH the engine's kernels and the collective, so
+            # ordering is plain stream order: kernels -> all_gather (RCCL waits on / signals this stream) -> kernels.
+            self.stream = torch.cuda.Stream()
+            engine.set_stream(self.stream.cuda_stream)
+            torch.cuda.synchronize()       # the zero-fills above ran on the default stream
         engine.set_exchange_buffers(self.send.data_ptr(), self.recv.data_ptr())
 
+    def _on_stream(self):
+        import contextlib
+        return self.torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+
     def _exchange(self):
-        if self.world == 1 or self.dist is None:
-            self.recv.copy_(self.send)
-        else:
-            self.dist.all_gather_into_tensor(self.recv, self.send)
+        with self._on_stream():
+            if self.world == 1 or self.dist is None:
+                self.recv.copy_(self.send)
+            else:
+                self.dist.all_gather_into_tensor(self.recv, self.send)
 
     def upload(self, state):
         self.e.upload(state)
@@ -88,9 +98,12 @@ class ShardedGbp:
             return ev
         torch = self.torch
         keys = ["sum_norm", "sum_half_sq", "n_active", "n_relin", "n_robust", "n_nonfinite"]
-        mine = torch.tensor([float(ev[k]) for k in keys], dtype=torch.float64, device=self.send.device)
-        allv = torch.zeros(self.world * len(keys), dtype=torch.float64, device=self.send.device)
-        self.dist.all_gather_into_tensor(allv, mine)
+        with self._on_stream():
+            mine = torch.tensor([float(ev[k]) for k in keys], dtype=torch.float64, device=self.send.device)
+            allv = torch.zeros(self.world * len(keys), dtype=torch.float64, device=self.send.device)
+            self.dist.all_gather_into_tensor(allv, mine)
+        if self.stream is not None:
+            self.stream.synchronize()
         allv = allv.view(self.world, len(keys)).cpu().numpy()
         out = {}
         for j, k in enumerate(keys):
@@ -103,3 +116,5 @@ class ShardedGbp:
     def sync(self):
         if hasattr(self.e, "sync"):
             self.e.sync()
+        if self.stream is not None:
+            self.stream.synchronize()

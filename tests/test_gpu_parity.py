@@ -397,3 +397,107 @@ def test_golden_sequence_snapshots():
         ev = eng.eval()
         m = ev["sum_norm"] / ev["n_active"]
         assert abs(m - g["traj_fr2robot2"][it + 1, 1]) <= 1e-4 * m, (it, m)
+
+
+# ---- sharded (multi-GPU) kernels exercised on ONE GPU -----------------------------------------------------
+
+class _FakeDist:
+    """all_gather between shard engines living in one process: copies every rank's send buffer into every
+    rank's receive buffer (what RCCL does between GPUs)."""
+
+    def __init__(self):
+        self.members = []
+
+    def gather_all(self):
+        import torch
+        for m in self.members:
+            m.stream.synchronize()
+        for dst in self.members:
+            for r, src in enumerate(self.members):
+                n = src.send.numel()
+                dst.recv[r * n:(r + 1) * n].copy_(src.send)
+        torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_kernels_on_one_gpu_match_sharded_oracle(world, oracle_mod):
+    """`world` landmark-shard contexts on the same GPU, exchange done by device copies: the sharded C-ABI path
+    (gbp_iterate_begin/_end, refresh, linearise_factors, weaken on a sharded ctx, torch-owned buffers and
+    stream) against the oracle in `world`-shard device order, bit for bit, through relinearisations."""
+    import torch
+    from gbp_poplar_amd import driver, hostlib
+    from gbp_poplar_amd.distributed import ShardedGbp, landmark_partition
+    from gbp_poplar_amd.engine import GbpEngine
+    bal = _bal("fr2robot2")
+    opts = driver.Options()
+    K, state, _ = driver.build_inputs(bal, opts, hostlib)
+    bounds = landmark_partition(bal["lmk_id"], bal["n_lmks"], world)
+    fake = _FakeDist()
+    shards = []
+    for r in range(world):
+        eng = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K,
+                        shard=(r, world, int(bounds[r]), int(bounds[r + 1])))
+        sh = ShardedGbp(eng, bal["n_cams"], r, world, dist=None, device="cuda")
+        sh._exchange = lambda: None          # the exchange is performed for all shards at once below
+        fake.members.append(sh)
+        shards.append(sh)
+
+    def all_do(name, *a):
+        for sh in shards:
+            getattr(sh.e, name)(*a)
+
+    oracle_mod.set_trig_mode(1)
+    try:
+        orc = oracle_mod.Oracle(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K)
+        orc.set_sum_order(1, bounds)
+        orc.upload(state)
+        orc.linearise()
+        all_do("upload", state)
+        all_do("refresh_begin"); fake.gather_all(); all_do("refresh_end"); all_do("linearise_factors")
+        for it in range(24):
+            if (it + 1) % 2 == 0 and it < 10:
+                all_do("weaken_priors")
+                orc.weaken_priors()
+            all_do("iterate_begin"); fake.gather_all(); all_do("iterate_end")
+            orc.iterate(1)
+    finally:
+        oracle_mod.set_trig_mode(0)
+    ro = orc.read()
+    lmk = np.asarray(bal["lmk_id"])
+    n_relin = 0
+    for r, sh in enumerate(shards):
+        g = sh.read()
+        assert np.array_equal(g["cam_beliefs_eta"], ro["cam_beliefs_eta"])
+        assert np.array_equal(g["cam_beliefs_lambda"], ro["cam_beliefs_lambda"])
+        lo, hi = int(bounds[r]), int(bounds[r + 1])
+        assert np.array_equal(g["lmk_beliefs_eta"][3 * lo:3 * hi], ro["lmk_beliefs_eta"][3 * lo:3 * hi])
+        assert np.array_equal(g["lmk_beliefs_lambda"][9 * lo:9 * hi], ro["lmk_beliefs_lambda"][9 * lo:9 * hi])
+        own = (lmk >= lo) & (lmk < hi)
+        assert np.array_equal(g["damping_count"][own], ro["damping_count"][own])
+        assert np.array_equal(g["robust_flag"][own], ro["robust_flag"][own])
+        n_relin += int(np.sum(g["damping_count"][own] == -8))
+    assert n_relin > 0
+    evs = [sh.e.eval() for sh in shards]
+    tot = {k: sum(e[k] for e in evs) for k in ("sum_norm", "sum_half_sq", "n_active", "n_relin", "n_robust")}
+    eo = orc.eval()
+    assert tot["n_active"] == eo["n_active"] and tot["n_relin"] == eo["n_relin"] and tot["n_robust"] == eo["n_robust"]
+    assert abs(tot["sum_norm"] - eo["sum_norm"]) <= 1e-5 * eo["sum_norm"]
+
+
+def test_sharded_wrapper_world1_on_gpu(oracle_mod):
+    """ShardedGbp with world = 1 on the GPU (torch stream + torch-owned exchange buffers) == plain engine."""
+    from gbp_poplar_amd import driver, hostlib
+    from gbp_poplar_amd.distributed import ShardedGbp
+    from gbp_poplar_amd.engine import GbpEngine
+    bal = _bal("fr2robot2")
+    opts = driver.Options()
+    K, state, _ = driver.build_inputs(bal, opts, hostlib)
+    plain = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K)
+    eng = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K, shard=(0, 1, 0, bal["n_lmks"]))
+    sh = ShardedGbp(eng, bal["n_cams"], 0, 1, dist=None, device="cuda")
+    ta = driver.run_ba(plain, state, opts, n_iters=25, eval_every=5)
+    tb = driver.run_ba(sh, state, opts, n_iters=25, eval_every=5)
+    assert ta == tb
+    ra, rb = plain.read(), sh.read()
+    for k in ra:
+        assert np.array_equal(ra[k], rb[k]), k
