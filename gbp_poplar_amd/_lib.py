@@ -67,6 +67,16 @@ def load():
         raise RuntimeError(
             "native library %s is missing — build it with `python -m gbp_poplar_amd.build` "
             "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 and dlopens it by path, so
+    # if this library (linked against /opt/rocm's copy) initialised the GPU first, a later `import torch`
+    # would bring up a second runtime that finds "No HIP GPUs".  Loading torch's runtime first makes our
+    # DT_NEEDED libamdhip64.so.7 resolve to the copy already in the process.  (The C++ CLIs never load torch.)
+    if os.environ.get("GBP_NO_TORCH") != "1":
+        try:
+            import torch
+            torch.cuda.is_available()
+        except ImportError:
+            pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol

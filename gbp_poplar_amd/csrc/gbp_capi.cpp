@@ -42,7 +42,7 @@ struct gbp_ctx {
   uint32_t Ep = 0, n_tiles = 0, n_rows = 0;
   // device memory
   std::vector<DevBuf*> all;
-  DevBuf idx, state, fac, cmsg, mu, lmsg, camb, camp, lmkb, lmkp, rowp, local, d_cam_row_ptr, d_lmk_ptr, cwf, lwf,
+  DevBuf row_cam, lmk_idx, fac, cmsg, mu, lmsg, camb, camp, lmkb, lmkp, rowp, local, d_cam_row_ptr, d_lmk_ptr, cwf, lwf,
       cscale, lscale, cam_mu, lmk_mu, dK, evalp, hmu_c, hmu_l, d_lmk_fpos;
   bool hoist = true;  // per-variable belief means (k_sweep<true>); false = literal per-factor mu/oldmu tensors
   void* send_dev = nullptr;
@@ -86,7 +86,7 @@ template <class T> T* P(DevBuf& b) { return static_cast<T*>(b.p); }
 
 SweepArgs sweep_args(gbp_ctx* c) {
   SweepArgs a;
-  a.idx = P<int4>(c->idx); a.state = P<float4>(c->state); a.fac = P<float4>(c->fac); a.cmsg = P<float4>(c->cmsg);
+  a.row_cam = P<uint32_t>(c->row_cam); a.lmk_idx = P<uint32_t>(c->lmk_idx); a.fac = P<float4>(c->fac); a.cmsg = P<float4>(c->cmsg);
   a.mu = P<float4>(c->mu); a.lmsg = P<float4>(c->lmsg); a.camb = P<float4>(c->camb); a.lmkb = P<float4>(c->lmkb);
   a.rowp = P<float4>(c->rowp);
   a.cam_mu = P<float4>(c->hmu_c); a.lmk_mu = P<float4>(c->hmu_l);
@@ -159,6 +159,29 @@ void pack_lmk(const float* eta, const float* lam, uint32_t l0, uint32_t n, std::
     std::memcpy(&out[(size_t)i * 16], eta + (size_t)(l0 + i) * 3, 3 * 4);
     std::memcpy(&out[(size_t)i * 16 + 4], lam + (size_t)(l0 + i) * 9, 9 * 4);
   }
+}
+
+// Per-factor scalar state lives in the pad slots of the LMSG records (gbp_kernels.h): these two helpers
+// expose it to the host code as {damping, count, flags, variance} per device position.
+struct HostState { float damping; int32_t count; uint32_t flags; float var; };
+
+int download_lmsg(gbp_ctx* c, std::vector<float>& rec) {
+  rec.resize((size_t)c->Ep * 16);
+  HIPCHK(c, hipMemcpy(rec.data(), c->lmsg.p, rec.size() * 4, hipMemcpyDeviceToHost));
+  return GBP_OK;
+}
+inline HostState get_state(const std::vector<float>& rec, size_t p) {
+  HostState h;
+  int32_t packed;
+  std::memcpy(&packed, &rec[p * 16 + 13], 4);
+  h.damping = rec[p * 16 + 3]; h.count = packed >> 3; h.flags = (uint32_t)packed & 7u; h.var = rec[p * 16 + 14];
+  return h;
+}
+inline void put_state(std::vector<float>& rec, size_t p, const HostState& h) {
+  const int32_t packed = (int32_t)(((uint32_t)h.count << 3) | (h.flags & 7u));
+  rec[p * 16 + 3] = h.damping;
+  std::memcpy(&rec[p * 16 + 13], &packed, 4);
+  rec[p * 16 + 14] = h.var;
 }
 
 inline size_t tile_off(uint32_t p, int G, int f) {  // float offset of float f of position p in a G-group tiled array
@@ -254,7 +277,7 @@ int gbp_create(const gbp_problem* pr, const gbp_params* prm, const gbp_shard* sh
   int rc = GBP_OK;
   auto A = [&](DevBuf& b, size_t bytes) { if (rc == GBP_OK) rc = dev_alloc(c, b, bytes); };
   const size_t Ep = c->Ep;
-  A(c->idx, Ep * 16); A(c->state, Ep * 16); A(c->fac, Ep * kFacG * 16); A(c->cmsg, Ep * kCmsgG * 16);
+  A(c->row_cam, (Ep / kRow) * 4); A(c->lmk_idx, Ep * 4); A(c->fac, Ep * kFacG * 16); A(c->cmsg, Ep * kCmsgG * 16);
   A(c->mu, Ep * kMuG * 16); A(c->lmsg, Ep * 64); A(c->d_lmk_fpos, (size_t)c->E_loc * 4);
   A(c->camb, (size_t)C * kCamRec * 4); A(c->camp, (size_t)C * kCamRec * 4); A(c->local, (size_t)C * kCamRec * 4);
   A(c->lmkb, (size_t)c->L_loc * 64); A(c->lmkp, (size_t)c->L_loc * 64);
@@ -282,12 +305,10 @@ int gbp_create(const gbp_problem* pr, const gbp_params* prm, const gbp_shard* sh
     CK(hipMemcpy(c->d_lmk_fpos.p, fpos.data(), (size_t)c->E_loc * 4, hipMemcpyHostToDevice), "copy lmk_fpos");
   }
   {
-    std::vector<int32_t> idx(Ep * 4);
-    for (size_t p = 0; p < Ep; ++p) {
-      idx[4 * p] = (int32_t)c->pos_cam[p]; idx[4 * p + 1] = (int32_t)c->pos_lmk_loc[p];
-      idx[4 * p + 2] = (int32_t)c->pos_lpos[p]; idx[4 * p + 3] = (int32_t)c->pos_edge[p];
-    }
-    CK(hipMemcpy(c->idx.p, idx.data(), Ep * 16, hipMemcpyHostToDevice), "copy idx");
+    std::vector<uint32_t> rc_(Ep / kRow);
+    for (size_t r = 0; r < Ep / kRow; ++r) rc_[r] = c->pos_cam[r * kRow];
+    CK(hipMemcpy(c->row_cam.p, rc_.data(), rc_.size() * 4, hipMemcpyHostToDevice), "copy row_cam");
+    CK(hipMemcpy(c->lmk_idx.p, c->pos_lmk_loc.data(), Ep * 4, hipMemcpyHostToDevice), "copy lmk_idx");
   }
   if (rc != GBP_OK) { gbp_destroy(c); return rc; }
   *out = c;
@@ -331,30 +352,26 @@ int gbp_upload(gbp_ctx* c, const gbp_state_in* in) {
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const size_t Ep = c->Ep;
-  std::vector<float> st(Ep * 4, 0.f), fac(Ep * kFacG * 4, 0.f), mu(Ep * kMuG * 4, 0.f);
+  std::vector<float> rec0(Ep * 16, 0.f), fac(Ep * kFacG * 4, 0.f), mu(Ep * kMuG * 4, 0.f);
   for (size_t p = 0; p < Ep; ++p) {
     const uint32_t e = c->pos_edge[p];
-    uint32_t flags;
-    if (e == ~0u) {
-      flags = kFlagPad;
-    } else {
-      flags = (in->active_flag[e] == 1) ? kFlagActive : 0u;
-      st[4 * p] = in->damping ? in->damping[e] : 0.f;
-      const int32_t cnt = in->damping_count ? in->damping_count[e] : 0;
-      std::memcpy(&st[4 * p + 1], &cnt, 4);
-      st[4 * p + 3] = in->meas_variances[e];
+    HostState h{0.f, 0, kFlagPad, 0.f};
+    if (e != ~0u) {
+      h.flags = (in->active_flag[e] == 1) ? kFlagActive : 0u;
+      h.damping = in->damping ? in->damping[e] : 0.f;
+      h.count = in->damping_count ? in->damping_count[e] : 0;
+      h.var = in->meas_variances[e];
       fac[tile_off((uint32_t)p, kFacG, 54)] = in->measurements[2 * (size_t)e];
       fac[tile_off((uint32_t)p, kFacG, 55)] = in->measurements[2 * (size_t)e + 1];
       const float* om = in->oldmu ? in->oldmu : in->mu;
       if (om) for (int i = 0; i < 9; ++i) mu[tile_off((uint32_t)p, kMuG, i)] = om[(size_t)e * 9 + i];
     }
-    std::memcpy(&st[4 * p + 2], &flags, 4);
+    put_state(rec0, p, h);
   }
-  HIPCHK(c, hipMemcpy(c->state.p, st.data(), Ep * 16, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->lmsg.p, rec0.data(), rec0.size() * 4, hipMemcpyHostToDevice));   // zero messages + state
   HIPCHK(c, hipMemcpy(c->fac.p, fac.data(), fac.size() * 4, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->mu.p, mu.data(), mu.size() * 4, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemset(c->cmsg.p, 0, c->cmsg.bytes));
-  HIPCHK(c, hipMemset(c->lmsg.p, 0, c->lmsg.bytes));
   HIPCHK(c, hipMemset(c->rowp.p, 0, c->rowp.bytes));
   HIPCHK(c, hipMemset(c->local.p, 0, c->local.bytes));
   HIPCHK(c, hipMemset(c->camb.p, 0, c->camb.bytes));
@@ -514,16 +531,15 @@ int gbp_read(gbp_ctx* c, gbp_state_out* o) {
     }
   }
   if (o->damping || o->damping_count || o->robust_flag) {
-    std::vector<float> st((size_t)c->Ep * 4);
-    HIPCHK(c, hipMemcpy(st.data(), c->state.p, st.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<float> rec;
+    if (int rc = download_lmsg(c, rec)) return rc;
     for (size_t p = 0; p < c->Ep; ++p) {
       const uint32_t e = c->pos_edge[p];
       if (e == ~0u) continue;
-      uint32_t flags; int32_t cnt;
-      std::memcpy(&cnt, &st[4 * p + 1], 4); std::memcpy(&flags, &st[4 * p + 2], 4);
-      if (o->damping) o->damping[e] = st[4 * p];
-      if (o->damping_count) o->damping_count[e] = cnt;
-      if (o->robust_flag) o->robust_flag[e] = (flags & kFlagRobust) ? 1u : 0u;
+      const HostState h = get_state(rec, p);
+      if (o->damping) o->damping[e] = h.damping;
+      if (o->damping_count) o->damping_count[e] = h.count;
+      if (o->robust_flag) o->robust_flag[e] = (h.flags & kFlagRobust) ? 1u : 0u;
     }
   }
   return GBP_OK;
@@ -555,19 +571,17 @@ int gbp_new_keyframe(gbp_ctx* c, const gbp_kf_update* u) {
   if (!c || !u || !c->uploaded) return fail(c, GBP_ERR_STATE, "gbp_new_keyframe: upload first");
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (u->damping_count || u->active_flag) {
-    std::vector<float> st((size_t)c->Ep * 4);
-    HIPCHK(c, hipMemcpy(st.data(), c->state.p, st.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<float> rec;
+    if (int rc = download_lmsg(c, rec)) return rc;
     for (size_t p = 0; p < c->Ep; ++p) {
       const uint32_t e = c->pos_edge[p];
       if (e == ~0u) continue;
-      if (u->damping_count) std::memcpy(&st[4 * p + 1], &u->damping_count[e], 4);
-      if (u->active_flag) {
-        uint32_t flags; std::memcpy(&flags, &st[4 * p + 2], 4);
-        flags = (u->active_flag[e] == 1) ? (flags | kFlagActive) : (flags & ~kFlagActive);
-        std::memcpy(&st[4 * p + 2], &flags, 4);
-      }
+      HostState h = get_state(rec, p);
+      if (u->damping_count) h.count = u->damping_count[e];
+      if (u->active_flag) h.flags = (u->active_flag[e] == 1) ? (h.flags | kFlagActive) : (h.flags & ~kFlagActive);
+      put_state(rec, p, h);
     }
-    HIPCHK(c, hipMemcpy(c->state.p, st.data(), st.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->lmsg.p, rec.data(), rec.size() * 4, hipMemcpyHostToDevice));
   }
   if (u->cam_priors_eta && u->cam_priors_lambda) {
     std::vector<float> rec;
@@ -590,7 +604,7 @@ int gbp_eval(gbp_ctx* c, gbp_eval_out* o) {
   if (!c || !o || !c->uploaded) return fail(c, GBP_ERR_STATE, "gbp_eval: upload first");
   std::memset(o, 0, sizeof(*o));
   launch_means(P<float4>(c->camb), P<float4>(c->lmkb), P<float>(c->cam_mu), P<float>(c->lmk_mu), c->C, c->L_loc, c->stream);
-  launch_eval(P<int4>(c->idx), P<float4>(c->state), P<float4>(c->fac), P<float>(c->cam_mu), P<float>(c->lmk_mu),
+  launch_eval(P<uint32_t>(c->row_cam), P<uint32_t>(c->lmk_idx), P<float4>(c->lmsg), P<float4>(c->fac), P<float>(c->cam_mu), P<float>(c->lmk_mu),
               P<float>(c->dK), c->prm.num_undamped_iters, P<DeviceEval>(c->evalp), c->n_tiles, c->stream);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -686,13 +700,12 @@ int gbp_debug_get(gbp_ctx* c, int what, float* a, float* b) {
     std::vector<float> mc((size_t)c->C * 16), ml((size_t)c->L_loc * 8);
     HIPCHK(c, hipMemcpy(mc.data(), c->hmu_c.p, mc.size() * 4, hipMemcpyDeviceToHost));
     if (c->L_loc) HIPCHK(c, hipMemcpy(ml.data(), c->hmu_l.p, ml.size() * 4, hipMemcpyDeviceToHost));
-    std::vector<float> st((size_t)c->Ep * 4);
-    HIPCHK(c, hipMemcpy(st.data(), c->state.p, st.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<float> rec;
+    if (int rc = download_lmsg(c, rec)) return rc;
     for (size_t p = 0; p < c->Ep; ++p) {
       const uint32_t e = c->pos_edge[p];
       if (e == ~0u) continue;
-      uint32_t flags; std::memcpy(&flags, &st[4 * p + 2], 4);
-      if (!(flags & kFlagActive)) continue;  // inactive factors never update mu (gbp_codelets.cpp:242)
+      if (!(get_state(rec, p).flags & kFlagActive)) continue;  // inactive factors never update mu (gbp_codelets.cpp:242)
       for (int i = 0; i < 6; ++i) a[(size_t)e * 9 + i] = mc[(size_t)c->pos_cam[p] * 16 + 8 + i];
       for (int i = 0; i < 3; ++i) a[(size_t)e * 9 + 6 + i] = ml[(size_t)c->pos_lmk_loc[p] * 8 + 4 + i];
       b[e] = 0.f;

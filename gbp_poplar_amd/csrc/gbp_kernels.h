@@ -26,14 +26,16 @@ constexpr int kFacG = 14;
 constexpr int kCmsgG = 7;
 // MU: [0..8] mu (== oldmu between sweeps, ba.cpp:898)  [9] dmu
 constexpr int kMuG = 3;
-// STATE (1 group): x = damping, y = damping_count (int bits), z = flags (uint bits), w = meas_variance
+// Per-factor scalar state rides in the pad slots of the landmark-message record (below); flags:
 constexpr uint32_t kFlagActive = 1u, kFlagRobust = 2u, kFlagPad = 4u;
-// IDX (1 int4): x = camera, y = landmark (local index), z = slot record (landmark-major rank), w = file edge index
+// Indices: ROW_CAM[p/16] = camera of a row, LMK_IDX[p] = landmark (local index) of a factor.
 //
 // Landmark-side records are AoS of 16 floats (one 64-byte sector each):
 //   LMSG[p] (factor->landmark message of the factor at DEVICE position p; a landmark's records are found
 //   through LMK_FPOS[lmk_ptr[l] .. lmk_ptr[l+1]) in slot order), LMKB[l] / LMKP[l] beliefs / priors:
-//   [0..2] eta  [3] pad  [4..12] Lambda 3x3  [13..15] pad   (LMKB pads carry the hoisted dmu^2 pieces)
+//   [0..2] eta  [3] pad  [4..12] Lambda 3x3  [13..15] pad
+//   LMKB pads carry the hoisted dmu^2 pieces; LMSG pads carry the factor's scalar state:
+//   [3] damping  [13] (damping_count << 3) | flags (int bits)  [14] measurement variance
 constexpr int kLmkRec4 = 4;
 // Camera-side records are 44 floats (11 float4):  [0..5] eta  [6,7] pad  [8..43] Lambda 6x6
 //   CAMB[c] beliefs, CAMP[c] priors, ROWP[row] row partial sums, exchange buffers [rank][c]
@@ -50,8 +52,8 @@ struct Hyper {  // gbp_codelets.cpp:11-16
 };
 
 struct SweepArgs {
-  const int4* idx;
-  float4* state;
+  const uint32_t* row_cam;   // [Ep/16] camera of each 16-lane row
+  const uint32_t* lmk_idx;   // [Ep]    landmark (local index) of each factor
   float4* fac;
   float4* cmsg;
   float4* mu;
@@ -94,8 +96,9 @@ void launch_beliefs(BeliefArgs b, bool do_cam, bool do_lmk, hipStream_t s);
 void launch_weaken(float4* prior, const float* scaling, uint32_t* flag, uint32_t n, int rec4, hipStream_t s);
 void launch_means(const float4* camb, const float4* lmkb, float* cam_mu, float* lmk_mu, uint32_t n_cams,
                   uint32_t n_lmks, hipStream_t s);
-void launch_eval(const int4* idx, const float4* state, const float4* fac, const float* cam_mu, const float* lmk_mu,
-                 const float* K9_dev, int num_undamped_iters, DeviceEval* partials, uint32_t n_tiles, hipStream_t s);
+void launch_eval(const uint32_t* row_cam, const uint32_t* lmk_idx, const float4* lmsg, const float4* fac, const float* cam_mu,
+                 const float* lmk_mu, const float* K9_dev, int num_undamped_iters, DeviceEval* partials, uint32_t n_tiles,
+                 hipStream_t s);
 uint32_t eval_blocks(uint32_t n_tiles);
 
 }  // namespace gbp

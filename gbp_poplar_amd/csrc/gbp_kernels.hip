@@ -184,14 +184,8 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
   const uint32_t p = blockIdx.x * 256 + threadIdx.x;
   const uint32_t tile = p >> 6, lane = p & 63;
 
-  const int4 ix = a.idx[p];
-  float4 st = a.state[p];
-  float damping = st.x;
-  int count = __float_as_int(st.y);
-  uint32_t flags = __float_as_uint(st.z);
-  const float var = st.w;
-  const bool active = (flags & kFlagActive) != 0;
-  const bool is_pad = (flags & kFlagPad) != 0;
+  const uint32_t cam_i = a.row_cam[p >> 4];
+  const uint32_t lmk_i = __builtin_nontemporal_load(a.lmk_idx + p);
 
   float fac[56], cm[28], mu[12], lm[16], cb[44], lb[16];
   load_tile<kFacG>(a.fac, tile, lane, fac);
@@ -208,6 +202,8 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
   if (ABL & (1 | 16)) {  // 16 = no LMSG load (store stays), 32 = no LMSG store (load stays)
     GBP_UNROLL
     for (int i = 0; i < 16; ++i) lm[i] = 0.f;
+    lm[13] = __int_as_float((int)((5u << 3) | kFlagActive));
+    lm[14] = 4.f;
   } else {
     GBP_UNROLL
     for (int k = 0; k < 4; ++k) {
@@ -223,13 +219,21 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
       lm[4 * q] = v.x; lm[4 * q + 1] = v.y; lm[4 * q + 2] = v.z; lm[4 * q + 3] = v.w;
     }
   }
-  load_rec<kCamRec4>(a.camb + (size_t)(uint32_t)ix.x * kCamRec4, cb);
+  load_rec<kCamRec4>(a.camb + (size_t)cam_i * kCamRec4, cb);
   if (ABL & 2) {
     GBP_UNROLL
     for (int i = 0; i < 16; ++i) lb[i] = (i == 4 || i == 8 || i == 12) ? 1.f : 0.f;
   } else {
-    load_rec<kLmkRec4>(a.lmkb + (size_t)(uint32_t)ix.y * kLmkRec4, lb);
+    load_rec<kLmkRec4>(a.lmkb + (size_t)lmk_i * kLmkRec4, lb);
   }
+  // per-factor scalar state rides in the pad slots of the landmark-message record (read and rewritten
+  // every sweep anyway): [3] damping, [13] (damping_count << 3) | flags, [14] measurement variance
+  float damping = lm[3];
+  const int packed = __float_as_int(lm[13]);
+  int count = packed >> 3;
+  uint32_t flags = (uint32_t)packed & 7u;
+  const float var = lm[14];
+  const bool active = (flags & kFlagActive) != 0;
 
   float K[9];
   GBP_UNROLL
@@ -282,8 +286,8 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
     relin = (dmu < a.hp.dmu_threshold) && (count > a.hp.min_linear_iters - a.hp.num_undamped_iters);
     if (relin) {
       if (HOIST) {  // linearisation point = the hoisted means (rare path: loaded only here)
-        const float4 m0 = a.cam_mu[(size_t)(uint32_t)ix.x * 4], m1 = a.cam_mu[(size_t)(uint32_t)ix.x * 4 + 1];
-        const float4 l0 = a.lmk_mu[(size_t)(uint32_t)ix.y * 2];
+        const float4 m0 = a.cam_mu[(size_t)cam_i * 4], m1 = a.cam_mu[(size_t)cam_i * 4 + 1];
+        const float4 l0 = a.lmk_mu[(size_t)lmk_i * 2];
         x0c[0] = m0.x; x0c[1] = m0.y; x0c[2] = m0.z; x0c[3] = m0.w; x0c[4] = m1.x; x0c[5] = m1.y;
         x0l[0] = l0.x; x0l[1] = l0.y; x0l[2] = l0.z;
       }
@@ -395,6 +399,9 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
   }
 
   // ---- outputs --------------------------------------------------------------------------------
+  ol[3] = damping;
+  ol[13] = __int_as_float((int)(((uint32_t)count << 3) | flags));
+  ol[14] = var;
   if (!(ABL & (1 | 32))) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -434,7 +441,6 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
   }
   if (active) {
     if (!HOIST) store_tile<kMuG>(a.mu, tile, lane, mu);
-    a.state[p] = make_float4(damping, __int_as_float(count), __uint_as_float(flags), var);
     if (relin) store_tile<kFacG>(a.fac, tile, lane, fac);
   }
 }
@@ -445,23 +451,24 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
 __global__ __launch_bounds__(256) void k_linearise(const SweepArgs a) {
   const uint32_t p = blockIdx.x * 256 + threadIdx.x;
   const uint32_t tile = p >> 6, lane = p & 63;
-  const int4 ix = a.idx[p];
-  float4 st = a.state[p];
-  uint32_t flags = __float_as_uint(st.z);
+  const uint32_t cam_i = a.row_cam[p >> 4], lmk_i = a.lmk_idx[p];
+  float4 st = a.lmsg[(size_t)p * 4 + 3];   // record slots 12..15: y = packed count/flags, z = variance
+  int packed = __float_as_int(st.y);
+  uint32_t flags = (uint32_t)packed & 7u;
   if (flags & kFlagPad) return;
   float fac[56], cb[44], lb[16], K[9], x0c[6], x0l[3];
   load_tile<kFacG>(a.fac, tile, lane, fac);
-  load_rec<kCamRec4>(a.camb + (size_t)(uint32_t)ix.x * kCamRec4, cb);
-  load_rec<kLmkRec4>(a.lmkb + (size_t)(uint32_t)ix.y * kLmkRec4, lb);
+  load_rec<kCamRec4>(a.camb + (size_t)cam_i * kCamRec4, cb);
+  load_rec<kLmkRec4>(a.lmkb + (size_t)lmk_i * kLmkRec4, lb);
   GBP_UNROLL
   for (int i = 0; i < 9; ++i) K[i] = a.K[i];
   GBP_UNROLL
   for (int i = 0; i < 54; ++i) fac[i] = 0.f;
   belief_means(cb, lb, x0c, x0l);
-  const bool robust = relin_core(fac, x0c, x0l, K, st.w, a.hp.nstds);
+  const bool robust = relin_core(fac, x0c, x0l, K, st.z, a.hp.nstds);
   flags = robust ? (flags | kFlagRobust) : (flags & ~kFlagRobust);
-  st.z = __uint_as_float(flags);
-  a.state[p] = st;
+  st.y = __int_as_float((packed & ~7) | (int)flags);
+  a.lmsg[(size_t)p * 4 + 3] = st;
   store_tile<kFacG>(a.fac, tile, lane, fac);
 }
 
@@ -474,6 +481,15 @@ __global__ __launch_bounds__(256) void k_linearise(const SweepArgs a) {
 // Landmark beliefs: prior + messages in slot order.  With `hoist` the belief means (inf2mean, bafuncs.cpp:2-15)
 // and the dmu^2 pieces of the next sweep are computed here once per variable (see k_sweep<HOIST>).
 // =================================================================================================
+// float4 #q of the landmark-message record at device position pos, with the per-factor state that rides in
+// the record's pad slots (3, 13, 14, 15) blanked so that it never enters a belief sum
+GBP_DEV float4 lmsg_piece(const float4* lmsg, uint32_t pos, uint32_t q) {
+  float4 m = lmsg[(size_t)pos * 4 + q];
+  if (q == 0) m.w = 0.f;
+  if (q == 3) { m.y = 0.f; m.z = 0.f; m.w = 0.f; }
+  return m;
+}
+
 GBP_DEV void cam_mean(const float (&cb)[44], float (&x0c)[6]) {
   float Al[21], S6[36];
   GBP_UNROLL
@@ -563,7 +579,7 @@ __global__ __launch_bounds__(256) void k_beliefs(const BeliefArgs b) {
       GBP_UNROLL
       for (int k = 0; k < 8; ++k) pos[k] = b.lmk_fpos[s + k];
       GBP_UNROLL
-      for (int k = 0; k < 8; ++k) m[k] = b.lmsg[(size_t)pos[k] * 4 + q];
+      for (int k = 0; k < 8; ++k) m[k] = lmsg_piece(b.lmsg, pos[k], q);
       GBP_UNROLL
       for (int k = 0; k < 8; ++k) { acc.x = acc.x + m[k].x; acc.y = acc.y + m[k].y; acc.z = acc.z + m[k].z; acc.w = acc.w + m[k].w; }
     }
@@ -574,7 +590,7 @@ __global__ __launch_bounds__(256) void k_beliefs(const BeliefArgs b) {
       GBP_UNROLL
       for (int k = 0; k < 8; ++k) pos[k] = (uint32_t)k < n ? b.lmk_fpos[s + k] : 0u;
       GBP_UNROLL
-      for (int k = 0; k < 8; ++k) m[k] = (uint32_t)k < n ? b.lmsg[(size_t)pos[k] * 4 + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int k = 0; k < 8; ++k) m[k] = (uint32_t)k < n ? lmsg_piece(b.lmsg, pos[k], q) : make_float4(0.f, 0.f, 0.f, 0.f);
       GBP_UNROLL
       for (int k = 0; k < 8; ++k)
         if ((uint32_t)k < n) { acc.x = acc.x + m[k].x; acc.y = acc.y + m[k].y; acc.z = acc.z + m[k].z; acc.w = acc.w + m[k].w; }
@@ -689,26 +705,26 @@ uint32_t eval_blocks(uint32_t n_tiles) {
   return want < kEvalBlocks ? (want ? want : 1) : kEvalBlocks;
 }
 
-__global__ __launch_bounds__(256) void k_eval(const int4* __restrict__ idx, const float4* __restrict__ state,
-                                              const float4* __restrict__ fac, const float* __restrict__ cam_mu,
+__global__ __launch_bounds__(256) void k_eval(const uint32_t* __restrict__ row_cam, const uint32_t* __restrict__ lmk_idx,
+                                              const float4* __restrict__ lmsg, const float4* __restrict__ fac, const float* __restrict__ cam_mu,
                                               const float* __restrict__ lmk_mu, const float* __restrict__ Kd,
                                               int num_undamped, DeviceEval* partials, uint32_t n_tiles) {
   double s_norm = 0, s_half = 0;
   unsigned long long n_act = 0, n_rel = 0, n_rob = 0;
   const uint32_t total = n_tiles * 64;
   for (uint32_t p = blockIdx.x * 256 + threadIdx.x; p < total; p += gridDim.x * 256) {
-    const float4 st = state[p];
-    const uint32_t flags = __float_as_uint(st.z);
+    const int packed = __float_as_int(lmsg[(size_t)p * 4 + 3].y);
+    const uint32_t flags = (uint32_t)packed & 7u;
     if (flags & kFlagPad) continue;
     if (flags & kFlagRobust) ++n_rob;
-    if (__float_as_int(st.y) == -num_undamped) ++n_rel;
+    if ((packed >> 3) == -num_undamped) ++n_rel;
     if (!(flags & kFlagActive)) continue;
-    const int4 ix = idx[p];
+    const uint32_t cam_i = row_cam[p >> 4], lmk_i = lmk_idx[p];
     const uint32_t tile = p >> 6, lane = p & 63;
     const float4 zg = fac[((size_t)tile * kFacG + 13) * 64 + lane];  // floats 52..55: z = .z, .w
     float cm[6], lmu[3];
-    for (int i = 0; i < 6; ++i) cm[i] = cam_mu[(size_t)(uint32_t)ix.x * 6 + i];
-    for (int i = 0; i < 3; ++i) lmu[i] = lmk_mu[(size_t)(uint32_t)ix.y * 3 + i];
+    for (int i = 0; i < 6; ++i) cm[i] = cam_mu[(size_t)cam_i * 6 + i];
+    for (int i = 0; i < 3; ++i) lmu[i] = lmk_mu[(size_t)lmk_i * 3 + i];
     // eigenso3exp, util.cpp:20-32 (single expression)
     const float th = sqrtf(cm[3] * cm[3] + cm[4] * cm[4] + cm[5] * cm[5]);
     float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -799,9 +815,10 @@ void launch_means(const float4* camb, const float4* lmkb, float* cam_mu, float* 
   hipLaunchKernelGGL(k_means, dim3(blocks_for((uint64_t)n_cams + n_lmks)), dim3(256), 0, s, (const float*)camb,
                      (const float*)lmkb, cam_mu, lmk_mu, n_cams, n_lmks);
 }
-void launch_eval(const int4* idx, const float4* state, const float4* fac, const float* cam_mu, const float* lmk_mu,
-                 const float* K9_dev, int num_undamped_iters, DeviceEval* partials, uint32_t n_tiles, hipStream_t s) {
-  hipLaunchKernelGGL(k_eval, dim3(eval_blocks(n_tiles)), dim3(256), 0, s, idx, state, fac, cam_mu, lmk_mu, K9_dev,
+void launch_eval(const uint32_t* row_cam, const uint32_t* lmk_idx, const float4* lmsg, const float4* fac, const float* cam_mu,
+                 const float* lmk_mu, const float* K9_dev, int num_undamped_iters, DeviceEval* partials, uint32_t n_tiles,
+                 hipStream_t s) {
+  hipLaunchKernelGGL(k_eval, dim3(eval_blocks(n_tiles)), dim3(256), 0, s, row_cam, lmk_idx, lmsg, fac, cam_mu, lmk_mu, K9_dev,
                      num_undamped_iters, partials, n_tiles);
 }
 
