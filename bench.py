@@ -151,8 +151,15 @@ def main():
         tm = eng.timing(reset=True)
         sweep_s = tm["sweep_ms"] / 1e3 / a.profile_steps
         achieved = ALGO_BYTES_PER_FACTOR * e_local / sweep_s / 1e9
+        traffic = None     # HBM bytes per launch from the committed PMC passes of this same workload (profiles/run_profile.sh)
+        tpath = os.path.join(ROOT, "profiles", "traffic_S1.json")
+        if os.path.exists(tpath) and (a.cams, a.lmks, a.obs) == (1000, 100000, 10):
+            try:
+                traffic = int(json.load(open(tpath))["hbm_bytes_per_launch"])
+            except Exception:
+                traffic = None
         roof = {"bound": "hbm", "kernel": "k_sweep", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_FACTOR * e_local,
                 "avg_launch_us": round(sweep_s * 1e6, 2),
                 "belief_kernels_avg_us": round(tm["belief_ms"] * 1e3 / a.profile_steps, 2)}
