@@ -52,6 +52,7 @@ struct gbp_ctx {
   hipGraphExec_t graph_exec = nullptr;
   int graph_iters = 0;
   bool uploaded = false, beliefs_valid = false;
+  bool lmk_half_done = false;  // gbp_iterate_local already refreshed the landmark beliefs of this iteration
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
   bool profile_stages = false;
   double sweep_ms = 0, belief_ms = 0, total_ms = 0;
@@ -118,7 +119,7 @@ BeliefArgs belief_args(gbp_ctx* c) {
 // camera beliefs from stored partials (single GPU: d_local; multi: recv_dev) + landmark beliefs re-summed.
 // roll = true at the end of an iteration (the sweep has consumed the current means), false for
 // prior-only refreshes (WEAKEN_PRIORS, NEW_KEYFRAME, LINEARISE).
-int refresh_beliefs_from_partials(gbp_ctx* c, bool roll) {
+int refresh_beliefs_from_partials(gbp_ctx* c, bool roll, bool do_lmk = true) {
   BeliefArgs b = belief_args(c);
   if (c->world == 1) {
     b.gathered = P<float>(c->local); b.world = 1;
@@ -127,7 +128,7 @@ int refresh_beliefs_from_partials(gbp_ctx* c, bool roll) {
     b.gathered = static_cast<const float*>(c->recv_dev);
   }
   b.roll = roll ? 1 : 0;
-  launch_beliefs(b, true, true, c->stream);
+  launch_beliefs(b, true, do_lmk, c->stream);
   HIPCHK(c, hipGetLastError());
   return GBP_OK;
 }
@@ -440,9 +441,22 @@ int gbp_iterate_begin(gbp_ctx* c) {
   return GBP_OK;
 }
 
+// The landmark half of the belief update needs nothing from other ranks: a caller may run it while the
+// all-gather of the camera partials is in flight (between gbp_iterate_begin and gbp_iterate_end).
+int gbp_iterate_local(gbp_ctx* c) {
+  if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "upload first");
+  BeliefArgs b = belief_args(c);
+  b.roll = 1;
+  launch_beliefs(b, false, true, c->stream);
+  HIPCHK(c, hipGetLastError());
+  c->lmk_half_done = true;
+  return GBP_OK;
+}
+
 int gbp_iterate_end(gbp_ctx* c) {
   if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "upload first");
-  const int rc = refresh_beliefs_from_partials(c, true);
+  const int rc = refresh_beliefs_from_partials(c, true, !c->lmk_half_done);
+  c->lmk_half_done = false;
   if (rc == GBP_OK) c->beliefs_valid = true;
   return rc;
 }

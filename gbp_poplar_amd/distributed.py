@@ -74,9 +74,19 @@ class ShardedGbp:
         self.e.linearise_factors()
 
     def iterate(self, n=1):
+        overlap = self.dist is not None and self.world > 1 and self.stream is not None and hasattr(self.e, "iterate_local")
         for _ in range(int(n)):
-            self.e.iterate_begin()
-            self._exchange()
+            self.e.iterate_begin()                      # sweep + local camera partials -> send
+            if overlap:
+                # the collective runs on RCCL's stream (ordered after `send` is written); the landmark half of
+                # the belief update is rank-local and fills the GPU meanwhile; the camera combine waits for it
+                with self._on_stream():
+                    work = self.dist.all_gather_into_tensor(self.recv, self.send, async_op=True)
+                self.e.iterate_local()
+                with self._on_stream():
+                    work.wait()
+            else:
+                self._exchange()
             self.e.iterate_end()
 
     def weaken_priors(self):

@@ -115,6 +115,9 @@ class GbpEngine:
     def iterate_begin(self):
         self._chk(self.lib.gbp_iterate_begin(self.h), "gbp_iterate_begin")
 
+    def iterate_local(self):
+        self._chk(self.lib.gbp_iterate_local(self.h), "gbp_iterate_local")
+
     def iterate_end(self):
         self._chk(self.lib.gbp_iterate_end(self.h), "gbp_iterate_end")
 

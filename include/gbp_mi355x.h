@@ -176,7 +176,8 @@ int gbp_set_stream(gbp_ctx* ctx, void* hip_stream /* hipStream_t; NULL = ctx-own
 #define GBP_CAM_REC 44
 int gbp_set_exchange_buffers(gbp_ctx* ctx, void* send_dev, void* recv_dev);
 int gbp_iterate_begin(gbp_ctx* ctx);   /* prep + messages + local camera partial -> send_dev     */
-int gbp_iterate_end(gbp_ctx* ctx);     /* camera beliefs = prior + sum_r recv_dev[r]; landmark beliefs */
+int gbp_iterate_local(gbp_ctx* ctx);   /* optional: landmark beliefs now (rank-local), to overlap with the exchange */
+int gbp_iterate_end(gbp_ctx* ctx);     /* camera beliefs = prior + sum_r recv_dev[r]; landmark beliefs unless done */
 /* Re-derive beliefs after an exchange outside an iteration (LINEARISE / NEW_KEYFRAME on world>1):
  * gbp_refresh_begin computes the local camera partials into send_dev, gbp_refresh_end combines. */
 int gbp_refresh_begin(gbp_ctx* ctx);

@@ -458,7 +458,11 @@ def test_sharded_kernels_on_one_gpu_match_sharded_oracle(world, oracle_mod):
             if (it + 1) % 2 == 0 and it < 10:
                 all_do("weaken_priors")
                 orc.weaken_priors()
-            all_do("iterate_begin"); fake.gather_all(); all_do("iterate_end")
+            all_do("iterate_begin")
+            if it % 2:
+                all_do("iterate_local")          # landmark half first (what overlaps the all-gather on N GPUs)
+            fake.gather_all()
+            all_do("iterate_end")
             orc.iterate(1)
     finally:
         oracle_mod.set_trig_mode(0)
