@@ -66,7 +66,8 @@ class GbpKfUpdate(C.Structure):
 
 class GbpEvalOut(C.Structure):
     _fields_ = [("sum_norm", C.c_double), ("sum_half_sq", C.c_double), ("n_active", C.c_uint64),
-                ("n_relin", C.c_uint64), ("n_robust", C.c_uint64), ("n_nonfinite", C.c_uint64)]
+                ("n_relin", C.c_uint64), ("n_robust", C.c_uint64), ("n_nonfinite", C.c_uint64),
+                ("n_nonpd", C.c_uint64)]
 
 
 class GbpTimingOut(C.Structure):

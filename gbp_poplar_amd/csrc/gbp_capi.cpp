@@ -43,7 +43,7 @@ struct gbp_ctx {
   // device memory
   std::vector<DevBuf*> all;
   DevBuf row_cam, lmk_idx, fac, cmsg, mu, lmsg, camb, camp, lmkb, lmkp, rowp, local, d_cam_row_ptr, d_lmk_ptr, cwf, lwf,
-      cscale, lscale, cam_mu, lmk_mu, dK, evalp, hmu_c, hmu_l, d_lmk_fpos;
+      cscale, lscale, cam_mu, lmk_mu, dK, evalp, hmu_c, hmu_l, d_lmk_fpos, health;
   bool hoist = true;  // per-variable belief means (k_sweep<true>); false = literal per-factor mu/oldmu tensors
   void* send_dev = nullptr;
   void* recv_dev = nullptr;
@@ -286,7 +286,7 @@ int gbp_create(const gbp_problem* pr, const gbp_params* prm, const gbp_shard* sh
   A(c->d_cam_row_ptr, (size_t)(C + 1) * 4); A(c->d_lmk_ptr, (size_t)(c->L_loc + 1) * 4);
   A(c->cwf, (size_t)C * 4); A(c->lwf, (size_t)c->L_loc * 4); A(c->cscale, (size_t)C * 4); A(c->lscale, (size_t)c->L_loc * 4);
   A(c->cam_mu, (size_t)C * 6 * 4); A(c->lmk_mu, (size_t)c->L_loc * 3 * 4); A(c->dK, 16 * 4);
-  A(c->evalp, sizeof(DeviceEval) * 1024);
+  A(c->evalp, sizeof(DeviceEval) * 1024); A(c->health, 16);
   A(c->hmu_c, (size_t)C * 4 * 16); A(c->hmu_l, (size_t)c->L_loc * 2 * 16);
   if (rc != GBP_OK) { g_create_error = c->err; gbp_destroy(c); return rc; }
   auto CK = [&](hipError_t e, const char* what) {
@@ -617,7 +617,8 @@ int gbp_new_keyframe(gbp_ctx* c, const gbp_kf_update* u) {
 int gbp_eval(gbp_ctx* c, gbp_eval_out* o) {
   if (!c || !o || !c->uploaded) return fail(c, GBP_ERR_STATE, "gbp_eval: upload first");
   std::memset(o, 0, sizeof(*o));
-  launch_means(P<float4>(c->camb), P<float4>(c->lmkb), P<float>(c->cam_mu), P<float>(c->lmk_mu), c->C, c->L_loc, c->stream);
+  launch_means(P<float4>(c->camb), P<float4>(c->lmkb), P<float>(c->cam_mu), P<float>(c->lmk_mu), c->C, c->L_loc,
+               P<unsigned long long>(c->health), /*count_cams=*/c->rank == 0, c->stream);
   launch_eval(P<uint32_t>(c->row_cam), P<uint32_t>(c->lmk_idx), P<float4>(c->lmsg), P<float4>(c->fac), P<float>(c->cam_mu), P<float>(c->lmk_mu),
               P<float>(c->dK), c->prm.num_undamped_iters, P<DeviceEval>(c->evalp), c->n_tiles, c->stream);
   HIPCHK(c, hipGetLastError());
@@ -629,23 +630,13 @@ int gbp_eval(gbp_ctx* c, gbp_eval_out* o) {
     o->sum_norm += part[b].sum_norm; o->sum_half_sq += part[b].sum_half_sq;
     o->n_active += part[b].n_active; o->n_relin += part[b].n_relin; o->n_robust += part[b].n_robust;
   }
-  // non-finite guard (replaces the Poplar FP traps of ba.cpp:888-891): means of a broken belief are non-finite
+  // non-finite guard (replaces the Poplar FP traps of ba.cpp:888-891) + non-PD belief count;
+  // cameras are replicated, so only rank 0 counts them
   {
-    std::vector<float> cm((size_t)c->C * 6), lm((size_t)c->L_loc * 3);
-    HIPCHK(c, hipMemcpy(cm.data(), c->cam_mu.p, cm.size() * 4, hipMemcpyDeviceToHost));
-    if (c->L_loc) HIPCHK(c, hipMemcpy(lm.data(), c->lmk_mu.p, lm.size() * 4, hipMemcpyDeviceToHost));
-    auto finite = [](float x) { return x == x && x - x == 0.f; };
-    if (c->rank == 0)
-      for (uint32_t k = 0; k < c->C; ++k) {
-        bool bad = false;
-        for (int i = 0; i < 6; ++i) bad |= !finite(cm[(size_t)k * 6 + i]);
-        o->n_nonfinite += bad;
-      }
-    for (uint32_t l = 0; l < c->L_loc; ++l) {
-      bool bad = false;
-      for (int i = 0; i < 3; ++i) bad |= !finite(lm[(size_t)l * 3 + i]);
-      o->n_nonfinite += bad;
-    }
+    unsigned long long h[2] = {0, 0};
+    HIPCHK(c, hipMemcpy(h, c->health.p, 16, hipMemcpyDeviceToHost));
+    o->n_nonfinite = h[0];
+    o->n_nonpd = h[1];
   }
   return GBP_OK;
 }

@@ -683,19 +683,48 @@ GBP_DEV void solve_pivot(const float* A, int lda, const float* b, float* x) {
   }
 }
 
+// health check: a belief Lambda is usable by inv6x6 / inv3x3 only while the un-pivoted
+// LDL^T pivots of its lower triangle (matlib.cpp:193-206) stay positive; a non-PD landmark belief is the
+// early-warning sign of the blow-ups seen on fr1xyz.
+template <int N>
+GBP_DEV bool ldl_pivots_positive(const float* A, int lda) {
+  double L[N][N], D[N];
+  bool ok = true;
+  for (int j = 0; j < N; ++j) {
+    double d = A[j * lda + j];
+    for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k] * D[k];
+    D[j] = d;
+    if (!(d > 0.0)) ok = false;
+    for (int i = j + 1; i < N; ++i) {
+      double v = A[i * lda + j];
+      for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k] * D[k];
+      L[i][j] = v / d;
+    }
+  }
+  return ok;
+}
+
 __global__ __launch_bounds__(256) void k_means(const float* __restrict__ camb, const float* __restrict__ lmkb,
                                                float* __restrict__ cam_mu, float* __restrict__ lmk_mu, uint32_t n_cams,
-                                               uint32_t n_lmks) {
+                                               uint32_t n_lmks, unsigned long long* health, int count_cams) {
   const uint32_t t = blockIdx.x * 256 + threadIdx.x;
   if (t < n_cams) {
     float x[6];
     solve_pivot<6>(camb + (size_t)t * kCamRec + 8, 6, camb + (size_t)t * kCamRec, x);
-    for (int i = 0; i < 6; ++i) cam_mu[(size_t)t * 6 + i] = x[i];
+    bool finite = true;
+    for (int i = 0; i < 6; ++i) { cam_mu[(size_t)t * 6 + i] = x[i]; finite &= (x[i] - x[i] == 0.f); }
+    if (count_cams) {
+      if (!finite) atomicAdd(&health[0], 1ull);
+      if (!ldl_pivots_positive<6>(camb + (size_t)t * kCamRec + 8, 6)) atomicAdd(&health[1], 1ull);
+    }
   } else if (t - n_cams < n_lmks) {
     const uint32_t l = t - n_cams;
     float x[3];
     solve_pivot<3>(lmkb + (size_t)l * 16 + 4, 3, lmkb + (size_t)l * 16, x);
-    for (int i = 0; i < 3; ++i) lmk_mu[(size_t)l * 3 + i] = x[i];
+    bool finite = true;
+    for (int i = 0; i < 3; ++i) { lmk_mu[(size_t)l * 3 + i] = x[i]; finite &= (x[i] - x[i] == 0.f); }
+    if (!finite) atomicAdd(&health[0], 1ull);
+    if (!ldl_pivots_positive<3>(lmkb + (size_t)l * 16 + 4, 3)) atomicAdd(&health[1], 1ull);
   }
 }
 
@@ -811,9 +840,10 @@ void launch_weaken(float4* prior, const float* scaling, uint32_t* flag, uint32_t
   hipLaunchKernelGGL(k_weaken_flags, dim3(blocks_for(n)), dim3(256), 0, s, flag, n);
 }
 void launch_means(const float4* camb, const float4* lmkb, float* cam_mu, float* lmk_mu, uint32_t n_cams, uint32_t n_lmks,
-                  hipStream_t s) {
+                  unsigned long long* health2, bool count_cams, hipStream_t s) {
+  (void)hipMemsetAsync(health2, 0, 16, s);
   hipLaunchKernelGGL(k_means, dim3(blocks_for((uint64_t)n_cams + n_lmks)), dim3(256), 0, s, (const float*)camb,
-                     (const float*)lmkb, cam_mu, lmk_mu, n_cams, n_lmks);
+                     (const float*)lmkb, cam_mu, lmk_mu, n_cams, n_lmks, health2, count_cams ? 1 : 0);
 }
 void launch_eval(const uint32_t* row_cam, const uint32_t* lmk_idx, const float4* lmsg, const float4* fac, const float* cam_mu,
                  const float* lmk_mu, const float* K9_dev, int num_undamped_iters, DeviceEval* partials, uint32_t n_tiles,

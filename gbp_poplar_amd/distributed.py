@@ -107,7 +107,7 @@ class ShardedGbp:
         if self.world == 1 or self.dist is None:
             return ev
         torch = self.torch
-        keys = ["sum_norm", "sum_half_sq", "n_active", "n_relin", "n_robust", "n_nonfinite"]
+        keys = ["sum_norm", "sum_half_sq", "n_active", "n_relin", "n_robust", "n_nonfinite", "n_nonpd"]
         with self._on_stream():
             mine = torch.tensor([float(ev[k]) for k in keys], dtype=torch.float64, device=self.send.device)
             allv = torch.zeros(self.world * len(keys), dtype=torch.float64, device=self.send.device)

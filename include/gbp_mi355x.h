@@ -136,7 +136,9 @@ typedef struct {
   uint64_t n_active;
   uint64_t n_relin;      /* #(damping_count == -num_undamped_iters)   ba.cpp:1016-1020         */
   uint64_t n_robust;     /* sum robust_flag                            ba.cpp:1013-1015        */
-  uint64_t n_nonfinite;  /* beliefs with a non-finite entry (replaces Poplar FP traps, ba.cpp:888-891) */
+  uint64_t n_nonfinite;  /* variables whose belief mean is non-finite (replaces Poplar FP traps, ba.cpp:888-891) */
+  uint64_t n_nonpd;      /* variables whose belief Lambda has a non-positive un-pivoted LDL^T pivot: what
+                            inv6x6 / inv3x3 (matlib.cpp:143-222) silently accept; early warning of divergence */
 } gbp_eval_out;
 
 typedef struct {

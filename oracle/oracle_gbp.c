@@ -867,6 +867,24 @@ int orc_eval_host_f32(const gbp_problem* p, const uint32_t* active, const float*
   return 0;
 }
 
+/* un-pivoted LDL^T pivots of the lower triangle (the test inv6x6/inv3x3 never make) in fp64 */
+static int ldl_positive(const float* A, int n) {
+  double Lm[6][6], D[6];
+  int i, j, k, ok = 1;
+  for (j = 0; j < n; ++j) {
+    double d = A[j * n + j];
+    for (k = 0; k < j; ++k) d -= Lm[j][k] * Lm[j][k] * D[k];
+    D[j] = d;
+    if (!(d > 0.0)) ok = 0;
+    for (i = j + 1; i < n; ++i) {
+      double v = A[i * n + j];
+      for (k = 0; k < j; ++k) v -= Lm[i][k] * Lm[j][k] * D[k];
+      Lm[i][j] = v / d;
+    }
+  }
+  return ok;
+}
+
 int orc_eval(orc_ctx* o, gbp_eval_out* out) {
   gbp_problem p;
   uint32_t e;
@@ -887,12 +905,14 @@ int orc_eval(orc_ctx* o, gbp_eval_out* out) {
     for (k = 0; k < 6; ++k) if (!isfinite(o->cbe[i * 6 + k])) bad = 1;
     for (k = 0; k < 36; ++k) if (!isfinite(o->cbl[i * 36 + k])) bad = 1;
     out->n_nonfinite += bad;
+    out->n_nonpd += !ldl_positive(o->cbl + i * 36, 6);
   }
   for (i = 0; i < (size_t)o->L; ++i) {
     int k, bad = 0;
     for (k = 0; k < 3; ++k) if (!isfinite(o->lbe[i * 3 + k])) bad = 1;
     for (k = 0; k < 9; ++k) if (!isfinite(o->lbl[i * 9 + k])) bad = 1;
     out->n_nonfinite += bad;
+    if (o->sh_world == 1 || (i >= o->lb && i < o->le)) out->n_nonpd += !ldl_positive(o->lbl + i * 9, 3);
   }
   return 0;
 }

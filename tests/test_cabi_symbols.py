@@ -40,7 +40,7 @@ def test_struct_sizes_match_the_header():
     assert ctypes.sizeof(cabi.GbpParams) == 4 * 12
     assert ctypes.sizeof(cabi.GbpShard) == 16
     assert ctypes.sizeof(cabi.GbpProblem) == 16 + 16 + 36 + 4   # 3 x u32 (+pad), 2 pointers, K[9] (+pad)
-    assert ctypes.sizeof(cabi.GbpEvalOut) == 48
+    assert ctypes.sizeof(cabi.GbpEvalOut) == 56
     assert ctypes.sizeof(cabi.GbpStateIn) == 15 * 8 and ctypes.sizeof(cabi.GbpStateOut) == 7 * 8
 
 

@@ -505,3 +505,108 @@ def test_sharded_wrapper_world1_on_gpu(oracle_mod):
     ra, rb = plain.read(), sh.read()
     for k in ra:
         assert np.array_equal(ra[k], rb[k]), k
+
+
+# ---- edge cases and error behaviour of the C-ABI --------------------------------------------------------------
+
+def _tiny_problem(cam_id, lmk_id, C, L, seed=0):
+    """hand-made graph with well-posed geometry: cameras on a circle looking at points near the origin"""
+    rng = np.random.default_rng(seed)
+    cams = np.zeros((C, 6))
+    for c in range(C):
+        cams[c, :3] = [0.1 * c, -0.05 * c, 5.0 + 0.2 * c]
+        cams[c, 3:] = [0.05 + 0.01 * c, -0.04, 0.03 * (c + 1)]
+    pts = rng.uniform(-1, 1, (L, 3))
+    obs = np.zeros((len(cam_id), 2))
+    for e, (c, l) in enumerate(zip(cam_id, lmk_id)):
+        w = cams[c, 3:]
+        th = np.linalg.norm(w)
+        k = w / th
+        y = pts[l]
+        Ry = y * np.cos(th) + np.cross(k, y) * np.sin(th) + k * np.dot(k, y) * (1 - np.cos(th))
+        p = Ry + cams[c, :3]
+        obs[e] = [500 * p[0] / p[2] + 320 + rng.normal(), 500 * p[1] / p[2] + 240 + rng.normal()]
+    return {"n_cams": C, "n_lmks": L, "n_edges": len(cam_id), "fx": 500.0, "fy": 500.0, "cx": 320.0, "cy": 240.0,
+            "cam_id": np.asarray(cam_id, np.uint32), "lmk_id": np.asarray(lmk_id, np.uint32),
+            "observations": obs.ravel(), "cameras": (cams + rng.normal(0, 0.01, cams.shape) * (np.arange(C)[:, None] >= 2)).ravel(),
+            "points": (pts + rng.normal(0, 0.05, pts.shape)).ravel()}
+
+
+@pytest.mark.parametrize("case", ["three_factors", "camera_without_factors", "ragged_rows"])
+def test_degenerate_graph_shapes(case, oracle_mod):
+    """Fewer factors than one 16-lane row, a camera with no factor at all, cameras with 1, 16, 17 and 33
+    factors (row padding on every boundary): bit-exact against the oracle through 4 sweeps."""
+    if case == "three_factors":
+        cam_id, lmk_id, C, L = [0, 1, 2], [0, 0, 1], 3, 2
+    elif case == "camera_without_factors":
+        cam_id, lmk_id, C, L = [0, 0, 2, 2, 3], [0, 1, 0, 2, 1], 4, 3
+    else:
+        deg = [1, 16, 17, 33]
+        cam_id = sum(([c] * d for c, d in enumerate(deg)), [])
+        lmk_id = sum((list(range(d)) for d in deg), [])
+        C, L = 4, 33
+    bal = _tiny_problem(cam_id, lmk_id, C, L)
+    eng, orc, opts, state, _ = _setup(bal, oracle_mod, sum_order=1)
+    eng.linearise()
+    orc.linearise()
+    _sync_potentials(eng, orc)
+    for it in range(4):
+        if it == 1:
+            eng.weaken_priors()
+            orc.weaken_priors()
+        eng.iterate(1)
+        orc.iterate(1)
+        _assert_state_equal(eng, orc, exact=True)
+    g, o = eng.eval(), orc.eval()
+    assert g["n_active"] == o["n_active"] == len(cam_id) and g["n_nonfinite"] == 0 and g["n_nonpd"] == o["n_nonpd"]
+
+
+def test_error_codes_and_call_order():
+    from gbp_poplar_amd import driver, hostlib
+    from gbp_poplar_amd.engine import GbpEngine, GbpError
+    bal = small_synth(n_cams=4, n_lmks=20, obs=3, seed=5)
+    opts = driver.Options()
+    K, state, _ = driver.build_inputs(bal, opts, hostlib)
+    eng = GbpEngine(bal["cam_id"], bal["lmk_id"], 4, 20, K)
+    for call in (eng.linearise, lambda: eng.iterate(1), eng.weaken_priors, eng.eval):
+        with pytest.raises(GbpError, match="upload first"):          # GBP_ERR_STATE: nothing uploaded yet
+            call()
+    bad = dict(state)
+    del bad["cam_priors_lambda"]
+    with pytest.raises(GbpError, match="required"):
+        eng.upload(bad)
+    with pytest.raises(GbpError, match="out of range"):               # indices are validated at create
+        GbpEngine(np.array([0, 9], np.uint32), np.array([0, 1], np.uint32), 4, 20, K)
+    with pytest.raises(GbpError, match="bad shard"):
+        GbpEngine(bal["cam_id"], bal["lmk_id"], 4, 20, K, shard=(2, 2, 0, 20))
+    sh = GbpEngine(bal["cam_id"], bal["lmk_id"], 4, 20, K, shard=(0, 2, 0, 10))
+    sh.upload(state)
+    with pytest.raises(GbpError, match="sharded ctx"):
+        sh.linearise()
+    with pytest.raises(GbpError, match="sharded ctx"):
+        sh.iterate(1)
+    with pytest.raises(GbpError, match="exchange buffers not set"):
+        sh.iterate_begin()
+    eng.upload(state)
+    eng.linearise()
+    eng.iterate(0)                                                     # n = 0 is a no-op
+    eng.iterate(3)
+    t = eng.timing()
+    assert t["iterations"] == 3 and t["algorithmic_bytes_per_iter"] == 1112 * bal["n_edges"] + 336 * 4 + 96 * 20
+
+
+def test_health_counters(oracle_mod):
+    """A non-PD landmark prior (negative Lambda) must show up in n_nonpd after the belief refresh."""
+    from gbp_poplar_amd import driver, hostlib
+    bal = small_synth(n_cams=5, n_lmks=30, obs=3, seed=4)
+    eng, orc, opts, state, _ = _setup(bal, oracle_mod)
+    state = dict(state)
+    lam = state["lmk_priors_lambda"].copy()
+    lam[9 * 7:9 * 8] *= -1.0
+    state["lmk_priors_lambda"] = lam
+    eng.upload(state)
+    orc.upload(state)
+    eng.linearise()
+    orc.linearise()
+    g, o = eng.eval(), orc.eval()
+    assert g["n_nonpd"] == o["n_nonpd"] == 1 and g["n_nonfinite"] == 0
