@@ -1,0 +1,74 @@
+"""Multi-GPU front end with the `ba` flag set: what `./ba --ipus N` (reference ba/ba.cpp:414-417,617-649) maps to.
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           -m gbp_poplar_amd.ba_mp --bal_file F [--n_iters K] [--eval_every E] [... the ba flags]
+
+One process per GPU; landmarks are sharded over the ranks (gbp_poplar_amd.distributed), rank 0 prints the
+same lines as `./ba` (ba.cpp:996,1004,1026-1028).  With WORLD_SIZE unset it runs on one GPU.
+"""
+import argparse
+import os
+import sys
+import time
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="ba_mp")
+    ap.add_argument("--bal_file", required=True)
+    ap.add_argument("--n_iters", type=int, default=1500)
+    ap.add_argument("--reproj_meas_var", type=float, default=4.0)
+    ap.add_argument("--prior_std_weaker_factor", type=float, default=100.0)
+    ap.add_argument("--first_cam_prior_std", type=float, default=0.01)
+    ap.add_argument("--steps", type=float, default=5.0)
+    ap.add_argument("--undamped_start", type=int, default=15)
+    ap.add_argument("--eval_every", type=int, default=1)
+    a = ap.parse_args(argv)
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    if not torch.cuda.is_available():
+        print("Could not find a device", file=sys.stderr)
+        return 255
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from . import driver, hostlib
+    from .distributed import ShardedGbp, landmark_partition
+    from .engine import GbpEngine
+
+    log = print if rank == 0 else (lambda *x: None)
+    try:
+        bal = hostlib.bal_read(a.bal_file)
+    except IOError as e:
+        print(e, file=sys.stderr)
+        return 1
+    opts = driver.Options(n_iters=a.n_iters, reproj_meas_var=a.reproj_meas_var,
+                          prior_std_weaker_factor=a.prior_std_weaker_factor,
+                          first_cam_prior_std=a.first_cam_prior_std, steps=a.steps, undamped_start=a.undamped_start)
+    K, state, _ = driver.build_inputs(bal, opts, hostlib)
+    log("Completed loading data!\n\nBundle Adjustment\n")
+    log("Number of keyframe nodes in the graph: %d\nNumber of landmark nodes in the graph: %d\nNumber of edges in the graph: %d"
+        % (bal["n_cams"], bal["n_lmks"], bal["n_edges"]))
+    log("\nNumber of GPUs: %d" % world)
+    C, L = bal["n_cams"], bal["n_lmks"]
+    bounds = landmark_partition(bal["lmk_id"], L, world)
+    eng = GbpEngine(bal["cam_id"], bal["lmk_id"], C, L, K, shard=(rank, world, int(bounds[rank]), int(bounds[rank + 1])))
+    run = ShardedGbp(eng, C, rank, world, dist=dist, device="cuda")
+    t0 = time.perf_counter()
+    traj = driver.run_ba(run, state, opts, n_iters=a.n_iters, eval_every=a.eval_every, log=log)
+    run.sync()
+    log("\n Finished GBP.\nTotal time: %.3f s (%d iterations, %d GPUs)" % (time.perf_counter() - t0, a.n_iters, world))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if traj else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

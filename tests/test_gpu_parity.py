@@ -695,3 +695,13 @@ def test_full_size_s1_properties(s1):
     m0, m1 = driver.metric(eva[0]), driver.metric(eva[1])
     assert 7.0 < m0[2] < 10.0 and 1.25 < m1[2] < 1.40, (m0, m1)      # RMSE: 8.44 px -> 1.30 px (1 px pixel noise)
     assert eva[1]["n_nonfinite"] == 0 and eva[1]["n_nonpd"] == 0 and eva[1]["n_active"] == 1000000
+
+
+def test_ba_mp_front_end_single_gpu(capsys):
+    """`python -m gbp_poplar_amd.ba_mp` (the --ipus/--gpus N front end) on one GPU prints the ba lines and converges."""
+    from gbp_poplar_amd import ba_mp
+    rc = ba_mp.main(["--bal_file", seq_path("fr2robot2"), "--n_iters", "40", "--eval_every", "10"])
+    out = capsys.readouterr().out
+    assert rc == 0 and "Initial Reprojection error: 39.8638" in out and out.count("Weakening priors") == 5
+    last = [l for l in out.splitlines() if l.startswith("Iter 39 ")]
+    assert last and 0.5 < float(last[0].split("Reprojection error ")[1].split(" ")[0]) < 5.0
