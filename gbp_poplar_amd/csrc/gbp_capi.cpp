@@ -735,9 +735,17 @@ int gbp_debug_get(gbp_ctx* c, int what, float* a, float* b) {
 int gbp_debug_time_sweep(gbp_ctx* c, int ablation, int reps, double* avg_us) {
   if (!c || !avg_us || reps <= 0 || !c->uploaded) return GBP_ERR_INVALID;
   const SweepArgs a = sweep_args(c);
-  launch_sweep_ablated(a, c->n_tiles, ablation, c->stream);
+  auto one = [&]() {
+    if (ablation >= 100) {  // 100: k_beliefs, 101: camera part only, 102: landmark part only
+      BeliefArgs b = belief_args(c);
+      launch_beliefs(b, ablation != 102, ablation != 101, c->stream);
+    } else {
+      launch_sweep_ablated(a, c->n_tiles, ablation, c->stream);
+    }
+  };
+  one();
   HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-  for (int i = 0; i < reps; ++i) launch_sweep_ablated(a, c->n_tiles, ablation, c->stream);
+  for (int i = 0; i < reps; ++i) one();
   HIPCHK(c, hipEventRecord(c->ev2, c->stream));
   HIPCHK(c, hipEventSynchronize(c->ev2));
   float ms = 0;

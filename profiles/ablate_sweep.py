@@ -21,7 +21,8 @@ for it in range(20):
 names = {0: "full kernel", 1: "no LMSG gather/scatter", 2: "no landmark-belief gather", 3: "no LMSG, no lmk-belief gather",
          4: "no arithmetic", 7: "streams only (no LMSG, no lmkb, no arithmetic)", 8: "LMSG by position (streaming)",
          12: "LMSG by position, no arithmetic", 16: "no LMSG gather (scatter stays)", 32: "no LMSG scatter (gather stays)"}
-for abl in (0, 1, 16, 32, 2, 3, 4, 7, 8, 12, 0):
+names.update({100: "k_beliefs (camera + landmark parts)", 101: "k_beliefs camera part only", 102: "k_beliefs landmark part only"})
+for abl in (0, 1, 16, 32, 2, 3, 4, 7, 0, 100, 101, 102):
     us = C.c_double()
     rc = eng.lib.gbp_debug_time_sweep(eng.h, abl, 50, C.byref(us))
     print("ablation %2d  %-48s %8.2f us  rc=%d" % (abl, names[abl], us.value, rc))
