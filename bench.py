@@ -176,8 +176,8 @@ def main():
             "value": round(ips * E / 1e6, 2), "unit": "1M-factor GBP iters/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "S1 synthetic BAL graph x%d: %d cams x %d lmks x %d factors (seed %d), landmark-sharded"
-                                   % (world, C, L, E, a.seed),
+            "config": {"workload": "S1 synthetic BAL graph x%d: %d cams x %d lmks x %d factors (seed %d)%s"
+                                   % (world, C, L, E, a.seed, ", landmark-sharded over %d GPUs" % world if world > 1 else ""),
                        "cams": C, "lmks": L, "factors": E, "iters_per_sec": round(ips, 2),
                        "parallelism": "1 GPU, hipGraph x10 iterations" if world == 1 else "landmark shards x%d + all_gather(cam partials)" % world,
                        "reproj_rmse_px_initial": round(m0[2], 6), "reproj_rmse_px_final": round(m1[2], 6),

@@ -470,22 +470,28 @@ int gbp_iterate(gbp_ctx* c, int n) {
   const SweepArgs a = sweep_args(c);
   HIPCHK(c, hipEventRecord(c->ev0, c->stream));
   if (c->profile_stages) {
+    // Per-stage timing: all n iterations are queued back to back with a hipEvent before / between / after the
+    // two kernels, and read after ONE synchronisation, so a bracket holds the kernel (plus the ~1 us
+    // dependent-launch gap), not the idle-queue start-up latency a per-iteration sync would add.
+    std::vector<hipEvent_t> ev(2 * (size_t)n + 1, nullptr);
+    for (auto& e : ev) HIPCHK(c, hipEventCreate(&e));
+    HIPCHK(c, hipEventRecord(ev[0], c->stream));
     for (int i = 0; i < n; ++i) {
-      HIPCHK(c, hipEventRecord(c->ev1, c->stream));
       launch_sweep(a, c->n_tiles, c->hoist, c->stream);
-      HIPCHK(c, hipEventRecord(c->ev2, c->stream));
-      {
-        BeliefArgs b = belief_args(c);
-        b.roll = 1;
-        launch_beliefs(b, true, true, c->stream);
-      }
-      HIPCHK(c, hipEventRecord(c->ev3, c->stream));
-      HIPCHK(c, hipEventSynchronize(c->ev3));
+      HIPCHK(c, hipEventRecord(ev[2 * i + 1], c->stream));
+      BeliefArgs b = belief_args(c);
+      b.roll = 1;
+      launch_beliefs(b, true, true, c->stream);
+      HIPCHK(c, hipEventRecord(ev[2 * i + 2], c->stream));
+    }
+    HIPCHK(c, hipEventSynchronize(ev[2 * (size_t)n]));
+    for (int i = 0; i < n; ++i) {
       float a_ms = 0, b_ms = 0;
-      HIPCHK(c, hipEventElapsedTime(&a_ms, c->ev1, c->ev2));
-      HIPCHK(c, hipEventElapsedTime(&b_ms, c->ev2, c->ev3));
+      HIPCHK(c, hipEventElapsedTime(&a_ms, ev[2 * i], ev[2 * i + 1]));
+      HIPCHK(c, hipEventElapsedTime(&b_ms, ev[2 * i + 1], ev[2 * i + 2]));
       c->sweep_ms += a_ms; c->belief_ms += b_ms;
     }
+    for (auto& e : ev) (void)hipEventDestroy(e);
   } else {
     int left = n;
     const bool use_graph = (c->stream == c->own_stream) && c->prm.graph_unroll > 0 && n >= c->prm.graph_unroll;
