@@ -705,3 +705,30 @@ def test_ba_mp_front_end_single_gpu(capsys):
     assert rc == 0 and "Initial Reprojection error: 39.8638" in out and out.count("Weakening priors") == 5
     last = [l for l in out.splitlines() if l.startswith("Iter 39 ")]
     assert last and 0.5 < float(last[0].split("Reprojection error ")[1].split(" ")[0]) < 5.0
+
+
+@pytest.mark.parametrize("kw", [{"relin_mode": 1}, {"dmu_threshold": 3e-2, "maxeta_damping": 0.25, "nstds": 1.5,
+                                                     "num_undamped_iters": 4, "min_linear_iters": 6}])
+def test_non_default_parameters_bit_exact(kw, oracle_mod):
+    """gbp_params reach the kernels: relin_mode = reset (quirk C-1 'fixed') and non-default hyper-parameters
+    (gbp_codelets.cpp:11-16) give the oracle's result bit for bit through relinearisations."""
+    from gbp_poplar_amd import _cabi, driver, hostlib
+    from gbp_poplar_amd.engine import GbpEngine
+    bal = _bal("fr2robot2")
+    opts = driver.Options()
+    K, state, _ = driver.build_inputs(bal, opts, hostlib)
+    oracle_mod.set_trig_mode(1)
+    try:
+        eng = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K, params=_cabi.GbpParams.defaults(**kw))
+        orc = oracle_mod.Oracle(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K,
+                                params=_cabi.GbpParams.defaults(**kw))
+        orc.set_sum_order(1)
+        tg = driver.run_ba(eng, state, opts, n_iters=30, eval_every=30)
+        to = driver.run_ba(orc, state, opts, n_iters=30, eval_every=30)
+    finally:
+        oracle_mod.set_trig_mode(0)
+    g, o = eng.read(), orc.read()
+    for k in g:
+        assert np.array_equal(g[k], o[k]), k
+    assert tg[-1][3] == to[-1][3] and tg[-1][4] == to[-1][4]
+    assert np.sum(o["damping_count"] <= 0) > 0 or kw.get("relin_mode") == 1
