@@ -35,12 +35,13 @@ def landmark_partition(lmk_id, n_lmks, world):
 class ShardedGbp:
     """The Poplar program list over `world` ranks.  Same verbs as GbpEngine / the oracle."""
 
-    def __init__(self, engine, n_cams, rank, world, dist=None, device="cpu"):
+    def __init__(self, engine, n_cams, rank, world, dist=None, device="cpu", always_collective=False):
         import torch
         self.torch = torch
         self.e = engine
         self.C, self.rank, self.world = int(n_cams), int(rank), int(world)
         self.dist = dist
+        self.always_collective = always_collective   # run the all-gather even for world == 1 (exercises RCCL in tests)
         self.send = torch.zeros(self.C * CAM_REC, dtype=torch.float32, device=device)
         self.recv = torch.zeros(self.world * self.C * CAM_REC, dtype=torch.float32, device=device)
         self.stream = None
@@ -58,7 +59,7 @@ class ShardedGbp:
 
     def _exchange(self):
         with self._on_stream():
-            if self.world == 1 or self.dist is None:
+            if self.dist is None or (self.world == 1 and not self.always_collective):
                 self.recv.copy_(self.send)
             else:
                 self.dist.all_gather_into_tensor(self.recv, self.send)
@@ -74,7 +75,8 @@ class ShardedGbp:
         self.e.linearise_factors()
 
     def iterate(self, n=1):
-        overlap = self.dist is not None and self.world > 1 and self.stream is not None and hasattr(self.e, "iterate_local")
+        overlap = (self.dist is not None and (self.world > 1 or self.always_collective) and self.stream is not None
+                   and hasattr(self.e, "iterate_local"))
         for _ in range(int(n)):
             self.e.iterate_begin()                      # sweep + local camera partials -> send
             if overlap:

@@ -731,3 +731,33 @@ def test_non_default_parameters_bit_exact(kw, oracle_mod):
     for k in g:
         assert np.array_equal(g[k], o[k]), k
     assert tg[-1][3] == to[-1][3] and tg[-1][4] == to[-1][4]
+
+
+def test_rccl_single_rank_group_overlap_path():
+    """The exact code path of an N-GPU run (RCCL all_gather_into_tensor with async_op, landmark half overlapped,
+    stream-ordered camera combine) on a 1-rank RCCL group: must equal the plain single-GPU engine bit for bit."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from gbp_poplar_amd import driver, hostlib
+    from gbp_poplar_amd.distributed import ShardedGbp
+    from gbp_poplar_amd.engine import GbpEngine
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(29600 + os.getpid() % 300)
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        bal = _bal("fr2robot2")
+        opts = driver.Options()
+        K, state, _ = driver.build_inputs(bal, opts, hostlib)
+        plain = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K)
+        eng = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K, shard=(0, 1, 0, bal["n_lmks"]))
+        sh = ShardedGbp(eng, bal["n_cams"], 0, 1, dist=dist, device="cuda", always_collective=True)
+        ta = driver.run_ba(plain, state, opts, n_iters=30, eval_every=10)
+        tb = driver.run_ba(sh, state, opts, n_iters=30, eval_every=10)
+        assert ta == tb
+        ra, rb = plain.read(), sh.read()
+        for k in ra:
+            assert np.array_equal(ra[k], rb[k]), k
+    finally:
+        dist.destroy_process_group()
