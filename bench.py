@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--seed", type=int, default=20200303)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=20, help="per-stage hipEvent-timed iterations for the roofline")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="diagnostic: run the N>1 code path (shard ctx, RCCL all_gather, overlap) even with one rank")
     return ap.parse_args()
 
 
@@ -113,10 +115,14 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or a.force_sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if "RANK" not in os.environ:     # --force-sharded without a launcher: a 1-rank group
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from gbp_poplar_amd import driver, hostlib
     from gbp_poplar_amd.distributed import ShardedGbp, landmark_partition
@@ -128,14 +134,14 @@ def main():
     opts = driver.Options()
     K, state, _ = driver.build_inputs(bal, opts, hostlib)
 
-    if world == 1:
+    if world == 1 and not a.force_sharded:
         eng = GbpEngine(bal["cam_id"], bal["lmk_id"], C, L, K)
         run = eng
         e_local = E
     else:
         bounds = landmark_partition(bal["lmk_id"], L, world)
         eng = GbpEngine(bal["cam_id"], bal["lmk_id"], C, L, K, shard=(rank, world, int(bounds[rank]), int(bounds[rank + 1])))
-        run = ShardedGbp(eng, C, rank, world, dist=dist, device="cuda")
+        run = ShardedGbp(eng, C, rank, world, dist=dist, device="cuda", always_collective=a.force_sharded)
         e_local = int(((bal["lmk_id"] >= bounds[rank]) & (bal["lmk_id"] < bounds[rank + 1])).sum())
     run.upload(state)
     run.linearise()
@@ -162,7 +168,7 @@ def main():
 
     # ---- roofline of the dominant kernel (k_sweep), measured live with hipEvents on its stream ----
     roof = None
-    if world == 1 and a.profile_steps > 0:
+    if world == 1 and a.profile_steps > 0 and not a.force_sharded:
         eng.timing(reset=True)
         eng.set_profiling(True)
         eng.iterate(a.profile_steps)
