@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--profile-steps", type=int, default=20, help="per-stage hipEvent-timed iterations for the roofline")
     ap.add_argument("--force-sharded", action="store_true",
                     help="diagnostic: run the N>1 code path (shard ctx, RCCL all_gather, overlap) even with one rank")
+    ap.add_argument("--sharded-graph", type=int, default=0, help="capture sharded iterations (kernels + RCCL) in a hipGraph")
     return ap.parse_args()
 
 
@@ -141,12 +142,15 @@ def main():
     else:
         bounds = landmark_partition(bal["lmk_id"], L, world)
         eng = GbpEngine(bal["cam_id"], bal["lmk_id"], C, L, K, shard=(rank, world, int(bounds[rank]), int(bounds[rank + 1])))
-        run = ShardedGbp(eng, C, rank, world, dist=dist, device="cuda", always_collective=a.force_sharded)
+        run = ShardedGbp(eng, C, rank, world, dist=dist, device="cuda", always_collective=a.force_sharded,
+                         use_graph=bool(a.sharded_graph))
         e_local = int(((bal["lmk_id"] >= bounds[rank]) & (bal["lmk_id"] < bounds[rank + 1])).sum())
     run.upload(state)
     run.linearise()
     ev0 = run.eval()
     warm_start(run, opts, a.warmup)
+    if getattr(run, "use_graph", False):
+        run.iterate(run.graph_unroll + 3)      # un-timed: triggers the one-off capture of the sharded iteration graph
 
     def fence():
         run.sync()
@@ -210,7 +214,9 @@ def main():
                        "parallelism": "1 GPU, hipGraph x10 iterations" if world == 1 else "landmark shards x%d + all_gather(cam partials)" % world,
                        "reproj_rmse_px_initial": round(m0[2], 6), "reproj_rmse_px_final": round(m1[2], 6),
                        "mean_reproj_px_final": round(m1[0], 6), "iterations_run": a.warmup + a.steps,
-                       "nonfinite_beliefs": int(ev1["n_nonfinite"])},
+                       "nonfinite_beliefs": int(ev1["n_nonfinite"]),
+                       "sharded_graph": (getattr(run, "graph", None) is not None) if hasattr(run, "use_graph") else None,
+                       "sharded_graph_error": getattr(run, "graph_error", None)},
         }
         if roof:
             out["roofline"] = roof

@@ -35,13 +35,17 @@ def landmark_partition(lmk_id, n_lmks, world):
 class ShardedGbp:
     """The Poplar program list over `world` ranks.  Same verbs as GbpEngine / the oracle."""
 
-    def __init__(self, engine, n_cams, rank, world, dist=None, device="cpu", always_collective=False):
+    def __init__(self, engine, n_cams, rank, world, dist=None, device="cpu", always_collective=False, use_graph=False):
         import torch
         self.torch = torch
         self.e = engine
         self.C, self.rank, self.world = int(n_cams), int(rank), int(world)
         self.dist = dist
         self.always_collective = always_collective   # run the all-gather even for world == 1 (exercises RCCL in tests)
+        self.use_graph = use_graph                   # capture kernels + collective of `graph_unroll` iterations
+        self.graph_unroll = 10
+        self.graph = None
+        self.graph_error = None
         self.send = torch.zeros(self.C * CAM_REC, dtype=torch.float32, device=device)
         self.recv = torch.zeros(self.world * self.C * CAM_REC, dtype=torch.float32, device=device)
         self.stream = None
@@ -74,22 +78,59 @@ class ShardedGbp:
         self.e.refresh_end()
         self.e.linearise_factors()
 
+    def _one_iteration(self, overlap):
+        self.e.iterate_begin()                      # sweep + local camera partials -> send
+        if overlap:
+            # the collective runs on RCCL's stream (ordered after `send` is written); the landmark half of
+            # the belief update is rank-local and fills the GPU meanwhile; the camera combine waits for it
+            with self._on_stream():
+                work = self.dist.all_gather_into_tensor(self.recv, self.send, async_op=True)
+            self.e.iterate_local()
+            with self._on_stream():
+                work.wait()
+        else:
+            self._exchange()
+        self.e.iterate_end()
+
+    def _capture(self, overlap):
+        """Capture `graph_unroll` iterations (kernels of this engine AND the RCCL all-gather) into one hipGraph on
+        the shared stream.  Returns False (and stays on direct launches) if the runtime refuses the capture."""
+        torch = self.torch
+        try:
+            for _ in range(3):                       # RCCL must have run on this stream before a capture
+                self._one_iteration(overlap)
+            self.stream.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=self.stream):
+                for _ in range(self.graph_unroll):
+                    self._one_iteration(overlap)
+            self.graph = g
+            return 3
+        except Exception as exc:                     # noqa: BLE001 - any capture failure means "no graph"
+            self.graph = None
+            self.graph_error = repr(exc)
+            self.use_graph = False
+            try:
+                self.stream.synchronize()
+            except Exception:
+                pass
+            return None
+
     def iterate(self, n=1):
+        n = int(n)
         overlap = (self.dist is not None and (self.world > 1 or self.always_collective) and self.stream is not None
                    and hasattr(self.e, "iterate_local"))
-        for _ in range(int(n)):
-            self.e.iterate_begin()                      # sweep + local camera partials -> send
-            if overlap:
-                # the collective runs on RCCL's stream (ordered after `send` is written); the landmark half of
-                # the belief update is rank-local and fills the GPU meanwhile; the camera combine waits for it
+        if self.use_graph and self.stream is not None and self.dist is not None and n >= self.graph_unroll + 3:
+            if self.graph is None:
+                done = self._capture(overlap)
+                if done is not None:
+                    n -= done
+            while self.graph is not None and n >= self.graph_unroll:
                 with self._on_stream():
-                    work = self.dist.all_gather_into_tensor(self.recv, self.send, async_op=True)
-                self.e.iterate_local()
-                with self._on_stream():
-                    work.wait()
-            else:
-                self._exchange()
-            self.e.iterate_end()
+                    self.graph.replay()
+                n -= self.graph_unroll
+        for _ in range(n):
+            self._one_iteration(overlap)
 
     def weaken_priors(self):
         self.e.weaken_priors()          # priors are replicated / local: no exchange (partials unchanged)
