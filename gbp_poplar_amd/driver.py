@@ -47,7 +47,7 @@ def build_inputs(bal, opts, host, slam=False):
     state = {
         "damping": np.zeros(E, np.float32),
         "damping_count": np.full(E, -opts.undamped_start, np.int32),        # ba.cpp:581
-        "mu": np.zeros(9 * E, np.float32), "oldmu": np.zeros(9 * E, np.float32),
+        # mu / oldmu are zero in the reference (ba.cpp:582-583): left out = NULL = zeros in the C-ABI
         "cam_scaling": cs, "lmk_scaling": ls,
         "cam_priors_eta": cpe, "cam_priors_lambda": cpl, "lmk_priors_eta": lpe, "lmk_priors_lambda": lpl,
         "measurements": np.asarray(bal["observations"], dtype=np.float64).astype(np.float32),
