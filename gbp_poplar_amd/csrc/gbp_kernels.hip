@@ -193,11 +193,15 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
   if (!HOIST) load_tile<kMuG>(a.mu, tile, lane, mu);
   // Landmark messages live as 64-byte records in DEVICE (camera-major) order: the wave's 64 records are one
   // contiguous 4 KiB block, moved with four coalesced 1 KiB accesses and transposed through a wave-private
-  // LDS staging area (records padded to 80 B => conflict-free ds_read/ds_write_b128).  k_beliefs gathers
-  // the records of a landmark by position (random 64-B READS are ~2.3x cheaper than random 64-B writes,
-  // profiles/ablate_sweep.py).
-  __shared__ float4 lm_stage[4][64 * 5];
+  // LDS staging area.  Piece q of record r sits at float4 slot r*4 + (q ^ swz(r)), swz(r) = ((r>>2)&3) ^ (r&2):
+  // a permutation inside each 64-B record, so the tile-order accesses (whole records) and the record-order
+  // accesses (one piece per lane) are both bank-conflict-free for ds_read_b128 (16-lane groups, 64 banks)
+  // and ds_write_b128 (8-lane groups, 32 banks).  k_beliefs gathers the records of a landmark by position
+  // (random 64-B READS are ~2.3x cheaper than random 64-B writes, profiles/ablate_sweep.py).
+  __shared__ float4 lm_stage[4][64 * 4];
   float4* stage = lm_stage[threadIdx.x >> 6];
+  const uint32_t rec_t = lane >> 2;                                   // record handled in tile order (+16k)
+  const uint32_t swz_own = ((lane >> 2) & 3u) ^ (lane & 2u);          // swizzle of the lane's own record
   float4* lm_tile = a.lmsg + (size_t)tile * 256;
   if (ABL & (1 | 16)) {  // 16 = no LMSG load (store stays), 32 = no LMSG store (load stays)
     GBP_UNROLL
@@ -208,14 +212,15 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
     GBP_UNROLL
     for (int k = 0; k < 4; ++k) {
       const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(lm_tile) + k * 64 + lane);
-      stage[(k * 16 + (lane >> 2)) * 5 + (lane & 3)] = make_float4(v.x, v.y, v.z, v.w);
+      const uint32_t r = k * 16 + rec_t;
+      stage[r * 4 + ((lane & 3u) ^ (((r >> 2) & 3u) ^ (r & 2u)))] = make_float4(v.x, v.y, v.z, v.w);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     GBP_UNROLL
     for (int q = 0; q < 4; ++q) {
-      const float4 v = stage[lane * 5 + q];
+      const float4 v = stage[lane * 4 + ((uint32_t)q ^ swz_own)];
       lm[4 * q] = v.x; lm[4 * q + 1] = v.y; lm[4 * q + 2] = v.z; lm[4 * q + 3] = v.w;
     }
   }
@@ -406,12 +411,16 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     GBP_UNROLL
-    for (int q = 0; q < 4; ++q) stage[lane * 5 + q] = make_float4(ol[4 * q], ol[4 * q + 1], ol[4 * q + 2], ol[4 * q + 3]);
+    for (int q = 0; q < 4; ++q)
+      stage[lane * 4 + ((uint32_t)q ^ swz_own)] = make_float4(ol[4 * q], ol[4 * q + 1], ol[4 * q + 2], ol[4 * q + 3]);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     GBP_UNROLL
-    for (int k = 0; k < 4; ++k) lm_tile[k * 64 + lane] = stage[(k * 16 + (lane >> 2)) * 5 + (lane & 3)];
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t r = k * 16 + rec_t;
+      lm_tile[k * 64 + lane] = stage[r * 4 + ((lane & 3u) ^ (((r >> 2) & 3u) ^ (r & 2u)))];
+    }
   }
   {
     float cmo[28];
