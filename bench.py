@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--force-sharded", action="store_true",
                     help="diagnostic: run the N>1 code path (shard ctx, RCCL all_gather, overlap) even with one rank")
     ap.add_argument("--sharded-graph", type=int, default=0, help="capture sharded iterations (kernels + RCCL) in a hipGraph")
+    ap.add_argument("--exchange-chunks", type=int, default=None,
+                    help="camera ranges of the pipelined all-gather (default: 1 / 2 / 3 for 1 / 2-4 / 8 GPUs)")
     return ap.parse_args()
 
 
@@ -143,7 +145,7 @@ def main():
         bounds = landmark_partition(bal["lmk_id"], L, world)
         eng = GbpEngine(bal["cam_id"], bal["lmk_id"], C, L, K, shard=(rank, world, int(bounds[rank]), int(bounds[rank + 1])))
         run = ShardedGbp(eng, C, rank, world, dist=dist, device="cuda", always_collective=a.force_sharded,
-                         use_graph=bool(a.sharded_graph))
+                         use_graph=bool(a.sharded_graph), chunks=a.exchange_chunks)
         e_local = int(((bal["lmk_id"] >= bounds[rank]) & (bal["lmk_id"] < bounds[rank + 1])).sum())
     run.upload(state)
     run.linearise()
@@ -215,6 +217,7 @@ def main():
                        "reproj_rmse_px_initial": round(m0[2], 6), "reproj_rmse_px_final": round(m1[2], 6),
                        "mean_reproj_px_final": round(m1[0], 6), "iterations_run": a.warmup + a.steps,
                        "nonfinite_beliefs": int(ev1["n_nonfinite"]),
+                       "exchange_chunks": getattr(run, "chunks", None),
                        "sharded_graph": (getattr(run, "graph", None) is not None) if hasattr(run, "use_graph") else None,
                        "sharded_graph_error": getattr(run, "graph_error", None)},
         }

@@ -30,6 +30,8 @@ _SIGS = {
     "gbp_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gbp_set_exchange_buffers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "gbp_iterate_begin": (C.c_int, [C.c_void_p]),
+    "gbp_set_exchange_chunks": (C.c_int, [C.c_void_p, C.c_int]),
+    "gbp_iterate_begin_chunk": (C.c_int, [C.c_void_p, C.c_int]),
     "gbp_iterate_local": (C.c_int, [C.c_void_p]),
     "gbp_iterate_end": (C.c_int, [C.c_void_p]),
     "gbp_refresh_begin": (C.c_int, [C.c_void_p]),

@@ -52,7 +52,9 @@ struct gbp_ctx {
   hipGraphExec_t graph_exec = nullptr;
   int graph_iters = 0;
   bool uploaded = false, beliefs_valid = false;
-  bool lmk_half_done = false;  // gbp_iterate_local already refreshed the landmark beliefs of this iteration
+  bool lmk_half_done = false;
+  int exch_chunks = 1;                 // camera ranges of the pipelined exchange (gbp_set_exchange_chunks)
+  std::vector<uint32_t> chunk_start;   // [exch_chunks + 1] camera index where each chunk starts  // gbp_iterate_local already refreshed the landmark beliefs of this iteration
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
   bool profile_stages = false;
   double sweep_ms = 0, belief_ms = 0, total_ms = 0;
@@ -95,6 +97,7 @@ SweepArgs sweep_args(gbp_ctx* c) {
   a.hp.maxeta_damping = c->prm.maxeta_damping; a.hp.num_undamped_iters = c->prm.num_undamped_iters;
   a.hp.dmu_threshold = c->prm.dmu_threshold; a.hp.min_linear_iters = c->prm.min_linear_iters;
   a.hp.nstds = c->prm.nstds; a.hp.relin_mode = c->prm.relin_mode;
+  a.block0 = 0;
   return a;
 }
 
@@ -113,6 +116,9 @@ BeliefArgs belief_args(gbp_ctx* c) {
   b.lmk_fpos = P<uint32_t>(c->d_lmk_fpos);
   b.lmkb = P<float4>(c->lmkb); b.lmk_mu = P<float4>(c->hmu_l); b.n_lmks = c->L_loc;
   b.partial_only = 0; b.hoist = c->hoist ? 1 : 0; b.roll = 0;
+  b.cam0 = 0; b.cam1 = 0;
+  b.n_chunks = c->exch_chunks;
+  for (int i = 0; i <= c->exch_chunks; ++i) b.chunk_start[i] = c->chunk_start[i];
   return b;
 }
 
@@ -237,6 +243,7 @@ int gbp_create(const gbp_problem* pr, const gbp_params* prm, const gbp_shard* sh
     return fail(nullptr, GBP_ERR_INVALID, "gbp_create: bad shard");
   }
   c->L_loc = c->lmk_end - c->lmk_begin;
+  c->chunk_start = {0u, c->C};
 
   // ---- device order: camera-major, file order inside a camera, rows of 16, tiles of 64 ----
   const uint32_t C = c->C, E = c->E;
@@ -437,6 +444,40 @@ int gbp_iterate_begin(gbp_ctx* c) {
   if (!dst) return fail(c, GBP_ERR_STATE, "exchange buffers not set");
   launch_sweep(sweep_args(c), c->n_tiles, c->hoist, c->stream);
   enqueue_cam_partials(c, reinterpret_cast<float*>(dst));
+  HIPCHK(c, hipGetLastError());
+  return GBP_OK;
+}
+
+// Layout of the exchange buffers: n camera ranges [i*C/n, (i+1)*C/n), identical on every rank.  send_dev stays
+// [C][44]; recv_dev holds, for range i, [world][n_i][44] behind world * start_i * 44 floats (n = 1: [world][C][44]).
+int gbp_set_exchange_chunks(gbp_ctx* c, int n) {
+  if (!c || n < 1 || n > kMaxChunks) return fail(c, GBP_ERR_INVALID, "gbp_set_exchange_chunks: 1..8 chunks");
+  c->exch_chunks = n;
+  c->chunk_start.assign(n + 1, 0u);
+  for (int i = 0; i <= n; ++i) c->chunk_start[i] = (uint32_t)(((uint64_t)c->C * (uint64_t)i) / (uint64_t)n);
+  return GBP_OK;
+}
+
+// Piece `chunk` of a pipelined iteration: sweep the 256-factor blocks that complete the cameras of range `chunk`
+// (device order is camera-major) and reduce those cameras' local partial sums into send_dev.  After the call the
+// caller may start exchanging that range while the next piece runs.  Pieces must be issued in order 0..n-1.
+int gbp_iterate_begin_chunk(gbp_ctx* c, int chunk) {
+  if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "upload first");
+  if (chunk < 0 || chunk >= c->exch_chunks) return fail(c, GBP_ERR_INVALID, "gbp_iterate_begin_chunk: bad chunk");
+  float* dst = c->world > 1 ? static_cast<float*>(c->send_dev) : P<float>(c->local);
+  if (!dst) return fail(c, GBP_ERR_STATE, "exchange buffers not set");
+  const uint32_t n_blocks = c->n_tiles / 4;
+  auto block_end = [&](int i) -> uint32_t {  // first block boundary at/after the last row of the cameras of range i
+    if (i + 1 >= c->exch_chunks) return n_blocks;
+    const uint64_t pos = (uint64_t)c->cam_row_ptr[c->chunk_start[i + 1]] * kRow;
+    return (uint32_t)std::min<uint64_t>(n_blocks, (pos + 255) / 256);
+  };
+  const uint32_t b0 = chunk == 0 ? 0u : block_end(chunk - 1), b1 = block_end(chunk);
+  launch_sweep_blocks(sweep_args(c), b0, b1, c->hoist, c->stream);
+  BeliefArgs b = belief_args(c);
+  b.cam_local = dst; b.partial_only = 1;
+  b.cam0 = c->chunk_start[chunk]; b.cam1 = c->chunk_start[chunk + 1];
+  if (b.cam1 > b.cam0) launch_beliefs(b, true, false, c->stream);
   HIPCHK(c, hipGetLastError());
   return GBP_OK;
 }

@@ -65,7 +65,10 @@ struct SweepArgs {
   const float4* lmk_mu;   // [L][2]
   float K[9];
   Hyper hp;
+  uint32_t block0;           // first 256-factor block of this launch (pieces of a sweep: pipelined exchange)
 };
+
+constexpr int kMaxChunks = 8;
 
 struct BeliefArgs {
   // camera part
@@ -77,6 +80,10 @@ struct BeliefArgs {
   // landmark part
   const float4* lmk_prior; const float4* lmsg; const uint32_t* lmk_ptr; const uint32_t* lmk_fpos;
   float4* lmkb; float4* lmk_mu; uint32_t n_lmks;
+  // camera range of this launch [cam0, cam1) (0,0 = all) and chunk layout of `gathered` (see k_beliefs)
+  uint32_t cam0, cam1;
+  int n_chunks;
+  uint32_t chunk_start[kMaxChunks + 1];
   // control
   uint32_t cam_blocks;
   int partial_only;          // camera part writes cam_local only (multi-GPU: before the exchange)
@@ -90,6 +97,7 @@ struct DeviceEval {  // per-block partials, summed on the host in block order
 };
 
 void launch_sweep(const SweepArgs& a, uint32_t n_tiles, bool hoist, hipStream_t s);
+void launch_sweep_blocks(SweepArgs a, uint32_t block0, uint32_t block1, bool hoist, hipStream_t s);
 void launch_sweep_ablated(const SweepArgs& a, uint32_t n_tiles, int abl, hipStream_t s);  // timing experiments only
 void launch_linearise(const SweepArgs& a, uint32_t n_tiles, hipStream_t s);
 void launch_beliefs(BeliefArgs b, bool do_cam, bool do_lmk, hipStream_t s);

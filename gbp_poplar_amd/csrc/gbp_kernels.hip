@@ -181,7 +181,7 @@ GBP_DEV bool relin_core(float (&fac)[56], const float (&x0c)[6], const float (&x
 // 16 / 32 = no landmark-message load / store.
 template <bool HOIST, int ABL = 0>
 __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
-  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t p = (blockIdx.x + a.block0) * 256 + threadIdx.x;
   const uint32_t tile = p >> 6, lane = p & 63;
 
   const uint32_t cam_i = a.row_cam[p >> 4];
@@ -520,14 +520,19 @@ __global__ __launch_bounds__(256) void k_beliefs(const BeliefArgs b) {
   __shared__ float sh[4][48];
   if (blockIdx.x < b.cam_blocks) {
     const uint32_t w = threadIdx.x >> 6, j = threadIdx.x & 63;
-    const uint32_t c = blockIdx.x * 4 + w;
-    const bool live = c < b.n_cams && j < (uint32_t)kCamRec;
+    const uint32_t c = b.cam0 + blockIdx.x * 4 + w;
+    const bool live = c < b.cam1 && j < (uint32_t)kCamRec;
     float bel = 0.f;
     if (live) {
       if (b.gathered) {
+        // exchange layout: chunk i (cameras [chunk_start[i], chunk_start[i+1])) is stored as [world][n_i][44]
+        // behind world * chunk_start[i] * 44 floats; one chunk == the plain [world][C][44] layout
+        int ch = 0;
+        while (ch + 1 < b.n_chunks && c >= b.chunk_start[ch + 1]) ++ch;
+        const uint32_t c0 = b.chunk_start[ch], n_i = b.chunk_start[ch + 1] - c0;
+        const float* g = b.gathered + (size_t)b.world * c0 * kCamRec + (size_t)(c - c0) * kCamRec + j;
         float acc = b.cam_prior[(size_t)c * kCamRec + j];
-        const size_t n = (size_t)b.n_cams * kCamRec;
-        for (int r = 0; r < b.world; ++r) acc = acc + b.gathered[(size_t)r * n + (size_t)c * kCamRec + j];
+        for (int r = 0; r < b.world; ++r) acc = acc + g[(size_t)r * n_i * kCamRec];
         bel = acc;
       } else {
         const uint32_t r0 = b.cam_row_ptr[c], r1 = b.cam_row_ptr[c + 1];
@@ -819,8 +824,14 @@ __global__ __launch_bounds__(256) void k_eval(const uint32_t* __restrict__ row_c
 static inline uint32_t blocks_for(uint64_t threads) { return (uint32_t)((threads + 255) / 256); }
 
 void launch_sweep(const SweepArgs& a, uint32_t n_tiles, bool hoist, hipStream_t s) {
-  if (hoist) hipLaunchKernelGGL(k_sweep<true>, dim3(n_tiles / 4), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(k_sweep<false>, dim3(n_tiles / 4), dim3(256), 0, s, a);
+  launch_sweep_blocks(a, 0, n_tiles / 4, hoist, s);
+}
+// blocks [block0, block1) of the device order (256 factors each): pieces of one sweep for the pipelined exchange
+void launch_sweep_blocks(SweepArgs a, uint32_t block0, uint32_t block1, bool hoist, hipStream_t s) {
+  if (block1 <= block0) return;
+  a.block0 = block0;
+  if (hoist) hipLaunchKernelGGL(k_sweep<true>, dim3(block1 - block0), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(k_sweep<false>, dim3(block1 - block0), dim3(256), 0, s, a);
 }
 void launch_sweep_ablated(const SweepArgs& a, uint32_t n_tiles, int abl, hipStream_t s) {
   const dim3 g(n_tiles / 4), b(256);
@@ -839,7 +850,9 @@ void launch_linearise(const SweepArgs& a, uint32_t n_tiles, hipStream_t s) {
   hipLaunchKernelGGL(k_linearise, dim3(n_tiles / 4), dim3(256), 0, s, a);
 }
 void launch_beliefs(BeliefArgs b, bool do_cam, bool do_lmk, hipStream_t s) {
-  b.cam_blocks = do_cam ? (b.n_cams + 3) / 4 : 0;
+  if (b.cam1 == 0 && b.cam0 == 0) b.cam1 = b.n_cams;  // default: all cameras
+  if (b.n_chunks <= 0) { b.n_chunks = 1; b.chunk_start[0] = 0; b.chunk_start[1] = b.n_cams; }
+  b.cam_blocks = do_cam ? (b.cam1 - b.cam0 + 3) / 4 : 0;
   const uint32_t lmk_blocks = do_lmk ? blocks_for((uint64_t)b.n_lmks * 4) : 0;
   if (b.cam_blocks + lmk_blocks == 0) return;
   hipLaunchKernelGGL(k_beliefs, dim3(b.cam_blocks + lmk_blocks), dim3(256), 0, s, b);

@@ -32,10 +32,20 @@ def landmark_partition(lmk_id, n_lmks, world):
     return np.asarray(bounds, dtype=np.uint32)
 
 
+def default_chunks(world):
+    """Pieces of the pipelined camera exchange (override: GBP_EXCHANGE_CHUNKS)."""
+    import os
+    env = os.environ.get("GBP_EXCHANGE_CHUNKS")
+    if env:
+        return int(env)
+    return 1 if world <= 1 else (2 if world <= 4 else 3)
+
+
 class ShardedGbp:
     """The Poplar program list over `world` ranks.  Same verbs as GbpEngine / the oracle."""
 
-    def __init__(self, engine, n_cams, rank, world, dist=None, device="cpu", always_collective=False, use_graph=False):
+    def __init__(self, engine, n_cams, rank, world, dist=None, device="cpu", always_collective=False, use_graph=False,
+                 chunks=None):
         import torch
         self.torch = torch
         self.e = engine
@@ -56,6 +66,21 @@ class ShardedGbp:
             engine.set_stream(self.stream.cuda_stream)
             torch.cuda.synchronize()       # the zero-fills above ran on the default stream
         engine.set_exchange_buffers(self.send.data_ptr(), self.recv.data_ptr())
+        # Pipelined exchange: the camera partials are exchanged in `chunks` camera ranges; range i is all-gathered
+        # while the sweep of range i+1 runs, so only the last range's transfer (and the landmark half of the belief
+        # update, which overlaps it) is exposed.  The all-gather volume grows with world^2 under weak scaling
+        # (world x 1000 cameras x 176 B per rank), hence more pieces for more ranks.
+        if chunks is None:
+            chunks = default_chunks(self.world)
+        self.chunks = max(1, min(int(chunks), 8, self.C))
+        if self.chunks > 1 and not hasattr(engine, "iterate_begin_chunk"):
+            self.chunks = 1
+        if self.chunks > 1:
+            engine.set_exchange_chunks(self.chunks)
+        st = [self.C * i // self.chunks for i in range(self.chunks + 1)]
+        self.send_views = [self.send[st[i] * CAM_REC:st[i + 1] * CAM_REC] for i in range(self.chunks)]
+        self.recv_views = [self.recv[self.world * st[i] * CAM_REC:self.world * st[i + 1] * CAM_REC]
+                           for i in range(self.chunks)]
 
     def _on_stream(self):
         import contextlib
@@ -64,9 +89,10 @@ class ShardedGbp:
     def _exchange(self):
         with self._on_stream():
             if self.dist is None or (self.world == 1 and not self.always_collective):
-                self.recv.copy_(self.send)
+                self.recv.copy_(self.send)           # world == 1: the chunked layout equals the plain one
             else:
-                self.dist.all_gather_into_tensor(self.recv, self.send)
+                for rv, sv in zip(self.recv_views, self.send_views):
+                    self.dist.all_gather_into_tensor(rv, sv)
 
     def upload(self, state):
         self.e.upload(state)
@@ -79,16 +105,24 @@ class ShardedGbp:
         self.e.linearise_factors()
 
     def _one_iteration(self, overlap):
-        self.e.iterate_begin()                      # sweep + local camera partials -> send
         if overlap:
-            # the collective runs on RCCL's stream (ordered after `send` is written); the landmark half of
-            # the belief update is rank-local and fills the GPU meanwhile; the camera combine waits for it
-            with self._on_stream():
-                work = self.dist.all_gather_into_tensor(self.recv, self.send, async_op=True)
+            # Each collective runs on RCCL's stream, ordered after the piece that filled its slice of `send`; the
+            # next piece of the sweep — and finally the rank-local landmark half of the belief update — fill the
+            # GPU meanwhile; the camera combine waits for all of them.
+            works = []
+            for i in range(self.chunks):
+                if self.chunks > 1:
+                    self.e.iterate_begin_chunk(i)       # part of the sweep + partials of camera range i -> send
+                else:
+                    self.e.iterate_begin()
+                with self._on_stream():
+                    works.append(self.dist.all_gather_into_tensor(self.recv_views[i], self.send_views[i], async_op=True))
             self.e.iterate_local()
             with self._on_stream():
-                work.wait()
+                for w in works:
+                    w.wait()
         else:
+            self.e.iterate_begin()                      # sweep + local camera partials -> send
             self._exchange()
         self.e.iterate_end()
 

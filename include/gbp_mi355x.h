@@ -178,6 +178,14 @@ int gbp_set_stream(gbp_ctx* ctx, void* hip_stream /* hipStream_t; NULL = ctx-own
 #define GBP_CAM_REC 44
 int gbp_set_exchange_buffers(gbp_ctx* ctx, void* send_dev, void* recv_dev);
 int gbp_iterate_begin(gbp_ctx* ctx);   /* prep + messages + local camera partial -> send_dev     */
+/* Pipelined exchange (optional).  gbp_set_exchange_chunks(n) splits the cameras into n ranges [i*C/n,(i+1)*C/n)
+ * (same on every rank) and changes the layout of recv_dev to: for range i, [world][n_i][GBP_CAM_REC] floats
+ * behind world * start_i * GBP_CAM_REC floats (send_dev stays [C][GBP_CAM_REC]; n = 1 is the plain layout).
+ * gbp_iterate_begin_chunk(i), i = 0..n-1 in order, sweeps the part of the (camera-major) device order that
+ * completes range i and writes that range's partial sums, so the caller can all-gather range i while piece
+ * i+1 runs.  The n calls together equal one gbp_iterate_begin. */
+int gbp_set_exchange_chunks(gbp_ctx* ctx, int n_chunks /* 1..8 */);
+int gbp_iterate_begin_chunk(gbp_ctx* ctx, int chunk);
 int gbp_iterate_local(gbp_ctx* ctx);   /* optional: landmark beliefs now (rank-local), to overlap with the exchange */
 int gbp_iterate_end(gbp_ctx* ctx);     /* camera beliefs = prior + sum_r recv_dev[r]; landmark beliefs unless done */
 /* Re-derive beliefs after an exchange outside an iteration (LINEARISE / NEW_KEYFRAME on world>1):

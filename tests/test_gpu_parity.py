@@ -417,13 +417,14 @@ class _FakeDist:
             m.stream.synchronize()
         for dst in self.members:
             for r, src in enumerate(self.members):
-                n = src.send.numel()
-                dst.recv[r * n:(r + 1) * n].copy_(src.send)
+                for i in range(dst.chunks):          # chunk i of the receive buffer is [world][n_i * 44]
+                    n_i = src.send_views[i].numel()
+                    dst.recv_views[i][r * n_i:(r + 1) * n_i].copy_(src.send_views[i])
         torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_kernels_on_one_gpu_match_sharded_oracle(world, oracle_mod):
+@pytest.mark.parametrize("world,chunks", [(2, 1), (3, 1), (2, 2), (3, 4)])
+def test_sharded_kernels_on_one_gpu_match_sharded_oracle(world, chunks, oracle_mod):
     """`world` landmark-shard contexts on the same GPU, exchange done by device copies: the sharded C-ABI path
     (gbp_iterate_begin/_end, refresh, linearise_factors, weaken on a sharded ctx, torch-owned buffers and
     stream) against the oracle in `world`-shard device order, bit for bit, through relinearisations."""
@@ -440,7 +441,7 @@ def test_sharded_kernels_on_one_gpu_match_sharded_oracle(world, oracle_mod):
     for r in range(world):
         eng = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K,
                         shard=(r, world, int(bounds[r]), int(bounds[r + 1])))
-        sh = ShardedGbp(eng, bal["n_cams"], r, world, dist=None, device="cuda")
+        sh = ShardedGbp(eng, bal["n_cams"], r, world, dist=None, device="cuda", chunks=chunks)
         sh._exchange = lambda: None          # the exchange is performed for all shards at once below
         fake.members.append(sh)
         shards.append(sh)
@@ -461,7 +462,11 @@ def test_sharded_kernels_on_one_gpu_match_sharded_oracle(world, oracle_mod):
             if (it + 1) % 2 == 0 and it < 10:
                 all_do("weaken_priors")
                 orc.weaken_priors()
-            all_do("iterate_begin")
+            if chunks > 1 and it % 3:                # pipelined pieces of the sweep (camera ranges) ...
+                for i in range(chunks):
+                    all_do("iterate_begin_chunk", i)
+            else:                                    # ... or the sweep in one piece: same result
+                all_do("iterate_begin")
             if it % 2:
                 all_do("iterate_local")          # landmark half first (what overlaps the all-gather on N GPUs)
             fake.gather_all()
@@ -733,7 +738,8 @@ def test_non_default_parameters_bit_exact(kw, oracle_mod):
     assert tg[-1][3] == to[-1][3] and tg[-1][4] == to[-1][4]
 
 
-def test_rccl_single_rank_group_overlap_path():
+@pytest.mark.parametrize("chunks", [1, 3])
+def test_rccl_single_rank_group_overlap_path(chunks):
     """The exact code path of an N-GPU run (RCCL all_gather_into_tensor with async_op, landmark half overlapped,
     stream-ordered camera combine) on a 1-rank RCCL group: must equal the plain single-GPU engine bit for bit."""
     import os
@@ -752,7 +758,7 @@ def test_rccl_single_rank_group_overlap_path():
         K, state, _ = driver.build_inputs(bal, opts, hostlib)
         plain = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K)
         eng = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K, shard=(0, 1, 0, bal["n_lmks"]))
-        sh = ShardedGbp(eng, bal["n_cams"], 0, 1, dist=dist, device="cuda", always_collective=True)
+        sh = ShardedGbp(eng, bal["n_cams"], 0, 1, dist=dist, device="cuda", always_collective=True, chunks=chunks)
         ta = driver.run_ba(plain, state, opts, n_iters=30, eval_every=10)
         tb = driver.run_ba(sh, state, opts, n_iters=30, eval_every=10)
         assert ta == tb
