@@ -38,7 +38,11 @@ def default_chunks(world):
     env = os.environ.get("GBP_EXCHANGE_CHUNKS")
     if env:
         return int(env)
-    return 1 if world <= 1 else (2 if world <= 4 else 3)
+    # Measured on one GPU with a 1-rank RCCL group (bench.py --force-sharded --exchange-chunks K): splitting the
+    # sweep into K same-stream pieces costs 25-35 us per extra piece (piece drain/ramp + the partial-sum kernel
+    # between pieces), more than an all-gather of this size is expected to cost, so the default is ONE piece;
+    # the pipelined path stays available for experiments on real multi-GPU nodes.
+    return 1
 
 
 class ShardedGbp:
