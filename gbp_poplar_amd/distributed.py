@@ -185,7 +185,7 @@ class ShardedGbp:
     def eval(self):
         """Local shard sums, added over ranks (integers and fp64 partials; rank order fixed by all_gather)."""
         ev = self.e.eval()
-        if self.world == 1 or self.dist is None:
+        if self.dist is None or (self.world == 1 and not self.always_collective):
             return ev
         torch = self.torch
         keys = ["sum_norm", "sum_half_sq", "n_active", "n_relin", "n_robust", "n_nonfinite", "n_nonpd"]
