@@ -38,7 +38,8 @@ def build(force=False, verbose=False):
     cc = hipcc()
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "gbp_mi355x.h")]
     if force or _stale(LIB, deps):
-        cmd = [cc, "-shared", "-o", LIB] + FLAGS + ["-x", "hip"] + [os.path.join(CSRC, s) for s in LIB_SRCS]
+        extra = os.environ.get("GBP_EXTRA_HIPFLAGS", "").split()     # experiments only (e.g. -DGBP_FAC_TEMPORAL)
+        cmd = [cc, "-shared", "-o", LIB] + FLAGS + extra + ["-x", "hip"] + [os.path.join(CSRC, s) for s in LIB_SRCS]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
