@@ -791,6 +791,24 @@ def test_config1_fr1xyz_1500_sweeps_bit_exact(oracle_mod):
     assert 1.40 < tg[-1][1] < 1.50, tg[-1]          # converged runs sit at 1.42-1.47 px
 
 
+@pytest.mark.parametrize("name,band", [("fr1desk", (1.2, 1.8)), ("fr2robot2", (0.86, 0.89))])
+def test_other_sequences_1500_sweeps_bit_exact(name, band, oracle_mod):
+    """The two other shipped sequences through the full default `./ba` run (1500 sweeps), bit for bit."""
+    from gbp_poplar_amd import driver
+    oracle_mod.set_trig_mode(1)
+    try:
+        eng, orc, opts, state, _ = _setup(_bal(name), oracle_mod, sum_order=1)
+        tg = driver.run_ba(eng, state, opts, n_iters=1500, eval_every=500)
+        to = driver.run_ba(orc, state, opts, n_iters=1500, eval_every=500)
+    finally:
+        oracle_mod.set_trig_mode(0)
+    g, o = eng.read(), orc.read()
+    for k in g:
+        assert np.array_equal(g[k], o[k]), k
+    assert [t[3:] for t in tg] == [t[3:] for t in to]
+    assert band[0] < tg[-1][1] < band[1], tg[-1]
+
+
 def test_config3_slam_fr2robot2_full_run_bit_exact(oracle_mod):
     """`./slam fr2robot2` defaults (700 sweeps per keyframe, 13 299 sweeps, 18 keyframe insertions): bit for bit,
     and the final numbers against the reference-equivalent run of BASELINE.md (0.874272 px / RMSE 1.126136)."""
