@@ -131,7 +131,7 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "RANK" not in os.environ:     # --force-sharded without a launcher: a 1-rank group
-            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 1000))
             dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
