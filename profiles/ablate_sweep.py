@@ -8,10 +8,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gbp_poplar_amd import driver, hostlib          # noqa: E402
 from gbp_poplar_amd.engine import GbpEngine         # noqa: E402
 
-bal = hostlib.synth_generate(1000, 100000, 10, 20200303)
+NC = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+NL = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
+bal = hostlib.synth_generate(NC, NL, 10, 20200303)
 opts = driver.Options()
 K, state, _ = driver.build_inputs(bal, opts, hostlib)
-eng = GbpEngine(bal["cam_id"], bal["lmk_id"], 1000, 100000, K)
+eng = GbpEngine(bal["cam_id"], bal["lmk_id"], NC, NL, K)
 eng.upload(state)
 eng.linearise()
 for it in range(20):
