@@ -542,14 +542,22 @@ __global__ __launch_bounds__(256) void k_beliefs(const BeliefArgs b) {
           acc = row[0];
           uint32_t r = 1;
           const uint32_t n = r1 - r0;
-          for (; r + 8 <= n; r += 8) {  // loads of 8 rows in flight, adds in row order
-            float v[8];
+          for (; r + 16 <= n; r += 16) {  // loads of 16 rows in flight, adds in row order
+            float v[16];
             GBP_UNROLL
-            for (int k = 0; k < 8; ++k) v[k] = row[(size_t)(r + k) * kCamRec];
+            for (int k = 0; k < 16; ++k) v[k] = row[(size_t)(r + k) * kCamRec];
             GBP_UNROLL
-            for (int k = 0; k < 8; ++k) acc = acc + v[k];
+            for (int k = 0; k < 16; ++k) acc = acc + v[k];
           }
-          for (; r < n; ++r) acc = acc + row[(size_t)r * kCamRec];
+          {  // tail (< 16 rows) in one predicated batch as well: this chain is pure load latency
+            float v[16];
+            const uint32_t m = n - r;
+            GBP_UNROLL
+            for (int k = 0; k < 16; ++k) v[k] = (uint32_t)k < m ? row[(size_t)(r + k) * kCamRec] : 0.f;
+            GBP_UNROLL
+            for (int k = 0; k < 16; ++k)
+              if ((uint32_t)k < m) acc = acc + v[k];
+          }
         }
         b.cam_local[(size_t)c * kCamRec + j] = acc;
         bel = b.cam_prior[(size_t)c * kCamRec + j] + acc;
