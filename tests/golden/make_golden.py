@@ -101,11 +101,59 @@ def run_states(bal, variant, trig, sum_order, n_sweeps, prefix, out):
     return K, state
 
 
+VERTEX_SWEEPS = (0, 1, 17, 18, 100)
+VERTEX_WIDTH = {"fac_eta": 9, "fac_lambda": 81, "msg_cam_eta": 6, "msg_cam_lambda": 36, "msg_lmk_eta": 3,
+                "msg_lmk_lambda": 9, "mu": 9, "dmu": 1, "damping": 1, "damping_count": 1, "robust_flag": 1}
+
+
+def vertex_sample(o, ids):
+    """Per-factor outputs of the five vertices (relinearise/prep + four message vertices) for factors `ids`."""
+    r = o.read()
+    m = o.messages()
+    fe, fl = o.factor_potentials()
+    mu, dmu = o.mu()
+    full = {"fac_eta": fe, "fac_lambda": fl, "mu": mu, "dmu": dmu, "damping": r["damping"],
+            "damping_count": r["damping_count"], "robust_flag": r["robust_flag"]}
+    full.update({"msg_" + k: v for k, v in m.items()})
+    return {k: full[k].reshape(-1, w)[ids].copy() for k, w in VERTEX_WIDTH.items()}
+
+
+def vertex_vectors(name, n_sample=64):
+    """Vertex known answers on a real sequence at the sweeps where relinearisation first fires (17, 18 with
+    the default --undamped_start 15) plus 0, 1 and 100."""
+    host = OracleHost("ref")
+    bal = host.bal_read(os.path.join(ROOT, "data", "sequences", name + ".txt"))
+    K, state, _ = driver.build_inputs(bal, driver.Options(), host)
+    ids = np.sort(np.random.default_rng(7).choice(bal["n_edges"], n_sample, replace=False)).astype(np.int64)
+    out = {"ids": ids, "sweeps": np.array(VERTEX_SWEEPS)}
+    for prefix, variant, trig, order in (("ref", "ref", 0, 0), ("dev", "restatement", 1, 1)):
+        orc.set_trig_mode(trig, variant)
+        o = orc.Oracle(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K, variant=variant)
+        o.set_sum_order(order)
+        o.upload(state)
+        o.linearise()
+        n_relin = []
+        for it in range(max(VERTEX_SWEEPS) + 1):
+            if (it + 1) % 2 == 0 and it < 10:
+                o.weaken_priors()
+            o.iterate(1)
+            n_relin.append(o.eval()["n_relin"])
+            if it in VERTEX_SWEEPS:
+                for k, v in vertex_sample(o, ids).items():
+                    out["%s_it%d_%s" % (prefix, it, k)] = v
+        out[prefix + "_n_relin"] = np.array(n_relin)
+        orc.set_trig_mode(0, variant)
+    return out
+
+
 def main():
     if not orc.have("ref"):
         raise SystemExit("oracle/_ref is missing: run `make -C oracle ref` in the build container first")
     ref = orc.load("ref")
     assert ref.om_impl_name() == b"reference"
+    if sys.argv[1:] == ["vertex"]:          # only (re)write the vertex-level fixture
+        np.savez_compressed(os.path.join(HERE, "vertex_vectors.npz"), **vertex_vectors("fr2robot2"))
+        return
     np.savez_compressed(os.path.join(HERE, "math_vectors.npz"), **math_vectors(ref))
 
     # tiny synthetic graph: one-sweep state pairs (4 cams x 24 lmks)
@@ -145,6 +193,7 @@ def main():
                     snaps["it%d_%s" % (it, k)] = o.read()[k]
         snaps["traj_" + name] = np.array(traj, dtype=np.float64)
     np.savez_compressed(os.path.join(HERE, "sequence_snapshots.npz"), **snaps)
+    np.savez_compressed(os.path.join(HERE, "vertex_vectors.npz"), **vertex_vectors("fr2robot2"))
     print("golden fixtures written:", [f for f in os.listdir(HERE) if f.endswith(".npz")])
 
 

@@ -103,6 +103,43 @@ def test_sequence_snapshots_and_trajectories():
             assert abs(row[1] - km) <= max(TOL[int(row[0])], 2e-8) * km + 6e-7
 
 
+def test_vertex_known_answers_bit_for_bit():
+    """SURVEY 8c pin 2: per-factor outputs of the relinearise/prep and the four message vertices for 64 sampled
+    fr2robot2 factors at sweeps {0, 1, 17, 18 (first data-driven relinearisations), 100}.  `ref_`: produced
+    with the reference's math layer; `dev_`: same restatement in device conventions."""
+    g = np.load(os.path.join(GOLD, "vertex_vectors.npz"))
+    ids, sweeps = g["ids"], [int(s) for s in g["sweeps"]]
+    host = OracleHost("restatement")
+    bal = host.bal_read(seq_path("fr2robot2"))
+    K, state, _ = driver.build_inputs(bal, driver.Options(), host)
+    assert 0 < g["ref_n_relin"][17] < bal["n_edges"] and 0 < g["ref_n_relin"][18] < bal["n_edges"]
+    for prefix, trig, so in (("ref", 0, 0), ("dev", 1, 1)):
+        orc.set_trig_mode(trig)
+        try:
+            o = orc.Oracle(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K)
+            o.set_sum_order(so)
+            o.upload(state)
+            o.linearise()
+            for it in range(max(sweeps) + 1):
+                if (it + 1) % 2 == 0 and it < 10:
+                    o.weaken_priors()
+                o.iterate(1)
+                assert o.eval()["n_relin"] == g[prefix + "_n_relin"][it], (prefix, it)
+                if it in sweeps:
+                    r, m = o.read(), o.messages()
+                    fe, fl = o.factor_potentials()
+                    mu, dmu = o.mu()
+                    full = {"fac_eta": (fe, 9), "fac_lambda": (fl, 81), "mu": (mu, 9), "dmu": (dmu, 1),
+                            "damping": (r["damping"], 1), "damping_count": (r["damping_count"], 1),
+                            "robust_flag": (r["robust_flag"], 1), "msg_cam_eta": (m["cam_eta"], 6),
+                            "msg_cam_lambda": (m["cam_lambda"], 36), "msg_lmk_eta": (m["lmk_eta"], 3),
+                            "msg_lmk_lambda": (m["lmk_lambda"], 9)}
+                    for k, (v, w) in full.items():
+                        assert np.array_equal(v.reshape(-1, w)[ids], g["%s_it%d_%s" % (prefix, it, k)]), (prefix, it, k)
+        finally:
+            orc.set_trig_mode(0)
+
+
 @pytest.mark.skipif(not orc.have("ref"), reason="oracle/_ref not built (needs /root/reference)")
 def test_long_chaotic_trajectory_equals_reference_math_build():
     """fr1xyz is chaotic in fp32 (ulp differences blow up within ~25 sweeps): 200 sweeps with
