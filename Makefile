@@ -1,5 +1,5 @@
 # Top-level build for C/C++ users (the Python entry point __graft_entry__.build() does the same).
-#   make            libgbp_mi355x.so (HIP kernels + C-ABI + host helpers, gfx950) and bin/ba, bin/slam
+#   make            libgbp_mi355x.so (HIP kernels + C-ABI + host helpers, gfx950) and bin/ba, bin/slam, bin/bal_convert
 #   make oracle     the CPU oracle (test infrastructure)
 #   make test       CPU test suite
 HIPCC   ?= hipcc
@@ -10,7 +10,7 @@ CSRC    := $(PKG)/csrc
 LIB     := $(PKG)/libgbp_mi355x.so
 HIPFLAGS := -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=$(ARCH) -Wall -Wno-unused-function
 
-all: $(LIB) $(PKG)/bin/ba $(PKG)/bin/slam
+all: $(LIB) $(PKG)/bin/ba $(PKG)/bin/slam $(PKG)/bin/bal_convert
 
 $(LIB): $(CSRC)/gbp_kernels.hip $(CSRC)/gbp_capi.cpp $(CSRC)/gbp_host.cpp $(CSRC)/gbp_kernels.h $(CSRC)/gbp_device_math.hpp include/gbp_mi355x.h
 	$(HIPCC) -shared -o $@ $(HIPFLAGS) -x hip $(CSRC)/gbp_kernels.hip $(CSRC)/gbp_capi.cpp $(CSRC)/gbp_host.cpp
@@ -27,7 +27,7 @@ test: all oracle
 	python -m pytest tests -x -q -m "not gpu"
 
 clean:
-	rm -f $(LIB) $(PKG)/bin/ba $(PKG)/bin/slam
+	rm -f $(LIB) $(PKG)/bin/ba $(PKG)/bin/slam $(PKG)/bin/bal_convert
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle test clean

@@ -44,6 +44,8 @@ _SIGS = {
     "gbp_bal_read_header": (C.c_int, [C.c_char_p, C.POINTER(cabi.GbpBal)]),
     "gbp_bal_read": (C.c_int, [C.c_char_p, C.POINTER(cabi.GbpBal)]),
     "gbp_bal_write": (C.c_int, [C.c_char_p, C.POINTER(cabi.GbpBal)]),
+    "gbp_bal_import_standard_header": (C.c_int, [C.c_char_p, C.POINTER(cabi.GbpBal)]),
+    "gbp_bal_import_standard": (C.c_int, [C.c_char_p, C.POINTER(cabi.GbpBal)]),
     "gbp_set_prior_lambda": (C.c_int, [C.POINTER(cabi.GbpProblem), C.c_float] + [cabi.c_f32p] * 8),
     "gbp_prior_scalings": (C.c_int, [C.c_uint32, C.c_uint32, cabi.c_f32p, C.c_float, C.c_float, C.c_float,
                                      cabi.c_f32p, cabi.c_f32p]),

@@ -1,6 +1,6 @@
 """Build recipe of the native library (in-tree, gfx950 only).
 
-    python -m gbp_poplar_amd.build        -> gbp_poplar_amd/libgbp_mi355x.so  (+ bin/ba, bin/slam when sources exist)
+    python -m gbp_poplar_amd.build        -> gbp_poplar_amd/libgbp_mi355x.so  (+ bin/ba, bin/slam, bin/bal_convert)
 
 hipcc cross-compiles for gfx950 without a GPU.  -ffp-contract=off: results are compared
 bit-for-bit with the CPU oracle, so no FMA contraction on either side.
@@ -17,7 +17,7 @@ BIN = os.path.join(HERE, "bin")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function"]
 LIB_SRCS = ["gbp_kernels.hip", "gbp_capi.cpp", "gbp_host.cpp"]
-CLI_SRCS = {"ba": "ba_main.cpp", "slam": "slam_main.cpp"}
+CLI_SRCS = {"ba": "ba_main.cpp", "slam": "slam_main.cpp", "bal_convert": "bal_convert_main.cpp"}
 
 
 def hipcc():

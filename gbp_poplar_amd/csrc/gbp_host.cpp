@@ -10,6 +10,7 @@
 //   gbp_slam_initialise_new_kf initialise_new_kf               util.cpp:183-197
 //   gbp_eval_host              eval_reprojection_error         util.cpp:74-144
 //   gbp_synth_generate         synthetic BAL graphs (the reference ships none)
+//   gbp_bal_import_standard    9-parameter "Bundle Adjustment in the Large" files -> the reference's format
 // The reference's O(E^2) / O((C+L)E) host loops (ba.cpp:267-279, dataio.cpp:76-116) are replaced by
 // single O(E) passes with identical results.  Eigen is not used; where the reference calls
 // Eigen's general inverse we solve in fp64 with partial pivoting.
@@ -183,6 +184,100 @@ int gbp_bal_write(const char* path, const gbp_bal* b) {
   for (uint32_t i = 0; i < 6 * b->n_cams; ++i) std::fprintf(f, "%.16e\n", b->cameras[i]);
   for (uint32_t i = 0; i < 3 * b->n_lmks; ++i) std::fprintf(f, "%.16e\n", b->points[i]);
   return std::fclose(f) == 0 ? GBP_OK : GBP_ERR_IO;
+}
+
+// ---- standard "Bundle Adjustment in the Large" files -> the reference's format --------------
+// Published BAL model (9 parameters per camera: Rodrigues R, t, f, k1, k2): P = R X + t, p = -P / P.z,
+// pixel = f (1 + k1 |p|^2 + k2 |p|^4) p, image origin at the centre, y up, camera looking down -z.
+// The reference wants one shared pin-hole K, no distortion, +z cameras stored as [t, w] (sequences/README.md:5-16):
+//   * frame: P' = S P with S = diag(1,-1,-1) (a rotation by pi about x): R' = S R, t' = S t, (u', v') = (u, -v);
+//   * lens: every observation is undistorted (Newton on the radial polynomial) and rescaled from its camera's f
+//     to the shared focal length f_bar = mean f, principal point (0, 0);
+//   * edges are re-sorted by (camera, landmark): the reference's SLAM mode and metric rely on camera-sorted files
+//     (util.cpp:95-99, dataio.cpp:483-486), standard BAL files are sorted by point.
+int gbp_bal_import_standard_header(const char* path, gbp_bal* h) {
+  if (!path || !h) return GBP_ERR_INVALID;
+  FILE* f = std::fopen(path, "r");
+  if (!f) return GBP_ERR_IO;
+  int c = 0, l = 0, e = 0;
+  const bool ok = std::fscanf(f, "%d %d %d", &c, &l, &e) == 3 && c > 0 && l > 0 && e > 0;
+  std::fclose(f);
+  if (!ok) return GBP_ERR_IO;
+  h->n_cams = static_cast<uint32_t>(c);
+  h->n_lmks = static_cast<uint32_t>(l);
+  h->n_edges = static_cast<uint32_t>(e);
+  h->fx = h->fy = h->cx = h->cy = 0.0;
+  return GBP_OK;
+}
+
+int gbp_bal_import_standard(const char* path, gbp_bal* b) {
+  if (!path || !b || !b->cam_id || !b->lmk_id || !b->observations || !b->cameras || !b->points) return GBP_ERR_INVALID;
+  FILE* f = std::fopen(path, "r");
+  if (!f) return GBP_ERR_IO;
+  int c = 0, l = 0, e = 0;
+  bool ok = std::fscanf(f, "%d %d %d", &c, &l, &e) == 3 && static_cast<uint32_t>(c) == b->n_cams &&
+            static_cast<uint32_t>(l) == b->n_lmks && static_cast<uint32_t>(e) == b->n_edges;
+  struct Obs { uint32_t cam, lmk; double x, y; };
+  std::vector<Obs> obs(ok ? e : 0);
+  for (int i = 0; ok && i < e; ++i) {
+    int ci, li;
+    ok = std::fscanf(f, "%d %d %lf %lf", &ci, &li, &obs[i].x, &obs[i].y) == 4 && ci >= 0 && ci < c && li >= 0 && li < l;
+    if (ok) { obs[i].cam = static_cast<uint32_t>(ci); obs[i].lmk = static_cast<uint32_t>(li); }
+  }
+  std::vector<double> cam9(ok ? 9ull * c : 0);
+  for (size_t i = 0; ok && i < cam9.size(); ++i) ok = std::fscanf(f, "%lf", &cam9[i]) == 1;
+  for (int i = 0; ok && i < 3 * l; ++i) ok = std::fscanf(f, "%lf", &b->points[i]) == 1;
+  std::fclose(f);
+  if (!ok) return GBP_ERR_IO;
+
+  double fbar = 0.0;
+  for (int i = 0; i < c; ++i) fbar += cam9[9ull * i + 6];
+  fbar /= c;
+  b->fx = b->fy = fbar;
+  b->cx = b->cy = 0.0;
+
+  for (int i = 0; i < c; ++i) {
+    const double* w = &cam9[9ull * i];
+    // R = exp([w]x) as a unit quaternion, then q' = q_S * q with q_S = (0; 1,0,0) (rotation by pi about x)
+    const double th = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    const double k = th < 1e-12 ? 0.5 : std::sin(0.5 * th) / th;
+    const double q[4] = {std::cos(0.5 * th), k * w[0], k * w[1], k * w[2]};
+    double r[4] = {-q[1], q[0], -q[3], q[2]};   // (0,1,0,0) * (q0,q1,q2,q3)
+    if (r[0] < 0) for (double& v : r) v = -v;   // angle in [0, pi]
+    const double vn = std::sqrt(r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
+    const double ang = 2.0 * std::atan2(vn, r[0]);
+    const double sc = vn < 1e-300 ? 0.0 : ang / vn;
+    double* out = &b->cameras[6ull * i];
+    out[0] = w[3]; out[1] = -w[4]; out[2] = -w[5];                  // t' = S t
+    out[3] = sc * r[1]; out[4] = sc * r[2]; out[5] = sc * r[3];      // w' = log(S R)
+  }
+
+  // undistort + rescale + flip v, then order by (camera, landmark)
+  for (Obs& o : obs) {
+    const double* p9 = &cam9[9ull * o.cam];
+    const double fi = p9[6], k1 = p9[7], k2 = p9[8];
+    if (!(fi > 0)) return GBP_ERR_INVALID;
+    const double dx = o.x / fi, dy = o.y / fi, rd = std::sqrt(dx * dx + dy * dy);
+    double ru = rd;                                // solve ru (1 + k1 ru^2 + k2 ru^4) = rd
+    for (int it = 0; it < 50; ++it) {
+      const double r2 = ru * ru, g = ru * (1 + k1 * r2 + k2 * r2 * r2) - rd, dg = 1 + 3 * k1 * r2 + 5 * k2 * r2 * r2;
+      if (!(std::fabs(dg) > 1e-12)) break;
+      const double step = g / dg;
+      ru -= step;
+      if (std::fabs(step) <= 1e-16 * std::fabs(ru)) break;
+    }
+    const double s = rd > 0 ? ru / rd : 1.0;
+    o.x = fbar * s * dx;
+    o.y = -fbar * s * dy;
+  }
+  std::stable_sort(obs.begin(), obs.end(), [](const Obs& a, const Obs& c2) {
+    return a.cam != c2.cam ? a.cam < c2.cam : a.lmk < c2.lmk;
+  });
+  for (int i = 0; i < e; ++i) {
+    b->cam_id[i] = obs[i].cam; b->lmk_id[i] = obs[i].lmk;
+    b->observations[2ull * i] = obs[i].x; b->observations[2ull * i + 1] = obs[i].y;
+  }
+  return GBP_OK;
 }
 
 int gbp_set_prior_lambda(const gbp_problem* p, float var, const float* cam_file, const float* lmk_file,

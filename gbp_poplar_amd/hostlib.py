@@ -45,6 +45,19 @@ def bal_read(path):
     return _finish_bal(h, out)
 
 
+def bal_import_standard(path):
+    """Standard 9-parameter "Bundle Adjustment in the Large" file -> the reference's format (shared pin-hole K,
+    +z cameras [t, w], edges sorted by camera then landmark); see gbp_bal_import_standard in the header."""
+    lib = load()
+    h = cabi.GbpBal()
+    if lib.gbp_bal_import_standard_header(path.encode(), C.byref(h)) != 0:
+        raise IOError("ERROR: unable to open file %s" % path)
+    out = _alloc_bal(h)
+    if lib.gbp_bal_import_standard(path.encode(), C.byref(h)) != 0:
+        raise IOError("Invalid BAL data file: %s" % path)
+    return _finish_bal(h, out)
+
+
 def bal_write(path, bal):
     lib = load()
     h = cabi.GbpBal()

@@ -225,6 +225,15 @@ typedef struct {
 int gbp_bal_read_header(const char* path, gbp_bal* hdr);
 int gbp_bal_read(const char* path, gbp_bal* bal);
 int gbp_bal_write(const char* path, const gbp_bal* bal);
+/* Import of a standard "Bundle Adjustment in the Large" text file (C L E; E x "cam point x y"; 9 values per
+ * camera: Rodrigues R, t, f, k1, k2; 3 per point; camera looks down -z, image origin at the centre, y up) into
+ * the reference's conventions (sequences/README.md:5-16: one shared pin-hole K, cameras [t_cw, w_cw] looking
+ * down +z): frame flipped by diag(1,-1,-1), observations undistorted and rescaled to the mean focal length
+ * (fx = fy = mean f, cx = cy = 0), edges sorted by (camera, landmark) as util.cpp:95-99 / dataio.cpp:483-486
+ * assume.  Same two-call pattern as gbp_bal_read; the result can be written with gbp_bal_write and fed to
+ * ./ba or ./slam.  Not in the reference. */
+int gbp_bal_import_standard_header(const char* path, gbp_bal* hdr);
+int gbp_bal_import_standard(const char* path, gbp_bal* bal);
 
 /* set_prior_lambda (dataio.cpp:67-117 + util.cpp:48-72), O(E).  cam_file/lmk_file are the FILE
  * values cast to float (the linearisation point of the prior strength), *_mean the (possibly

@@ -12,6 +12,7 @@ from tests.conftest import seq_path
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BA = os.path.join(ROOT, "gbp_poplar_amd", "bin", "ba")
 SLAM = os.path.join(ROOT, "gbp_poplar_amd", "bin", "slam")
+CONVERT = os.path.join(ROOT, "gbp_poplar_amd", "bin", "bal_convert")
 
 
 def run(cmd):
@@ -21,7 +22,7 @@ def run(cmd):
 
 @pytest.fixture(scope="module", autouse=True)
 def _built():
-    if not (os.path.exists(BA) and os.path.exists(SLAM)):
+    if not (os.path.exists(BA) and os.path.exists(SLAM) and os.path.exists(CONVERT)):
         from gbp_poplar_amd import build
         build.build()
 
@@ -46,6 +47,22 @@ def test_argument_errors():
     assert rc == 1 and "bogus" in err
     rc, _, err = run([BA, "--bal_file", seq_path("fr2robot2"), "--n_iters", "abc"])
     assert rc == 1
+
+
+def test_bal_convert_tool(tmp_path):
+    """bin/bal_convert writes what hostlib.bal_import_standard returns, in the reference's text format."""
+    from gbp_poplar_amd import hostlib
+    from tests.test_hostlib import _write_standard_bal
+    src, dst = str(tmp_path / "standard.txt"), str(tmp_path / "out.txt")
+    _write_standard_bal(src, np.random.default_rng(11), n_cams=5, n_lmks=30)
+    rc, out, err = run([CONVERT, src, dst])
+    assert rc == 0 and "5 cameras, 30 landmarks, 120 observations" in out, (rc, out, err)
+    a, b = hostlib.bal_read(dst), hostlib.bal_import_standard(src)
+    for k in ("cam_id", "lmk_id", "observations", "cameras", "points"):
+        assert np.array_equal(a[k], b[k]), k
+    assert a["fx"] == b["fx"] and a["cy"] == 0.0
+    assert run([CONVERT, str(tmp_path / "missing.txt"), dst])[0] == 1
+    assert run([CONVERT, src])[0] == 2
 
 
 def test_no_device_is_a_loud_failure():

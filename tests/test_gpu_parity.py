@@ -454,6 +454,23 @@ def test_golden_vertex_vectors(per_factor_mu):
                 assert np.array_equal(v, ref), ("ref", it, k)
 
 
+def test_imported_standard_bal_problem_runs_bit_exact(tmp_path, oracle_mod):
+    """A standard 9-parameter BAL file (per-camera focal length + radial distortion, -z cameras, landmark-major
+    edges) goes through gbp_bal_import_standard and is then solved like any sequence: GPU == oracle bit for bit,
+    and the error falls from the perturbed start to the pixel level."""
+    from gbp_poplar_amd import driver, hostlib
+    from tests.test_hostlib import _write_standard_bal
+    src = str(tmp_path / "standard.txt")
+    _write_standard_bal(src, np.random.default_rng(3), n_cams=12, n_lmks=300, point_noise=0.03)
+    bal = hostlib.bal_import_standard(src)
+    eng, orc, opts, state, _ = _setup(bal, oracle_mod)
+    tg = driver.run_ba(eng, state, opts, n_iters=150, eval_every=50)
+    to = driver.run_ba(orc, state, opts, n_iters=150, eval_every=50)
+    assert tg == to
+    _assert_state_equal(eng, orc)
+    assert tg[0][1] > 2.0 and tg[-1][1] < 0.05 * tg[0][1], (tg[0], tg[-1])
+
+
 # ---- sharded (multi-GPU) kernels exercised on ONE GPU -----------------------------------------------------
 
 class _FakeDist:

@@ -138,3 +138,95 @@ def test_synthetic_graph_converges_under_the_oracle():
     traj = driver.run_ba(o, state, opts, n_iters=80, eval_every=80)
     assert 5.0 < traj[0][1] < 12.0 and 1.0 < traj[-1][1] < 1.35, traj
     assert o.eval()["n_nonfinite"] == 0
+
+
+# ---- standard "Bundle Adjustment in the Large" import ------------------------------------------
+
+def _rodrigues(w):
+    th = np.linalg.norm(w)
+    if th < 1e-12:
+        return np.eye(3)
+    k = w / th
+    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * (Kx @ Kx)
+
+
+def _write_standard_bal(path, rng, n_cams=7, n_lmks=40, point_noise=0.0):
+    """Synthetic file in the published BAL model: P = R X + t, p = -P/P.z, pixel = f (1 + k1 r^2 + k2 r^4) p.
+    Landmark-major edge order (as the public files), per-camera f / k1 / k2, cameras looking down -z."""
+    pts = rng.uniform(-1, 1, (n_lmks, 3))
+    cams = np.zeros((n_cams, 9))
+    for c in range(n_cams):
+        w = rng.normal(0, 0.15, 3)
+        if c == 0:
+            w[:] = 0                       # identity: becomes a rotation by exactly pi after the frame flip
+        if c == 1:
+            w[:] = [np.pi - 1e-3, 0, 0]    # becomes a near-zero rotation after the flip
+        R = _rodrigues(w)
+        centre = R.T @ np.array([0.0, 0.0, 6.0 + rng.uniform(-1, 1)])   # scene sits at z = -6 in camera coordinates
+        cams[c, :3], cams[c, 3:6] = w, -R @ centre
+        cams[c, 6:] = [rng.uniform(400, 650), rng.normal(0, 5e-2), rng.normal(0, 5e-3)]
+    edges = []
+    for l in range(n_lmks):
+        for c in sorted(rng.choice(n_cams, 4, replace=False)):
+            P = _rodrigues(cams[c, :3]) @ pts[l] + cams[c, 3:6]
+            assert P[2] < 0
+            p = -P[:2] / P[2]
+            r2 = p @ p
+            edges.append((c, l) + tuple(cams[c, 6] * (1 + cams[c, 7] * r2 + cams[c, 8] * r2 * r2) * p))
+    with open(path, "w") as f:
+        f.write("%d %d %d\n" % (n_cams, n_lmks, len(edges)))
+        for c, l, x, y in edges:
+            f.write("%d %d %.17e %.17e\n" % (c, l, x, y))
+        for v in cams.ravel():
+            f.write("%.17e\n" % v)
+        for v in (pts + rng.normal(0, point_noise, pts.shape) if point_noise else pts).ravel():
+            f.write("%.17e\n" % v)
+    return cams, pts, edges
+
+
+def test_standard_bal_import(tmp_path):
+    rng = np.random.default_rng(5)
+    src = str(tmp_path / "standard.txt")
+    cams, pts, edges = _write_standard_bal(src, rng)
+    bal = hostlib.bal_import_standard(src)
+    assert (bal["n_cams"], bal["n_lmks"], bal["n_edges"]) == (7, 40, len(edges))
+    assert bal["fx"] == bal["fy"] == pytest.approx(cams[:, 6].mean(), rel=1e-15) and bal["cx"] == bal["cy"] == 0.0
+    assert np.array_equal(bal["points"].reshape(-1, 3), pts)
+    # edges: same multiset, now sorted by (camera, landmark) as the reference's SLAM mode / metric assume
+    key = bal["cam_id"].astype(np.int64) * 10**6 + bal["lmk_id"]
+    assert np.all(np.diff(key) > 0)
+    assert sorted((int(c), int(l)) for c, l in zip(bal["cam_id"], bal["lmk_id"])) == sorted((int(c), l) for c, l, _, _ in edges)
+    # the converted cameras, used the REFERENCE's way (x_cam = exp(w) y + t, u = fx X/Z + cx; bafuncs.cpp:58-103),
+    # reproduce the converted observations: the undistortion and the frame flip are consistent
+    cam6, obs = bal["cameras"].reshape(-1, 6), bal["observations"].reshape(-1, 2)
+    S = np.diag([1.0, -1.0, -1.0])
+    for c in range(7):
+        assert np.allclose(_rodrigues(cam6[c, 3:]), S @ _rodrigues(cams[c, :3]), atol=1e-12)
+        assert np.allclose(cam6[c, :3], S @ cams[c, 3:6], atol=0)
+    assert np.linalg.norm(cam6[0, 3:]) == pytest.approx(np.pi, abs=1e-12)      # identity -> rotation by pi about x
+    assert np.linalg.norm(cam6[1, 3:]) == pytest.approx(1e-3, rel=1e-9)
+    for e in range(bal["n_edges"]):
+        c, l = bal["cam_id"][e], bal["lmk_id"][e]
+        X = _rodrigues(cam6[c, 3:]) @ pts[l] + cam6[c, :3]
+        assert X[2] > 0
+        assert np.allclose(bal["fx"] * X[:2] / X[2], obs[e], rtol=1e-10, atol=1e-9), (e, c, l)
+    # round trip through the reference's text format
+    out = str(tmp_path / "converted.txt")
+    hostlib.bal_write(out, bal)
+    back = hostlib.bal_read(out)
+    for k in ("cam_id", "lmk_id", "observations", "cameras", "points"):
+        assert np.array_equal(back[k], bal[k]), k
+
+
+def test_standard_bal_import_errors(tmp_path):
+    with pytest.raises(IOError):
+        hostlib.bal_import_standard(str(tmp_path / "missing.txt"))
+    p = tmp_path / "truncated.txt"
+    p.write_text("2 3 4\n0 0 1.0 2.0\n0 1 1.0 2.0\n")
+    with pytest.raises(IOError):
+        hostlib.bal_import_standard(str(p))
+    p = tmp_path / "bad_index.txt"
+    p.write_text("1 1 1\n0 5 1.0 2.0\n" + "0.0\n" * 12)
+    with pytest.raises(IOError):
+        hostlib.bal_import_standard(str(p))
