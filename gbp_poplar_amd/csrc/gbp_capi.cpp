@@ -14,6 +14,8 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -52,9 +54,9 @@ struct gbp_ctx {
   hipGraphExec_t graph_exec = nullptr;
   int graph_iters = 0;
   bool uploaded = false, beliefs_valid = false;
-  bool lmk_half_done = false;
+  bool lmk_half_done = false;          // gbp_iterate_local already refreshed the landmark beliefs of this iteration
   int exch_chunks = 1;                 // camera ranges of the pipelined exchange (gbp_set_exchange_chunks)
-  std::vector<uint32_t> chunk_start;   // [exch_chunks + 1] camera index where each chunk starts  // gbp_iterate_local already refreshed the landmark beliefs of this iteration
+  std::vector<uint32_t> chunk_start;   // [exch_chunks + 1] camera index where each chunk starts
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
   bool profile_stages = false;
   double sweep_ms = 0, belief_ms = 0, total_ms = 0;
@@ -191,6 +193,17 @@ inline void put_state(std::vector<float>& rec, size_t p, const HostState& h) {
   rec[p * 16 + 14] = h.var;
 }
 
+// No C++ exception crosses the C-ABI: every entry point that allocates host memory runs inside this guard.
+template <class F> int guarded(gbp_ctx* c, const char* what, F&& body) {
+  try {
+    return body();
+  } catch (const std::bad_alloc&) {
+    return fail(c, GBP_ERR_NOMEM, std::string(what) + ": out of host memory");
+  } catch (const std::exception& e) {
+    return fail(c, GBP_ERR_INVALID, std::string(what) + ": " + e.what());
+  }
+}
+
 inline size_t tile_off(uint32_t p, int G, int f) {  // float offset of float f of position p in a G-group tiled array
   return (((size_t)(p >> 6) * G + (f >> 2)) * 64 + (p & 63)) * 4 + (f & 3);
 }
@@ -222,13 +235,14 @@ void gbp_destroy(gbp_ctx* c) {
   delete c;
 }
 
-int gbp_create(const gbp_problem* pr, const gbp_params* prm, const gbp_shard* sh, gbp_ctx** out) {
+static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_shard* sh, gbp_ctx** out) {
   if (!pr || !out || !pr->cam_id || !pr->lmk_id || pr->n_cams == 0 || pr->n_lmks == 0 || pr->n_edges == 0)
     return fail(nullptr, GBP_ERR_INVALID, "gbp_create: null or empty problem");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     return fail(nullptr, GBP_ERR_NO_DEVICE, "gbp_create: no HIP device (the product has no CPU fallback)");
   gbp_ctx* c = new gbp_ctx();
+  struct Owner { gbp_ctx* p; ~Owner() { if (p) gbp_destroy(p); } } owner{c};   // released on success only
   c->C = pr->n_cams; c->L = pr->n_lmks; c->E = pr->n_edges;
   std::memcpy(c->K, pr->K, sizeof(c->K));
   if (prm) c->prm = *prm; else gbp_default_params(&c->prm);
@@ -238,10 +252,8 @@ int gbp_create(const gbp_problem* pr, const gbp_params* prm, const gbp_shard* sh
   c->world = sh ? sh->world : 1;
   c->lmk_begin = sh ? sh->lmk_begin : 0;
   c->lmk_end = sh ? sh->lmk_end : c->L;
-  if (c->world < 1 || c->rank < 0 || c->rank >= c->world || c->lmk_begin > c->lmk_end || c->lmk_end > c->L) {
-    delete c;
+  if (c->world < 1 || c->rank < 0 || c->rank >= c->world || c->lmk_begin > c->lmk_end || c->lmk_end > c->L)
     return fail(nullptr, GBP_ERR_INVALID, "gbp_create: bad shard");
-  }
   c->L_loc = c->lmk_end - c->lmk_begin;
   c->chunk_start = {0u, c->C};
 
@@ -250,11 +262,17 @@ int gbp_create(const gbp_problem* pr, const gbp_params* prm, const gbp_shard* sh
   std::vector<uint32_t> deg(C, 0), ldeg(c->L_loc, 0);
   for (uint32_t e = 0; e < E; ++e) {
     const uint32_t cam = pr->cam_id[e], l = pr->lmk_id[e];
-    if (cam >= C || l >= c->L) { delete c; return fail(nullptr, GBP_ERR_INVALID, "gbp_create: index out of range"); }
+    if (cam >= C || l >= c->L) return fail(nullptr, GBP_ERR_INVALID, "gbp_create: index out of range");
     if (l >= c->lmk_begin && l < c->lmk_end) { deg[cam]++; ldeg[l - c->lmk_begin]++; c->E_loc++; }
   }
   c->cam_row_ptr.assign(C + 1, 0);
   for (uint32_t k = 0; k < C; ++k) c->cam_row_ptr[k + 1] = c->cam_row_ptr[k] + (deg[k] + kRow - 1) / kRow;
+  {  // device positions are 32-bit: rows of 16 per camera, padded to whole 256-factor blocks
+    uint64_t rows = 0;
+    for (uint32_t k = 0; k < C; ++k) rows += (deg[k] + kRow - 1) / kRow;
+    if (((rows * kRow + 255) / 256) * 256 >= (1ull << 32))
+      return fail(nullptr, GBP_ERR_INVALID, "gbp_create: more than 2^32 padded factor positions on one GPU; shard by landmark (gbp_shard)");
+  }
   c->n_rows = c->cam_row_ptr[C];
   c->Ep = ((c->n_rows * kRow + 255) / 256) * 256;
   if (c->Ep == 0) c->Ep = 256;
@@ -286,7 +304,8 @@ int gbp_create(const gbp_problem* pr, const gbp_params* prm, const gbp_shard* sh
   auto A = [&](DevBuf& b, size_t bytes) { if (rc == GBP_OK) rc = dev_alloc(c, b, bytes); };
   const size_t Ep = c->Ep;
   A(c->row_cam, (Ep / kRow) * 4); A(c->lmk_idx, Ep * 4); A(c->fac, Ep * kFacG * 16); A(c->cmsg, Ep * kCmsgG * 16);
-  A(c->mu, Ep * kMuG * 16); A(c->lmsg, Ep * 64); A(c->d_lmk_fpos, (size_t)c->E_loc * 4);
+  A(c->mu, c->hoist ? 0 : Ep * kMuG * 16);   // literal mu/oldmu tensor: only with per_factor_mu
+  A(c->lmsg, Ep * 64); A(c->d_lmk_fpos, (size_t)c->E_loc * 4);
   A(c->camb, (size_t)C * kCamRec * 4); A(c->camp, (size_t)C * kCamRec * 4); A(c->local, (size_t)C * kCamRec * 4);
   A(c->lmkb, (size_t)c->L_loc * 64); A(c->lmkp, (size_t)c->L_loc * 64);
   A(c->rowp, (Ep / kRow) * kCamRec * 4);
@@ -295,7 +314,7 @@ int gbp_create(const gbp_problem* pr, const gbp_params* prm, const gbp_shard* sh
   A(c->cam_mu, (size_t)C * 6 * 4); A(c->lmk_mu, (size_t)c->L_loc * 3 * 4); A(c->dK, 16 * 4);
   A(c->evalp, sizeof(DeviceEval) * 1024); A(c->health, 16);
   A(c->hmu_c, (size_t)C * 4 * 16); A(c->hmu_l, (size_t)c->L_loc * 2 * 16);
-  if (rc != GBP_OK) { g_create_error = c->err; gbp_destroy(c); return rc; }
+  if (rc != GBP_OK) { g_create_error = c->err; return rc; }
   auto CK = [&](hipError_t e, const char* what) {
     if (e != hipSuccess && rc == GBP_OK) { g_create_error = std::string(what) + ": " + hipGetErrorString(e); rc = GBP_ERR_HIP; }
   };
@@ -318,7 +337,8 @@ int gbp_create(const gbp_problem* pr, const gbp_params* prm, const gbp_shard* sh
     CK(hipMemcpy(c->row_cam.p, rc_.data(), rc_.size() * 4, hipMemcpyHostToDevice), "copy row_cam");
     CK(hipMemcpy(c->lmk_idx.p, c->pos_lmk_loc.data(), Ep * 4, hipMemcpyHostToDevice), "copy lmk_idx");
   }
-  if (rc != GBP_OK) { gbp_destroy(c); return rc; }
+  if (rc != GBP_OK) return rc;
+  owner.p = nullptr;
   *out = c;
   return GBP_OK;
 }
@@ -344,7 +364,7 @@ int gbp_sync(gbp_ctx* c) {
 
 // WRITE_PROG (ba.cpp:868-886).  Also zeroes every tensor the reference leaves uninitialised
 // (messages, factor potentials, beliefs: ba.cpp:668-687,759-775).
-int gbp_upload(gbp_ctx* c, const gbp_state_in* in) {
+static int upload_impl(gbp_ctx* c, const gbp_state_in* in) {
   if (!c || !in) return GBP_ERR_INVALID;
   if (!in->cam_priors_eta || !in->cam_priors_lambda || !in->lmk_priors_eta || !in->lmk_priors_lambda ||
       !in->measurements || !in->meas_variances || !in->active_flag)
@@ -360,7 +380,7 @@ int gbp_upload(gbp_ctx* c, const gbp_state_in* in) {
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const size_t Ep = c->Ep;
-  std::vector<float> rec0(Ep * 16, 0.f), fac(Ep * kFacG * 4, 0.f), mu(Ep * kMuG * 4, 0.f);
+  std::vector<float> rec0(Ep * 16, 0.f), fac(Ep * kFacG * 4, 0.f), mu(c->hoist ? 0 : Ep * kMuG * 4, 0.f);
   for (size_t p = 0; p < Ep; ++p) {
     const uint32_t e = c->pos_edge[p];
     HostState h{0.f, 0, kFlagPad, 0.f};
@@ -372,13 +392,13 @@ int gbp_upload(gbp_ctx* c, const gbp_state_in* in) {
       fac[tile_off((uint32_t)p, kFacG, 54)] = in->measurements[2 * (size_t)e];
       fac[tile_off((uint32_t)p, kFacG, 55)] = in->measurements[2 * (size_t)e + 1];
       const float* om = in->oldmu ? in->oldmu : in->mu;
-      if (om) for (int i = 0; i < 9; ++i) mu[tile_off((uint32_t)p, kMuG, i)] = om[(size_t)e * 9 + i];
+      if (om && !c->hoist) for (int i = 0; i < 9; ++i) mu[tile_off((uint32_t)p, kMuG, i)] = om[(size_t)e * 9 + i];
     }
     put_state(rec0, p, h);
   }
   HIPCHK(c, hipMemcpy(c->lmsg.p, rec0.data(), rec0.size() * 4, hipMemcpyHostToDevice));   // zero messages + state
   HIPCHK(c, hipMemcpy(c->fac.p, fac.data(), fac.size() * 4, hipMemcpyHostToDevice));
-  HIPCHK(c, hipMemcpy(c->mu.p, mu.data(), mu.size() * 4, hipMemcpyHostToDevice));
+  if (!c->hoist) HIPCHK(c, hipMemcpy(c->mu.p, mu.data(), mu.size() * 4, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemset(c->cmsg.p, 0, c->cmsg.bytes));
   HIPCHK(c, hipMemset(c->rowp.p, 0, c->rowp.bytes));
   HIPCHK(c, hipMemset(c->local.p, 0, c->local.bytes));
@@ -450,7 +470,7 @@ int gbp_iterate_begin(gbp_ctx* c) {
 
 // Layout of the exchange buffers: n camera ranges [i*C/n, (i+1)*C/n), identical on every rank.  send_dev stays
 // [C][44]; recv_dev holds, for range i, [world][n_i][44] behind world * start_i * 44 floats (n = 1: [world][C][44]).
-int gbp_set_exchange_chunks(gbp_ctx* c, int n) {
+static int set_exchange_chunks_impl(gbp_ctx* c, int n) {
   if (!c || n < 1 || n > kMaxChunks) return fail(c, GBP_ERR_INVALID, "gbp_set_exchange_chunks: 1..8 chunks");
   c->exch_chunks = n;
   c->chunk_start.assign(n + 1, 0u);
@@ -504,7 +524,7 @@ int gbp_iterate_end(gbp_ctx* c) {
 
 // GBP_PROG x n (ba.cpp:895-905) on one GPU: replay of a captured hipGraph of `graph_unroll`
 // iterations, remainder launched directly.
-int gbp_iterate(gbp_ctx* c, int n) {
+static int iterate_impl(gbp_ctx* c, int n) {
   if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "gbp_iterate: upload first");
   if (n <= 0) return GBP_OK;
   if (c->world > 1) return fail(c, GBP_ERR_STATE, "sharded ctx: use gbp_iterate_begin / exchange / gbp_iterate_end");
@@ -572,7 +592,7 @@ int gbp_weaken_priors(gbp_ctx* c) {
 }
 
 // READ_PROG (ba.cpp:908-916)
-int gbp_read(gbp_ctx* c, gbp_state_out* o) {
+static int read_impl(gbp_ctx* c, gbp_state_out* o) {
   if (!c || !o) return GBP_ERR_INVALID;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (o->cam_beliefs_eta || o->cam_beliefs_lambda) {
@@ -607,7 +627,7 @@ int gbp_read(gbp_ctx* c, gbp_state_out* o) {
 }
 
 // READ_PRIORS (slam.cpp:913-917)
-int gbp_read_priors(gbp_ctx* c, gbp_priors_out* o) {
+static int read_priors_impl(gbp_ctx* c, gbp_priors_out* o) {
   if (!c || !o) return GBP_ERR_INVALID;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   std::vector<float> rec((size_t)c->C * kCamRec);
@@ -628,7 +648,7 @@ int gbp_read_priors(gbp_ctx* c, gbp_priors_out* o) {
 }
 
 // NEW_KEYFRAME (slam.cpp:919-928): re-upload damping_count, priors, flags; then prog_ub.
-int gbp_new_keyframe(gbp_ctx* c, const gbp_kf_update* u) {
+static int new_keyframe_impl(gbp_ctx* c, const gbp_kf_update* u) {
   if (!c || !u || !c->uploaded) return fail(c, GBP_ERR_STATE, "gbp_new_keyframe: upload first");
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (u->damping_count || u->active_flag) {
@@ -661,7 +681,7 @@ int gbp_new_keyframe(gbp_ctx* c, const gbp_kf_update* u) {
 }
 
 // eval_reprojection_error (util.cpp:74-144) + counters (ba.cpp:1011-1020) over the local shard
-int gbp_eval(gbp_ctx* c, gbp_eval_out* o) {
+static int eval_impl(gbp_ctx* c, gbp_eval_out* o) {
   if (!c || !o || !c->uploaded) return fail(c, GBP_ERR_STATE, "gbp_eval: upload first");
   std::memset(o, 0, sizeof(*o));
   launch_means(P<float4>(c->camb), P<float4>(c->lmkb), P<float>(c->cam_mu), P<float>(c->lmk_mu), c->C, c->L_loc,
@@ -710,7 +730,7 @@ int gbp_set_profiling(gbp_ctx* c, int per_stage_events) {
 //   what = 2: factor->landmark messages: eta [3E] + Lambda [9E]
 //   what = 3: mu [9E] + dmu [E]
 // Entries of factors outside the local shard are left untouched.
-int gbp_debug_get(gbp_ctx* c, int what, float* a, float* b) {
+static int debug_get_impl(gbp_ctx* c, int what, float* a, float* b) {
   if (!c || !a || !b) return GBP_ERR_INVALID;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   auto tri = [](int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; };
@@ -803,7 +823,7 @@ int gbp_debug_time_sweep(gbp_ctx* c, int ablation, int reps, double* avg_us) {
 
 // Inverse of gbp_debug_get(what = 0): overwrite the factor potentials (lower triangles of the
 // symmetric blocks and Lambda_cl are taken; Lambda_lc is implied).  Test hook only.
-int gbp_debug_set_factor_potentials(gbp_ctx* c, const float* eta9E, const float* lam81E) {
+static int debug_set_factor_potentials_impl(gbp_ctx* c, const float* eta9E, const float* lam81E) {
   if (!c || !eta9E || !lam81E) return GBP_ERR_INVALID;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   auto tri = [](int i, int j) { return i * (i + 1) / 2 + j; };
@@ -820,6 +840,22 @@ int gbp_debug_set_factor_potentials(gbp_ctx* c, const float* eta9E, const float*
   }
   HIPCHK(c, hipMemcpy(c->fac.p, f.data(), f.size() * 4, hipMemcpyHostToDevice));
   return GBP_OK;
+}
+
+// ---- exported wrappers of the entry points that allocate host memory -----------------------------------------
+int gbp_create(const gbp_problem* pr, const gbp_params* prm, const gbp_shard* sh, gbp_ctx** out) {
+  return guarded(nullptr, "gbp_create", [&] { return create_impl(pr, prm, sh, out); });
+}
+int gbp_upload(gbp_ctx* c, const gbp_state_in* in) { return guarded(c, "gbp_upload", [&] { return upload_impl(c, in); }); }
+int gbp_set_exchange_chunks(gbp_ctx* c, int n) { return guarded(c, "gbp_set_exchange_chunks", [&] { return set_exchange_chunks_impl(c, n); }); }
+int gbp_iterate(gbp_ctx* c, int n) { return guarded(c, "gbp_iterate", [&] { return iterate_impl(c, n); }); }
+int gbp_read(gbp_ctx* c, gbp_state_out* o) { return guarded(c, "gbp_read", [&] { return read_impl(c, o); }); }
+int gbp_read_priors(gbp_ctx* c, gbp_priors_out* o) { return guarded(c, "gbp_read_priors", [&] { return read_priors_impl(c, o); }); }
+int gbp_new_keyframe(gbp_ctx* c, const gbp_kf_update* u) { return guarded(c, "gbp_new_keyframe", [&] { return new_keyframe_impl(c, u); }); }
+int gbp_eval(gbp_ctx* c, gbp_eval_out* o) { return guarded(c, "gbp_eval", [&] { return eval_impl(c, o); }); }
+int gbp_debug_get(gbp_ctx* c, int what, float* a, float* b) { return guarded(c, "gbp_debug_get", [&] { return debug_get_impl(c, what, a, b); }); }
+int gbp_debug_set_factor_potentials(gbp_ctx* c, const float* eta9E, const float* lam81E) {
+  return guarded(c, "gbp_debug_set_factor_potentials", [&] { return debug_set_factor_potentials_impl(c, eta9E, lam81E); });
 }
 
 }  // extern "C"

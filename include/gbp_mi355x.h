@@ -30,7 +30,8 @@ typedef enum {
   GBP_ERR_NO_DEVICE = -2,  /* no gfx950 device (ref: ba.cpp:652-655 exit(-1)) */
   GBP_ERR_HIP = -3,        /* a HIP runtime call failed                    */
   GBP_ERR_STATE = -4,      /* call order violated (e.g. iterate before upload) */
-  GBP_ERR_IO = -5          /* file could not be read (ref: ba.cpp:484-487)  */
+  GBP_ERR_IO = -5,         /* file could not be read (ref: ba.cpp:484-487)  */
+  GBP_ERR_NOMEM = -6       /* host allocation failed (no C++ exception ever crosses this ABI) */
 } gbp_status;
 
 typedef struct gbp_ctx gbp_ctx;
