@@ -644,6 +644,55 @@ def test_degenerate_graph_shapes(case, oracle_mod):
     assert g["n_nonfinite"] == (1 if case == "camera_without_factors" else 0)   # the factor-less camera has a 0/0 mean
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_random_graph_structures_bit_exact(seed, oracle_mod):
+    """Random wiring the shipped files never show: UNSORTED edge lists (slot order = file order, ba.cpp:267-279,
+    must survive the device's camera-major re-ordering), duplicate (camera, landmark) factors, a hub landmark seen
+    by every camera many times, landmarks without factors, random inactive factors, both mu modes.
+    14 sweeps with prior weakening and frequent relinearisations (`--undamped_start 1`, loose dmu threshold):
+    every belief, message, factor potential and damping state equals the oracle's bit for bit."""
+    from gbp_poplar_amd import _cabi, driver, hostlib
+    from gbp_poplar_amd.engine import GbpEngine
+    rng = np.random.default_rng(100 + seed)
+    C, L = int(rng.integers(2, 40)), int(rng.integers(3, 200))
+    E = int(rng.integers(max(C, L), 12 * L))
+    cam_id = rng.integers(0, C, E)
+    lmk_id = rng.integers(0, max(1, L - 2), E)          # the last two landmarks stay factor-less
+    lmk_id[rng.random(E) < 0.15] = 0                    # hub landmark
+    cam_id[:C] = np.arange(C)                           # every camera has a factor (else its prior is NaN by design)
+    bal = _tiny_problem(list(cam_id), list(lmk_id), C, L, seed=seed)
+    opts = driver.Options()
+    opts.undamped_start = 1
+    K, state, _ = driver.build_inputs(bal, opts, hostlib)
+    state["active_flag"] = (rng.random(E) < 0.9).astype(np.uint32)
+    oracle_mod.set_trig_mode(1)
+    try:
+        kw = dict(dmu_threshold=0.05, min_linear_iters=3, num_undamped_iters=2)    # relinearise early and often
+        eng = GbpEngine(bal["cam_id"], bal["lmk_id"], C, L, K, params=_cabi.GbpParams.defaults(per_factor_mu=seed % 2, **kw))
+        orc = oracle_mod.Oracle(bal["cam_id"], bal["lmk_id"], C, L, K, params=_cabi.GbpParams.defaults(**kw))
+        orc.set_sum_order(1)
+        for x in (eng, orc):
+            x.upload(state)
+            x.linearise()
+        n_relin = 0
+        for it in range(14):
+            if (it + 1) % 2 == 0 and it < 10:
+                eng.weaken_priors()
+                orc.weaken_priors()
+            eng.iterate(1)
+            orc.iterate(1)
+            _assert_state_equal(eng, orc, exact=True)
+            g, o = eng.eval(), orc.eval()
+            assert (g["n_relin"], g["n_robust"], g["n_active"]) == (o["n_relin"], o["n_robust"], o["n_active"])
+            n_relin += g["n_relin"]
+        fe, fl = eng.factor_potentials()
+        oe, ol = orc.factor_potentials()
+        assert np.array_equal(fe, oe) and np.array_equal(fl, ol)
+    finally:
+        oracle_mod.set_trig_mode(0)
+    assert n_relin > 0
+
+
 def test_error_codes_and_call_order():
     from gbp_poplar_amd import driver, hostlib
     from gbp_poplar_amd.engine import GbpEngine, GbpError
