@@ -182,18 +182,26 @@ def main():
     ev1 = run.eval()
 
     # ---- roofline of the dominant kernel (k_sweep), measured live with hipEvents on its stream ----
+    graph_used = (getattr(run, "graph", None) is not None) if hasattr(run, "use_graph") else None
     roof = None
-    if world == 1 and a.profile_steps > 0 and not a.force_sharded:
+    if a.profile_steps > 0:
+        sharded = world > 1 or a.force_sharded
         eng.timing(reset=True)
         eng.set_profiling(True)
-        eng.iterate(a.profile_steps)
+        if sharded:      # split-phase path: gbp_iterate_begin brackets its sweep launch; every rank runs the iterations
+            if getattr(run, "use_graph", False):
+                run.use_graph, run.graph = False, None
+            run.iterate(a.profile_steps)
+            fence()
+        else:
+            eng.iterate(a.profile_steps)
         eng.set_profiling(False)
         tm = eng.timing(reset=True)
         sweep_s = tm["sweep_ms"] / 1e3 / a.profile_steps
         achieved = ALGO_BYTES_PER_FACTOR * e_local / sweep_s / 1e9
         traffic = None     # HBM bytes per launch from the committed PMC passes of this same workload (profiles/run_profile.sh)
         tpath = os.path.join(ROOT, "profiles", "traffic_S1.json")
-        if os.path.exists(tpath) and (a.cams, a.lmks, a.obs) == (1000, 100000, 10):
+        if os.path.exists(tpath) and (a.cams, a.lmks, a.obs) == (1000, 100000, 10) and world == 1:
             try:
                 traffic = int(json.load(open(tpath))["hbm_bytes_per_launch"])
             except Exception:
@@ -202,7 +210,8 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_FACTOR * e_local,
                 "avg_launch_us": round(sweep_s * 1e6, 2),
-                "belief_kernels_avg_us": round(tm["belief_ms"] * 1e3 / a.profile_steps, 2)}
+                "belief_kernels_avg_us": round(tm["belief_ms"] * 1e3 / a.profile_steps, 2) if not sharded else None,
+                "measured_on": "rank 0" if world > 1 else "the GPU"}
 
     cpu = None
     if rank == 0 and world == 1 and a.cpu_seconds > 0:
@@ -222,12 +231,12 @@ def main():
             "config": {"workload": "S1 synthetic BAL graph x%d: %d cams x %d lmks x %d factors (seed %d)%s"
                                    % (world, C, L, E, a.seed, ", landmark-sharded over %d GPUs" % world if world > 1 else ""),
                        "cams": C, "lmks": L, "factors": E, "iters_per_sec": round(ips, 2),
-                       "parallelism": "1 GPU, hipGraph x10 iterations" if world == 1 else "landmark shards x%d + all_gather(cam partials)" % world,
+                       "parallelism": "1 GPU, hipGraph x10 iterations" if (world == 1 and not a.force_sharded) else "landmark shards x%d + all_gather(cam partials)" % world,
                        "reproj_rmse_px_initial": round(m0[2], 6), "reproj_rmse_px_final": round(m1[2], 6),
                        "mean_reproj_px_final": round(m1[0], 6), "iterations_run": a.warmup + a.steps,
                        "nonfinite_beliefs": int(ev1["n_nonfinite"]),
                        "exchange_chunks": getattr(run, "chunks", None),
-                       "sharded_graph": (getattr(run, "graph", None) is not None) if hasattr(run, "use_graph") else None,
+                       "sharded_graph": graph_used,
                        "sharded_graph_error": getattr(run, "graph_error", None)},
         }
         if roof:

@@ -59,6 +59,7 @@ struct gbp_ctx {
   std::vector<uint32_t> chunk_start;   // [exch_chunks + 1] camera index where each chunk starts
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
   bool profile_stages = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_sweep_ev;  // split-phase profiling: brackets not yet read
   double sweep_ms = 0, belief_ms = 0, total_ms = 0;
   uint64_t timed_iters = 0, dev_bytes = 0;
   std::string err;
@@ -226,6 +227,7 @@ const char* gbp_last_error(const gbp_ctx* ctx) { return ctx ? ctx->err.c_str() :
 void gbp_destroy(gbp_ctx* c) {
   if (!c) return;
   drop_graph(c);
+  for (auto& pr : c->pending_sweep_ev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   for (DevBuf* b : c->all) if (b->p) (void)hipFree(b->p);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -458,11 +460,21 @@ int gbp_linearise(gbp_ctx* c) {
   return rc;
 }
 
-int gbp_iterate_begin(gbp_ctx* c) {
+static int iterate_begin_impl(gbp_ctx* c) {
   if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "upload first");
   float4* dst = c->world > 1 ? static_cast<float4*>(c->send_dev) : P<float4>(c->local);
   if (!dst) return fail(c, GBP_ERR_STATE, "exchange buffers not set");
-  launch_sweep(sweep_args(c), c->n_tiles, c->hoist, c->stream);
+  if (c->profile_stages) {  // bracket the sweep launch; the pair is read (and timed_iters counted) by gbp_timing
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIPCHK(c, hipEventCreate(&e0));
+    HIPCHK(c, hipEventCreate(&e1));
+    c->pending_sweep_ev.emplace_back(e0, e1);
+    HIPCHK(c, hipEventRecord(e0, c->stream));
+    launch_sweep(sweep_args(c), c->n_tiles, c->hoist, c->stream);
+    HIPCHK(c, hipEventRecord(e1, c->stream));
+  } else {
+    launch_sweep(sweep_args(c), c->n_tiles, c->hoist, c->stream);
+  }
   enqueue_cam_partials(c, reinterpret_cast<float*>(dst));
   HIPCHK(c, hipGetLastError());
   return GBP_OK;
@@ -710,6 +722,16 @@ static int eval_impl(gbp_ctx* c, gbp_eval_out* o) {
 
 int gbp_timing(gbp_ctx* c, gbp_timing_out* t, int reset) {
   if (!c || !t) return GBP_ERR_INVALID;
+  for (auto& pr : c->pending_sweep_ev) {   // split-phase brackets recorded by gbp_iterate_begin
+    float ms = 0;
+    if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+      c->sweep_ms += ms;
+      c->timed_iters += 1;
+    }
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
+  c->pending_sweep_ev.clear();
   t->sweep_ms = c->sweep_ms; t->belief_ms = c->belief_ms; t->total_ms = c->total_ms; t->iterations = c->timed_iters;
   t->algorithmic_bytes_per_iter = 1112ull * c->E_loc + 336ull * c->C + 96ull * c->L_loc;
   t->device_bytes_allocated = c->dev_bytes;
@@ -849,6 +871,7 @@ int gbp_create(const gbp_problem* pr, const gbp_params* prm, const gbp_shard* sh
 int gbp_upload(gbp_ctx* c, const gbp_state_in* in) { return guarded(c, "gbp_upload", [&] { return upload_impl(c, in); }); }
 int gbp_set_exchange_chunks(gbp_ctx* c, int n) { return guarded(c, "gbp_set_exchange_chunks", [&] { return set_exchange_chunks_impl(c, n); }); }
 int gbp_iterate(gbp_ctx* c, int n) { return guarded(c, "gbp_iterate", [&] { return iterate_impl(c, n); }); }
+int gbp_iterate_begin(gbp_ctx* c) { return guarded(c, "gbp_iterate_begin", [&] { return iterate_begin_impl(c); }); }
 int gbp_read(gbp_ctx* c, gbp_state_out* o) { return guarded(c, "gbp_read", [&] { return read_impl(c, o); }); }
 int gbp_read_priors(gbp_ctx* c, gbp_priors_out* o) { return guarded(c, "gbp_read_priors", [&] { return read_priors_impl(c, o); }); }
 int gbp_new_keyframe(gbp_ctx* c, const gbp_kf_update* u) { return guarded(c, "gbp_new_keyframe", [&] { return new_keyframe_impl(c, u); }); }

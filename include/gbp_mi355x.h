@@ -197,7 +197,9 @@ int gbp_linearise_factors(gbp_ctx* ctx);  /* the factor half of LINEARISE_PROG (
 
 /* ---- measurement / test hooks -------------------------------------------------------------- */
 /* per_stage_events != 0: gbp_iterate launches kernels directly with a hipEvent pair around the
- * sweep and the belief kernels of every iteration (feeds gbp_timing.sweep_ms / belief_ms). */
+ * sweep and the belief kernels of every iteration (feeds gbp_timing.sweep_ms / belief_ms); in the
+ * split-phase path gbp_iterate_begin brackets its sweep launch the same way (sweep_ms and iterations
+ * only; the pairs are read by the next gbp_timing call). */
 int gbp_set_profiling(gbp_ctx* ctx, int per_stage_events);
 /* Raw internal state in the reference's tensor layouts (ba.cpp:665-687,759-775):
  *   what 0: a = factor_potentials_eta [9E],  b = factor_potentials_lambda [81E] = [cc36|cl18|lc18|ll9]
