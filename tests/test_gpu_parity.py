@@ -587,6 +587,17 @@ def test_sharded_wrapper_world1_on_gpu(oracle_mod):
     ra, rb = plain.read(), sh.read()
     for k in ra:
         assert np.array_equal(ra[k], rb[k]), k
+    # split-phase profiling (bench.py's roofline at N > 1): every gbp_iterate_begin brackets its sweep launch
+    eng.timing(reset=True)
+    eng.set_profiling(True)
+    sh.iterate(7)
+    eng.set_profiling(False)
+    tm = eng.timing(reset=True)
+    assert tm["iterations"] == 7 and 0.0 < tm["sweep_ms"] / 7 < 1.0, tm
+    plain.iterate(7)
+    ra, rb = plain.read(), sh.read()
+    for k in ra:
+        assert np.array_equal(ra[k], rb[k]), k
 
 
 # ---- edge cases and error behaviour of the C-ABI --------------------------------------------------------------
