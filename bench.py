@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--sharded-graph", type=int, default=0, help="capture sharded iterations (kernels + RCCL) in a hipGraph")
     ap.add_argument("--exchange-chunks", type=int, default=None,
                     help="camera ranges of the pipelined all-gather (default: 1 / 2 / 3 for 1 / 2-4 / 8 GPUs)")
+    ap.add_argument("--tile-order", type=int, default=0, help="gbp_params.tile_order: 0 = XCD-aware (default), 1 = sequential")
     return ap.parse_args()
 
 
@@ -146,13 +147,16 @@ def main():
     opts = driver.Options()
     K, state, _ = driver.build_inputs(bal, opts, hostlib)
 
+    from gbp_poplar_amd import _cabi
+    prm = _cabi.GbpParams.defaults(tile_order=a.tile_order)
     if world == 1 and not a.force_sharded:
-        eng = GbpEngine(bal["cam_id"], bal["lmk_id"], C, L, K)
+        eng = GbpEngine(bal["cam_id"], bal["lmk_id"], C, L, K, params=prm)
         run = eng
         e_local = E
     else:
         bounds = landmark_partition(bal["lmk_id"], L, world)
-        eng = GbpEngine(bal["cam_id"], bal["lmk_id"], C, L, K, shard=(rank, world, int(bounds[rank]), int(bounds[rank + 1])))
+        eng = GbpEngine(bal["cam_id"], bal["lmk_id"], C, L, K, params=prm,
+                        shard=(rank, world, int(bounds[rank]), int(bounds[rank + 1])))
         run = ShardedGbp(eng, C, rank, world, dist=dist, device="cuda", always_collective=a.force_sharded,
                          use_graph=bool(a.sharded_graph), chunks=a.exchange_chunks)
         e_local = int(((bal["lmk_id"] >= bounds[rank]) & (bal["lmk_id"] < bounds[rank + 1])).sum())

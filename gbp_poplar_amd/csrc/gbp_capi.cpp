@@ -45,7 +45,8 @@ struct gbp_ctx {
   // device memory
   std::vector<DevBuf*> all;
   DevBuf row_cam, lmk_idx, fac, cmsg, mu, lmsg, camb, camp, lmkb, lmkp, rowp, local, d_cam_row_ptr, d_lmk_ptr, cwf, lwf,
-      cscale, lscale, cam_mu, lmk_mu, dK, evalp, hmu_c, hmu_l, d_lmk_fpos, health;
+      cscale, lscale, cam_mu, lmk_mu, dK, evalp, hmu_c, hmu_l, d_lmk_fpos, health, tile_perm;
+  bool use_tile_perm = false;
   bool hoist = true;  // per-variable belief means (k_sweep<true>); false = literal per-factor mu/oldmu tensors
   void* send_dev = nullptr;
   void* recv_dev = nullptr;
@@ -101,6 +102,7 @@ SweepArgs sweep_args(gbp_ctx* c) {
   a.hp.dmu_threshold = c->prm.dmu_threshold; a.hp.min_linear_iters = c->prm.min_linear_iters;
   a.hp.nstds = c->prm.nstds; a.hp.relin_mode = c->prm.relin_mode;
   a.block0 = 0;
+  a.tile_perm = c->use_tile_perm ? P<uint32_t>(c->tile_perm) : nullptr;
   return a;
 }
 
@@ -339,6 +341,35 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
     CK(hipMemcpy(c->row_cam.p, rc_.data(), rc_.size() * 4, hipMemcpyHostToDevice), "copy row_cam");
     CK(hipMemcpy(c->lmk_idx.p, c->pos_lmk_loc.data(), Ep * 4, hipMemcpyHostToDevice), "copy lmk_idx");
   }
+  if (rc == GBP_OK && c->prm.tile_order != 1) {
+    // XCD-aware execution order of the sweep.  Workgroup w lands on XCD (w mod 8) (observed placement; only speed
+    // depends on it) and its wave v runs tile perm[4w + v].  Tiles are ranked by their lowest landmark index and the
+    // ranking is cut into 8 equal runs, one per XCD, so each private 4 MiB L2 serves one slice of the gathered
+    // landmark tables (beliefs + hoisted means) instead of a random 4 MiB / table-size share of all of them.
+    const uint32_t nt = c->n_tiles, nb = nt / 4;
+    std::vector<uint64_t> key(nt);
+    for (uint32_t t = 0; t < nt; ++t) {
+      uint32_t lo = ~0u;
+      for (uint32_t i = 0; i < kTile; ++i) {
+        const size_t p = (size_t)t * kTile + i;
+        if (c->pos_edge[p] != ~0u) lo = std::min(lo, c->pos_lmk_loc[p]);
+      }
+      key[t] = ((uint64_t)lo << 32) | t;
+    }
+    std::sort(key.begin(), key.end());
+    std::vector<uint32_t> perm(nt);
+    const uint32_t q = nb / 8, r = nb % 8;   // XCD group g owns q+1 workgroups if g < r, else q (bijective for any nb)
+    uint32_t next = 0;
+    for (uint32_t g = 0; g < 8; ++g) {
+      const uint32_t n_wg = q + (g < r ? 1u : 0u);
+      for (uint32_t k = 0; k < n_wg; ++k)
+        for (uint32_t v = 0; v < 4; ++v) perm[(size_t)(8 * k + g) * 4 + v] = (uint32_t)(key[next++] & 0xffffffffu);
+    }
+    rc = dev_alloc(c, c->tile_perm, (size_t)nt * 4);
+    if (rc == GBP_OK) CK(hipMemcpy(c->tile_perm.p, perm.data(), (size_t)nt * 4, hipMemcpyHostToDevice), "copy tile_perm");
+    else g_create_error = c->err;
+    c->use_tile_perm = rc == GBP_OK;
+  }
   if (rc != GBP_OK) return rc;
   owner.p = nullptr;
   *out = c;
@@ -505,7 +536,9 @@ int gbp_iterate_begin_chunk(gbp_ctx* c, int chunk) {
     return (uint32_t)std::min<uint64_t>(n_blocks, (pos + 255) / 256);
   };
   const uint32_t b0 = chunk == 0 ? 0u : block_end(chunk - 1), b1 = block_end(chunk);
-  launch_sweep_blocks(sweep_args(c), b0, b1, c->hoist, c->stream);
+  SweepArgs sa = sweep_args(c);
+  sa.tile_perm = nullptr;   // a piece must sweep exactly the blocks of its camera range
+  launch_sweep_blocks(sa, b0, b1, c->hoist, c->stream);
   BeliefArgs b = belief_args(c);
   b.cam_local = dst; b.partial_only = 1;
   b.cam0 = c->chunk_start[chunk]; b.cam1 = c->chunk_start[chunk + 1];

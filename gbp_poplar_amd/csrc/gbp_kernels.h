@@ -66,6 +66,9 @@ struct SweepArgs {
   float K[9];
   Hyper hp;
   uint32_t block0;           // first 256-factor block of this launch (pieces of a sweep: pipelined exchange)
+  const uint32_t* tile_perm; // [n_tiles] or NULL: wave slot (4 * block + wave) -> tile.  XCD-aware execution order:
+                             // workgroups are dealt round-robin over the 8 XCDs, the table hands every XCD the tiles of
+                             // one landmark range so that its private L2 holds that slice of the gathered landmark tables
 };
 
 constexpr int kMaxChunks = 8;

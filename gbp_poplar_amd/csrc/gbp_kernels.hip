@@ -181,8 +181,9 @@ GBP_DEV bool relin_core(float (&fac)[56], const float (&x0c)[6], const float (&x
 // 16 / 32 = no landmark-message load / store.
 template <bool HOIST, int ABL = 0>
 __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
-  const uint32_t p = (blockIdx.x + a.block0) * 256 + threadIdx.x;
-  const uint32_t tile = p >> 6, lane = p & 63;
+  const uint32_t wslot = (blockIdx.x + a.block0) * 4 + (threadIdx.x >> 6);
+  const uint32_t tile = a.tile_perm ? (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tile_perm[wslot]) : wslot;
+  const uint32_t lane = threadIdx.x & 63, p = tile * 64 + lane;
 
   const uint32_t cam_i = a.row_cam[p >> 4];
   const uint32_t lmk_i = __builtin_nontemporal_load(a.lmk_idx + p);

@@ -64,7 +64,10 @@ typedef struct {
                                   to the per-factor recomputation of gbp_codelets.cpp:264-277, requires the
                                   uploaded mu/oldmu to be zero as in ba.cpp:582-583); 1: keep the literal
                                   per-factor mu/oldmu tensors                                            */
-  int32_t reserved[4];
+  int32_t tile_order;          /* execution order of the sweep's 64-factor tiles: 0 (default) = XCD-aware (each of the
+                                  8 XCDs sweeps one landmark range, so its private L2 keeps that slice of the gathered
+                                  landmark tables), 1 = sequential device order.  Results are identical.            */
+  int32_t reserved[3];
 } gbp_params;
 
 /* Landmark shard of a multi-GPU run (one process per GPU).  The global problem is passed to
