@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--sharded-graph", type=int, default=0, help="capture sharded iterations (kernels + RCCL) in a hipGraph")
     ap.add_argument("--exchange-chunks", type=int, default=None,
                     help="camera ranges of the pipelined all-gather (default: 1 / 2 / 3 for 1 / 2-4 / 8 GPUs)")
-    ap.add_argument("--tile-order", type=int, default=0, help="gbp_params.tile_order: 0 = XCD-aware (default), 1 = sequential")
+    ap.add_argument("--tile-order", type=int, default=0, help="gbp_params.tile_order: 0 = default, 1 = sequential, 2 = sweep tiles XCD-aware too")
     return ap.parse_args()
 
 

@@ -122,6 +122,7 @@ BeliefArgs belief_args(gbp_ctx* c) {
   b.lmkb = P<float4>(c->lmkb); b.lmk_mu = P<float4>(c->hmu_l); b.n_lmks = c->L_loc;
   b.partial_only = 0; b.hoist = c->hoist ? 1 : 0; b.roll = 0;
   b.cam0 = 0; b.cam1 = 0;
+  b.lmk_blocks = 0; b.lmk_xcd_order = c->prm.tile_order != 1 ? 1 : 0;
   b.n_chunks = c->exch_chunks;
   for (int i = 0; i <= c->exch_chunks; ++i) b.chunk_start[i] = c->chunk_start[i];
   return b;
@@ -341,8 +342,9 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
     CK(hipMemcpy(c->row_cam.p, rc_.data(), rc_.size() * 4, hipMemcpyHostToDevice), "copy row_cam");
     CK(hipMemcpy(c->lmk_idx.p, c->pos_lmk_loc.data(), Ep * 4, hipMemcpyHostToDevice), "copy lmk_idx");
   }
-  if (rc == GBP_OK && c->prm.tile_order != 1) {
-    // XCD-aware execution order of the sweep.  Workgroup w lands on XCD (w mod 8) (observed placement; only speed
+  if (rc == GBP_OK && c->prm.tile_order == 2) {
+    // XCD-aware execution order of the sweep (optional: 11 % less fabric traffic, but ~2 % slower than the sequential
+    // order on S1 — consecutive tiles of an XCD then sit ~200 KB apart in every stream; profiles/r01_ablation.md).  Workgroup w lands on XCD (w mod 8) (observed placement; only speed
     // depends on it) and its wave v runs tile perm[4w + v].  Tiles are ranked by their lowest landmark index and the
     // ranking is cut into 8 equal runs, one per XCD, so each private 4 MiB L2 serves one slice of the gathered
     // landmark tables (beliefs + hoisted means) instead of a random 4 MiB / table-size share of all of them.

@@ -66,9 +66,10 @@ struct SweepArgs {
   float K[9];
   Hyper hp;
   uint32_t block0;           // first 256-factor block of this launch (pieces of a sweep: pipelined exchange)
-  const uint32_t* tile_perm; // [n_tiles] or NULL: wave slot (4 * block + wave) -> tile.  XCD-aware execution order:
-                             // workgroups are dealt round-robin over the 8 XCDs, the table hands every XCD the tiles of
-                             // one landmark range so that its private L2 holds that slice of the gathered landmark tables
+  const uint32_t* tile_perm; // [n_tiles] or NULL (default): wave slot (4 * block + wave) -> tile.  Optional XCD-aware
+                             // order (gbp_params.tile_order = 2): workgroups are dealt round-robin over the 8 XCDs, the
+                             // table hands every XCD the tiles of one landmark range so that its private L2 holds that
+                             // slice of the gathered landmark tables
 };
 
 constexpr int kMaxChunks = 8;
@@ -89,6 +90,8 @@ struct BeliefArgs {
   uint32_t chunk_start[kMaxChunks + 1];
   // control
   uint32_t cam_blocks;
+  uint32_t lmk_blocks;       // landmark blocks of this launch
+  int lmk_xcd_order;         // 1: blocks with equal (index mod 8) — one XCD — take a contiguous landmark range
   int partial_only;          // camera part writes cam_local only (multi-GPU: before the exchange)
   int hoist;                 // compute per-variable means + dmu^2 pieces
   int roll;                  // end of an iteration: "means used by the last sweep" := current means, then recompute

@@ -588,7 +588,16 @@ __global__ __launch_bounds__(256) void k_beliefs(const BeliefArgs b) {
     return;
   }
   // ---- landmark part ----
-  const uint32_t t = (blockIdx.x - b.cam_blocks) * 256 + threadIdx.x;
+  uint32_t lb = blockIdx.x - b.cam_blocks;
+  if (b.lmk_xcd_order) {
+    // XCD-aware order: the blocks that share an XCD (equal index mod 8 under round-robin placement) take one contiguous
+    // run of landmarks.  The 64-B message records of two neighbouring factors share a 128-B line, and the partner's
+    // landmark is a near neighbour (factors are sorted by landmark inside a camera): with both in one XCD's L2 about
+    // half of the partner fetches disappear (k_beliefs: 25.6 -> 21.3 us on S1, profiles/r01_ablation.md).
+    const uint32_t qn = b.lmk_blocks / 8, rn = b.lmk_blocks % 8, g = lb & 7u;
+    lb = g * qn + (g < rn ? g : rn) + (lb >> 3);
+  }
+  const uint32_t t = lb * 256 + threadIdx.x;
   const uint32_t l = t >> 2, q = t & 3;
   const bool live = l < b.n_lmks;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -863,6 +872,7 @@ void launch_beliefs(BeliefArgs b, bool do_cam, bool do_lmk, hipStream_t s) {
   if (b.n_chunks <= 0) { b.n_chunks = 1; b.chunk_start[0] = 0; b.chunk_start[1] = b.n_cams; }
   b.cam_blocks = do_cam ? (b.cam1 - b.cam0 + 3) / 4 : 0;
   const uint32_t lmk_blocks = do_lmk ? blocks_for((uint64_t)b.n_lmks * 4) : 0;
+  b.lmk_blocks = lmk_blocks;
   if (b.cam_blocks + lmk_blocks == 0) return;
   hipLaunchKernelGGL(k_beliefs, dim3(b.cam_blocks + lmk_blocks), dim3(256), 0, s, b);
 }

@@ -64,9 +64,13 @@ typedef struct {
                                   to the per-factor recomputation of gbp_codelets.cpp:264-277, requires the
                                   uploaded mu/oldmu to be zero as in ba.cpp:582-583); 1: keep the literal
                                   per-factor mu/oldmu tensors                                            */
-  int32_t tile_order;          /* execution order of the sweep's 64-factor tiles: 0 (default) = XCD-aware (each of the
-                                  8 XCDs sweeps one landmark range, so its private L2 keeps that slice of the gathered
-                                  landmark tables), 1 = sequential device order.  Results are identical.            */
+  int32_t tile_order;          /* XCD-aware execution order (results are identical in every mode):
+                                  0 (default) = the landmark blocks of the belief kernel that share an XCD take one
+                                      contiguous landmark range (both 64-B halves of a 128-B message line then meet in
+                                      one L2), sweep tiles run in device order;
+                                  1 = everything sequential;
+                                  2 = as 0, and each XCD also sweeps the tiles of one landmark range (11 % less fabric
+                                      traffic, slightly slower: kept for measurements)                              */
   int32_t reserved[3];
 } gbp_params;
 
