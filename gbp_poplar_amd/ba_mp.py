@@ -1,10 +1,12 @@
-"""Multi-GPU front end with the `ba` flag set: what `./ba --ipus N` (reference ba/ba.cpp:414-417,617-649) maps to.
+"""Multi-GPU front end with the `ba` / `slam` flag sets: what `./ba --ipus N` and `./slam --ipus N` (reference
+ba/ba.cpp:414-417,617-649, ba/slam.cpp:422-425) map to.
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            -m gbp_poplar_amd.ba_mp --bal_file F [--n_iters K] [--eval_every E] [... the ba flags]
 
 One process per GPU; landmarks are sharded over the ranks (gbp_poplar_amd.distributed), rank 0 prints the
-same lines as `./ba` (ba.cpp:996,1004,1026-1028).  With WORLD_SIZE unset it runs on one GPU.
+same lines as `./ba` (ba.cpp:996,1004,1026-1028) or, with `--slam`, as `./slam` (slam.cpp:1073-1076; keyframes
+every `--iters_between_kfs` sweeps).  With WORLD_SIZE unset it runs on one GPU.
 """
 import argparse
 import os
@@ -22,6 +24,8 @@ def main(argv=None):
     ap.add_argument("--steps", type=float, default=5.0)
     ap.add_argument("--undamped_start", type=int, default=15)
     ap.add_argument("--eval_every", type=int, default=1)
+    ap.add_argument("--slam", action="store_true", help="incremental SLAM flow of ./slam instead of batch BA")
+    ap.add_argument("--iters_between_kfs", type=int, default=700)
     a = ap.parse_args(argv)
 
     rank = int(os.environ.get("RANK", "0"))
@@ -51,8 +55,9 @@ def main(argv=None):
     opts = driver.Options(n_iters=a.n_iters, reproj_meas_var=a.reproj_meas_var,
                           prior_std_weaker_factor=a.prior_std_weaker_factor,
                           first_cam_prior_std=a.first_cam_prior_std, steps=a.steps, undamped_start=a.undamped_start)
-    K, state, _ = driver.build_inputs(bal, opts, hostlib)
-    log("Completed loading data!\n\nBundle Adjustment\n")
+    opts.iters_between_kfs = a.iters_between_kfs
+    K, state, extra = driver.build_inputs(bal, opts, hostlib, slam=a.slam)
+    log("Completed loading data!\n\n%s\n" % ("Incremental SLAM" if a.slam else "Bundle Adjustment"))
     log("Number of keyframe nodes in the graph: %d\nNumber of landmark nodes in the graph: %d\nNumber of edges in the graph: %d"
         % (bal["n_cams"], bal["n_lmks"], bal["n_edges"]))
     log("\nNumber of GPUs: %d" % world)
@@ -61,9 +66,14 @@ def main(argv=None):
     eng = GbpEngine(bal["cam_id"], bal["lmk_id"], C, L, K, shard=(rank, world, int(bounds[rank]), int(bounds[rank + 1])))
     run = ShardedGbp(eng, C, rank, world, dist=dist, device="cuda")
     t0 = time.perf_counter()
-    traj = driver.run_ba(run, state, opts, n_iters=a.n_iters, eval_every=a.eval_every, log=log)
+    if a.slam:
+        traj = driver.run_slam(run, hostlib, bal, state, extra, opts, eval_every=a.eval_every, log=log)
+        n_done = (C - 1) * a.iters_between_kfs - 1
+    else:
+        traj = driver.run_ba(run, state, opts, n_iters=a.n_iters, eval_every=a.eval_every, log=log)
+        n_done = a.n_iters
     run.sync()
-    log("\n Finished GBP.\nTotal time: %.3f s (%d iterations, %d GPUs)" % (time.perf_counter() - t0, a.n_iters, world))
+    log("\n Finished GBP.\nTotal time: %.3f s (%d iterations, %d GPUs)" % (time.perf_counter() - t0, n_done, world))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

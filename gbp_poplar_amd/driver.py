@@ -112,6 +112,8 @@ def run_slam(engine, host, bal, state, extra, opts, iters_between_kfs=None, max_
     ev = engine.eval()
     m = metric(ev)
     traj.append((-1, m[0], m[1], int(ev["n_relin"]), int(ev["n_robust"])))
+    if log:
+        log("Initial Reprojection error: %.6f Cost %.6f" % (m[0], m[1]))
     niters = (C - 1) * ibk - 1                                              # slam.cpp:1013
     if max_iters is not None:
         niters = min(niters, max_iters)

@@ -60,6 +60,7 @@ int orc_refresh_begin(orc_ctx* o, float* send);
 int orc_refresh_end(orc_ctx* o, const float* recv);
 int orc_linearise_factors(orc_ctx* o);
 int orc_weaken_priors_sharded(orc_ctx* o, const float* recv);
+int orc_new_keyframe_sharded(orc_ctx* o, const gbp_kf_update* upd, const float* recv);
 
 /* raw internal state for stage-level parity (reference tensor names, ba.cpp:665-687,759-775) */
 int orc_get_factor_potentials(orc_ctx* o, float* eta9E, float* lambda81E);

@@ -610,6 +610,21 @@ int orc_weaken_priors_sharded(orc_ctx* o, const float* recv) {
   return 0;
 }
 
+/* NEW_KEYFRAME on a shard: the same re-upload as orc_new_keyframe, then beliefs from the partials of the last
+ * exchange (factor messages are untouched by the program, slam.cpp:919-928, so the partials are still valid) */
+int orc_new_keyframe_sharded(orc_ctx* o, const gbp_kf_update* u, const float* recv) {
+  if (u->damping_count) memcpy(o->count, u->damping_count, (size_t)o->E * 4);
+  if (u->cam_priors_eta) memcpy(o->cpe, u->cam_priors_eta, (size_t)o->C * 6 * 4);
+  if (u->cam_priors_lambda) memcpy(o->cpl, u->cam_priors_lambda, (size_t)o->C * 36 * 4);
+  if (u->lmk_priors_eta) memcpy(o->lpe + (size_t)o->lb * 3, u->lmk_priors_eta + (size_t)o->lb * 3, (size_t)(o->le - o->lb) * 3 * 4);
+  if (u->lmk_priors_lambda) memcpy(o->lpl + (size_t)o->lb * 9, u->lmk_priors_lambda + (size_t)o->lb * 9, (size_t)(o->le - o->lb) * 9 * 4);
+  if (u->active_flag) memcpy(o->active, u->active_flag, (size_t)o->E * 4);
+  if (u->cam_weaken_flag) memcpy(o->cwf, u->cam_weaken_flag, (size_t)o->C * 4);
+  if (u->lmk_weaken_flag) memcpy(o->lwf, u->lmk_weaken_flag, (size_t)o->L * 4);
+  beliefs_from_gathered(o, recv);
+  return 0;
+}
+
 /* ------------------------------------------------------------------------------------------
  * Host-side restatements (Eigen-free).
  * ------------------------------------------------------------------------------------------ */

@@ -21,6 +21,7 @@ class OracleShardEngine(orc.Oracle):
             getattr(lib, n).argtypes = [C.c_void_p, C.c_void_p]
         lib.orc_linearise_factors.argtypes = [C.c_void_p]
         self._chk(lib.orc_set_shard(self.h, rank, world, lb, le), "set_shard")
+        self.shard = shard
         self.send = self.recv = None
         self.world, self.chunks = world, 1
         self._flat = None
@@ -71,6 +72,22 @@ class OracleShardEngine(orc.Oracle):
 
     def weaken_priors(self):
         self._chk(self.lib.orc_weaken_priors_sharded(self.h, self._recv_ptr()), "weaken_priors")
+
+    def new_keyframe(self, upd):
+        keep = []
+        s = cabi.fill_struct(cabi.GbpKfUpdate(), upd, keep)
+        self.lib.orc_new_keyframe_sharded.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        self._chk(self.lib.orc_new_keyframe_sharded(self.h, C.byref(s), self._recv_ptr()), "new_keyframe")
+
+    def read_priors(self):
+        """Like the sharded C-ABI ctx: camera priors complete, landmark priors of the owned range only."""
+        p = super().read_priors()
+        lo, hi = self.shard[2], self.shard[3]
+        for k, w in (("lmk_priors_eta", 3), ("lmk_priors_lambda", 9)):
+            v = np.zeros_like(p[k])
+            v[w * lo:w * hi] = p[k][w * lo:w * hi]
+            p[k] = v
+        return p
 
     def iterate_local(self):
         pass                                  # the oracle does the landmark half inside iterate_end

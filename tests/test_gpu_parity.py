@@ -570,6 +570,97 @@ def test_sharded_kernels_on_one_gpu_match_sharded_oracle(world, chunks, oracle_m
     assert abs(tot["sum_norm"] - eo["sum_norm"]) <= 1e-5 * eo["sum_norm"]
 
 
+def test_sharded_slam_keyframes_on_one_gpu(oracle_mod):
+    """READ_PRIORS / NEW_KEYFRAME on landmark-shard contexts (two shards on one GPU, exchange by device copies): the
+    incremental SLAM flow of slam.cpp:1018-1055 with a keyframe every 12 sweeps == the oracle in 2-shard order."""
+    from gbp_poplar_amd import driver, hostlib
+    from gbp_poplar_amd.distributed import ShardedGbp, landmark_partition
+    from gbp_poplar_amd.engine import GbpEngine
+    world = 2
+    bal = _bal("fr2robot2")
+    opts = driver.Options()
+    K, state, extra = driver.build_inputs(bal, opts, hostlib, slam=True)
+    C, L, E = bal["n_cams"], bal["n_lmks"], bal["n_edges"]
+    bounds = landmark_partition(bal["lmk_id"], L, world)
+    fake = _FakeDist()
+    shards = []
+    for r in range(world):
+        eng = GbpEngine(bal["cam_id"], bal["lmk_id"], C, L, K, shard=(r, world, int(bounds[r]), int(bounds[r + 1])))
+        sh = ShardedGbp(eng, C, r, world, dist=None, device="cuda")
+        sh._exchange = lambda: None
+        fake.members.append(sh)
+        shards.append(sh)
+
+    class Group:                                  # the verbs run_slam calls, applied to every shard + one exchange
+        def upload(self, st):
+            for sh in shards:
+                sh.e.upload(st)
+
+        def linearise(self):
+            for sh in shards:
+                sh.e.refresh_begin()
+            fake.gather_all()
+            for sh in shards:
+                sh.e.refresh_end()
+                sh.e.linearise_factors()
+
+        def iterate(self, n=1):
+            for _ in range(n):
+                for sh in shards:
+                    sh.e.iterate_begin()
+                fake.gather_all()
+                for sh in shards:
+                    sh.e.iterate_end()
+
+        def weaken_priors(self):
+            for sh in shards:
+                sh.e.weaken_priors()
+
+        def read(self):
+            out = shards[0].read()
+            for r, sh in enumerate(shards[1:], 1):
+                g = sh.read()
+                lo, hi = int(bounds[r]), int(bounds[r + 1])
+                out["lmk_beliefs_eta"][3 * lo:3 * hi] = g["lmk_beliefs_eta"][3 * lo:3 * hi]
+                out["lmk_beliefs_lambda"][9 * lo:9 * hi] = g["lmk_beliefs_lambda"][9 * lo:9 * hi]
+                own = (np.asarray(bal["lmk_id"]) >= lo) & (np.asarray(bal["lmk_id"]) < hi)
+                for k in ("damping", "damping_count", "robust_flag"):
+                    out[k][own] = g[k][own]
+            return out
+
+        def read_priors(self):
+            out = shards[0].read_priors()
+            for r, sh in enumerate(shards[1:], 1):
+                g = sh.read_priors()
+                lo, hi = int(bounds[r]), int(bounds[r + 1])
+                out["lmk_priors_eta"][3 * lo:3 * hi] = g["lmk_priors_eta"][3 * lo:3 * hi]
+                out["lmk_priors_lambda"][9 * lo:9 * hi] = g["lmk_priors_lambda"][9 * lo:9 * hi]
+            return out
+
+        def new_keyframe(self, upd):
+            for sh in shards:
+                sh.e.new_keyframe(upd)
+
+        def eval(self):
+            evs = [sh.e.eval() for sh in shards]
+            return {k: sum(e[k] for e in evs) for k in evs[0]}
+
+    oracle_mod.set_trig_mode(1)
+    try:
+        orc = oracle_mod.Oracle(bal["cam_id"], bal["lmk_id"], C, L, K)
+        orc.set_sum_order(1, bounds)
+        tg = driver.run_slam(Group(), hostlib, bal, state, extra, opts, iters_between_kfs=12, max_iters=70, eval_every=5)
+        to = driver.run_slam(orc, hostlib, bal, state, extra, opts, iters_between_kfs=12, max_iters=70, eval_every=5)
+    finally:
+        oracle_mod.set_trig_mode(0)
+    g, o = Group().read(), orc.read()
+    for k in g:
+        assert np.array_equal(g[k], o[k], equal_nan=True), k
+    for (i, mg, cg, rg, bg), (_, mo, co, ro_, bo) in zip(tg, to):
+        assert abs(mg - mo) <= 1e-5 * mo and rg == ro_ and bg == bo, (i, mg, mo)
+    assert len(tg) > 10 and tg[-1][1] < tg[0][1]
+
+
 def test_sharded_wrapper_world1_on_gpu(oracle_mod):
     """ShardedGbp with world = 1 on the GPU (torch stream + torch-owned exchange buffers) == plain engine."""
     from gbp_poplar_amd import driver, hostlib
@@ -869,6 +960,17 @@ def test_ba_mp_front_end_single_gpu(capsys):
     assert rc == 0 and "Initial Reprojection error: 39.8638" in out and out.count("Weakening priors") == 5
     last = [l for l in out.splitlines() if l.startswith("Iter 39 ")]
     assert last and 0.5 < float(last[0].split("Reprojection error ")[1].split(" ")[0]) < 5.0
+
+
+def test_ba_mp_front_end_slam_mode(capsys):
+    """`ba_mp --slam` (what `./slam --ipus N` maps to) on one GPU: keyframes are added and the slam lines printed."""
+    from gbp_poplar_amd import ba_mp
+    rc = ba_mp.main(["--bal_file", seq_path("fr2robot2"), "--slam", "--iters_between_kfs", "20", "--eval_every", "19"])
+    out = capsys.readouterr().out
+    assert rc == 0 and "Initial Reprojection error: 32.7526" in out          # BASELINE.md: two keyframes active
+    assert out.count("Adding keyframe") == 18 and "Adding keyframe 19," in out   # cameras 2..19 join one by one
+    last = [l for l in out.splitlines() if l.startswith("Iters ")][-1]
+    assert 0.5 < float(last.split("Reprojection error ")[1].split(" ")[0]) < 10.0
 
 
 @pytest.mark.parametrize("kw", [{"relin_mode": 1}, {"dmu_threshold": 3e-2, "maxeta_damping": 0.25, "nstds": 1.5,
