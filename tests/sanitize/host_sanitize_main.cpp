@@ -152,6 +152,10 @@ int main(int argc, char** argv) {
       exchange();
       for (int k = 0; k < 2; ++k) REQUIRE(orc_iterate_end(sh[k], recv.data()) == GBP_OK);
     }
+    gbp_kf_update kf{};
+    kf.damping_count = count.data(); kf.active_flag = active.data(); kf.cam_weaken_flag = cw.data(); kf.lmk_weaken_flag = lw.data();
+    kf.lmk_priors_eta = le.data(); kf.lmk_priors_lambda = ll.data();
+    for (int k = 0; k < 2; ++k) REQUIRE(orc_new_keyframe_sharded(sh[k], &kf, recv.data()) == GBP_OK);
     gbp_eval_out a{}, b{};
     REQUIRE(orc_eval(sh[0], &a) == GBP_OK && orc_eval(sh[1], &b) == GBP_OK && a.n_active + b.n_active == E);
     orc_destroy(sh[0]);
