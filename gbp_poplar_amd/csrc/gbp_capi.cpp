@@ -345,8 +345,8 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
   if (rc == GBP_OK && c->prm.tile_order == 2) {
     // XCD-aware execution order of the sweep (optional: 11 % less fabric traffic, but ~2 % slower than the sequential
     // order on S1 — consecutive tiles of an XCD then sit ~200 KB apart in every stream; profiles/r01_ablation.md).  Workgroup w lands on XCD (w mod 8) (observed placement; only speed
-    // depends on it) and its wave v runs tile perm[4w + v].  Tiles are ranked by their lowest landmark index and the
-    // ranking is cut into 8 equal runs, one per XCD, so each private 4 MiB L2 serves one slice of the gathered
+    // depends on it) and its wave v runs tile perm[4w + v].  Tiles are ranked by the octile of their lowest landmark
+    // index (memory order inside an octile) and the ranking is cut into 8 equal runs, one per XCD, so each private 4 MiB L2 serves one slice of the gathered
     // landmark tables (beliefs + hoisted means) instead of a random 4 MiB / table-size share of all of them.
     const uint32_t nt = c->n_tiles, nb = nt / 4;
     std::vector<uint64_t> key(nt);
@@ -356,7 +356,8 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
         const size_t p = (size_t)t * kTile + i;
         if (c->pos_edge[p] != ~0u) lo = std::min(lo, c->pos_lmk_loc[p]);
       }
-      key[t] = ((uint64_t)lo << 32) | t;
+      const uint64_t run = lo == ~0u ? 8u : (uint64_t)lo * 8u / std::max<uint32_t>(c->L_loc, 1u);  // landmark octile
+      key[t] = (run << 32) | t;   // memory order inside a run
     }
     std::sort(key.begin(), key.end());
     std::vector<uint32_t> perm(nt);
