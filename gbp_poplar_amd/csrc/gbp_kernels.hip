@@ -179,9 +179,13 @@ GBP_DEV bool relin_core(float (&fac)[56], const float (&x0c)[6], const float (&x
 // ABL != 0 builds timing-only ablations of the same instruction stream (gbp_debug_time_sweep; results are
 // garbage): 1 = no landmark-message stream, 2 = no landmark-belief gather, 4 = no arithmetic (pass-through),
 // 16 / 32 = no landmark-message load / store.
+#ifndef GBP_SWEEP_WPB
+#define GBP_SWEEP_WPB 4      // wavefronts per workgroup of the sweep (1, 2 or 4; the waves of a workgroup share nothing)
+#endif
+constexpr int kWpb = GBP_SWEEP_WPB;
 template <bool HOIST, int ABL = 0>
-__global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
-  const uint32_t wslot = (blockIdx.x + a.block0) * 4 + (threadIdx.x >> 6);
+__global__ __launch_bounds__(64 * kWpb) void k_sweep(const SweepArgs a) {
+  const uint32_t wslot = (blockIdx.x + a.block0 * (4 / kWpb)) * kWpb + (threadIdx.x >> 6);
   const uint32_t tile = a.tile_perm ? (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tile_perm[wslot]) : wslot;
   const uint32_t lane = threadIdx.x & 63, p = tile * 64 + lane;
 
@@ -199,7 +203,7 @@ __global__ __launch_bounds__(256) void k_sweep(const SweepArgs a) {
   // accesses (one piece per lane) are both bank-conflict-free for ds_read_b128 (16-lane groups, 64 banks)
   // and ds_write_b128 (8-lane groups, 32 banks).  k_beliefs gathers the records of a landmark by position
   // (random 64-B READS are ~2.3x cheaper than random 64-B writes, profiles/ablate_sweep.py).
-  __shared__ float4 lm_stage[4][64 * 4];
+  __shared__ float4 lm_stage[kWpb][64 * 4];
   float4* stage = lm_stage[threadIdx.x >> 6];
   const uint32_t rec_t = lane >> 2;                                   // record handled in tile order (+16k)
   const uint32_t swz_own = ((lane >> 2) & 3u) ^ (lane & 2u);          // swizzle of the lane's own record
@@ -848,11 +852,12 @@ void launch_sweep(const SweepArgs& a, uint32_t n_tiles, bool hoist, hipStream_t 
 void launch_sweep_blocks(SweepArgs a, uint32_t block0, uint32_t block1, bool hoist, hipStream_t s) {
   if (block1 <= block0) return;
   a.block0 = block0;
-  if (hoist) hipLaunchKernelGGL(k_sweep<true>, dim3(block1 - block0), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(k_sweep<false>, dim3(block1 - block0), dim3(256), 0, s, a);
+  const dim3 g((block1 - block0) * (4 / kWpb)), b(64 * kWpb);
+  if (hoist) hipLaunchKernelGGL(k_sweep<true>, g, b, 0, s, a);
+  else hipLaunchKernelGGL(k_sweep<false>, g, b, 0, s, a);
 }
 void launch_sweep_ablated(const SweepArgs& a, uint32_t n_tiles, int abl, hipStream_t s) {
-  const dim3 g(n_tiles / 4), b(256);
+  const dim3 g(n_tiles / kWpb), b(64 * kWpb);
   switch (abl) {
     case 1: hipLaunchKernelGGL((k_sweep<true, 1>), g, b, 0, s, a); break;
     case 2: hipLaunchKernelGGL((k_sweep<true, 2>), g, b, 0, s, a); break;
