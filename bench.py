@@ -118,6 +118,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if rank != 0:      # only rank 0 may write to stdout (libraries such as RCCL print banners through C stdio)
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
     if world != a.gpus and world != 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     if a.gpus > 1 and world == 1:
@@ -247,10 +249,15 @@ def main():
             out["roofline"] = roof
         if cpu:
             out["cpu_baseline"] = cpu
-        print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    # The JSON line must be the LAST line on stdout: RCCL prints a version banner through C stdio, which is fully
+    # buffered when redirected and would otherwise be flushed at exit, after Python's own output.
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
