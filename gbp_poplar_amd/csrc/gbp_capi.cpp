@@ -900,6 +900,31 @@ static int debug_set_factor_potentials_impl(gbp_ctx* c, const float* eta9E, cons
   return GBP_OK;
 }
 
+// Device math layer on caller-supplied vectors (test hook, see k_debug_math): HIP vs the reference's own
+// matlib.cpp / bafuncs.cpp outputs, no ctx and no restated vertex layer involved.
+int gbp_debug_math(int op, const float* in, float* out, int n) {
+  int in_w = 0, out_w = 0;
+  if (!in || !out || n <= 0 || !debug_math_widths(op, &in_w, &out_w))
+    return fail(nullptr, GBP_ERR_INVALID, "gbp_debug_math: bad op / arguments");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(nullptr, GBP_ERR_NO_DEVICE, "gbp_debug_math: no HIP device (the product has no CPU fallback)");
+  float *d_in = nullptr, *d_out = nullptr;
+  auto done = [&](int rc, const char* what, hipError_t e) {
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    return rc == GBP_OK ? rc : fail(nullptr, rc, std::string(what) + ": " + hipGetErrorString(e));
+  };
+  hipError_t e;
+  if ((e = hipMalloc(&d_in, (size_t)n * in_w * 4)) != hipSuccess) return done(GBP_ERR_HIP, "hipMalloc", e);
+  if ((e = hipMalloc(&d_out, (size_t)n * out_w * 4)) != hipSuccess) return done(GBP_ERR_HIP, "hipMalloc", e);
+  if ((e = hipMemcpy(d_in, in, (size_t)n * in_w * 4, hipMemcpyHostToDevice)) != hipSuccess) return done(GBP_ERR_HIP, "hipMemcpy", e);
+  launch_debug_math(op, d_in, d_out, n, nullptr);
+  if ((e = hipGetLastError()) != hipSuccess) return done(GBP_ERR_HIP, "k_debug_math", e);
+  if ((e = hipMemcpy(out, d_out, (size_t)n * out_w * 4, hipMemcpyDeviceToHost)) != hipSuccess) return done(GBP_ERR_HIP, "hipMemcpy", e);
+  return done(GBP_OK, "", hipSuccess);
+}
+
 // ---- exported wrappers of the entry points that allocate host memory -----------------------------------------
 int gbp_create(const gbp_problem* pr, const gbp_params* prm, const gbp_shard* sh, gbp_ctx** out) {
   return guarded(nullptr, "gbp_create", [&] { return create_impl(pr, prm, sh, out); });

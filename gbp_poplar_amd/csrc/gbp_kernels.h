@@ -115,5 +115,7 @@ void launch_eval(const uint32_t* row_cam, const uint32_t* lmk_idx, const float4*
                  const float* lmk_mu, const float* K9_dev, int num_undamped_iters, DeviceEval* partials, uint32_t n_tiles,
                  hipStream_t s);
 uint32_t eval_blocks(uint32_t n_tiles);
+bool debug_math_widths(int op, int* in_w, int* out_w);   // floats per vector of k_debug_math's op
+void launch_debug_math(int op, const float* in, float* out, int n, hipStream_t s);  // test hook
 
 }  // namespace gbp

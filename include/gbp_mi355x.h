@@ -221,6 +221,15 @@ int gbp_debug_time_sweep(gbp_ctx* ctx, int ablation, int reps, double* avg_us);
 /* Overwrite the factor potentials from reference-layout arrays (inverse of what 0). Test hook. */
 int gbp_debug_set_factor_potentials(gbp_ctx* ctx, const float* eta9E, const float* lambda81E);
 
+/* The device math layer on caller-supplied vectors, one GPU lane per vector (no ctx): lets a test compare the HIP
+ * routines directly with outputs of the reference's own matlib.cpp / bafuncs.cpp.  in/out are [n][width] fp32:
+ *   op 0 inv3x3 9 -> 9 (matlib.cpp:143-161)        op 1 inv6x6 36 -> 36 (matlib.cpp:180-222)
+ *   op 2 so3exp 3 -> 9 (bafuncs.cpp:31-55)         op 3 hfunc + Jac: cam6 lmk3 K9 -> hx2 Jkf12 Jlmk6 (bafuncs.cpp:82-213)
+ *   op 4 P(6x3) += B(6x6) A(6x3), op 5 P(3x6) += A^T B: A18 B36 P18 -> 18;  op 6 P(6x6) += A A^T: A18 P36 -> 36
+ *        (matMul and its transpose modes, matlib.cpp:47-89)
+ *   op 7 inf2mean6x6: eta6 Lambda36 -> 6;  op 8 inf2mean3x3: eta3 Lambda9 -> 3 (bafuncs.cpp:2-15)                */
+int gbp_debug_math(int op, const float* in, float* out, int n);
+
 /* ---- host-side helpers of the path's callers (pure CPU, no device needed) ---------------- */
 /* BALProblem::LoadFile (dataio.cpp:17-57).  Two-call pattern: pass NULL arrays to get sizes. */
 typedef struct {

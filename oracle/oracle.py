@@ -85,7 +85,8 @@ def load(variant="restatement"):
     for name, args in (("om_matmul", [cabi.c_f32p, C.c_int, C.c_int, cabi.c_f32p, C.c_int, C.c_int,
                                       cabi.c_f32p, C.c_int, C.c_int, C.c_int]),
                        ("om_inv3x3", [cabi.c_f32p] * 2), ("om_inv6x6", [cabi.c_f32p] * 2),
-                       ("om_so3exp", [cabi.c_f32p] * 2), ("om_hfunc", [cabi.c_f32p] * 4),
+                       ("om_so3exp", [cabi.c_f32p] * 2),
+                       ("om_inf2mean6x6", [cabi.c_f32p] * 3), ("om_inf2mean3x3", [cabi.c_f32p] * 3), ("om_hfunc", [cabi.c_f32p] * 4),
                        ("om_jac", [cabi.c_f32p] * 5)):
         getattr(lib, name).argtypes = args
         getattr(lib, name).restype = None

@@ -240,14 +240,11 @@ static void update_beliefs(orc_ctx* o) {
 /* linearisation point = belief means: inf2mean6x6 / inf2mean3x3, bafuncs.cpp:2-15 */
 static void belief_means(const orc_ctx* o, uint32_t e, float* x0c, float* x0l) {
   uint32_t c = o->cam_id[e], l = o->lmk_id[e];
-  float Sc[36] = {0}, Sl[9] = {0};
   int i;
   for (i = 0; i < 6; ++i) x0c[i] = 0.f;
   for (i = 0; i < 3; ++i) x0l[i] = 0.f;
-  om_inv6x6(o->cbl + (size_t)c * 36, Sc);
-  om_matmul(Sc, 6, 6, o->cbe + (size_t)c * 6, 6, 1, x0c, 1, 0, 0);
-  om_inv3x3(o->lbl + (size_t)l * 9, Sl);
-  om_matmul(Sl, 3, 3, o->lbe + (size_t)l * 3, 3, 1, x0l, 1, 0, 0);
+  om_inf2mean6x6(o->cbe + (size_t)c * 6, o->cbl + (size_t)c * 36, x0c);
+  om_inf2mean3x3(o->lbe + (size_t)l * 3, o->lbl + (size_t)l * 9, x0l);
 }
 
 /* Shared body of gbp_codelets.cpp:90-168 and :294-373: accumulate J^T J and J^T(Jx0+z-h(x0))

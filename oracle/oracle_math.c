@@ -93,6 +93,18 @@ void om_inv6x6(const float* A, float* Ainv) {
   om_matmul(W, 6, 6, LTi, 6, 6, Ainv, 6, 0, 1);
 }
 
+/* reference ba/bafuncs.cpp:2-15: Sigma = Lambda^-1, mean += Sigma eta */
+void om_inf2mean6x6(const float* eta, const float* lambda, float* mean) {
+  float S[36] = {0};
+  om_inv6x6(lambda, S);
+  om_matmul(S, 6, 6, eta, 6, 1, mean, 1, 0, 0);
+}
+void om_inf2mean3x3(const float* eta, const float* lambda, float* mean) {
+  float S[9] = {0};
+  om_inv3x3(lambda, S);
+  om_matmul(S, 3, 3, eta, 3, 1, mean, 1, 0, 0);
+}
+
 /* reference ba/bafuncs.cpp:19-28 */
 static void hat3(const float* v, float* H /* zeroed */) {
   H[1] = -v[2]; H[2] = v[1];

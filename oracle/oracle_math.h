@@ -23,6 +23,8 @@ void om_matmul(const float* A, int ar, int ac, const float* B, int br, int bc,
 void om_inv3x3(const float* M, float* inv);              /* matlib.cpp:143-161 */
 void om_inv6x6(const float* A, float* Ainv_zeroed);      /* matlib.cpp:180-222 */
 void om_so3exp(const float* v, float* R_zeroed);         /* bafuncs.cpp:31-55  */
+void om_inf2mean6x6(const float* eta6, const float* lambda36, float* mean6_zeroed);   /* bafuncs.cpp:2-7   */
+void om_inf2mean3x3(const float* eta3, const float* lambda9, float* mean3_zeroed);    /* bafuncs.cpp:10-15 */
 void om_hfunc(const float* cam6, const float* lmk3, const float* K9, float* hx2);   /* bafuncs.cpp:82-103 */
 void om_jac(const float* cam6, const float* lmk3, const float* K9,
             float* Jkf12_zeroed, float* Jlmk6_zeroed);   /* bafuncs.cpp:106-213 */

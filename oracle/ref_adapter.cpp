@@ -34,6 +34,18 @@ void om_inv6x6(const float* A, float* Ainv) {
   inv6x6(a, o);
 }
 
+void om_inf2mean6x6(const float* eta, const float* lambda, float* mean) {
+  float S[36] = {0};
+  Mat<float> e(const_cast<float*>(eta), 6, 1), l(const_cast<float*>(lambda), 6, 6), m(mean, 6, 1), s(S, 6, 6);
+  inf2mean6x6(e, l, m, s);
+}
+
+void om_inf2mean3x3(const float* eta, const float* lambda, float* mean) {
+  float S[9] = {0};
+  Mat<float> e(const_cast<float*>(eta), 3, 1), l(const_cast<float*>(lambda), 3, 3), m(mean, 3, 1), s(S, 3, 3);
+  inf2mean3x3(e, l, m, s);
+}
+
 void om_so3exp(const float* v, float* R) {
   Mat<float> vv(const_cast<float*>(v), 3, 1), r(R, 3, 3);
   so3exp(vv, r);

@@ -22,6 +22,7 @@ from oracle import oracle as orc            # noqa: E402
 from gbp_poplar_amd import _cabi as cabi    # noqa: E402
 from gbp_poplar_amd import driver           # noqa: E402
 from tests.oracle_host import OracleHost    # noqa: E402
+from tests.traj_util import EvalAt, wanted   # noqa: E402
 
 P = lambda a: cabi.ptr(a, cabi.c_f32p)
 
@@ -67,6 +68,15 @@ def math_vectors(lib):
         lib.om_matmul(P(x), x.shape[0], x.shape[1], P(y), y.shape[0], y.shape[1], P(p), pc, ta, tb)
         out["mm_" + name] = p
     out.update(mm_A=A, mm_B=B)
+    # inf2mean6x6 / inf2mean3x3 (bafuncs.cpp:2-15) — drawn AFTER everything above so the older vectors keep their values
+    e6, e3 = rng.standard_normal((n, 6)).astype(np.float32), rng.standard_normal((n, 3)).astype(np.float32)
+    l6 = np.stack([spd(rng, 6, 1.5) for _ in range(n)])
+    l3 = np.stack([spd(rng, 3, 1.5) for _ in range(n)])
+    m6, m3 = np.zeros((n, 6), np.float32), np.zeros((n, 3), np.float32)
+    for k in range(n):
+        lib.om_inf2mean6x6(P(e6[k]), P(l6[k]), P(m6[k]))
+        lib.om_inf2mean3x3(P(e3[k]), P(l3[k]), P(m3[k]))
+    out.update(mean6_eta=e6, mean6_lambda=l6, mean6_out=m6, mean3_eta=e3, mean3_lambda=l3, mean3_out=m3)
     return out
 
 
@@ -146,6 +156,32 @@ def vertex_vectors(name, n_sample=64):
     return out
 
 
+def trajectories():
+    """printed metric trajectory (iteration, mean reproj, cost, RMSE, n_relins, n_robust, n_active) of
+    `./ba` on fr1xyz / fr2robot2 (1500 sweeps) and `./slam` on fr2robot2 (700 sweeps per keyframe), from the
+    reference-math oracle in the literal conventions (libm trig, slot-order sums)."""
+    host = OracleHost("ref")
+    opts = driver.Options()
+    out = {}
+    for name in ("fr2robot2", "fr1xyz"):
+        bal = host.bal_read(os.path.join(ROOT, "data", "sequences", name + ".txt"))
+        K, state, _ = driver.build_inputs(bal, opts, host)
+        o = orc.Oracle(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K, variant="ref")
+        w = EvalAt(o, wanted(opts.n_iters))
+        t = driver.run_ba(w, state, opts, eval_every=0)
+        out["ba_%s" % name] = np.array(w.rows, dtype=np.float64)
+        out["ba_%s_initial" % name] = np.array(t[0][1:3], dtype=np.float64)
+        if name == "fr2robot2":
+            K, state, extra = driver.build_inputs(bal, opts, host, slam=True)
+            o = orc.Oracle(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K, variant="ref")
+            n_total = (bal["n_cams"] - 1) * opts.iters_between_kfs - 1
+            w = EvalAt(o, wanted(n_total, head=30, every=700, tail=50))
+            t = driver.run_slam(w, host, bal, state, extra, opts, eval_every=0)
+            out["slam_%s" % name] = np.array(w.rows, dtype=np.float64)
+            out["slam_%s_initial" % name] = np.array(t[0][1:3], dtype=np.float64)
+    return out
+
+
 def main():
     if not orc.have("ref"):
         raise SystemExit("oracle/_ref is missing: run `make -C oracle ref` in the build container first")
@@ -153,6 +189,12 @@ def main():
     assert ref.om_impl_name() == b"reference"
     if sys.argv[1:] == ["vertex"]:          # only (re)write the vertex-level fixture
         np.savez_compressed(os.path.join(HERE, "vertex_vectors.npz"), **vertex_vectors("fr2robot2"))
+        return
+    if sys.argv[1:] == ["math"]:
+        np.savez_compressed(os.path.join(HERE, "math_vectors.npz"), **math_vectors(ref))
+        return
+    if sys.argv[1:] == ["traj"]:
+        np.savez_compressed(os.path.join(HERE, "trajectories.npz"), **trajectories())
         return
     np.savez_compressed(os.path.join(HERE, "math_vectors.npz"), **math_vectors(ref))
 
@@ -194,6 +236,7 @@ def main():
         snaps["traj_" + name] = np.array(traj, dtype=np.float64)
     np.savez_compressed(os.path.join(HERE, "sequence_snapshots.npz"), **snaps)
     np.savez_compressed(os.path.join(HERE, "vertex_vectors.npz"), **vertex_vectors("fr2robot2"))
+    np.savez_compressed(os.path.join(HERE, "trajectories.npz"), **trajectories())
     print("golden fixtures written:", [f for f in os.listdir(HERE) if f.endswith(".npz")])
 
 

@@ -29,6 +29,11 @@ def _setup(bal, oracle_mod, slam=False, sum_order=1, per_factor_mu=0):
     return eng, orc, opts, state, extra
 
 
+def _golden(name):
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", name))
+
+
 def _bal(name):
     from gbp_poplar_amd import hostlib
     return hostlib.bal_read(seq_path(name))
@@ -149,19 +154,21 @@ def test_relinearising_sweeps_bit_exact(per_factor_mu, oracle_mod):
 
 
 def test_relinearising_sweep_vs_libm_oracle(oracle_mod):
-    """Same sweep against the literal restatement (glibc sinf/cosf): ulp-level trig differences are
-    amplified by Jac's 1/|w|^2 (bafuncs.cpp:197-204), so most factors agree bit-for-bit and all within 1e-3."""
+    """The first relinearising sweep (17) from identical state against the LITERAL restatement (glibc sinf/cosf):
+    SURVEY 8c's tolerances as written — relinearised potentials <= 1e-5 per factor, the state after the sweep <= 1e-4.
+    (glibc's sinf/cosf differ from the correctly rounded value for ~1-2 % of arguments; one camera in ten then carries a
+    1-ulp different sin or cos, which moves its factors' potentials by <= 4e-6 — measured on all three sequences,
+    tests/test_oracle_trig_sensitivity.py.)"""
     eng, orc, opts, *_ = _setup(_bal("fr2robot2"), oracle_mod, sum_order=1)
     _run_to_relin(eng, orc)
     eng.iterate(1)
     orc.iterate(1)
     assert np.array_equal(eng.read()["damping_count"], orc.read()["damping_count"])
+    assert int(np.sum(orc.read()["damping_count"] == -8)) > 500
     ge, gl = eng.factor_potentials()
     oe, ol = orc.factor_potentials()
-    same = np.all(gl.reshape(-1, 81) == ol.reshape(-1, 81), axis=1)
-    assert same.mean() > 0.5, same.mean()
-    assert per_var_rel(ge, oe, 9) <= 1e-3 and per_var_rel(gl, ol, 81) <= 1e-3
-    _assert_state_equal(eng, orc, exact=False, tol=1e-3)
+    assert per_var_rel(ge, oe, 9) <= 1e-5 and per_var_rel(gl, ol, 81) <= 1e-5
+    _assert_state_equal(eng, orc, exact=False, tol=1e-4)
 
 
 def test_eval_matches_oracle(oracle_mod):
@@ -204,21 +211,22 @@ def test_ba_trajectory_fr2robot2(oracle_mod):
 
 
 def test_ba_trajectory_vs_libm_oracle(oracle_mod):
-    """Same flow against the literal (glibc trig, slot-order sums) oracle: 1e-4 (north_star tolerance) up
-    to the first relinearisation (sweep 17).  Beyond it the relinearisation DECISION (dmu < 3e-3,
-    gbp_codelets.cpp:280) flips for individual factors under ulp-level differences and trajectories of ANY
-    two arithmetic variants (even oracle vs oracle) separate by >10 % — SURVEY 6; only the band is checked."""
+    """Same flow against the literal (glibc trig, slot-order sums) oracle and against the committed golden trajectory
+    of the reference-math build: 1e-4 (north_star tolerance) for the first sweeps, 1e-3 up to the first
+    relinearisation (sweep 17; ulp differences amplify ~x3 per sweep).  Beyond it the relinearisation
+    DECISION (dmu < 3e-3, gbp_codelets.cpp:280) flips for individual factors and any two arithmetic variants separate;
+    the end-to-end statement for this sequence is the mean over the last 50 of 1500 iterations
+    (test_other_sequences_1500_sweeps_bit_exact)."""
     from gbp_poplar_amd import driver
     eng, orc, opts, state, _ = _setup(_bal("fr2robot2"), oracle_mod, sum_order=0)
-    tg = driver.run_ba(eng, state, opts, n_iters=30)
-    to = driver.run_ba(orc, state, opts, n_iters=30)
-    for (i, mg, *_), (_, mo, *_2) in zip(tg, to):
-        if i < 6:
-            assert abs(mg - mo) <= 1e-4 * mo, (i, mg, mo)
-        elif i < 17:
-            assert abs(mg - mo) <= 1e-3 * mo, (i, mg, mo)     # ulp differences amplify ~x3 per sweep (SURVEY 6)
-        else:
-            assert 0.5 * mo <= mg <= 2.0 * mo, (i, mg, mo)
+    tg = driver.run_ba(eng, state, opts, n_iters=17)
+    to = driver.run_ba(orc, state, opts, n_iters=17)
+    gold = _golden("trajectories.npz")["ba_fr2robot2"]
+    for (i, mg, cg, *_), (_, mo, co, *_2) in zip(tg, to):
+        tol = 1e-4 if i < 6 else 1e-3
+        assert abs(mg - mo) <= tol * mo and abs(cg - co) <= 2 * tol * co, (i, mg, mo)
+        if i >= 0:
+            assert gold[i, 0] == i and abs(mg - gold[i, 1]) <= tol * gold[i, 1], (i, mg, gold[i, 1])
 
 
 def test_synthetic_end_to_end(oracle_mod):
@@ -324,11 +332,6 @@ def test_graph_replay_equals_direct_launches(oracle_mod):
 
 
 # ---- committed golden fixtures (tests/golden/*.npz, produced with the REFERENCE's math layer) ----------------
-
-def _golden(name):
-    import os
-    return np.load(os.path.join(os.path.dirname(__file__), "golden", name))
-
 
 def _gpu_snapshot(eng):
     r, m = eng.read(), eng.messages()
@@ -1032,60 +1035,95 @@ def test_rccl_single_rank_group_overlap_path(chunks):
 
 # ---- BASELINE.json configs 1-3 end to end, bit for bit ---------------------------------------------------------
 
+def _run_ba_recorded(engine, state, opts, n_iters):
+    from gbp_poplar_amd import driver
+    from tests.traj_util import EvalAt, wanted
+    w = EvalAt(engine, wanted(n_iters))
+    t = driver.run_ba(w, state, opts, n_iters=n_iters, eval_every=0)
+    return t[0], w.array()
+
+
+def _check_against_golden_trajectory(rows, initial, gold, gold_initial, end_to_end_tol):
+    """SURVEY 8c tolerances, literally, against the reference-math trajectory (libm trig, slot-order sums):
+    initial error and <= 3 sweeps within 1e-4; end to end = mean over the last 50 iterations within `end_to_end_tol`
+    (None: chaotic input, band check by the caller)."""
+    assert abs(initial[1] - gold_initial[0]) <= 1e-5 * gold_initial[0]
+    assert np.array_equal(rows[:, 0], gold[:, 0])
+    for k in range(3):
+        assert abs(rows[k, 1] - gold[k, 1]) <= 1e-4 * gold[k, 1], (k, rows[k, 1], gold[k, 1])
+        assert abs(rows[k, 3] - gold[k, 3]) <= 1e-4 * gold[k, 3], (k, rows[k, 3], gold[k, 3])
+        assert rows[k, 5] == gold[k, 5] and rows[k, 6] == gold[k, 6]
+    if end_to_end_tol is not None:
+        for col in (1, 3):              # mean reprojection error, RMSE
+            a, b = rows[-50:, col].mean(), gold[-50:, col].mean()
+            assert abs(a - b) <= end_to_end_tol * b, (col, a, b)
+
+
 def test_config1_fr1xyz_1500_sweeps_bit_exact(oracle_mod):
     """`./ba fr1xyz` defaults (1500 sweeps).  fr1xyz is chaotic in fp32 — ulp-level differences blow up within ~25
     sweeps — so equality of every belief after 1500 sweeps with ~1.5 M relinearisations is the strongest
-    parity statement available; the final error must also sit in the converged band of BASELINE.md."""
-    from gbp_poplar_amd import driver
+    parity statement available; against the reference-math golden trajectory the first sweeps agree to 1e-4 and the
+    final error sits in the converged band of BASELINE.md (end-to-end 1e-4 is not defined on a chaotic input)."""
     oracle_mod.set_trig_mode(1)
     try:
         eng, orc, opts, state, _ = _setup(_bal("fr1xyz"), oracle_mod, sum_order=1)
-        tg = driver.run_ba(eng, state, opts, n_iters=1500, eval_every=250)
-        to = driver.run_ba(orc, state, opts, n_iters=1500, eval_every=250)
+        ig, tg = _run_ba_recorded(eng, state, opts, 1500)
+        io, to = _run_ba_recorded(orc, state, opts, 1500)
     finally:
         oracle_mod.set_trig_mode(0)
     g, o = eng.read(), orc.read()
     for k in g:
         assert np.array_equal(g[k], o[k]), k
-    for (i, mg, cg, rg, bg), (_, mo, co, ro, bo) in zip(tg, to):
-        assert abs(mg - mo) <= 1e-5 * mo and rg == ro and bg == bo, (i, mg, mo)
-    assert 1.40 < tg[-1][1] < 1.50, tg[-1]          # BASELINE.md: converged runs sit at 1.42-1.47 px
+    assert np.array_equal(tg[:, [0, 4, 5, 6]], to[:, [0, 4, 5, 6]])
+    assert np.max(np.abs(tg[:, 1] - to[:, 1]) / to[:, 1]) <= 1e-5      # the metric's own trig: device vs glibc
+    gold = _golden("trajectories.npz")
+    _check_against_golden_trajectory(tg, ig, gold["ba_fr1xyz"], gold["ba_fr1xyz_initial"], None)
+    assert 1.40 < tg[-1, 1] < 1.50, tg[-1]          # BASELINE.md: converged runs sit at 1.42-1.47 px
+    assert 1.42 < gold["ba_fr1xyz"][-1, 1] < 1.47
 
 
 @pytest.mark.parametrize("name,band", [("fr1desk", (1.2, 1.8)), ("fr2robot2", (0.86, 0.89))])
 def test_other_sequences_1500_sweeps_bit_exact(name, band, oracle_mod):
-    """The two other shipped sequences through the full default `./ba` run (1500 sweeps), bit for bit."""
-    from gbp_poplar_amd import driver
+    """The two other shipped sequences through the full default `./ba` run (1500 sweeps), bit for bit against the
+    oracle in device conventions; fr2robot2 (well conditioned) also END TO END against the reference-math golden
+    trajectory: mean reprojection error and RMSE averaged over the last 50 iterations within 2e-4 (SURVEY 8c asks 1e-3)."""
     oracle_mod.set_trig_mode(1)
     try:
         eng, orc, opts, state, _ = _setup(_bal(name), oracle_mod, sum_order=1)
-        tg = driver.run_ba(eng, state, opts, n_iters=1500, eval_every=500)
-        to = driver.run_ba(orc, state, opts, n_iters=1500, eval_every=500)
+        ig, tg = _run_ba_recorded(eng, state, opts, 1500)
+        io, to = _run_ba_recorded(orc, state, opts, 1500)
     finally:
         oracle_mod.set_trig_mode(0)
     g, o = eng.read(), orc.read()
     for k in g:
         assert np.array_equal(g[k], o[k]), k
-    assert [t[3:] for t in tg] == [t[3:] for t in to]
-    assert band[0] < tg[-1][1] < band[1], tg[-1]
+    assert np.array_equal(tg[:, [0, 4, 5, 6]], to[:, [0, 4, 5, 6]])
+    assert band[0] < tg[-1, 1] < band[1], tg[-1]
+    if name == "fr2robot2":
+        gold = _golden("trajectories.npz")
+        _check_against_golden_trajectory(tg, ig, gold["ba_fr2robot2"], gold["ba_fr2robot2_initial"], 2e-4)   # measured 6e-5
 
 
 def test_config3_slam_fr2robot2_full_run_bit_exact(oracle_mod):
-    """`./slam fr2robot2` defaults (700 sweeps per keyframe, 13 299 sweeps, 18 keyframe insertions): bit for bit,
-    and the final numbers against the reference-equivalent run of BASELINE.md (0.874272 px / RMSE 1.126136)."""
+    """`./slam fr2robot2` defaults (700 sweeps per keyframe, 13 299 sweeps, 18 keyframe insertions): bit for bit
+    against the oracle in device conventions, and end to end against the reference-math golden trajectory: first
+    sweeps 1e-4, mean error / RMSE over the last 50 iterations within 2e-4 (SURVEY 8c asks 1e-3)."""
     from gbp_poplar_amd import driver, hostlib
+    from tests.traj_util import EvalAt, wanted
     bal = _bal("fr2robot2")
+    n_total = (bal["n_cams"] - 1) * 700 - 1
     oracle_mod.set_trig_mode(1)
     try:
         eng, orc, opts, state, extra = _setup(bal, oracle_mod, slam=True, sum_order=1)
-        tg = driver.run_slam(eng, hostlib, bal, state, extra, opts, eval_every=700)
-        to = driver.run_slam(orc, hostlib, bal, state, extra, opts, eval_every=700)
+        wg, wo = (EvalAt(x, wanted(n_total, head=30, every=700, tail=50)) for x in (eng, orc))
+        ig = driver.run_slam(wg, hostlib, bal, state, extra, opts, eval_every=0)[0]
+        driver.run_slam(wo, hostlib, bal, state, extra, opts, eval_every=0)
     finally:
         oracle_mod.set_trig_mode(0)
     g, o = eng.read(), orc.read()
     for k in g:
         assert np.array_equal(g[k], o[k]), k
-    assert len(tg) == len(to) and all(a[3:] == b[3:] for a, b in zip(tg, to))
-    mean, cost = tg[-1][1], tg[-1][2]
-    rmse = np.sqrt(2 * cost / bal["n_edges"])
-    assert abs(mean - 0.874272) < 2e-3 and abs(rmse - 1.126136) < 2e-3, (mean, rmse)
+    tg, to = wg.array(), wo.array()
+    assert np.array_equal(tg[:, [0, 4, 5, 6]], to[:, [0, 4, 5, 6]])
+    gold = _golden("trajectories.npz")
+    _check_against_golden_trajectory(tg, ig, gold["slam_fr2robot2"], gold["slam_fr2robot2_initial"], 2e-4)   # measured 5e-5

@@ -27,6 +27,11 @@ def _apply(lib, g=G):
                        np.ascontiguousarray(g["proj_K"]))
         lib.om_hfunc(P(cam), P(lmk), P(K), P(o["hfunc_out"][k]))
         lib.om_jac(P(cam), P(lmk), P(K), P(o["jac_kf"][k]), P(o["jac_lmk"][k]))
+    if "mean6_eta" in getattr(g, "files", g):
+        o["mean6_out"], o["mean3_out"] = np.zeros_like(g["mean6_eta"]), np.zeros_like(g["mean3_eta"])
+        for k in range(g["mean6_eta"].shape[0]):
+            lib.om_inf2mean6x6(P(np.ascontiguousarray(g["mean6_eta"][k])), P(np.ascontiguousarray(g["mean6_lambda"][k])), P(o["mean6_out"][k]))
+            lib.om_inf2mean3x3(P(np.ascontiguousarray(g["mean3_eta"][k])), P(np.ascontiguousarray(g["mean3_lambda"][k])), P(o["mean3_out"][k]))
     A, B = np.ascontiguousarray(g["mm_A"]), np.ascontiguousarray(g["mm_B"])
     for name, (x, y, ta, tb, pr, pc) in {"nn": (B, A, 0, 0, 6, 3), "tn": (A, B, 1, 0, 3, 6), "nt": (A, A, 0, 1, 6, 6)}.items():
         p = np.full((pr, pc), 0.25, np.float32)
@@ -70,6 +75,8 @@ def test_restatement_equals_reference_code_on_fresh_inputs():
     g["proj_cam"], g["proj_lmk"] = cam, rng.standard_normal((n, 3)).astype(np.float32)
     g["proj_K"] = np.array([500, 0, 320, 0, 500, 240, 0, 0, 1], np.float32)
     g["mm_A"], g["mm_B"] = rng.standard_normal((6, 3)).astype(np.float32), rng.standard_normal((6, 6)).astype(np.float32)
+    g["mean6_eta"], g["mean3_eta"] = rng.standard_normal((n, 6)).astype(np.float32), rng.standard_normal((n, 3)).astype(np.float32)
+    g["mean6_lambda"], g["mean3_lambda"] = g["inv6_in"], g["inv3_in"]
     for k in ("inv3_out", "inv6_out"):
         g[k] = np.zeros_like(g[k.replace("out", "in")])
     g["so3_out"] = np.zeros((n, 9), np.float32)

@@ -1,0 +1,53 @@
+"""The travelling oracle (oracle/_build, restated math) against tests/golden/trajectories.npz, which the
+reference-math build (oracle/_ref: the reference's own matlib.cpp / bafuncs.cpp) produced in the literal conventions.
+The two math layers are bit-identical (tests/test_oracle_math.py), so whole chaotic trajectories must coincide."""
+import os
+
+import numpy as np
+
+from gbp_poplar_amd import driver
+from tests.conftest import seq_path
+from tests.traj_util import EvalAt, wanted
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "trajectories.npz"))
+
+
+def _ba(name, oracle_mod, oracle_host, n_iters):
+    bal = oracle_host.bal_read(seq_path(name))
+    opts = driver.Options()
+    K, state, _ = driver.build_inputs(bal, opts, oracle_host)
+    o = oracle_mod.Oracle(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K)
+    w = EvalAt(o, [i for i in wanted(opts.n_iters) if i < n_iters])
+    t = driver.run_ba(w, state, opts, n_iters=n_iters, eval_every=0)
+    return t, w.array()
+
+
+def test_fr2robot2_ba_full_trajectory_equals_the_golden(oracle_mod, oracle_host):
+    t, rows = _ba("fr2robot2", oracle_mod, oracle_host, 1500)
+    g = G["ba_fr2robot2"]
+    assert np.array_equal(rows, g)
+    assert np.array_equal(np.array(t[0][1:3]), G["ba_fr2robot2_initial"])
+    # the end-to-end figures SURVEY 8c quotes for this sequence (mean of the last 50 iterations)
+    assert abs(g[-50:, 1].mean() - 0.8742) < 5e-4 and abs(g[-50:, 3].mean() - 1.1260) < 5e-4
+
+
+def test_fr1xyz_ba_first_150_sweeps_equal_the_golden(oracle_mod, oracle_host):
+    """fr1xyz is chaotic: an ulp of difference anywhere would be O(1) after ~25 sweeps."""
+    t, rows = _ba("fr1xyz", oracle_mod, oracle_host, 150)
+    g = G["ba_fr1xyz"]
+    assert np.array_equal(rows, g[g[:, 0] < 150])
+    assert 1.42 < g[-1, 1] < 1.47          # the golden run itself ends in BASELINE.md's converged band
+
+
+def test_fr2robot2_slam_prefix_equals_the_golden(oracle_mod, oracle_host):
+    bal = oracle_host.bal_read(seq_path("fr2robot2"))
+    opts = driver.Options()
+    K, state, extra = driver.build_inputs(bal, opts, oracle_host, slam=True)
+    o = oracle_mod.Oracle(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K)
+    n_total = (bal["n_cams"] - 1) * opts.iters_between_kfs - 1
+    n = 1500                               # two keyframe insertions
+    w = EvalAt(o, [i for i in wanted(n_total, head=30, every=700, tail=50) if i < n])
+    t = driver.run_slam(w, oracle_host, bal, state, extra, opts, max_iters=n, eval_every=0)
+    g = G["slam_fr2robot2"]
+    assert np.array_equal(w.array(), g[g[:, 0] < n])
+    assert np.array_equal(np.array(t[0][1:3]), G["slam_fr2robot2_initial"])
