@@ -1,25 +1,48 @@
 #!/usr/bin/env python3
-"""bench.py — GBP iterations/second on the synthetic 1M-factor BAL graph (BASELINE.json configs[3], "S1").
+"""bench.py — GBP iterations/second on synthetic BAL graphs (BASELINE.json configs[3] "S1" and configs[4] "S8").
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-         bench.py --gpus N --steps K --warmup W
 
-A "step" is one synchronous GBP iteration (GBP_PROG of the reference, ba/ba.cpp:895-905: prep ->
-messages -> beliefs) over the whole factor graph, inputs resident in HBM, no host read-back inside the
-timed region.  N = 1 runs S1 = 1 000 cameras x 100 000 landmarks x 1 000 000 factors.  N > 1 is WEAK
-scaling: N x S1 (1000 N cameras, 100k N landmarks, 1M N factors), landmark-sharded, one all-gather of
-camera partials per iteration.  `value` = iterations/s x (total factors / 1e6), i.e. "1M-factor-graph
-GBP iterations per second": at N = 1 it is exactly BASELINE.json's metric, and it aggregates over
-ranks like tokens/s does (raw iterations/s of the N x larger graph is in config.iters_per_sec).
+A "step" is one synchronous GBP iteration (GBP_PROG of the reference, ba/ba.cpp:895-905: prep -> messages ->
+beliefs) over the whole factor graph, inputs resident in HBM, no host read-back inside the timed region.
 
-The warm-up runs the reference's start of a BA run (LINEARISE, prior weakening on iterations 1,3,5,7,9)
-so the timed iterations are steady-state sweeps of a converging problem.
+Workloads
+  N = 1   S1 = 1 000 cameras x 100 000 landmarks x 1 000 000 factors (the configuration BASELINE.json's metric is
+          quoted on), one GPU, the iteration replayed from a hipGraph.
+  N > 1   BASELINE config 5 and its weak-scaling family: 1 000 N cameras x 125 000 N landmarks x 1 250 000 N factors,
+          landmark-sharded over N GPUs, one all-gather of camera partial sums per iteration; N = 8 is exactly config 5
+          (8 000 cameras x 1 000 000 landmarks x 10 000 000 factors).  `--weak-s1` selects N x S1 instead.
+          Without a launcher (no RANK in the environment) this script starts the N ranks itself
+          (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...`, before anything touches the GPU),
+          relays rank 0's JSON line as its own last line of stdout and exits with the launcher's status.
+`value` = iterations/s x (total factors / 1e6), i.e. "1M-factor-graph GBP iterations per second": at N = 1 it is
+exactly BASELINE.json's metric, and it aggregates over ranks like tokens/s does (raw iterations/s of the larger
+graph is in config.iters_per_sec).
+
+The warm-up runs the reference's start of a BA run (LINEARISE, prior weakening on iterations 1,3,5,7,9) so the timed
+iterations are steady-state sweeps of a converging problem.
+
+roofline (dominant kernel k_sweep; `kernels` carries the same figures for k_beliefs):
+  achieved / frac_algorithmic   SURVEY 8(d)'s ALGORITHMIC bytes (1112 B per factor-iteration: the reference's tensor
+                                formulation) / live launch time.  > 1 x peak by construction: symmetric packing,
+                                in-place messages and hoisted means remove bytes the reference formulation moves.
+  layout_bytes_per_factor       the compulsory bytes of THIS layout and their fraction of peak.
+  traffic / achieved_traffic    HBM bytes per launch from rocprofv3 PMC passes of this same build and workload
+                                (FETCH_SIZE, WRITE_SIZE in separate passes, read side doubled: gfx950 tallies wide
+                                streaming reads at 1/2 — MI355X_MICROARCH.md, HBM), taken LIVE by this script
+                                (rank 0, N = 1) in child processes before the parent touches the GPU; a stamped
+                                profiles/traffic_S1.json is used only if the live passes fail and its stamp matches.
+  frac                          achieved_traffic / peak — the physically meaningful HBM fraction (headline).
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -27,27 +50,198 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 ALGO_BYTES_PER_FACTOR = 1112   # algorithmic bytes per factor-iteration of the sweep
+# compulsory streams of this layout per factor-iteration of k_sweep: FAC 224 R + CMSG 112 R + 112 W +
+# LMSG 64 R + 64 W + LMK_IDX 4 R + ROWP 11 W = 591 B; landmark-table gathers (belief 64 B + hoisted mean) come on top
+LAYOUT_BYTES_PER_FACTOR = 591
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--cams", type=int, default=1000, help="cameras per GPU")
-    ap.add_argument("--lmks", type=int, default=100000, help="landmarks per GPU")
+    ap.add_argument("--cams", type=int, default=None, help="cameras per GPU (default 1000)")
+    ap.add_argument("--lmks", type=int, default=None, help="landmarks per GPU (default: 100000 at N = 1, 125000 at N > 1)")
     ap.add_argument("--obs", type=int, default=10, help="observations per landmark")
+    ap.add_argument("--weak-s1", action="store_true", help="N > 1: N x S1 (100000 landmarks per GPU) instead of the config-5 family")
     ap.add_argument("--seed", type=int, default=20200303)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=20, help="per-stage hipEvent-timed iterations for the roofline")
+    ap.add_argument("--pmc", choices=["live", "file", "off"], default="live",
+                    help="roofline.traffic: live rocprofv3 PMC passes (N = 1), the stamped profiles/traffic_S1.json, or none")
+    ap.add_argument("--save-traffic", default=None, help="write the live PMC traffic + its build stamp to this JSON file")
+    ap.add_argument("--keep-pmc", default=None, help="keep the rocprofv3 PMC output of the live passes in this directory")
     ap.add_argument("--force-sharded", action="store_true",
                     help="diagnostic: run the N>1 code path (shard ctx, RCCL all_gather, overlap) even with one rank")
     ap.add_argument("--sharded-graph", type=int, default=0, help="capture sharded iterations (kernels + RCCL) in a hipGraph")
     ap.add_argument("--exchange-chunks", type=int, default=None,
-                    help="camera ranges of the pipelined all-gather (default: 1 / 2 / 3 for 1 / 2-4 / 8 GPUs)")
+                    help="camera ranges of the pipelined all-gather (default: 1)")
     ap.add_argument("--tile-order", type=int, default=0, help="gbp_params.tile_order: 0 = default, 1 = sequential, 2 = sweep tiles XCD-aware too")
-    return ap.parse_args()
+    ap.add_argument("--master-port", type=int, default=0, help="self-launch: rendezvous port (0 = pick a free one)")
+    # internal modes
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)       # the process rocprofv3 profiles
+    ap.add_argument("--launch-selftest", action="store_true", help=argparse.SUPPRESS)  # CPU test of the self-launcher (gloo)
+    ap.add_argument("--selftest-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
+    a = ap.parse_args(argv)
+    if a.cams is None:
+        a.cams = 1000
+    if a.lmks is None:
+        a.lmks = 100000 if (a.gpus == 1 or a.weak_s1) else 125000
+    return a
 
+
+# ---- self-launch of the N ranks (before any GPU call in this process) ---------------------------------------------
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def last_json_line(text):
+    for line in reversed(text.splitlines()):
+        line = line.strip()
+        if line.startswith("{") and line.endswith("}"):
+            try:
+                json.loads(line)
+                return line
+            except ValueError:
+                continue
+    return None
+
+
+def self_launch(a, argv):
+    """`bench.py --gpus N` without a launcher: one child process per GPU through torch.distributed.run.  This process
+    never touches the GPU (no torch.cuda call, no HIP library loaded): it only relays and propagates the status."""
+    port = a.master_port or free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: required for RCCL across processes on this stack
+    env.setdefault("OMP_NUM_THREADS", "2")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    sys.stderr.write(p.stderr[-8000:])
+    line = last_json_line(p.stdout)
+    other = [l for l in p.stdout.splitlines() if l.strip() and l.strip() != line]
+    if other:
+        sys.stderr.write("\n".join(other[-40:]) + "\n")
+    if line is not None:
+        print(line, flush=True)
+    if p.returncode != 0:
+        return p.returncode
+    return 0 if line is not None else 3
+
+
+def launch_selftest(a):
+    """What the ranks do under --launch-selftest: a gloo group on the CPU, one all_reduce, rank 0 prints a JSON line.
+    Exercises exactly the launcher plumbing of an N-GPU run (environment, rendezvous, relay, exit status)."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group(backend="gloo")
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == a.selftest_fail_rank:
+        return 7
+    if rank == 0:
+        print("noise before the JSON line")
+        print(json.dumps({"selftest": True, "n_gpus": world, "sum_of_ranks_plus_1": float(t.item()), "steps": a.steps}), flush=True)
+    return 0
+
+
+# ---- HBM traffic from rocprofv3 PMC passes ----------------------------------------------------------------------
+
+def build_stamp(a):
+    """Identifies the kernels + workload a traffic figure belongs to: hash of the device sources and the shapes."""
+    h = hashlib.sha256()
+    for f in ("gbp_kernels.hip", "gbp_kernels.h", "gbp_device_math.hpp", "gbp_capi.cpp"):
+        h.update(open(os.path.join(ROOT, "gbp_poplar_amd", "csrc", f), "rb").read())
+    return {"source_sha16": h.hexdigest()[:16], "workload": [a.cams, a.lmks, a.obs, a.seed], "tile_order": a.tile_order}
+
+
+def parse_pmc_csv(directory, counter):
+    """{kernel short name: mean counter value per dispatch} from a rocprofv3 counter_collection CSV."""
+    import csv
+    agg = {}
+    for f in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") != counter:
+                continue
+            name = r.get("Kernel_Name", "")
+            for short in ("k_sweep", "k_beliefs", "k_relin"):
+                if short in name:
+                    v = agg.setdefault(short, [0, 0.0])
+                    v[0] += 1
+                    v[1] += float(r.get("Counter_Value", 0))
+    return {k: (s / n, n) for k, (n, s) in agg.items() if n}
+
+
+def measure_traffic_live(a, keep_dir=None):
+    """Two rocprofv3 passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE: the TCC slots do not hold both) over a short run of
+    the same workload in child processes.  Returns {"k_sweep": {...}, "k_beliefs": {...}} or None."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    tmp = os.path.abspath(keep_dir) if keep_dir else tempfile.mkdtemp(prefix="gbp_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    child = ["python3", os.path.abspath(__file__), "--pmc-child", "--steps", "4", "--warmup", "12", "--cams", str(a.cams),
+             "--lmks", str(a.lmks), "--obs", str(a.obs), "--seed", str(a.seed), "--tile-order", str(a.tile_order)]
+    vals = {}
+    try:
+        for counter, tag in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+            d = os.path.join(tmp, tag)
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", tag, "--"] + child
+            p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+            if p.returncode != 0:
+                return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (counter, p.returncode, p.stderr[-300:])
+            vals[tag] = parse_pmc_csv(d, counter)
+            if "k_sweep" not in vals[tag]:
+                return None, "no k_sweep dispatch in the %s pass" % counter
+    except Exception as exc:       # noqa: BLE001 — the bench line must still be produced
+        return None, repr(exc)
+    finally:
+        if keep_dir is None:
+            shutil.rmtree(tmp, ignore_errors=True)
+    out = {}
+    for k in vals["fetch"]:
+        if k not in vals["write"]:
+            continue
+        f_kb, n = vals["fetch"][k]
+        w_kb, _ = vals["write"][k]
+        # k_sweep / k_relin read wide coalesced streams (counted at 1/2 on gfx950 -> doubled); k_beliefs reads 64-B records
+        # at random: one request per record, uncalibrated, reported uncorrected with the doubled figure as upper bound
+        mult = 1.0 if k == "k_beliefs" else 2.0
+        out[k] = {"fetch_kb": f_kb, "write_kb": w_kb, "dispatches": n,
+                  "hbm_bytes_per_launch": int((mult * f_kb + w_kb) * 1024),
+                  "hbm_bytes_upper_bound": int((2.0 * f_kb + w_kb) * 1024)}
+    return out, None
+
+
+def pmc_child(a):
+    """The process rocprofv3 profiles: the bench workload, a few direct-launch iterations, no output."""
+    import torch  # noqa: F401  (one HIP runtime per process, see gbp_poplar_amd/_lib.py)
+    from gbp_poplar_amd import _cabi, driver, hostlib
+    from gbp_poplar_amd.engine import GbpEngine
+    bal = hostlib.synth_generate(a.cams, a.lmks, a.obs, a.seed)
+    opts = driver.Options()
+    K, state, _ = driver.build_inputs(bal, opts, hostlib)
+    eng = GbpEngine(bal["cam_id"], bal["lmk_id"], a.cams, a.lmks, K, params=_cabi.GbpParams.defaults(tile_order=a.tile_order))
+    eng.upload(state)
+    eng.linearise()
+    warm_start(eng, opts, a.warmup)
+    for _ in range(a.steps):
+        eng.iterate(1)
+    eng.sync()
+    eng.close()
+    return 0
+
+
+# ---- the measured run ---------------------------------------------------------------------------------------
 
 def warm_start(eng, opts, warmup):
     """ba.cpp:1001-1008 for `warmup` iterations (weaken priors on 1,3,5,7,9).  Warm-up iterations beyond the
@@ -66,9 +260,7 @@ def warm_start(eng, opts, warmup):
             it += 10
 
 
-def cpu_baseline(bal, K, state, opts, budget_s):
-    """The CPU oracle (OpenMP over factors / variables) timed on this host on the SAME graph."""
-    from oracle import oracle as orc
+def host_cores():
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:  # honour a cgroup CPU quota (containers): "max 100000" or "<quota> <period>"
         q, p = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -76,6 +268,13 @@ def cpu_baseline(bal, K, state, opts, budget_s):
             cores = max(1, min(cores, int(float(q) / float(p) + 0.5)))
     except Exception:
         pass
+    return cores
+
+
+def cpu_baseline(bal, K, state, opts, budget_s):
+    """The CPU oracle (OpenMP over factors / variables) timed on this host on the SAME graph."""
+    from oracle import oracle as orc
+    cores = host_cores()
     orc.set_threads(cores)
     o = orc.Oracle(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K)
     o.upload(state)
@@ -113,8 +312,24 @@ def gpu_accuracy_run(bal, K, state, opts, n):
     return {"rmse_px": float((2.0 * ev["sum_half_sq"] / max(ev["n_active"], 1)) ** 0.5), "mean_reproj_px": traj[-1][1]}
 
 
-def main():
-    a = parse()
+def workload_name(a, world, C, L, E):
+    if world == 1:
+        base = "S1" if (a.cams, a.lmks, a.obs) == (1000, 100000, 10) else "synthetic"
+        return "%s synthetic BAL graph: %d cams x %d lmks x %d factors (seed %d)" % (base, C, L, E, a.seed)
+    fam = "N x S1" if a.weak_s1 else ("BASELINE config 5" if (world, a.cams, a.lmks, a.obs) == (8, 1000, 125000, 10)
+                                      else "BASELINE config-5 family")
+    return "%s: %d cams x %d lmks x %d factors (seed %d), landmark-sharded over %d GPUs" % (fam, C, L, E, a.seed, world)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    a = parse(argv)
+    if a.gpus > 1 and "RANK" not in os.environ:
+        return self_launch(a, argv)                      # nothing in this process has touched the GPU
+    if a.launch_selftest:
+        return launch_selftest(a)
+    if a.pmc_child:
+        return pmc_child(a)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -122,24 +337,45 @@ def main():
         os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
     if world != a.gpus and world != 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
-    if a.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with torch.distributed.run (one process per GPU)")
+
+    sharded = world > 1 or a.force_sharded
+    # ---- HBM traffic of the kernels: live PMC passes in child processes, BEFORE this process touches the GPU ----
+    traffic, traffic_src, traffic_err = None, None, None
+    s1_like = world == 1 and not a.force_sharded
+    if rank == 0 and s1_like and a.profile_steps > 0 and a.pmc == "live":
+        traffic, traffic_err = measure_traffic_live(a, keep_dir=a.keep_pmc)
+        if traffic and a.save_traffic:
+            json.dump({"stamp": build_stamp(a), "kernels": traffic,
+                       "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (KB per dispatch, mean); "
+                               "read side of the streaming kernels doubled (gfx950 correction, MI355X_MICROARCH.md HBM)"},
+                      open(a.save_traffic, "w"), indent=1)
+        traffic_src = "live rocprofv3 --pmc passes of this run's build and workload" if traffic else None
+    if rank == 0 and s1_like and traffic is None and a.pmc in ("live", "file"):
+        tpath = os.path.join(ROOT, "profiles", "traffic_S1.json")
+        try:
+            t = json.load(open(tpath))
+            if t.get("stamp") == build_stamp(a):         # a figure of other kernels / another workload is refused
+                traffic, traffic_src = t["kernels"], "profiles/traffic_S1.json (stamp matches this build and workload)"
+            else:
+                traffic_err = (traffic_err or "") + " | profiles/traffic_S1.json is stale (stamp mismatch)"
+        except Exception as exc:  # noqa: BLE001
+            traffic_err = (traffic_err or "") + " | " + repr(exc)
 
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1 or a.force_sharded:
+    if sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "RANK" not in os.environ:     # --force-sharded without a launcher: a 1-rank group
-            os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 1000))
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
             dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    from gbp_poplar_amd import driver, hostlib
+    from gbp_poplar_amd import _cabi, driver, hostlib
     from gbp_poplar_amd.distributed import ShardedGbp, landmark_partition
     from gbp_poplar_amd.engine import GbpEngine
 
@@ -149,9 +385,8 @@ def main():
     opts = driver.Options()
     K, state, _ = driver.build_inputs(bal, opts, hostlib)
 
-    from gbp_poplar_amd import _cabi
     prm = _cabi.GbpParams.defaults(tile_order=a.tile_order)
-    if world == 1 and not a.force_sharded:
+    if not sharded:
         eng = GbpEngine(bal["cam_id"], bal["lmk_id"], C, L, K, params=prm)
         run = eng
         e_local = E
@@ -191,9 +426,9 @@ def main():
     graph_used = (getattr(run, "graph", None) is not None) if hasattr(run, "use_graph") else None
     roof = None
     if a.profile_steps > 0:
-        sharded = world > 1 or a.force_sharded
         eng.timing(reset=True)
         eng.set_profiling(True)
+        t0 = time.perf_counter()
         if sharded:      # split-phase path: gbp_iterate_begin brackets its sweep launch; every rank runs the iterations
             if getattr(run, "use_graph", False):
                 run.use_graph, run.graph = False, None
@@ -201,23 +436,51 @@ def main():
             fence()
         else:
             eng.iterate(a.profile_steps)
+            eng.sync()
+        prof_wall = time.perf_counter() - t0
         eng.set_profiling(False)
         tm = eng.timing(reset=True)
         sweep_s = tm["sweep_ms"] / 1e3 / a.profile_steps
-        achieved = ALGO_BYTES_PER_FACTOR * e_local / sweep_s / 1e9
-        traffic = None     # HBM bytes per launch from the committed PMC passes of this same workload (profiles/run_profile.sh)
-        tpath = os.path.join(ROOT, "profiles", "traffic_S1.json")
-        if os.path.exists(tpath) and (a.cams, a.lmks, a.obs) == (1000, 100000, 10) and world == 1:
-            try:
-                traffic = int(json.load(open(tpath))["hbm_bytes_per_launch"])
-            except Exception:
-                traffic = None
-        roof = {"bound": "hbm", "kernel": "k_sweep", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "algorithmic_bytes_per_launch": ALGO_BYTES_PER_FACTOR * e_local,
+        belief_s = tm["belief_ms"] / 1e3 / a.profile_steps if not sharded else None
+        algo = ALGO_BYTES_PER_FACTOR * e_local
+        layout = LAYOUT_BYTES_PER_FACTOR * e_local
+        tr = (traffic or {}).get("k_sweep")
+        tr_bytes = tr["hbm_bytes_per_launch"] if tr else None
+        frac_algo = algo / sweep_s / 1e9 / HBM_PEAK_GBS
+        roof = {"bound": "hbm", "kernel": "k_sweep",
+                "achieved": round(algo / sweep_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(tr_bytes / sweep_s / 1e9 / HBM_PEAK_GBS, 4) if tr_bytes else None,
+                "frac_is": "traffic / launch time / peak (measured HBM-side bytes)" if tr_bytes else
+                           "unavailable: no PMC traffic for this run (see frac_algorithmic, frac_layout)",
+                "traffic": tr_bytes,
+                "achieved_traffic": round(tr_bytes / sweep_s / 1e9, 1) if tr_bytes else None,
+                "frac_algorithmic": round(frac_algo, 4),
+                "frac_algorithmic_note": "1112 B/factor of the reference's tensor formulation (SURVEY 8d) / launch time / peak; "
+                                         "exceeds 1 because packing, in-place messages and hoisted means remove bytes",
+                "algorithmic_bytes_per_launch": algo,
+                "layout_bytes_per_factor": LAYOUT_BYTES_PER_FACTOR,
+                "frac_layout": round(layout / sweep_s / 1e9 / HBM_PEAK_GBS, 4),
+                "traffic_over_layout": round(tr_bytes / layout, 3) if tr_bytes else None,
+                "traffic_source": traffic_src, "traffic_error": None if tr_bytes else traffic_err,
                 "avg_launch_us": round(sweep_s * 1e6, 2),
-                "belief_kernels_avg_us": round(tm["belief_ms"] * 1e3 / a.profile_steps, 2) if not sharded else None,
+                "belief_kernels_avg_us": round(belief_s * 1e6, 2) if belief_s is not None else None,
+                "profiled_ms_per_step": round(tm["total_ms"] / a.profile_steps, 4) if not sharded else round(prof_wall / a.profile_steps * 1e3, 4),
+                "profiled_note": "direct launches with an event between kernels: sweep + beliefs + two dependent-launch gaps; "
+                                 "ms_per_step is the hipGraph replay of the same kernels" if not sharded else
+                                 "split-phase iterations (sweep, partials, all-gather, combine), wall clock per iteration",
                 "measured_on": "rank 0" if world > 1 else "the GPU"}
+        if not sharded:
+            kb = (traffic or {}).get("k_beliefs")
+            bel_algo = 336 * C + 96 * L
+            roof["kernels"] = [
+                {"kernel": "k_sweep", "avg_us": roof["avg_launch_us"], "traffic": tr_bytes, "frac": roof["frac"],
+                 "algorithmic_bytes": algo, "layout_bytes": layout},
+                {"kernel": "k_beliefs", "avg_us": roof["belief_kernels_avg_us"],
+                 "traffic": kb["hbm_bytes_per_launch"] if kb else None,
+                 "traffic_upper_bound": kb["hbm_bytes_upper_bound"] if kb else None,
+                 "frac": round(kb["hbm_bytes_per_launch"] / belief_s / 1e9 / HBM_PEAK_GBS, 4) if kb else None,
+                 "algorithmic_bytes": bel_algo,
+                 "note": "random 64-B record gathers: FETCH_SIZE taken uncorrected (one request per record), doubled figure as upper bound"}]
 
     cpu = None
     if rank == 0 and world == 1 and a.cpu_seconds > 0:
@@ -234,10 +497,9 @@ def main():
             "value": round(ips * E / 1e6, 2), "unit": "1M-factor GBP iters/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "S1 synthetic BAL graph x%d: %d cams x %d lmks x %d factors (seed %d)%s"
-                                   % (world, C, L, E, a.seed, ", landmark-sharded over %d GPUs" % world if world > 1 else ""),
+            "config": {"workload": workload_name(a, world, C, L, E),
                        "cams": C, "lmks": L, "factors": E, "iters_per_sec": round(ips, 2),
-                       "parallelism": "1 GPU, hipGraph x10 iterations" if (world == 1 and not a.force_sharded) else "landmark shards x%d + all_gather(cam partials)" % world,
+                       "parallelism": "1 GPU, hipGraph x10 iterations" if not sharded else "landmark shards x%d + all_gather(cam partials)" % world,
                        "reproj_rmse_px_initial": round(m0[2], 6), "reproj_rmse_px_final": round(m1[2], 6),
                        "mean_reproj_px_final": round(m1[0], 6), "iterations_run": a.warmup + a.steps,
                        "nonfinite_beliefs": int(ev1["n_nonfinite"]),
@@ -258,7 +520,8 @@ def main():
     ctypes.CDLL(None).fflush(None)
     if rank == 0:
         print(json.dumps(out), flush=True)
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -1,0 +1,44 @@
+"""bench.py --gpus N without a launcher starts the N ranks itself (torch.distributed.run children, before any GPU
+call), relays rank 0's JSON line as the LAST line of its stdout and propagates a failing rank's status.  Exercised here
+on the CPU with the --launch-selftest mode (gloo group, one all_reduce) — the same plumbing an N-GPU run goes through."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*extra):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-selftest", *extra],
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=240)
+
+
+def test_self_launch_relays_rank0_json_as_last_stdout_line():
+    p = _run("--steps", "3")
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    out = json.loads(lines[-1])
+    assert len(lines) == 1                                 # rank noise goes to stderr, stdout carries the JSON line only
+    assert out == {"selftest": True, "n_gpus": 2, "sum_of_ranks_plus_1": 3.0, "steps": 3}
+
+
+def test_self_launch_propagates_a_failing_rank():
+    p = _run("--selftest-fail-rank", "1")
+    assert p.returncode != 0
+
+
+def test_default_workloads():
+    sys.path.insert(0, ROOT)
+    import bench
+    a1, a8, a4 = bench.parse([]), bench.parse(["--gpus", "8"]), bench.parse(["--gpus", "4", "--weak-s1"])
+    assert (a1.cams, a1.lmks) == (1000, 100000)                       # S1
+    assert (a8.cams * 8, a8.lmks * 8, a8.obs) == (8000, 1000000, 10)  # BASELINE config 5: 8 000 x 1 000 000 x 10 M
+    assert (a4.cams, a4.lmks) == (1000, 100000)
+    assert "BASELINE config 5:" in bench.workload_name(a8, 8, 8000, 1000000, 10000000)
+    assert bench.workload_name(a1, 1, 1000, 100000, 1000000).startswith("S1 ")
+    s = bench.build_stamp(a1)
+    assert len(s["source_sha16"]) == 16 and s["workload"] == [1000, 100000, 10, 20200303]
