@@ -50,6 +50,8 @@ _SIGS = {
     "gbp_set_prior_lambda": (C.c_int, [C.POINTER(cabi.GbpProblem), C.c_float] + [cabi.c_f32p] * 8),
     "gbp_prior_scalings": (C.c_int, [C.c_uint32, C.c_uint32, cabi.c_f32p, C.c_float, C.c_float, C.c_float,
                                      cabi.c_f32p, cabi.c_f32p]),
+    "gbp_init_add_noise": (C.c_int, [C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_uint64, cabi.c_f32p, cabi.c_f32p]),
+    "gbp_init_av_depth": (C.c_int, [C.POINTER(cabi.GbpProblem), cabi.c_f32p, cabi.c_f32p]),
     "gbp_slam_create_flags": (C.c_int, [C.POINTER(cabi.GbpProblem), C.c_uint32] + [cabi.c_u32p] * 4),
     "gbp_slam_update_flags": (C.c_int, [C.POINTER(cabi.GbpProblem), C.c_uint32, C.c_uint32] + [cabi.c_u32p] * 4
                               + [cabi.c_i32p]),

@@ -23,6 +23,12 @@ def main(argv=None):
     ap.add_argument("--first_cam_prior_std", type=float, default=0.01)
     ap.add_argument("--steps", type=float, default=5.0)
     ap.add_argument("--undamped_start", type=int, default=15)
+    ap.add_argument("--tn", type=float, default=0.0, help="std (m) of the noise on keyframe translation initialisations")
+    ap.add_argument("--rn", type=float, default=0.0, help="std (degrees) of the noise on keyframe rotation initialisations")
+    ap.add_argument("--ltn", type=float, default=0.0, help="std (m) of the noise on landmark initialisations")
+    ap.add_argument("--avdepth_on", type=int, default=0, help="initialise landmarks one unit in front of their first keyframe")
+    ap.add_argument("--avdepth", type=float, default=1.0)
+    ap.add_argument("--seed", type=int, default=0, help="seed of the initialisation noise (0 = from the OS)")
     ap.add_argument("--eval_every", type=int, default=1)
     ap.add_argument("--slam", action="store_true", help="incremental SLAM flow of ./slam instead of batch BA")
     ap.add_argument("--iters_between_kfs", type=int, default=700)
@@ -54,7 +60,11 @@ def main(argv=None):
         return 1
     opts = driver.Options(n_iters=a.n_iters, reproj_meas_var=a.reproj_meas_var,
                           prior_std_weaker_factor=a.prior_std_weaker_factor,
-                          first_cam_prior_std=a.first_cam_prior_std, steps=a.steps, undamped_start=a.undamped_start)
+                          first_cam_prior_std=a.first_cam_prior_std, steps=a.steps, undamped_start=a.undamped_start,
+                          tn=a.tn, rn=a.rn, ltn=a.ltn, avdepth_on=bool(a.avdepth_on), seed=a.seed)
+    if world > 1 and (a.tn or a.rn or a.ltn) and not a.seed:
+        print("--tn/--rn/--ltn on several ranks need --seed (every rank must draw the same noise)", file=sys.stderr)
+        return 2
     opts.iters_between_kfs = a.iters_between_kfs
     K, state, extra = driver.build_inputs(bal, opts, hostlib, slam=a.slam)
     log("Completed loading data!\n\n%s\n" % ("Incremental SLAM" if a.slam else "Bundle Adjustment"))

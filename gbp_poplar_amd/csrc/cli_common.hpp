@@ -129,92 +129,6 @@ struct Problem {
   gbp_problem prob{};
 };
 
-// tiny deterministic normal generator for the optional initialisation noise
-struct Noise {
-  unsigned long long s;
-  explicit Noise(unsigned long long seed) : s(seed ? seed : (unsigned long long)std::chrono::system_clock::now().time_since_epoch().count()) {}
-  unsigned long long next() {
-    s += 0x9E3779B97F4A7C15ull;
-    unsigned long long x = s;
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-    return x ^ (x >> 31);
-  }
-  double uni() { return ((double)(next() >> 11) + 0.5) / 9007199254740992.0; }
-  float normal(float sd) { return sd * (float)(std::sqrt(-2.0 * std::log(uni())) * std::cos(6.283185307179586 * uni())); }
-};
-
-inline void rodrigues(const float* w, float* R) {
-  const float th = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
-  const float W[9] = {0.f, -w[2], w[1], w[2], 0.f, -w[0], -w[1], w[0], 0.f};
-  for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.f : 0.f;
-  if (th < 1e-6) return;
-  const float a = std::sin(th) / th, b = (1 - std::cos(th)) / (th * th);
-  for (int r = 0; r < 3; ++r)
-    for (int c = 0; c < 3; ++c) {
-      float ww = 0.f;
-      for (int k = 0; k < 3; ++k) ww += W[r * 3 + k] * W[k * 3 + c];
-      R[r * 3 + c] += a * W[r * 3 + c] + b * ww;
-    }
-}
-
-// add_cam_rot_noise, dataio.cpp:345-400: rotate the camera-to-world orientation about a random axis
-inline void add_rot_noise(std::vector<float>& cam, uint32_t C, float sd_deg, Noise& rng) {
-  for (uint32_t c = 2; c < C; ++c) {
-    const float ang = rng.normal(sd_deg) * (float)M_PI / 180.f;
-    const int axis = (int)(rng.next() % 3);
-    float Rn[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    const float cs = std::cos(ang), sn = std::sin(ang);
-    if (axis == 0) { Rn[4] = cs; Rn[5] = -sn; Rn[7] = sn; Rn[8] = cs; }
-    else if (axis == 1) { Rn[0] = cs; Rn[2] = sn; Rn[6] = -sn; Rn[8] = cs; }
-    else { Rn[0] = cs; Rn[1] = -sn; Rn[3] = sn; Rn[4] = cs; }
-    float Rw2c[9];
-    rodrigues(&cam[6 * c + 3], Rw2c);
-    // Tc2w = [R^T, -R^T t]; rotate its rotation block: Rc2w' = Rn * R^T, translation (camera centre) kept
-    float Rc2w[9], ctr[3], Rnew[9];
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j) Rc2w[i * 3 + j] = Rw2c[j * 3 + i];
-    for (int i = 0; i < 3; ++i) ctr[i] = -(Rc2w[i * 3] * cam[6 * c] + Rc2w[i * 3 + 1] * cam[6 * c + 1] + Rc2w[i * 3 + 2] * cam[6 * c + 2]);
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j) {
-        float s = 0.f;
-        for (int k = 0; k < 3; ++k) s += Rn[i * 3 + k] * Rc2w[k * 3 + j];
-        Rnew[i * 3 + j] = s;
-      }
-    // back to world->camera: R' = Rnew^T, t' = -R' ctr
-    float Rp[9];
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j) Rp[i * 3 + j] = Rnew[j * 3 + i];
-    for (int i = 0; i < 3; ++i) cam[6 * c + i] = -(Rp[i * 3] * ctr[0] + Rp[i * 3 + 1] * ctr[1] + Rp[i * 3 + 2] * ctr[2]);
-    // so3log, util.cpp:34-46
-    const float d = 0.5f * (Rp[0] + Rp[4] + Rp[8] - 1);
-    const float f = std::acos(d) / (2 * std::sqrt(1 - d * d));
-    cam[6 * c + 3] = f * (Rp[7] - Rp[5]);
-    cam[6 * c + 4] = f * (Rp[2] - Rp[6]);
-    cam[6 * c + 5] = f * (Rp[3] - Rp[1]);
-  }
-}
-
-// av_depth_init, dataio.cpp:417-453: landmarks start one unit in front of the first keyframe observing them
-// (the reference uses the literal depth 1.0, not --avdepth, dataio.cpp:437)
-inline void av_depth_init(const Problem& P, std::vector<float>& lmk_mean) {
-  const uint32_t C = P.bal.n_cams, E = P.bal.n_edges;
-  std::vector<char> done(P.bal.n_lmks, 0);
-  std::vector<float> spot(3 * (size_t)C);
-  for (uint32_t c = 0; c < C; ++c) {
-    float R[9];
-    rodrigues(&P.cam_mean[6 * c + 3], R);
-    const float v[3] = {0.f - P.cam_mean[6 * c], 0.f - P.cam_mean[6 * c + 1], 1.f - P.cam_mean[6 * c + 2]};
-    for (int i = 0; i < 3; ++i) spot[3 * c + i] = R[i] * v[0] + R[3 + i] * v[1] + R[6 + i] * v[2];  // R^T (p - t)
-  }
-  for (uint32_t c = 0; c < C; ++c)  // camera-major visiting order of the reference (O(E) because files are camera-sorted)
-    for (uint32_t e = 0; e < E; ++e)
-      if (P.cam_id[e] == c && !done[P.lmk_id[e]]) {
-        for (int i = 0; i < 3; ++i) lmk_mean[3 * (size_t)P.lmk_id[e] + i] = spot[3 * c + i];
-        done[P.lmk_id[e]] = 1;
-      }
-}
-
 inline int load_problem(const Options& o, Problem& P) {
   if (gbp_bal_read_header(o.bal_file.c_str(), &P.bal) != GBP_OK) {
     std::cerr << "ERROR: unable to open file " << o.bal_file << "\n";  // ba.cpp:484-487
@@ -239,21 +153,19 @@ inline int load_problem(const Options& o, Problem& P) {
   P.prob.n_cams = C; P.prob.n_lmks = L; P.prob.n_edges = E; P.prob.cam_id = P.cam_id.data(); P.prob.lmk_id = P.lmk_id.data();
   std::memcpy(P.prob.K, P.K.data(), 9 * sizeof(float));
 
-  Noise rng(o.seed);  // ba.cpp:536-548
-  if (o.transnoise != 0.f) {
+  // ba.cpp:536-548; the reference seeds from the clock (dataio.cpp:334,349,406): --seed 0 does the same
+  const unsigned long long seed = o.seed ? o.seed : (unsigned long long)std::chrono::system_clock::now().time_since_epoch().count();
+  if (o.transnoise != 0.f)
     std::cout << "\nAdding Gaussian noise with std: " << o.transnoise << "m to the keyframe translaton intialisations\n";
-    for (uint32_t c = 2; c < C; ++c) for (int i = 0; i < 3; ++i) P.cam_mean[6 * (size_t)c + i] += rng.normal(o.transnoise);
-  }
-  if (o.rotnoise != 0.f) {
+  if (o.rotnoise != 0.f)
     std::cout << "Adding Gaussian noise with std: " << o.rotnoise << " to the keyframe rotation intialisations\n";
-    add_rot_noise(P.cam_mean, C, o.rotnoise, rng);
-  }
-  if (o.lmktrans_noise != 0.f && !o.av_depth_on) {
+  const bool lmk_noise = o.lmktrans_noise != 0.f && !o.av_depth_on;
+  if (lmk_noise)
     std::cout << "Adding Gaussian noise with std: " << o.lmktrans_noise << "m to the landmark intialisations\n";
-    for (float& x : P.lmk_mean) x += rng.normal(o.lmktrans_noise);
-  } else if (o.av_depth_on) {
+  gbp_init_add_noise(C, L, o.transnoise, o.rotnoise, lmk_noise ? o.lmktrans_noise : 0.f, seed, P.cam_mean.data(), P.lmk_mean.data());
+  if (o.av_depth_on) {
     std::cout << "Initialising all landmarks at an average depth of: " << o.av_depth << "\n";
-    av_depth_init(P, P.lmk_mean);
+    gbp_init_av_depth(&P.prob, P.cam_mean.data(), P.lmk_mean.data());
   }
 
   P.cpe.resize(6 * (size_t)C); P.cpl.resize(36 * (size_t)C); P.lpe.resize(3 * (size_t)L); P.lpl.resize(9 * (size_t)L);

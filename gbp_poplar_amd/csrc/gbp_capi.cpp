@@ -46,6 +46,8 @@ struct gbp_ctx {
   std::vector<DevBuf*> all;
   DevBuf row_cam, lmk_idx, fac, cmsg, mu, lmsg, camb, camp, lmkb, lmkp, rowp, local, d_cam_row_ptr, d_lmk_ptr, cwf, lwf,
       cscale, lscale, cam_mu, lmk_mu, dK, evalp, hmu_c, hmu_l, d_lmk_fpos, health, tile_perm;
+  DevBuf st_a, st_b;                   // [Ep] scratch of the per-factor state get / set kernels
+  std::vector<uint8_t> active_host;    // [Ep] host shadow of the active flags (hoist guard of gbp_new_keyframe)
   bool use_tile_perm = false;
   bool hoist = true;  // per-variable belief means (k_sweep<true>); false = literal per-factor mu/oldmu tensors
   void* send_dev = nullptr;
@@ -54,6 +56,7 @@ struct gbp_ctx {
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
   int graph_iters = 0;
+  bool graph_failed = false;           // a capture / instantiation failed once: direct launches from then on
   bool uploaded = false, beliefs_valid = false;
   bool lmk_half_done = false;          // gbp_iterate_local already refreshed the landmark beliefs of this iteration
   int exch_chunks = 1;                 // camera ranges of the pipelined exchange (gbp_set_exchange_chunks)
@@ -81,7 +84,7 @@ int fail(gbp_ctx* c, int code, const std::string& msg) {
   } while (0)
 
 int dev_alloc(gbp_ctx* c, DevBuf& b, size_t bytes) {
-  b.bytes = bytes ? bytes : 16;
+  b.bytes = bytes < 256 ? 256 : bytes;   // >= one camera / landmark record: pad lanes of an empty shard read index 0
   HIPCHK(c, hipMalloc(&b.p, b.bytes));
   HIPCHK(c, hipMemset(b.p, 0, b.bytes));
   c->dev_bytes += b.bytes;
@@ -195,6 +198,20 @@ inline void put_state(std::vector<float>& rec, size_t p, const HostState& h) {
   rec[p * 16 + 3] = h.damping;
   std::memcpy(&rec[p * 16 + 13], &packed, 4);
   rec[p * 16 + 14] = h.var;
+}
+
+// split-phase profiling: read (and free) the sweep brackets recorded by gbp_iterate_begin
+void drain_sweep_events(gbp_ctx* c) {
+  for (auto& pr : c->pending_sweep_ev) {
+    float ms = 0;
+    if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+      c->sweep_ms += ms;
+      c->timed_iters += 1;
+    }
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
+  c->pending_sweep_ev.clear();
 }
 
 // No C++ exception crosses the C-ABI: every entry point that allocates host memory runs inside this guard.
@@ -319,6 +336,7 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
   A(c->cam_mu, (size_t)C * 6 * 4); A(c->lmk_mu, (size_t)c->L_loc * 3 * 4); A(c->dK, 16 * 4);
   A(c->evalp, sizeof(DeviceEval) * 1024); A(c->health, 16);
   A(c->hmu_c, (size_t)C * 4 * 16); A(c->hmu_l, (size_t)c->L_loc * 2 * 16);
+  A(c->st_a, Ep * 4); A(c->st_b, Ep * 4);
   if (rc != GBP_OK) { g_create_error = c->err; return rc; }
   auto CK = [&](hipError_t e, const char* what) {
     if (e != hipSuccess && rc == GBP_OK) { g_create_error = std::string(what) + ": " + hipGetErrorString(e); rc = GBP_ERR_HIP; }
@@ -417,11 +435,13 @@ static int upload_impl(gbp_ctx* c, const gbp_state_in* in) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const size_t Ep = c->Ep;
   std::vector<float> rec0(Ep * 16, 0.f), fac(Ep * kFacG * 4, 0.f), mu(c->hoist ? 0 : Ep * kMuG * 4, 0.f);
+  c->active_host.assign(Ep, 0);
   for (size_t p = 0; p < Ep; ++p) {
     const uint32_t e = c->pos_edge[p];
     HostState h{0.f, 0, kFlagPad, 0.f};
     if (e != ~0u) {
       h.flags = (in->active_flag[e] == 1) ? kFlagActive : 0u;
+      c->active_host[p] = in->active_flag[e] == 1;
       h.damping = in->damping ? in->damping[e] : 0.f;
       h.count = in->damping_count ? in->damping_count[e] : 0;
       h.var = in->meas_variances[e];
@@ -499,9 +519,13 @@ static int iterate_begin_impl(gbp_ctx* c) {
   float4* dst = c->world > 1 ? static_cast<float4*>(c->send_dev) : P<float4>(c->local);
   if (!dst) return fail(c, GBP_ERR_STATE, "exchange buffers not set");
   if (c->profile_stages) {  // bracket the sweep launch; the pair is read (and timed_iters counted) by gbp_timing
+    if (c->pending_sweep_ev.size() >= 256) drain_sweep_events(c);   // bounded: long profiled runs never pile up events
     hipEvent_t e0 = nullptr, e1 = nullptr;
     HIPCHK(c, hipEventCreate(&e0));
-    HIPCHK(c, hipEventCreate(&e1));
+    if (hipError_t e_ = hipEventCreate(&e1); e_ != hipSuccess) {
+      (void)hipEventDestroy(e0);
+      return fail(c, GBP_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e_));
+    }
     c->pending_sweep_ev.emplace_back(e0, e1);
     HIPCHK(c, hipEventRecord(e0, c->stream));
     launch_sweep(sweep_args(c), c->n_tiles, c->hoist, c->stream);
@@ -582,7 +606,12 @@ static int iterate_impl(gbp_ctx* c, int n) {
     // Per-stage timing: all n iterations are queued back to back with a hipEvent before / between / after the
     // two kernels, and read after ONE synchronisation, so a bracket holds the kernel (plus the ~1 us
     // dependent-launch gap), not the idle-queue start-up latency a per-iteration sync would add.
-    std::vector<hipEvent_t> ev(2 * (size_t)n + 1, nullptr);
+    struct Events {   // freed on every exit path
+      std::vector<hipEvent_t> v;
+      ~Events() { for (hipEvent_t e : v) if (e) (void)hipEventDestroy(e); }
+    } evs;
+    evs.v.assign(2 * (size_t)n + 1, nullptr);
+    std::vector<hipEvent_t>& ev = evs.v;
     for (auto& e : ev) HIPCHK(c, hipEventCreate(&e));
     HIPCHK(c, hipEventRecord(ev[0], c->stream));
     for (int i = 0; i < n; ++i) {
@@ -600,18 +629,28 @@ static int iterate_impl(gbp_ctx* c, int n) {
       HIPCHK(c, hipEventElapsedTime(&b_ms, ev[2 * i + 1], ev[2 * i + 2]));
       c->sweep_ms += a_ms; c->belief_ms += b_ms;
     }
-    for (auto& e : ev) (void)hipEventDestroy(e);
   } else {
     int left = n;
-    const bool use_graph = (c->stream == c->own_stream) && c->prm.graph_unroll > 0 && n >= c->prm.graph_unroll;
-    if (use_graph) {
-      if (!c->graph_exec) {
-        HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    bool use_graph = (c->stream == c->own_stream) && c->prm.graph_unroll > 0 && n >= c->prm.graph_unroll && !c->graph_failed;
+    if (use_graph && !c->graph_exec) {
+      // Capture `graph_unroll` iterations once.  Any failure leaves the stream out of capture mode, drops the partial
+      // graph and falls back to direct launches for the life of the ctx (results are identical either way).
+      hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
+      if (e == hipSuccess) {
         for (int i = 0; i < c->prm.graph_unroll; ++i) enqueue_iteration(c, a);
-        HIPCHK(c, hipStreamEndCapture(c->stream, &c->graph));
-        HIPCHK(c, hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0));
+        e = hipStreamEndCapture(c->stream, &c->graph);          // also ends a capture that was invalidated on the way
+        if (e == hipSuccess) e = hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0);
+      }
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        drop_graph(c);
+        c->graph_failed = true;
+        use_graph = false;
+      } else {
         c->graph_iters = c->prm.graph_unroll;
       }
+    }
+    if (use_graph) {
       while (left >= c->graph_iters) {
         HIPCHK(c, hipGraphLaunch(c->graph_exec, c->stream));
         left -= c->graph_iters;
@@ -660,15 +699,20 @@ static int read_impl(gbp_ctx* c, gbp_state_out* o) {
     }
   }
   if (o->damping || o->damping_count || o->robust_flag) {
-    std::vector<float> rec;
-    if (int rc = download_lmsg(c, rec)) return rc;
+    // per-factor scalars ride in the message records: a small kernel extracts them into two compact arrays
+    launch_state_get(P<float4>(c->lmsg), P<float>(c->st_a), P<int>(c->st_b), c->Ep, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<float> damp(c->Ep);
+    std::vector<int32_t> packed(c->Ep);
+    HIPCHK(c, hipMemcpy(damp.data(), c->st_a.p, (size_t)c->Ep * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(packed.data(), c->st_b.p, (size_t)c->Ep * 4, hipMemcpyDeviceToHost));
     for (size_t p = 0; p < c->Ep; ++p) {
       const uint32_t e = c->pos_edge[p];
       if (e == ~0u) continue;
-      const HostState h = get_state(rec, p);
-      if (o->damping) o->damping[e] = h.damping;
-      if (o->damping_count) o->damping_count[e] = h.count;
-      if (o->robust_flag) o->robust_flag[e] = (h.flags & kFlagRobust) ? 1u : 0u;
+      if (o->damping) o->damping[e] = damp[p];
+      if (o->damping_count) o->damping_count[e] = packed[p] >> 3;
+      if (o->robust_flag) o->robust_flag[e] = ((uint32_t)packed[p] & kFlagRobust) ? 1u : 0u;
     }
   }
   return GBP_OK;
@@ -700,17 +744,34 @@ static int new_keyframe_impl(gbp_ctx* c, const gbp_kf_update* u) {
   if (!c || !u || !c->uploaded) return fail(c, GBP_ERR_STATE, "gbp_new_keyframe: upload first");
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (u->damping_count || u->active_flag) {
-    std::vector<float> rec;
-    if (int rc = download_lmsg(c, rec)) return rc;
+    // edit the per-factor scalars in place on the device: 8 bytes per factor go over PCIe, not the 64-byte records
+    std::vector<int32_t> cnt(c->Ep, 0);
+    std::vector<uint32_t> ctl(c->Ep, 0u);
+    const int thr = c->prm.min_linear_iters - c->prm.num_undamped_iters;
     for (size_t p = 0; p < c->Ep; ++p) {
       const uint32_t e = c->pos_edge[p];
       if (e == ~0u) continue;
-      HostState h = get_state(rec, p);
-      if (u->damping_count) h.count = u->damping_count[e];
-      if (u->active_flag) h.flags = (u->active_flag[e] == 1) ? (h.flags | kFlagActive) : (h.flags & ~kFlagActive);
-      put_state(rec, p, h);
+      if (u->damping_count) { cnt[p] = u->damping_count[e]; ctl[p] |= 1u; }
+      if (u->active_flag) {
+        const bool on = u->active_flag[e] == 1;
+        // Hoisted means (k_sweep<HOIST>): a factor's FIRST active sweep measures dmu against the variable's previous
+        // mean where the reference measures it against the factor's own zero-initialised oldmu (ba.cpp:582-583).  The
+        // two agree as long as that sweep cannot relinearise, i.e. count + 1 <= min_linear_iters - num_undamped_iters
+        // (gbp_codelets.cpp:280) — true for the reference's re-arm value -15 (slam.cpp:1040) and its defaults.
+        if (c->hoist && on && !c->active_host[p] && u->damping_count && u->damping_count[e] + 1 > thr)
+          return fail(c, GBP_ERR_INVALID, "gbp_new_keyframe: a factor activated with damping_count + 1 > min_linear_iters - "
+                                          "num_undamped_iters could relinearise on its first sweep; that needs gbp_params.per_factor_mu = 1");
+        ctl[p] |= 2u | (on ? 4u : 0u);
+      }
     }
-    HIPCHK(c, hipMemcpy(c->lmsg.p, rec.data(), rec.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->st_b.p, cnt.data(), (size_t)c->Ep * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->st_a.p, ctl.data(), (size_t)c->Ep * 4, hipMemcpyHostToDevice));
+    launch_state_set(P<float4>(c->lmsg), P<int>(c->st_b), P<uint32_t>(c->st_a), c->Ep, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (u->active_flag)
+      for (size_t p = 0; p < c->Ep; ++p)
+        if (c->pos_edge[p] != ~0u) c->active_host[p] = u->active_flag[c->pos_edge[p]] == 1;
   }
   if (u->cam_priors_eta && u->cam_priors_lambda) {
     std::vector<float> rec;
@@ -758,16 +819,7 @@ static int eval_impl(gbp_ctx* c, gbp_eval_out* o) {
 
 int gbp_timing(gbp_ctx* c, gbp_timing_out* t, int reset) {
   if (!c || !t) return GBP_ERR_INVALID;
-  for (auto& pr : c->pending_sweep_ev) {   // split-phase brackets recorded by gbp_iterate_begin
-    float ms = 0;
-    if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
-      c->sweep_ms += ms;
-      c->timed_iters += 1;
-    }
-    (void)hipEventDestroy(pr.first);
-    (void)hipEventDestroy(pr.second);
-  }
-  c->pending_sweep_ev.clear();
+  drain_sweep_events(c);   // split-phase brackets recorded by gbp_iterate_begin
   t->sweep_ms = c->sweep_ms; t->belief_ms = c->belief_ms; t->total_ms = c->total_ms; t->iterations = c->timed_iters;
   t->algorithmic_bytes_per_iter = 1112ull * c->E_loc + 336ull * c->C + 96ull * c->L_loc;
   t->device_bytes_allocated = c->dev_bytes;
@@ -860,15 +912,17 @@ static int debug_get_impl(gbp_ctx* c, int what, float* a, float* b) {
 int gbp_debug_time_sweep(gbp_ctx* c, int ablation, int reps, double* avg_us) {
   if (!c || !avg_us || reps <= 0 || !c->uploaded) return GBP_ERR_INVALID;
   const SweepArgs a = sweep_args(c);
+  bool built = true;
   auto one = [&]() {
     if (ablation >= 100) {  // 100: k_beliefs, 101: camera part only, 102: landmark part only
       BeliefArgs b = belief_args(c);
       launch_beliefs(b, ablation != 102, ablation != 101, c->stream);
     } else {
-      launch_sweep_ablated(a, c->n_tiles, ablation, c->stream);
+      built = launch_sweep_ablated(a, c->n_tiles, ablation, c->stream) && built;
     }
   };
   one();
+  if (!built) return fail(c, GBP_ERR_INVALID, "gbp_debug_time_sweep: ablated sweeps are compiled only with -DGBP_BUILD_ABLATIONS");
   HIPCHK(c, hipEventRecord(c->ev1, c->stream));
   for (int i = 0; i < reps; ++i) one();
   HIPCHK(c, hipEventRecord(c->ev2, c->stream));

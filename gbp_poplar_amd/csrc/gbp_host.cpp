@@ -133,6 +133,23 @@ void rodrigues_f64(const double* w, double* R) {
     }
 }
 
+
+// counter-based generator for the optional initialisation noise (splitmix64 -> Box-Muller): the reference seeds
+// std::default_random_engine from the clock (dataio.cpp:334,349,406), which no test can pin
+struct NoiseGen {
+  unsigned long long s;
+  explicit NoiseGen(unsigned long long seed) : s(seed) {}
+  unsigned long long next() {
+    s += 0x9E3779B97F4A7C15ull;
+    unsigned long long x = s;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+  }
+  double uni() { return ((double)(next() >> 11) + 0.5) / 9007199254740992.0; }
+  float normal(float sd) { return sd * (float)(std::sqrt(-2.0 * std::log(uni())) * std::cos(6.283185307179586 * uni())); }
+};
+
 }  // namespace
 
 extern "C" {
@@ -382,6 +399,71 @@ int gbp_eval_host(const gbp_problem* p, const uint32_t* active, const float* mea
     ++n;
   }
   *sum_norm = a; *sum_half_sq = b; *n_active = n;
+  return GBP_OK;
+}
+
+// add_cam_trans_noise / add_cam_rot_noise / add_lmk_noise (dataio.cpp:330-415) with an explicit seed.  The first two
+// cameras anchor the gauge and stay exact (dataio.h:114-119, k = 2).  Draw order: translations, rotations, landmarks.
+int gbp_init_add_noise(uint32_t C, uint32_t L, float tn, float rn_deg, float ltn, uint64_t seed, float* cam, float* lmk) {
+  if (!cam || !lmk) return GBP_ERR_INVALID;
+  NoiseGen rng(seed);
+  if (tn != 0.f)
+    for (uint32_t c = 2; c < C; ++c)
+      for (int i = 0; i < 3; ++i) cam[6 * (size_t)c + i] += rng.normal(tn);
+  if (rn_deg != 0.f) {
+    for (uint32_t c = 2; c < C; ++c) {   // dataio.cpp:345-400: rotate the camera-to-world orientation about a random axis
+      const float ang = rng.normal(rn_deg) * (float)M_PI / 180.f;
+      const int axis = (int)(rng.next() % 3);
+      float Rn[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+      const float cs = std::cos(ang), sn = std::sin(ang);
+      if (axis == 0) { Rn[4] = cs; Rn[5] = -sn; Rn[7] = sn; Rn[8] = cs; }
+      else if (axis == 1) { Rn[0] = cs; Rn[2] = sn; Rn[6] = -sn; Rn[8] = cs; }
+      else { Rn[0] = cs; Rn[1] = -sn; Rn[3] = sn; Rn[4] = cs; }
+      float* x = cam + 6 * (size_t)c;
+      const Rot3 Rw2c = rodrigues_host(x + 3);
+      // Tc2w = [R^T, -R^T t]; its rotation block becomes Rn R^T, its translation (the camera centre) is kept
+      float Rc2w[9], ctr[3], Rp[9];
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Rc2w[i * 3 + j] = Rw2c.m[j * 3 + i];
+      for (int i = 0; i < 3; ++i) ctr[i] = -(Rc2w[i * 3] * x[0] + Rc2w[i * 3 + 1] * x[1] + Rc2w[i * 3 + 2] * x[2]);
+      for (int i = 0; i < 3; ++i)      // back to world->camera: R' = (Rn Rc2w)^T
+        for (int j = 0; j < 3; ++j) {
+          float acc = 0.f;
+          for (int k = 0; k < 3; ++k) acc += Rn[j * 3 + k] * Rc2w[k * 3 + i];
+          Rp[i * 3 + j] = acc;
+        }
+      for (int i = 0; i < 3; ++i) x[i] = -(Rp[i * 3] * ctr[0] + Rp[i * 3 + 1] * ctr[1] + Rp[i * 3 + 2] * ctr[2]);
+      const float d = 0.5f * (Rp[0] + Rp[4] + Rp[8] - 1);                 // so3log, util.cpp:34-46
+      const float f = std::acos(d) / (2 * std::sqrt(1 - d * d));
+      x[3] = f * (Rp[7] - Rp[5]);
+      x[4] = f * (Rp[2] - Rp[6]);
+      x[5] = f * (Rp[3] - Rp[1]);
+    }
+  }
+  if (ltn != 0.f)
+    for (size_t i = 0; i < 3 * (size_t)L; ++i) lmk[i] += rng.normal(ltn);
+  return GBP_OK;
+}
+
+// av_depth_init (dataio.cpp:417-453): every landmark starts at the point (0,0,1) of the camera frame of the LOWEST-indexed
+// keyframe observing it (the reference passes av_depth but uses the literal depth 1.0, dataio.cpp:437).  One O(E) pass:
+// the reference's camera-major visiting order picks, for each landmark, its observer with the smallest camera index.
+int gbp_init_av_depth(const gbp_problem* p, const float* cam_mean, float* lmk_mean) {
+  if (!p || !cam_mean || !lmk_mean) return GBP_ERR_INVALID;
+  std::vector<uint32_t> first(p->n_lmks, ~0u);
+  for (uint32_t e = 0; e < p->n_edges; ++e) {
+    if (p->cam_id[e] >= p->n_cams || p->lmk_id[e] >= p->n_lmks) return GBP_ERR_INVALID;
+    first[p->lmk_id[e]] = std::min(first[p->lmk_id[e]], p->cam_id[e]);
+  }
+  std::vector<float> spot(3 * (size_t)p->n_cams);
+  for (uint32_t c = 0; c < p->n_cams; ++c) {
+    const Rot3 R = rodrigues_host(cam_mean + 6 * (size_t)c + 3);
+    const float v[3] = {0.f - cam_mean[6 * (size_t)c], 0.f - cam_mean[6 * (size_t)c + 1], 1.f - cam_mean[6 * (size_t)c + 2]};
+    for (int i = 0; i < 3; ++i) spot[3 * (size_t)c + i] = R.m[i] * v[0] + R.m[3 + i] * v[1] + R.m[6 + i] * v[2];  // R^T (p - t)
+  }
+  for (uint32_t l = 0; l < p->n_lmks; ++l)
+    if (first[l] != ~0u)
+      for (int i = 0; i < 3; ++i) lmk_mean[3 * (size_t)l + i] = spot[3 * (size_t)first[l] + i];
   return GBP_OK;
 }
 

@@ -104,10 +104,12 @@ struct DeviceEval {  // per-block partials, summed on the host in block order
 
 void launch_sweep(const SweepArgs& a, uint32_t n_tiles, bool hoist, hipStream_t s);
 void launch_sweep_blocks(SweepArgs a, uint32_t block0, uint32_t block1, bool hoist, hipStream_t s);
-void launch_sweep_ablated(const SweepArgs& a, uint32_t n_tiles, int abl, hipStream_t s);  // timing experiments only
+bool launch_sweep_ablated(const SweepArgs& a, uint32_t n_tiles, int abl, hipStream_t s);  // timing experiments; false = not built in
 void launch_linearise(const SweepArgs& a, uint32_t n_tiles, hipStream_t s);
 void launch_beliefs(BeliefArgs b, bool do_cam, bool do_lmk, hipStream_t s);
 void launch_weaken(float4* prior, const float* scaling, uint32_t* flag, uint32_t n, int rec4, hipStream_t s);
+void launch_state_get(const float4* lmsg, float* damping, int* packed, uint32_t n, hipStream_t s);
+void launch_state_set(float4* lmsg, const int* new_count, const uint32_t* ctl, uint32_t n, hipStream_t s);
 void launch_means(const float4* camb, const float4* lmkb, float* cam_mu, float* lmk_mu, uint32_t n_cams,
                   uint32_t n_lmks, unsigned long long* health2 /* [0] non-finite means, [1] non-PD beliefs */,
                   bool count_cams, hipStream_t s);

@@ -668,6 +668,35 @@ __global__ __launch_bounds__(256) void k_beliefs(const BeliefArgs b) {
   if (live) b.lmkb[(size_t)l * 4 + q] = acc;
 }
 
+// Per-factor scalar state (damping, damping_count, flags: pad slots 3 / 13 of the LMSG record) <-> compact
+// per-position arrays, so that READ_PROG's damping / damping_count / robust_flag streams (ba.cpp:912-914) and
+// NEW_KEYFRAME's damping_count / active_flag streams (slam.cpp:920,926) move 8 bytes per factor over PCIe instead of the
+// whole 64-byte message record.
+__global__ __launch_bounds__(256) void k_state_get(const float4* __restrict__ lmsg, float* __restrict__ damping,
+                                                   int* __restrict__ packed, uint32_t n) {
+  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  damping[p] = lmsg[(size_t)p * 4].w;
+  packed[p] = __float_as_int(lmsg[(size_t)p * 4 + 3].y);
+}
+// ctl bit 0: damping_count := new_count;  bit 1: active flag := bit 2
+__global__ __launch_bounds__(256) void k_state_set(float4* __restrict__ lmsg, const int* __restrict__ new_count,
+                                                   const uint32_t* __restrict__ ctl, uint32_t n) {
+  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  const uint32_t c = ctl[p];
+  if (!(c & 3u)) return;
+  float4 st = lmsg[(size_t)p * 4 + 3];
+  const int packed = __float_as_int(st.y);
+  int count = packed >> 3;
+  uint32_t flags = (uint32_t)packed & 7u;
+  if (flags & kFlagPad) return;
+  if (c & 1u) count = new_count[p];
+  if (c & 2u) flags = (c & 4u) ? (flags | kFlagActive) : (flags & ~kFlagActive);
+  st.y = __int_as_float((int)(((uint32_t)count << 3) | flags));
+  lmsg[(size_t)p * 4 + 3] = st;
+}
+
 // WeakenPriorVertex: one lane per float4 of a prior record; lane q == 0 updates the flag
 __global__ __launch_bounds__(256) void k_weaken(float4* prior, const float* __restrict__ scaling, uint32_t* flag, uint32_t n,
                                                 int rec4) {
@@ -963,8 +992,14 @@ void launch_sweep_blocks(SweepArgs a, uint32_t block0, uint32_t block1, bool hoi
   if (hoist) hipLaunchKernelGGL(k_sweep<true>, g, b, 0, s, a);
   else hipLaunchKernelGGL(k_sweep<false>, g, b, 0, s, a);
 }
-void launch_sweep_ablated(const SweepArgs& a, uint32_t n_tiles, int abl, hipStream_t s) {
+// Timing-only ablations of the sweep (profiles/ablate_sweep.py): compiled only with -DGBP_BUILD_ABLATIONS, the product
+// library carries the one real instantiation.
+bool launch_sweep_ablated(const SweepArgs& a, uint32_t n_tiles, int abl, hipStream_t s) {
   const dim3 g(n_tiles / kWpb), b(64 * kWpb);
+#ifndef GBP_BUILD_ABLATIONS
+  if (abl != 0) return false;
+  hipLaunchKernelGGL((k_sweep<true, 0>), g, b, 0, s, a);
+#else
   switch (abl) {
     case 1: hipLaunchKernelGGL((k_sweep<true, 1>), g, b, 0, s, a); break;
     case 2: hipLaunchKernelGGL((k_sweep<true, 2>), g, b, 0, s, a); break;
@@ -975,6 +1010,8 @@ void launch_sweep_ablated(const SweepArgs& a, uint32_t n_tiles, int abl, hipStre
     case 32: hipLaunchKernelGGL((k_sweep<true, 32>), g, b, 0, s, a); break;
     default: hipLaunchKernelGGL((k_sweep<true, 0>), g, b, 0, s, a); break;
   }
+#endif
+  return true;
 }
 bool debug_math_widths(int op, int* in_w, int* out_w) {
   static const int iw[9] = {9, 36, 3, 18, 72, 72, 54, 42, 12}, ow[9] = {9, 36, 9, 20, 18, 18, 36, 6, 3};
@@ -1002,6 +1039,12 @@ void launch_beliefs(BeliefArgs b, bool do_cam, bool do_lmk, hipStream_t s) {
 void launch_weaken(float4* prior, const float* scaling, uint32_t* flag, uint32_t n, int rec4, hipStream_t s) {
   hipLaunchKernelGGL(k_weaken, dim3(blocks_for((uint64_t)n * rec4)), dim3(256), 0, s, prior, scaling, flag, n, rec4);
   hipLaunchKernelGGL(k_weaken_flags, dim3(blocks_for(n)), dim3(256), 0, s, flag, n);
+}
+void launch_state_get(const float4* lmsg, float* damping, int* packed, uint32_t n, hipStream_t s) {
+  hipLaunchKernelGGL(k_state_get, dim3(blocks_for(n)), dim3(256), 0, s, lmsg, damping, packed, n);
+}
+void launch_state_set(float4* lmsg, const int* new_count, const uint32_t* ctl, uint32_t n, hipStream_t s) {
+  hipLaunchKernelGGL(k_state_set, dim3(blocks_for(n)), dim3(256), 0, s, lmsg, new_count, ctl, n);
 }
 void launch_means(const float4* camb, const float4* lmkb, float* cam_mu, float* lmk_mu, uint32_t n_cams, uint32_t n_lmks,
                   unsigned long long* health2, bool count_cams, hipStream_t s) {

@@ -26,6 +26,12 @@ class Options:
     first_cam_prior_std: float = 0.01
     steps: float = 5.0
     undamped_start: int = 15
+    # initialisation options, ba.cpp:422-441 (+ --seed: the reference seeds its noise from the clock)
+    tn: float = 0.0
+    rn: float = 0.0
+    ltn: float = 0.0
+    avdepth_on: bool = False
+    seed: int = 0
 
 
 def k_matrix(bal):
@@ -40,6 +46,12 @@ def build_inputs(bal, opts, host, slam=False):
     cam_file = np.asarray(bal["cameras"], dtype=np.float64).astype(np.float32)   # ba.cpp:523-528
     lmk_file = np.asarray(bal["points"], dtype=np.float64).astype(np.float32)    # ba.cpp:529-534
     cam_mean, lmk_mean = cam_file.copy(), lmk_file.copy()                       # no init noise by default
+    if getattr(opts, "tn", 0) or getattr(opts, "rn", 0) or (getattr(opts, "ltn", 0) and not opts.avdepth_on):   # ba.cpp:536-545
+        seed = opts.seed or int.from_bytes(__import__("os").urandom(8), "little")
+        cam_mean, lmk_mean = host.init_add_noise(C, L, cam_mean, lmk_mean, opts.tn, opts.rn,
+                                                 0.0 if opts.avdepth_on else opts.ltn, seed)
+    if getattr(opts, "avdepth_on", False):                                       # ba.cpp:546-548
+        lmk_mean = host.init_av_depth(bal["cam_id"], bal["lmk_id"], C, L, cam_mean, lmk_mean)
     cpe, cpl, lpe, lpl = host.set_prior_lambda(bal["cam_id"], bal["lmk_id"], C, L, K, opts.reproj_meas_var,
                                                cam_file, lmk_file, cam_mean, lmk_mean)
     cs, ls = host.prior_scalings(C, L, cpl, opts.steps, opts.prior_std_weaker_factor, opts.first_cam_prior_std)

@@ -109,6 +109,23 @@ def prior_scalings(n_cams, n_lmks, cam_priors_lambda, steps, weaker, first_std):
     return cs, ls
 
 
+def init_add_noise(n_cams, n_lmks, cam_mean, lmk_mean, trans_std=0.0, rot_std_deg=0.0, lmk_std=0.0, seed=1):
+    """ba.cpp:536-545 -> dataio.cpp:330-415 with an explicit seed; returns noised copies of the prior means."""
+    cam, lmk = _f32(cam_mean).copy(), _f32(lmk_mean).copy()
+    _chk(load().gbp_init_add_noise(int(n_cams), int(n_lmks), float(trans_std), float(rot_std_deg), float(lmk_std),
+                                   int(seed), cabi.ptr(cam, cabi.c_f32p), cabi.ptr(lmk, cabi.c_f32p)), "gbp_init_add_noise")
+    return cam, lmk
+
+
+def init_av_depth(cam_id, lmk_id, n_cams, n_lmks, cam_mean, lmk_mean):
+    """ba.cpp:546-548 -> av_depth_init, dataio.cpp:417-453; returns the new landmark means."""
+    keep = []
+    p = cabi.make_problem(cam_id, lmk_id, n_cams, n_lmks, [0] * 9, keep)
+    cam, lmk = _f32(cam_mean), _f32(lmk_mean).copy()
+    _chk(load().gbp_init_av_depth(C.byref(p), cabi.ptr(cam, cabi.c_f32p), cabi.ptr(lmk, cabi.c_f32p)), "gbp_init_av_depth")
+    return lmk
+
+
 def slam_create_flags(cam_id, lmk_id, n_cams, n_lmks, steps):
     lib = load()
     keep = []

@@ -266,6 +266,14 @@ int gbp_set_prior_lambda(const gbp_problem* problem, float reproj_meas_var,
 int gbp_prior_scalings(uint32_t n_cams, uint32_t n_lmks, const float* cam_priors_lambda,
                        float steps, float prior_std_weaker_factor, float first_cam_prior_std,
                        float* cam_scaling, float* lmk_scaling);
+/* Initialisation options of ba.cpp:536-548.  gbp_init_add_noise = add_cam_trans_noise (--tn, metres), add_cam_rot_noise
+ * (--rn, degrees about a random axis, camera centre kept) and add_lmk_noise (--ltn), dataio.cpp:330-415, on the prior
+ * MEANS in place; cameras 0 and 1 stay exact (dataio.h:114-119).  The reference seeds from the clock; here the seed is
+ * explicit (`--seed`), zero stds draw nothing.  gbp_init_av_depth = av_depth_init (--avdepth_on,
+ * dataio.cpp:417-453): every landmark is placed one unit in front of the lowest-indexed camera observing it. */
+int gbp_init_add_noise(uint32_t n_cams, uint32_t n_lmks, float trans_std, float rot_std_deg, float lmk_std,
+                       uint64_t seed, float* cam_mean /*[6C] in/out*/, float* lmk_mean /*[3L] in/out*/);
+int gbp_init_av_depth(const gbp_problem* problem, const float* cam_mean /*[6C]*/, float* lmk_mean /*[3L] out*/);
 /* SLAM flag bookkeeping (dataio.cpp:455-475, 477-508).  update returns n_new_lmks via out. */
 int gbp_slam_create_flags(const gbp_problem* problem, uint32_t steps, uint32_t* active_flag,
                           uint32_t* cam_weaken_flag, uint32_t* lmk_weaken_flag,

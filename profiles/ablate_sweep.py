@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Timing-only ablations of k_sweep on the S1 graph (see gbp_debug_time_sweep): which stream costs what."""
+"""Timing-only ablations of k_sweep on the S1 graph (see gbp_debug_time_sweep): which stream costs what.
+The ablated instantiations are not part of the product library: rebuild first with
+    GBP_EXTRA_HIPFLAGS=-DGBP_BUILD_ABLATIONS python -m gbp_poplar_amd.build --force
+(and rebuild without the flag afterwards)."""
 import ctypes as C
 import os
 import sys

@@ -1,5 +1,5 @@
-import sys, time
-sys.path.insert(0, "/root/repo")
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from gbp_poplar_amd import driver, hostlib
 from gbp_poplar_amd.engine import GbpEngine

@@ -117,3 +117,35 @@ def test_slam_run_matches_oracle(oracle_mod, oracle_host):
         # 8 iterations per keyframe leave the graph far from converged (errors of 50-100 px): ulp-level
         # differences grow quickly, so only the first keyframes are compared tightly
         assert abs(float(m) - mean) <= (5e-3 if i < 40 else 1e-1) * mean + 1e-4, (i, m, mean)
+
+
+@pytest.mark.gpu
+def test_init_option_flags_are_reproducible_with_a_seed():
+    """--tn / --rn / --ltn with --seed (ba.cpp:422-433,536-545): same seed -> identical run, other seed -> another start;
+    the solver still pulls the perturbed start down to the pixel level."""
+    base = [BA, "--bal_file", seq_path("fr2robot2"), "--n_iters", "60", "--tn", "0.02", "--rn", "0.5", "--ltn", "0.02"]
+    rc1, out1, err1 = run(base + ["--seed", "5"])
+    rc2, out2, _ = run(base + ["--seed", "5"])
+    rc3, out3, _ = run(base + ["--seed", "6"])
+    assert rc1 == rc2 == rc3 == 0, err1
+    strip = lambda s: [l for l in s.splitlines() if not l.startswith(("Total time", " Total time"))]
+    rows1, rows2, rows3 = (LINE.findall(o) for o in (out1, out2, out3))
+    assert len(rows1) == 60 and rows1 == rows2 and rows1 != rows3
+    assert [l for l in strip(out1) if "time" not in l.lower()] == [l for l in strip(out2) if "time" not in l.lower()]
+    for msg in ("to the keyframe translaton intialisations", "to the keyframe rotation intialisations", "to the landmark intialisations"):
+        assert msg in out1                                                     # dataio.cpp:332,347,404
+    init = float(re.search(r"Initial Reprojection error: (\S+)", out1).group(1))
+    clean = float(re.search(r"Initial Reprojection error: (\S+)", run([BA, "--bal_file", seq_path("fr2robot2"), "--n_iters", "1"])[1]).group(1))
+    assert init > 1.2 * clean and float(rows1[-1][1]) < 0.2 * init, (init, clean, rows1[-1])
+
+
+@pytest.mark.gpu
+def test_avdepth_flag():
+    """--avdepth_on 1 (ba.cpp:434-441,546-548): landmarks start one unit in front of their first keyframe (a much worse
+    start than the file values) and the run still converges; it overrides --ltn."""
+    rc, out, err = run([BA, "--bal_file", seq_path("fr2robot2"), "--n_iters", "300", "--avdepth_on", "1", "--ltn", "0.3"])
+    assert rc == 0, err
+    assert "Initialising all landmarks at an average depth of: 1" in out and "to the landmark intialisations" not in out
+    rows = LINE.findall(out)
+    init = float(re.search(r"Initial Reprojection error: (\S+)", out).group(1))
+    assert init > 45.0 and float(rows[-1][1]) < 0.25 * init, (init, rows[-1])

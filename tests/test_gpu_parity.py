@@ -1002,6 +1002,87 @@ def test_non_default_parameters_bit_exact(kw, oracle_mod):
     assert tg[-1][3] == to[-1][3] and tg[-1][4] == to[-1][4]
 
 
+def test_slam_non_default_parameters_and_hoist_guard(oracle_mod):
+    """SLAM flow with non-default hyper-parameters (hoisted means, the default): bit for bit against the oracle.  And
+    the one combination the hoisted path cannot reproduce — a factor that could relinearise on its FIRST active sweep
+    (damping_count + 1 > min_linear_iters - num_undamped_iters) — is refused by gbp_new_keyframe unless the ctx keeps the
+    literal per-factor mu tensors, with which it matches the oracle again."""
+    from gbp_poplar_amd import _cabi, driver, hostlib
+    from gbp_poplar_amd.engine import GbpEngine, GbpError
+    bal = _bal("fr2robot2")
+    opts = driver.Options()
+    K, state, extra = driver.build_inputs(bal, opts, hostlib, slam=True)
+
+    def run(kw, per_factor_mu, n=80):
+        eng = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K,
+                        params=_cabi.GbpParams.defaults(per_factor_mu=per_factor_mu, **kw))
+        orc = oracle_mod.Oracle(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K, params=_cabi.GbpParams.defaults(**kw))
+        orc.set_sum_order(1)
+        tg = driver.run_slam(eng, hostlib, bal, state, extra, opts, iters_between_kfs=20, max_iters=n, eval_every=10)
+        to = driver.run_slam(orc, hostlib, bal, state, extra, opts, iters_between_kfs=20, max_iters=n, eval_every=10)
+        g, o = eng.read(), orc.read()
+        for k in g:
+            assert np.array_equal(g[k], o[k]), (kw, k)
+        assert [t[3:] for t in tg] == [t[3:] for t in to]
+        return sum(t[3] for t in tg)
+
+    oracle_mod.set_trig_mode(1)
+    try:
+        assert run({"dmu_threshold": 3e-2, "maxeta_damping": 0.25, "nstds": 1.5, "num_undamped_iters": 4, "min_linear_iters": 6}, 0) > 0
+        risky = {"dmu_threshold": 10.0, "num_undamped_iters": 20, "min_linear_iters": 0}     # threshold -20 < -15 + 1
+        with pytest.raises(GbpError, match="per_factor_mu"):
+            run(risky, 0)
+        assert run(risky, 1) > 0
+    finally:
+        oracle_mod.set_trig_mode(0)
+
+
+def test_empty_landmark_shard(oracle_mod):
+    """A rank whose landmark range is empty (more ranks than populated landmark ranges) still takes part in every
+    exchange: its kernels run over pad tiles only, its partial sums are zero, the group result is unchanged."""
+    from gbp_poplar_amd import driver, hostlib
+    from gbp_poplar_amd.distributed import ShardedGbp
+    from gbp_poplar_amd.engine import GbpEngine
+    bal = small_synth(n_cams=6, n_lmks=40, obs=3, seed=9)
+    opts = driver.Options()
+    K, state, _ = driver.build_inputs(bal, opts, hostlib)
+    L = bal["n_lmks"]
+    bounds = [0, L, L]                                   # rank 1 owns nothing
+    fake = _FakeDist()
+    shards = []
+    for r in range(2):
+        eng = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], L, K, shard=(r, 2, bounds[r], bounds[r + 1]))
+        sh = ShardedGbp(eng, bal["n_cams"], r, 2, dist=None, device="cuda")
+        fake.members.append(sh)
+        shards.append(sh)
+    plain = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], L, K)
+    plain.upload(state)
+    plain.linearise()
+    for sh in shards:
+        sh.e.upload(state)
+        sh.e.refresh_begin()
+    fake.gather_all()
+    for sh in shards:
+        sh.e.refresh_end()
+        sh.e.linearise_factors()
+    for it in range(6):
+        if it % 2:
+            plain.weaken_priors()
+            for sh in shards:
+                sh.e.weaken_priors()
+        plain.iterate(1)
+        for sh in shards:
+            sh.e.iterate_begin()
+        fake.gather_all()
+        for sh in shards:
+            sh.e.iterate_end()
+    a, b, c = plain.read(), shards[0].read(), shards[1].read()
+    for k in ("cam_beliefs_eta", "cam_beliefs_lambda"):
+        assert np.array_equal(a[k], b[k]) and np.array_equal(a[k], c[k]), k      # one non-empty shard == the plain engine
+    assert np.array_equal(a["lmk_beliefs_eta"], b["lmk_beliefs_eta"])
+    assert shards[1].e.eval()["n_active"] == 0
+
+
 @pytest.mark.parametrize("chunks", [1, 3])
 def test_rccl_single_rank_group_overlap_path(chunks):
     """The exact code path of an N-GPU run (RCCL all_gather_into_tensor with async_op, landmark half overlapped,

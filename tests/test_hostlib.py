@@ -230,3 +230,100 @@ def test_standard_bal_import_errors(tmp_path):
     p.write_text("1 1 1\n0 5 1.0 2.0\n" + "0.0\n" * 12)
     with pytest.raises(IOError):
         hostlib.bal_import_standard(str(p))
+
+
+# ---- initialisation options (ba.cpp:536-548 -> dataio.cpp:330-453), SURVEY 8f-3 ------------------------------------
+
+def _rodrigues(w):
+    th = np.linalg.norm(w)
+    W = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    return np.eye(3) if th < 1e-6 else np.eye(3) + np.sin(th) / th * W + (1 - np.cos(th)) / th ** 2 * (W @ W)
+
+
+def _means(name="fr1xyz"):
+    bal = hostlib.bal_read(seq_path(name))
+    return bal, bal["cameras"].astype(np.float32), bal["points"].astype(np.float32)
+
+
+def test_init_noise_is_reproducible_and_spares_the_anchors():
+    bal, cam, lmk = _means()
+    C, L = bal["n_cams"], bal["n_lmks"]
+    a = hostlib.init_add_noise(C, L, cam, lmk, 0.05, 2.0, 0.1, seed=7)
+    b = hostlib.init_add_noise(C, L, cam, lmk, 0.05, 2.0, 0.1, seed=7)
+    c = hostlib.init_add_noise(C, L, cam, lmk, 0.05, 2.0, 0.1, seed=8)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])            # --seed: same draw
+    assert not np.array_equal(a[0], c[0]) and not np.array_equal(a[1], c[1])
+    assert np.array_equal(a[0][:12], cam[:12])                                  # cameras 0 and 1 anchor the gauge (k = 2)
+    assert np.all(a[0].reshape(-1, 6)[2:, :3] != cam.reshape(-1, 6)[2:, :3])
+    z = hostlib.init_add_noise(C, L, cam, lmk, 0.0, 0.0, 0.0, seed=7)
+    assert np.array_equal(z[0], cam) and np.array_equal(z[1], lmk)              # zero std: nothing is drawn
+    d = (a[1] - lmk).astype(np.float64)
+    assert abs(d.std() - 0.1) < 0.01 and abs(d.mean()) < 0.01                   # N(0, ltn^2) on 6 582 coordinates
+    t_only = hostlib.init_add_noise(C, L, cam, lmk, 0.05, 0.0, 0.0, seed=7)
+    dt = (t_only[0] - cam).reshape(-1, 6)
+    assert np.all(dt[:, 3:] == 0) and abs(dt[2:, :3].std() - 0.05) < 0.02       # --tn touches translations only
+
+
+def test_rotation_noise_keeps_the_camera_centre_and_turns_about_one_axis():
+    """add_cam_rot_noise (dataio.cpp:345-400): Tc2w's rotation block is pre-multiplied by a rotation about a coordinate
+    axis, its translation (the camera centre) is kept, and the result goes back through so3log (util.cpp:34-46)."""
+    bal, cam, lmk = _means("fr2robot2")
+    C = bal["n_cams"]
+    out, _ = hostlib.init_add_noise(C, bal["n_lmks"], cam, lmk, 0.0, 3.0, 0.0, seed=11)
+    angles = []
+    for c in range(2, C):
+        x0, x1 = cam[6 * c:6 * c + 6].astype(np.float64), out[6 * c:6 * c + 6].astype(np.float64)
+        R0, R1 = _rodrigues(x0[3:]), _rodrigues(x1[3:])
+        assert np.allclose(-R0.T @ x0[:3], -R1.T @ x1[:3], atol=2e-5)           # camera centre unchanged
+        Rn = R1.T @ R0                                                          # Rc2w' Rc2w^T = the injected rotation
+        assert np.allclose(Rn @ Rn.T, np.eye(3), atol=1e-5)                     # so3log -> so3exp round trip stays on SO(3)
+        ang = np.degrees(np.arccos(np.clip((np.trace(Rn) - 1) / 2, -1, 1)))
+        axis = np.array([Rn[2, 1] - Rn[1, 2], Rn[0, 2] - Rn[2, 0], Rn[1, 0] - Rn[0, 1]])
+        if ang > 0.05:
+            assert np.sort(np.abs(axis / np.linalg.norm(axis)))[1] < 2e-2       # a coordinate axis
+        angles.append(ang)
+    assert 1.0 < np.sqrt(np.mean(np.square(angles))) < 6.0                      # ~ N(0, 3 deg)
+
+
+@pytest.mark.parametrize("shuffle", [False, True])
+def test_av_depth_init_equals_the_reference_loops(shuffle):
+    """A literal numpy restatement of av_depth_init's camera-major double loop (dataio.cpp:417-453) against the O(E)
+    implementation, also on an UNSORTED edge list."""
+    bal, cam, lmk = _means("fr2robot2")
+    C, L, E = bal["n_cams"], bal["n_lmks"], bal["n_edges"]
+    cid, lid = np.asarray(bal["cam_id"]).copy(), np.asarray(bal["lmk_id"]).copy()
+    if shuffle:
+        p = np.random.default_rng(0).permutation(E)
+        cid, lid = cid[p], lid[p]
+    got = hostlib.init_av_depth(cid, lid, C, L, cam, lmk)
+    want = lmk.copy()
+    done = np.zeros(L, bool)
+    for c in range(C):                                                          # dataio.cpp:424-452
+        x = cam[6 * c:6 * c + 6].astype(np.float64)
+        R = _rodrigues(x[3:])
+        spot = R.T @ (np.array([0.0, 0.0, 1.0]) - x[:3])                        # Tw2c^-1 (0,0,1,1)
+        for e in np.nonzero(cid == c)[0]:
+            if not done[lid[e]]:
+                want[3 * lid[e]:3 * lid[e] + 3] = spot
+                done[lid[e]] = True
+    assert done.all()
+    assert np.allclose(got, want, atol=5e-6)
+    # every landmark now projects to the principal point of its first observer, at depth 1
+    c0 = np.array([np.min(cid[lid == l]) for l in range(L)])
+    for l in (0, L // 2, L - 1):
+        x = cam[6 * c0[l]:6 * c0[l] + 6].astype(np.float64)
+        assert np.allclose(_rodrigues(x[3:]) @ got[3 * l:3 * l + 3] + x[:3], [0, 0, 1], atol=1e-5)
+
+
+def test_build_inputs_applies_the_init_options():
+    bal = hostlib.bal_read(seq_path("fr2robot2"))
+    base = driver.build_inputs(bal, driver.Options(), hostlib)[1]
+    a = driver.build_inputs(bal, driver.Options(tn=0.05, ltn=0.05, seed=3), hostlib)[1]
+    b = driver.build_inputs(bal, driver.Options(tn=0.05, ltn=0.05, seed=3), hostlib)[1]
+    assert np.array_equal(a["cam_priors_eta"], b["cam_priors_eta"]) and np.array_equal(a["lmk_priors_eta"], b["lmk_priors_eta"])
+    assert not np.array_equal(a["cam_priors_eta"], base["cam_priors_eta"])
+    # prior STRENGTH is evaluated at the file values (dataio.cpp:76-116), so Lambda is untouched by the noise
+    assert np.array_equal(a["cam_priors_lambda"], base["cam_priors_lambda"])
+    d = driver.build_inputs(bal, driver.Options(avdepth_on=True, ltn=0.5, seed=3), hostlib)[1]    # --avdepth_on wins over --ltn
+    e = driver.build_inputs(bal, driver.Options(avdepth_on=True), hostlib)[1]
+    assert np.array_equal(d["lmk_priors_eta"], e["lmk_priors_eta"]) and not np.array_equal(e["lmk_priors_eta"], base["lmk_priors_eta"])
