@@ -955,6 +955,118 @@ def test_full_size_s1_properties(s1):
     assert eva[1]["n_nonfinite"] == 0 and eva[1]["n_nonpd"] == 0 and eva[1]["n_active"] == 1000000
 
 
+# ---- BASELINE config 5 at size: 8 000 cams x 1 000 000 lmks x 10 000 000 factors, 8 landmark shards ------------------------
+
+def test_config5_at_size_eight_shards_on_one_gpu(oracle_mod):
+    """The graph of BASELINE config 5 through the SHARDED kernels: eight landmark-shard contexts (what the eight ranks
+    of an 8-GPU run hold) on one GPU, camera partial sums exchanged by device copies (what the RCCL all-gather moves).
+      * LINEARISE + 2 sweeps (one prior weakening): every belief and the damping / robust state bit for bit against the
+        oracle in 8-shard order;
+      * against the unsharded engine on the same graph: <= 2e-6 per sweep (only the association order of the camera
+        sums differs: rows of 16 per shard, then rank order);
+      * run-to-run determinism (second run from a fresh upload on the same contexts: identical bits);
+      * 50 iterations of the ./ba flow converge to the pixel-noise floor (RMSE ~1.30 px), no non-finite / non-PD belief."""
+    from gbp_poplar_amd import driver, hostlib
+    from gbp_poplar_amd.distributed import ShardedGbp, landmark_partition
+    from gbp_poplar_amd.engine import GbpEngine
+    world = 8
+    bal = hostlib.synth_generate(8000, 1000000, 10, 20200303)
+    C, L, E = bal["n_cams"], bal["n_lmks"], bal["n_edges"]
+    assert (C, L, E) == (8000, 1000000, 10000000)
+    opts = driver.Options()
+    K, state, _ = driver.build_inputs(bal, opts, hostlib)
+    bounds = landmark_partition(bal["lmk_id"], L, world)
+    lmk = np.asarray(bal["lmk_id"])
+    per_shard = np.diff(np.searchsorted(np.sort(lmk), bounds))
+    assert per_shard.sum() == E and per_shard.max() - per_shard.min() <= 20           # balanced by factor count
+    fake = _FakeDist()
+    shards = []
+    for r in range(world):
+        eng = GbpEngine(bal["cam_id"], bal["lmk_id"], C, L, K, shard=(r, world, int(bounds[r]), int(bounds[r + 1])))
+        sh = ShardedGbp(eng, C, r, world, dist=None, device="cuda")
+        sh._exchange = lambda: None
+        fake.members.append(sh)
+        shards.append(sh)
+
+    def all_do(name, *a):
+        for sh in shards:
+            getattr(sh.e, name)(*a)
+
+    def group_start():
+        all_do("upload", state)
+        all_do("refresh_begin"); fake.gather_all(); all_do("refresh_end"); all_do("linearise_factors")
+
+    def group_iterate(n, first=0):
+        for it in range(first, first + n):
+            if (it + 1) % 2 == 0 and it < 10:
+                all_do("weaken_priors")
+            all_do("iterate_begin")
+            if it % 2:
+                all_do("iterate_local")
+            fake.gather_all()
+            all_do("iterate_end")
+
+    def group_read():
+        out = shards[0].read()
+        for r, sh in enumerate(shards[1:], 1):
+            g = sh.read()
+            assert np.array_equal(g["cam_beliefs_eta"], out["cam_beliefs_eta"])       # replicated cameras: identical on all ranks
+            assert np.array_equal(g["cam_beliefs_lambda"], out["cam_beliefs_lambda"])
+            lo, hi = int(bounds[r]), int(bounds[r + 1])
+            out["lmk_beliefs_eta"][3 * lo:3 * hi] = g["lmk_beliefs_eta"][3 * lo:3 * hi]
+            out["lmk_beliefs_lambda"][9 * lo:9 * hi] = g["lmk_beliefs_lambda"][9 * lo:9 * hi]
+            own = (lmk >= lo) & (lmk < hi)
+            for k in ("damping", "damping_count", "robust_flag"):
+                out[k][own] = g[k][own]
+        return out
+
+    group_start()
+    group_iterate(2)
+    g = group_read()
+
+    oracle_mod.set_trig_mode(1)
+    try:
+        orc = oracle_mod.Oracle(bal["cam_id"], bal["lmk_id"], C, L, K)
+        orc.set_sum_order(1, bounds)
+        orc.upload(state)
+        orc.linearise()
+        orc.iterate(1)
+        orc.weaken_priors()
+        orc.iterate(1)
+        o = orc.read()
+        orc.close()
+        del orc
+    finally:
+        oracle_mod.set_trig_mode(0)
+    for k in g:
+        assert np.array_equal(g[k], o[k]), k
+
+    plain = GbpEngine(bal["cam_id"], bal["lmk_id"], C, L, K)
+    plain.upload(state)
+    plain.linearise()
+    plain.iterate(1)
+    plain.weaken_priors()
+    plain.iterate(1)
+    p = plain.read()
+    plain.close()
+    for k, w in (("cam_beliefs_eta", 6), ("cam_beliefs_lambda", 36), ("lmk_beliefs_eta", 3), ("lmk_beliefs_lambda", 9)):
+        assert per_var_rel(g[k], p[k], w) <= 4e-6, (k, per_var_rel(g[k], p[k], w))   # 2 sweeps x 2e-6
+    assert np.array_equal(g["damping_count"], p["damping_count"]) and np.array_equal(g["robust_flag"], p["robust_flag"])
+
+    group_start()                       # determinism: the same two sweeps again from a fresh upload
+    group_iterate(2)
+    g2 = group_read()
+    for k in g:
+        assert np.array_equal(g[k], g2[k]), ("determinism", k)
+
+    group_iterate(48, first=2)          # ... and on to 50 iterations of the ./ba flow
+    evs = [sh.e.eval() for sh in shards]
+    tot = {k: sum(e[k] for e in evs) for k in evs[0]}
+    m = driver.metric(tot)
+    assert tot["n_active"] == E and tot["n_nonfinite"] == 0 and tot["n_nonpd"] == 0
+    assert 1.25 < m[2] < 1.40, m        # RMSE at the 1 px pixel-noise floor (S1: 1.30)
+
+
 def test_ba_mp_front_end_single_gpu(capsys):
     """`python -m gbp_poplar_amd.ba_mp` (the --ipus/--gpus N front end) on one GPU prints the ba lines and converges."""
     from gbp_poplar_amd import ba_mp
