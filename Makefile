@@ -12,8 +12,8 @@ HIPFLAGS := -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=$(ARCH) -Wall 
 
 all: $(LIB) $(PKG)/bin/ba $(PKG)/bin/slam $(PKG)/bin/bal_convert
 
-$(LIB): $(CSRC)/gbp_kernels.hip $(CSRC)/gbp_capi.cpp $(CSRC)/gbp_host.cpp $(CSRC)/gbp_kernels.h $(CSRC)/gbp_device_math.hpp include/gbp_mi355x.h
-	$(HIPCC) -shared -o $@ $(HIPFLAGS) -x hip $(CSRC)/gbp_kernels.hip $(CSRC)/gbp_capi.cpp $(CSRC)/gbp_host.cpp
+$(LIB): $(CSRC)/gbp_kernels.hip $(CSRC)/gbp_capi.cpp $(CSRC)/gbp_comm.cpp $(CSRC)/gbp_comm.hpp $(CSRC)/gbp_host.cpp $(CSRC)/gbp_kernels.h $(CSRC)/gbp_device_math.hpp include/gbp_mi355x.h
+	$(HIPCC) -shared -o $@ $(HIPFLAGS) -x hip $(CSRC)/gbp_kernels.hip $(CSRC)/gbp_capi.cpp $(CSRC)/gbp_comm.cpp $(CSRC)/gbp_host.cpp -ldl
 
 $(PKG)/bin/%: $(CSRC)/%_main.cpp $(CSRC)/cli_common.hpp $(LIB)
 	@mkdir -p $(PKG)/bin

@@ -73,7 +73,10 @@ def parse(argv=None):
     ap.add_argument("--keep-pmc", default=None, help="keep the rocprofv3 PMC output of the live passes in this directory")
     ap.add_argument("--force-sharded", action="store_true",
                     help="diagnostic: run the N>1 code path (shard ctx, RCCL all_gather, overlap) even with one rank")
-    ap.add_argument("--sharded-graph", type=int, default=0, help="capture sharded iterations (kernels + RCCL) in a hipGraph")
+    ap.add_argument("--comm", choices=["native", "torch"], default="native",
+                    help="N > 1: who runs the all-gather — the C++ library's own RCCL communicator (gbp_comm_init_rccl; "
+                         "sharded iteration captured in a hipGraph) or torch.distributed around the split-phase C-ABI")
+    ap.add_argument("--sharded-graph", type=int, default=0, help="--comm torch: capture sharded iterations (kernels + RCCL) in a hipGraph")
     ap.add_argument("--exchange-chunks", type=int, default=None,
                     help="camera ranges of the pipelined all-gather (default: 1)")
     ap.add_argument("--tile-order", type=int, default=0, help="gbp_params.tile_order: 0 = default, 1 = sequential, 2 = sweep tiles XCD-aware too")
@@ -386,20 +389,39 @@ def main(argv=None):
     K, state, _ = driver.build_inputs(bal, opts, hostlib)
 
     prm = _cabi.GbpParams.defaults(tile_order=a.tile_order)
+    comm_error, exchange_kind = None, None
     if not sharded:
         eng = GbpEngine(bal["cam_id"], bal["lmk_id"], C, L, K, params=prm)
         run = eng
+        run_eval = eng.eval
         e_local = E
     else:
         bounds = landmark_partition(bal["lmk_id"], L, world)
         eng = GbpEngine(bal["cam_id"], bal["lmk_id"], C, L, K, params=prm,
                         shard=(rank, world, int(bounds[rank]), int(bounds[rank + 1])))
-        run = ShardedGbp(eng, C, rank, world, dist=dist, device="cuda", always_collective=a.force_sharded,
-                         use_graph=bool(a.sharded_graph), chunks=a.exchange_chunks)
         e_local = int(((bal["lmk_id"] >= bounds[rank]) & (bal["lmk_id"] < bounds[rank + 1])).sum())
+        run = None
+        if a.comm == "native":
+            # the exchange lives in the C++ library: rank 0 draws the RCCL id, torch.distributed only carries it around
+            try:
+                idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+                if rank == 0:
+                    idt.copy_(torch.frombuffer(bytearray(eng.comm_unique_id()), dtype=torch.uint8))
+                dist.broadcast(idt, src=0)
+                eng.comm_init_rccl(bytes(idt.cpu().numpy().tobytes()))
+                run = eng
+                run_eval = eng.eval_global
+                exchange_kind = "native: ncclAllGather issued by libgbp_mi355x.so (C++ host), overlapped with the landmark beliefs"
+            except Exception as exc:  # noqa: BLE001 — fall back to the torch.distributed exchange, and say so
+                comm_error = repr(exc)
+        if run is None:
+            run = ShardedGbp(eng, C, rank, world, dist=dist, device="cuda", always_collective=a.force_sharded,
+                             use_graph=bool(a.sharded_graph), chunks=a.exchange_chunks)
+            run_eval = run.eval
+            exchange_kind = "torch.distributed all_gather_into_tensor around the split-phase C-ABI"
     run.upload(state)
     run.linearise()
-    ev0 = run.eval()
+    ev0 = run_eval()
     warm_start(run, opts, a.warmup)
     if getattr(run, "use_graph", False):
         run.iterate(run.graph_unroll + 3)      # un-timed: triggers the one-off capture of the sharded iteration graph
@@ -420,10 +442,10 @@ def main(argv=None):
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    ev1 = run.eval()
+    ev1 = run_eval()
 
     # ---- roofline of the dominant kernel (k_sweep), measured live with hipEvents on its stream ----
-    graph_used = (getattr(run, "graph", None) is not None) if hasattr(run, "use_graph") else None
+    graph_used = (getattr(run, "graph", None) is not None) if hasattr(run, "use_graph") else (eng.graph_state() == 1)
     roof = None
     if a.profile_steps > 0:
         eng.timing(reset=True)
@@ -434,6 +456,8 @@ def main(argv=None):
                 run.use_graph, run.graph = False, None
             run.iterate(a.profile_steps)
             fence()
+            if run is eng:
+                eng.sync()
         else:
             eng.iterate(a.profile_steps)
             eng.sync()
@@ -504,7 +528,7 @@ def main(argv=None):
                        "mean_reproj_px_final": round(m1[0], 6), "iterations_run": a.warmup + a.steps,
                        "nonfinite_beliefs": int(ev1["n_nonfinite"]),
                        "exchange_chunks": getattr(run, "chunks", None),
-                       "sharded_graph": graph_used,
+                       "iteration_graph": graph_used, "exchange": exchange_kind, "comm_error": comm_error,
                        "sharded_graph_error": getattr(run, "graph_error", None)},
         }
         if roof:

@@ -37,6 +37,19 @@ _SIGS = {
     "gbp_refresh_begin": (C.c_int, [C.c_void_p]),
     "gbp_refresh_end": (C.c_int, [C.c_void_p]),
     "gbp_linearise_factors": (C.c_int, [C.c_void_p]),
+    "gbp_device_count": (C.c_int, []),
+    "gbp_set_device": (C.c_int, [C.c_int]),
+    "gbp_landmark_partition": (C.c_int, [C.POINTER(cabi.GbpProblem), C.c_int, cabi.c_u32p]),
+    "gbp_comm_region_abort": (None, [C.c_void_p]),
+    "gbp_comm_region_bytes": (C.c_size_t, [C.c_uint32, C.c_int]),
+    "gbp_comm_region_init": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32, C.c_int]),
+    "gbp_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "gbp_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "gbp_comm_init_rccl": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "gbp_comm_transport": (C.c_char_p, [C.c_void_p]),
+    "gbp_graph_state": (C.c_int, [C.c_void_p]),
+    "gbp_comm_barrier": (C.c_int, [C.c_void_p]),
+    "gbp_eval_global": (C.c_int, [C.c_void_p, C.POINTER(cabi.GbpEvalOut)]),
     "gbp_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "gbp_debug_get": (C.c_int, [C.c_void_p, C.c_int, cabi.c_f32p, cabi.c_f32p]),
     "gbp_debug_time_sweep": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]),

@@ -16,7 +16,7 @@ LIB = os.path.join(HERE, "libgbp_mi355x.so")
 BIN = os.path.join(HERE, "bin")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function"]
-LIB_SRCS = ["gbp_kernels.hip", "gbp_capi.cpp", "gbp_host.cpp"]
+LIB_SRCS = ["gbp_kernels.hip", "gbp_capi.cpp", "gbp_comm.cpp", "gbp_host.cpp"]
 CLI_SRCS = {"ba": "ba_main.cpp", "slam": "slam_main.cpp", "bal_convert": "bal_convert_main.cpp"}
 
 
@@ -39,7 +39,7 @@ def build(force=False, verbose=False):
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "gbp_mi355x.h")]
     if force or _stale(LIB, deps):
         extra = os.environ.get("GBP_EXTRA_HIPFLAGS", "").split()     # experiments only (e.g. -DGBP_FAC_TEMPORAL)
-        cmd = [cc, "-shared", "-o", LIB] + FLAGS + extra + ["-x", "hip"] + [os.path.join(CSRC, s) for s in LIB_SRCS]
+        cmd = [cc, "-shared", "-o", LIB] + FLAGS + extra + ["-x", "hip"] + [os.path.join(CSRC, s) for s in LIB_SRCS] + ["-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -3,12 +3,7 @@
 // engine replaced by the C-ABI: WRITE -> LINEARISE -> READ -> loop {WEAKEN_PRIORS?, GBP, READ, eval}.
 #include "cli_common.hpp"
 
-int main(int argc, char** argv) {
-  cli::Options o;
-  const int pr = cli::parse(argc, argv, /*slam=*/false, o);
-  if (pr) return pr == 1 ? 0 : 1;
-  cli::Problem P;
-  if (cli::load_problem(o, P)) return 1;
+static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
   const uint32_t C = P.bal.n_cams, L = P.bal.n_lmks, E = P.bal.n_edges;
 
   std::cout << "\nBundle Adjustment\n";                       // ba.cpp:587-590
@@ -18,14 +13,10 @@ int main(int argc, char** argv) {
   std::cout << "\nNumber of keyframe nodes in the graph: " << C << '\n';
   std::cout << "Number of landmark nodes in the graph: " << L << '\n';
   std::cout << "Number of edges in the graph: " << E << '\n';
-  if (o.gpus > 1) std::cout << "note: --gpus/--ipus > 1 runs one process per GPU (see bench.py / gbp_poplar_amd.distributed); this binary uses 1 GPU\n";
-  std::cout << "\nNumber of GPUs: 1\n\nAttaching to GPU device..." << std::endl;
+  std::cout << "\nNumber of GPUs: " << rk.world << "\n\nAttaching to GPU device..." << std::endl;
 
   gbp_ctx* ctx = nullptr;
-  if (gbp_create(&P.prob, nullptr, nullptr, &ctx) != GBP_OK) {
-    std::cout << "Could not find a device\n" << gbp_last_error(nullptr) << "\n";  // ba.cpp:652-655
-    return 255;
-  }
+  if (const int rc = cli::create_rank_ctx(o, P, rk, &ctx)) return rc;
   const auto t0 = std::chrono::steady_clock::now();
   std::cout << "Running program to stream initial data to GPU\n";
   const gbp_state_in in = cli::state_in(P);
@@ -36,7 +27,7 @@ int main(int argc, char** argv) {
 
   cli::Readback rb(C, L);
   gbp_eval_out ev{};
-  CLI_CHECK(ctx, gbp_eval(ctx, &ev));
+  CLI_CHECK(ctx, gbp_eval_global(ctx, &ev));
   std::cout << "Initial Reprojection error: " << (float)(ev.sum_norm / (double)ev.n_active) << " Cost " << (float)ev.sum_half_sq << "\n";
   std::cout << "Number of iterations: " << o.n_iters << "\n";
 
@@ -56,7 +47,7 @@ int main(int argc, char** argv) {
     i += burst - 1;
     iter += burst - 1;
     if ((i + 1) % o.eval_every == 0 || i + 1 == o.n_iters) {
-      CLI_CHECK(ctx, gbp_eval(ctx, &ev));
+      CLI_CHECK(ctx, gbp_eval_global(ctx, &ev));
       std::cout << "Iter " << iter << " // Reprojection error " << (float)(ev.sum_norm / (double)ev.n_active);
       std::cout << " // Cost " << (float)ev.sum_half_sq << " // n relins: " << ev.n_relin;
       std::cout << " // n robust edges " << ev.n_robust << "\n";
@@ -77,4 +68,14 @@ int main(int argc, char** argv) {
   if (o.profile) cli::write_profile(ctx, "ba", wall, o.n_iters);
   gbp_destroy(ctx);
   return 0;
+}
+
+int main(int argc, char** argv) {
+  cli::Options o;
+  const int pr = cli::parse(argc, argv, /*slam=*/false, o);
+  if (pr) return pr == 1 ? 0 : 1;
+  cli::Problem P;
+  if (cli::load_problem(o, P)) return 1;          // host only: the ranks are forked before anything touches HIP
+  const int world = cli::round_up_pow2(std::max(1, o.gpus));   // ba.cpp:617-621
+  return cli::run_ranks(world, P.bal.n_cams, o.force_sharded, [&](cli::RankCtx& rk) { return run(o, P, rk); });
 }

@@ -6,7 +6,9 @@
 // replaced by a small `--name value` / `--name=value` parser.  Differences, all deliberate:
 //   * `--help` prints the options and exits 0 (the reference throws an uncaught exception, ba.cpp:469-472);
 //   * a malformed data file is an error (the reference only prints "Invalid UW data file.");
-//   * `--ipus N` is kept as an alias of `--gpus N`; `--camspertile` is accepted and ignored;
+//   * `--ipus N` is kept as an alias of `--gpus N`: N > 1 starts one process per GPU (forked before anything touches
+//     HIP), landmark-sharded, camera partial sums all-gathered once per iteration by RCCL over xGMI
+//     (ba.cpp:414-417,617-649 spread one Poplar graph over N x 1216 tiles); `--camspertile` is accepted and ignored;
 //   * `--seed S` makes the initialisation-noise flags reproducible (the reference seeds from the clock,
 //     dataio.cpp:334,349,406); `--eval_every K` thins the per-iteration read-back + metric (default 1).
 #pragma once
@@ -22,6 +24,11 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+
+#include <signal.h>
+#include <sys/mman.h>
+#include <sys/wait.h>
+#include <unistd.h>
 
 namespace cli {
 
@@ -43,6 +50,8 @@ struct Options {
   bool verbose = false;
   unsigned long long seed = 0;
   int eval_every = 1;
+  int transport = 0;            // --transport: 0 auto, 1 RCCL, 2 host-staged (ranks sharing a GPU)
+  bool force_sharded = false;   // --force_sharded: run the multi-rank code path (fork, shard ctx, communicator) with one rank
 };
 
 inline void usage(bool slam) {
@@ -66,7 +75,8 @@ inline void usage(bool slam) {
                "  --undamped_start arg (=15)     Number of undamped iterations before damping GBP\n"
                "  --v arg (=0)                   Verbose: print beliefs\n"
                "  --seed arg (=0)                seed of the initialisation noise (0 = from the clock)\n"
-               "  --eval_every arg (=1)          read back + evaluate every K iterations\n";
+               "  --eval_every arg (=1)          read back + evaluate every K iterations\n"
+               "  --transport arg (=auto)        exchange between ranks: auto | rccl | host (ranks sharing one GPU)\n";
 }
 
 // returns 0 = run, 1 = exit with code 0 (help), 2 = exit with code 1 (error)
@@ -107,6 +117,8 @@ inline int parse(int argc, char** argv, bool slam, Options& o) {
       else if (k == "v") o.verbose = B(v);
       else if (k == "seed") o.seed = std::stoull(v);
       else if (k == "eval_every") o.eval_every = std::max(1, std::stoi(v));
+      else if (k == "force_sharded") o.force_sharded = B(v);
+      else if (k == "transport") o.transport = v == "rccl" ? 1 : (v == "host" ? 2 : (v == "auto" ? 0 : std::stoi(v)));
       else { std::cerr << "unrecognised option '--" << k << "'\n"; return 2; }
     }
   } catch (const std::exception&) {
@@ -211,6 +223,94 @@ inline void print_verbose(const Readback& r) {  // ba.cpp:1030-1051
   for (unsigned i = 0; i < 18; ++i) std::printf("%.12f  ", r.lbl[i]);
   std::cout << '\n';
   std::fflush(stdout);
+}
+
+// ---- one process per GPU (`--ipus N` / `--gpus N`) -------------------------------------------------------------------
+struct RankCtx {
+  int rank = 0, world = 1;
+  void* region = nullptr;       // shared rendezvous / staging region (gbp_comm_region_*), world > 1 only
+  gbp_shard shard{0, 1, 0, 0};
+};
+
+inline int round_up_pow2(int n) {   // ba.cpp:617-621: nIPUs is rounded up to a power of two
+  int p = 1;
+  while (p < n) p *= 2;
+  return p;
+}
+
+// Creates the ctx of this rank on its GPU, landmark-sharded for world > 1, with the communicator attached.
+inline int create_rank_ctx(const Options& o, const Problem& P, RankCtx& rk, gbp_ctx** ctx) {
+  const int ndev = gbp_device_count();
+  if (ndev <= 0) {
+    std::cout << "Could not find a device\n";                      // ba.cpp:652-655
+    return 255;
+  }
+  const bool sharded = rk.region != nullptr;
+  if (sharded) {
+    if (gbp_set_device(rk.rank % ndev) != GBP_OK) { std::cout << "Could not find a device\n" << gbp_last_error(nullptr) << "\n"; return 255; }
+    std::vector<uint32_t> bounds((size_t)rk.world + 1);
+    gbp_landmark_partition(&P.prob, rk.world, bounds.data());
+    rk.shard = gbp_shard{rk.rank, rk.world, bounds[rk.rank], bounds[rk.rank + 1]};
+  } else {
+    rk.shard = gbp_shard{0, 1, 0, P.bal.n_lmks};
+  }
+  if (gbp_create(&P.prob, nullptr, sharded ? &rk.shard : nullptr, ctx) != GBP_OK) {
+    std::cout << "Could not find a device\n" << gbp_last_error(nullptr) << "\n";
+    return 255;
+  }
+  if (sharded) {
+    if (gbp_comm_init(*ctx, rk.region, o.transport) != GBP_OK) {
+      std::cerr << "rank " << rk.rank << ": " << gbp_last_error(*ctx) << "\n";
+      return 1;
+    }
+    std::cout << "Exchange between the " << rk.world << " ranks: " << gbp_comm_transport(*ctx)
+              << (ndev < rk.world ? " (fewer GPUs than ranks: ranks share a GPU)" : "") << "\n";
+  }
+  return 0;
+}
+
+// Runs body(rank) in `world` processes forked from this one — which must not have touched HIP yet — and supervises them:
+// the exit status is the first failing rank's, and a rank that dies wakes the others out of their barriers.
+template <class F> int run_ranks(int world, uint32_t n_cams, bool force, F&& body) {
+  RankCtx rk;
+  if (world <= 1 && !force) return body(rk);
+  if (!std::getenv("HSA_ENABLE_IPC_MODE_LEGACY")) setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 1);   // dmabuf IPC for RCCL
+  const size_t bytes = gbp_comm_region_bytes(n_cams, world);
+  void* region = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+  if (region == MAP_FAILED || gbp_comm_region_init(region, bytes, n_cams, world) != GBP_OK) {
+    std::cerr << "could not create the shared region of the ranks\n";
+    return 1;
+  }
+  std::cout.flush();
+  std::fflush(nullptr);
+  std::vector<pid_t> pid((size_t)world, -1);
+  for (int r = 0; r < world; ++r) {
+    pid[r] = fork();
+    if (pid[r] < 0) { std::cerr << "fork failed\n"; gbp_comm_region_abort(region); break; }
+    if (pid[r] == 0) {
+      rk.rank = r; rk.world = world; rk.region = region;
+      if (r != 0 && !std::freopen("/dev/null", "w", stdout)) std::_Exit(1);     // rank 0 prints (ba.cpp:996,1026-1028)
+      int rc = 1;
+      try { rc = body(rk); } catch (const std::exception& e) { std::cerr << "rank " << r << ": " << e.what() << "\n"; }
+      std::cout.flush();
+      std::fflush(nullptr);
+      std::_Exit(rc);
+    }
+  }
+  int status = 0, left = 0, first_bad = 0;
+  for (pid_t p : pid) left += p > 0;
+  while (left > 0) {
+    const pid_t p = wait(&status);
+    if (p < 0) break;
+    --left;
+    const int code = WIFEXITED(status) ? WEXITSTATUS(status) : 128 + (WIFSIGNALED(status) ? WTERMSIG(status) : 0);
+    if (code != 0 && first_bad == 0) {
+      first_bad = code;
+      gbp_comm_region_abort(region);            // the others leave their barriers with an error instead of waiting
+    }
+  }
+  munmap(region, bytes);
+  return first_bad;
 }
 
 #define CLI_CHECK(ctx, call)                                                              \

@@ -7,6 +7,7 @@
 // into device order, builds the tile-coalesced arrays the kernels stream, and records the launch
 // sequence of one iteration as a hipGraph.
 #include "../../include/gbp_mi355x.h"
+#include "gbp_comm.hpp"
 #include "gbp_kernels.h"
 
 #include <hip/hip_runtime.h>
@@ -52,6 +53,13 @@ struct gbp_ctx {
   bool hoist = true;  // per-variable belief means (k_sweep<true>); false = literal per-factor mu/oldmu tensors
   void* send_dev = nullptr;
   void* recv_dev = nullptr;
+  // library-owned exchange (gbp_comm_init*): communicator, buffers, a second stream so the all-gather overlaps the
+  // rank-local landmark half of the belief update (fork / join through two events: capturable into the hipGraph)
+  gbp::Comm* comm = nullptr;
+  DevBuf xsend, xrecv;
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int comm_warm = 0;                   // sharded iterations run directly so far (RCCL must have run before a capture)
   hipStream_t own_stream = nullptr, stream = nullptr;
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
@@ -131,12 +139,15 @@ BeliefArgs belief_args(gbp_ctx* c) {
   return b;
 }
 
+// does this ctx combine camera partials through exchange buffers (sharded, or a 1-rank communicator)?
+inline bool exch(const gbp_ctx* c) { return c->world > 1 || c->comm != nullptr; }
+
 // camera beliefs from stored partials (single GPU: d_local; multi: recv_dev) + landmark beliefs re-summed.
 // roll = true at the end of an iteration (the sweep has consumed the current means), false for
 // prior-only refreshes (WEAKEN_PRIORS, NEW_KEYFRAME, LINEARISE).
 int refresh_beliefs_from_partials(gbp_ctx* c, bool roll, bool do_lmk = true) {
   BeliefArgs b = belief_args(c);
-  if (c->world == 1) {
+  if (!exch(c)) {
     b.gathered = P<float>(c->local); b.world = 1;
   } else {
     if (!c->recv_dev) return fail(c, GBP_ERR_STATE, "exchange buffers not set");
@@ -247,6 +258,10 @@ const char* gbp_last_error(const gbp_ctx* ctx) { return ctx ? ctx->err.c_str() :
 void gbp_destroy(gbp_ctx* c) {
   if (!c) return;
   drop_graph(c);
+  if (c->comm) { (void)hipStreamSynchronize(c->stream); if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream); delete c->comm; c->comm = nullptr; }
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
   for (auto& pr : c->pending_sweep_ev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   for (DevBuf* b : c->all) if (b->p) (void)hipFree(b->p);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -475,7 +490,7 @@ static int upload_impl(gbp_ctx* c, const gbp_state_in* in) {
     HIPCHK(c, hipMemcpy(c->lscale.p, in->lmk_scaling ? in->lmk_scaling + c->lmk_begin : zf.data(), (size_t)c->L_loc * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->lwf.p, in->lmk_weaken_flag ? in->lmk_weaken_flag + c->lmk_begin : zu.data(), (size_t)c->L_loc * 4, hipMemcpyHostToDevice));
   }
-  if (c->world > 1 && c->recv_dev) HIPCHK(c, hipMemsetAsync(c->recv_dev, 0, (size_t)c->world * c->C * kCamRec * 4, c->stream));
+  if (exch(c) && c->recv_dev) HIPCHK(c, hipMemsetAsync(c->recv_dev, 0, (size_t)c->world * c->C * kCamRec * 4, c->stream));
   c->uploaded = true;
   c->beliefs_valid = false;
   return GBP_OK;
@@ -483,7 +498,7 @@ static int upload_impl(gbp_ctx* c, const gbp_state_in* in) {
 
 int gbp_refresh_begin(gbp_ctx* c) {
   if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "upload first");
-  float4* dst = c->world > 1 ? static_cast<float4*>(c->send_dev) : P<float4>(c->local);
+  float4* dst = exch(c) ? static_cast<float4*>(c->send_dev) : P<float4>(c->local);
   if (!dst) return fail(c, GBP_ERR_STATE, "exchange buffers not set");
   enqueue_cam_partials(c, reinterpret_cast<float*>(dst));
   HIPCHK(c, hipGetLastError());
@@ -504,11 +519,119 @@ int gbp_linearise_factors(gbp_ctx* c) {
   return GBP_OK;
 }
 
+// ---- sharded ctx with a library-owned communicator (gbp_comm_init*) ----------------------------------------------------
+#define COMMCHK(ctx, expr)                                                       \
+  do {                                                                           \
+    std::string e_;                                                              \
+    if ((expr) != 0) return fail(ctx, GBP_ERR_COMM, "exchange: " + e_);          \
+  } while (0)
+
+// plain exchange on the ctx's stream (LINEARISE, refreshes): partials in send_dev -> recv_dev of every rank
+static int exchange_now(gbp_ctx* c) {
+  COMMCHK(c, c->comm->all_gather(static_cast<const float*>(c->send_dev), static_cast<float*>(c->recv_dev),
+                                 (size_t)c->C * kCamRec, c->stream, e_));
+  return GBP_OK;
+}
+
+// One iteration of a sharded ctx: sweep + local camera partials, the ALL-GATHER of the partials on the communication
+// stream while the rank-local landmark half of the belief update runs, then the camera combine.  With a stream-ordered
+// transport (RCCL) nothing here blocks the host, so the sequence can be captured into a hipGraph.
+static int enqueue_sharded_iteration(gbp_ctx* c, const SweepArgs& a) {
+  if (c->profile_stages) {
+    if (c->pending_sweep_ev.size() >= 256) drain_sweep_events(c);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIPCHK(c, hipEventCreate(&e0));
+    if (hipError_t e_ = hipEventCreate(&e1); e_ != hipSuccess) {
+      (void)hipEventDestroy(e0);
+      return fail(c, GBP_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e_));
+    }
+    c->pending_sweep_ev.emplace_back(e0, e1);
+    HIPCHK(c, hipEventRecord(e0, c->stream));
+    launch_sweep(a, c->n_tiles, c->hoist, c->stream);
+    HIPCHK(c, hipEventRecord(e1, c->stream));
+  } else {
+    launch_sweep(a, c->n_tiles, c->hoist, c->stream);
+  }
+  enqueue_cam_partials(c, static_cast<float*>(c->send_dev));
+  const bool ordered = c->comm->stream_ordered();
+  if (ordered) {
+    HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_fork, 0));
+    COMMCHK(c, c->comm->all_gather(static_cast<const float*>(c->send_dev), static_cast<float*>(c->recv_dev),
+                                   (size_t)c->C * kCamRec, c->comm_stream, e_));
+    HIPCHK(c, hipEventRecord(c->ev_join, c->comm_stream));
+  }
+  {  // the landmark half needs nothing from other ranks
+    BeliefArgs b = belief_args(c);
+    b.roll = 1;
+    launch_beliefs(b, false, true, c->stream);
+  }
+  if (ordered) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+  else if (int rc = exchange_now(c)) return rc;
+  {
+    BeliefArgs b = belief_args(c);
+    b.gathered = static_cast<const float*>(c->recv_dev);
+    b.roll = 1;
+    launch_beliefs(b, true, false, c->stream);
+  }
+  HIPCHK(c, hipGetLastError());
+  return GBP_OK;
+}
+
+static int iterate_sharded(gbp_ctx* c, int n) {
+  const SweepArgs a = sweep_args(c);
+  HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+  int left = n;
+  const bool can_graph = c->comm->stream_ordered() && !c->profile_stages && c->prm.graph_unroll > 0 && !c->graph_failed &&
+                         c->stream == c->own_stream;
+  // RCCL sets itself up lazily (channels, proxy threads): a few direct iterations must have run before a capture
+  while (left > 0 && (!can_graph || c->comm_warm < 3 || left < c->prm.graph_unroll)) {
+    if (int rc = enqueue_sharded_iteration(c, a)) return rc;
+    c->comm_warm++;
+    --left;
+  }
+  if (left >= c->prm.graph_unroll && can_graph) {
+    if (!c->graph_exec) {
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed);
+      int rc = GBP_OK;
+      if (e == hipSuccess) {
+        for (int i = 0; i < c->prm.graph_unroll && rc == GBP_OK; ++i) rc = enqueue_sharded_iteration(c, a);
+        e = hipStreamEndCapture(c->stream, &c->graph);
+        if (e == hipSuccess && rc == GBP_OK) e = hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0);
+      }
+      if (e != hipSuccess || rc != GBP_OK) {     // no graph for this ctx: direct launches (identical results)
+        (void)hipGetLastError();
+        drop_graph(c);
+        c->graph_failed = true;
+      } else {
+        c->graph_iters = c->prm.graph_unroll;
+      }
+    }
+    while (c->graph_exec && left >= c->graph_iters) {
+      HIPCHK(c, hipGraphLaunch(c->graph_exec, c->stream));
+      left -= c->graph_iters;
+    }
+  }
+  for (; left > 0; --left)
+    if (int rc = enqueue_sharded_iteration(c, a)) return rc;
+  HIPCHK(c, hipEventRecord(c->ev3, c->stream));
+  HIPCHK(c, hipEventSynchronize(c->ev3));
+  float ms = 0;
+  HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev3));
+  c->total_ms += ms;
+  if (!c->profile_stages) c->timed_iters += (uint64_t)n;    // with profiling the sweep brackets count the iterations
+  c->beliefs_valid = true;
+  return GBP_OK;
+}
+
 // LINEARISE_PROG (ba.cpp:890-893): prog_ub, then RelineariseFactorVertex on every factor.
 int gbp_linearise(gbp_ctx* c) {
   if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "gbp_linearise: upload first");
-  if (c->world > 1) return fail(c, GBP_ERR_STATE, "sharded ctx: use refresh_begin / exchange / refresh_end / linearise_factors");
+  if (c->world > 1 && !c->comm)
+    return fail(c, GBP_ERR_STATE, "sharded ctx without a communicator: gbp_comm_init first, or use refresh_begin / exchange / refresh_end / linearise_factors");
   int rc = gbp_refresh_begin(c);
+  if (rc == GBP_OK && c->comm) rc = exchange_now(c);
   if (rc == GBP_OK) rc = gbp_refresh_end(c);
   if (rc == GBP_OK) rc = gbp_linearise_factors(c);
   return rc;
@@ -516,7 +639,7 @@ int gbp_linearise(gbp_ctx* c) {
 
 static int iterate_begin_impl(gbp_ctx* c) {
   if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "upload first");
-  float4* dst = c->world > 1 ? static_cast<float4*>(c->send_dev) : P<float4>(c->local);
+  float4* dst = exch(c) ? static_cast<float4*>(c->send_dev) : P<float4>(c->local);
   if (!dst) return fail(c, GBP_ERR_STATE, "exchange buffers not set");
   if (c->profile_stages) {  // bracket the sweep launch; the pair is read (and timed_iters counted) by gbp_timing
     if (c->pending_sweep_ev.size() >= 256) drain_sweep_events(c);   // bounded: long profiled runs never pile up events
@@ -554,7 +677,7 @@ static int set_exchange_chunks_impl(gbp_ctx* c, int n) {
 int gbp_iterate_begin_chunk(gbp_ctx* c, int chunk) {
   if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "upload first");
   if (chunk < 0 || chunk >= c->exch_chunks) return fail(c, GBP_ERR_INVALID, "gbp_iterate_begin_chunk: bad chunk");
-  float* dst = c->world > 1 ? static_cast<float*>(c->send_dev) : P<float>(c->local);
+  float* dst = exch(c) ? static_cast<float*>(c->send_dev) : P<float>(c->local);
   if (!dst) return fail(c, GBP_ERR_STATE, "exchange buffers not set");
   const uint32_t n_blocks = c->n_tiles / 4;
   auto block_end = [&](int i) -> uint32_t {  // first block boundary at/after the last row of the cameras of range i
@@ -599,7 +722,9 @@ int gbp_iterate_end(gbp_ctx* c) {
 static int iterate_impl(gbp_ctx* c, int n) {
   if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "gbp_iterate: upload first");
   if (n <= 0) return GBP_OK;
-  if (c->world > 1) return fail(c, GBP_ERR_STATE, "sharded ctx: use gbp_iterate_begin / exchange / gbp_iterate_end");
+  if (c->comm) return iterate_sharded(c, n);
+  if (c->world > 1)
+    return fail(c, GBP_ERR_STATE, "sharded ctx without a communicator: gbp_comm_init first, or use gbp_iterate_begin / exchange / gbp_iterate_end");
   const SweepArgs a = sweep_args(c);
   HIPCHK(c, hipEventRecord(c->ev0, c->stream));
   if (c->profile_stages) {
@@ -951,6 +1076,94 @@ static int debug_set_factor_potentials_impl(gbp_ctx* c, const float* eta9E, cons
     for (int i = 0; i < 3; ++i) for (int j = 0; j <= i; ++j) f[tile_off((uint32_t)p, kFacG, 48 + tri(i, j))] = lam[72 + i * 3 + j];
   }
   HIPCHK(c, hipMemcpy(c->fac.p, f.data(), f.size() * 4, hipMemcpyHostToDevice));
+  return GBP_OK;
+}
+
+// ---- communicator: the exchange step owned by the library (RCCL over xGMI from the C++ host) ------------------------
+static int comm_attach(gbp_ctx* c, gbp::Comm* comm) {
+  c->comm = comm;
+  drop_graph(c);
+  int rc = GBP_OK;
+  if (!c->xsend.p) rc = dev_alloc(c, c->xsend, (size_t)c->C * kCamRec * 4);
+  if (rc == GBP_OK && !c->xrecv.p) rc = dev_alloc(c, c->xrecv, (size_t)c->world * c->C * kCamRec * 4);
+  if (rc != GBP_OK) return rc;
+  c->send_dev = c->xsend.p; c->recv_dev = c->xrecv.p;
+  if (!c->comm_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+  if (!c->ev_fork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  if (!c->ev_join) HIPCHK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  c->comm_warm = 0;
+  return GBP_OK;
+}
+
+int gbp_device_count(void) {
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
+int gbp_set_device(int device) {
+  if (hipSetDevice(device) != hipSuccess) return fail(nullptr, GBP_ERR_NO_DEVICE, "gbp_set_device: no such device");
+  return GBP_OK;
+}
+
+size_t gbp_comm_region_bytes(uint32_t n_cams, int world) { return gbp::comm_region_bytes(n_cams, world); }
+
+int gbp_comm_region_init(void* region, size_t bytes, uint32_t n_cams, int world) {
+  return gbp::comm_region_init(region, bytes, n_cams, world) == 0 ? GBP_OK : GBP_ERR_INVALID;
+}
+
+void gbp_comm_region_abort(void* region) { gbp::comm_region_abort(region); }
+
+int gbp_comm_init(gbp_ctx* c, void* region, int transport) {
+  if (!c || !region) return GBP_ERR_INVALID;
+  if (c->comm) return fail(c, GBP_ERR_STATE, "gbp_comm_init: the ctx already has a communicator");
+  std::string err;
+  gbp::Comm* comm = gbp::comm_create_from_region(region, c->rank, c->world, transport, err);
+  if (!comm) return fail(c, GBP_ERR_COMM, "gbp_comm_init: " + err);
+  return comm_attach(c, comm);
+}
+
+int gbp_comm_unique_id(void* id128) {
+  std::string err;
+  if (!id128) return GBP_ERR_INVALID;
+  if (gbp::comm_unique_id(id128, err) != 0) return fail(nullptr, GBP_ERR_COMM, "gbp_comm_unique_id: " + err);
+  return GBP_OK;
+}
+
+int gbp_comm_init_rccl(gbp_ctx* c, const void* id128) {
+  if (!c || !id128) return GBP_ERR_INVALID;
+  if (c->comm) return fail(c, GBP_ERR_STATE, "gbp_comm_init_rccl: the ctx already has a communicator");
+  std::string err;
+  gbp::Comm* comm = gbp::comm_create_rccl(id128, c->rank, c->world, err);
+  if (!comm) return fail(c, GBP_ERR_COMM, "gbp_comm_init_rccl: " + err);
+  return comm_attach(c, comm);
+}
+
+int gbp_graph_state(const gbp_ctx* c) { return !c ? 0 : (c->graph_exec ? 1 : (c->graph_failed ? -1 : 0)); }
+
+const char* gbp_comm_transport(const gbp_ctx* c) { return (c && c->comm) ? c->comm->name() : "none"; }
+
+int gbp_comm_barrier(gbp_ctx* c) {
+  if (!c || !c->comm) return GBP_ERR_STATE;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  COMMCHK(c, c->comm->barrier(e_));
+  return GBP_OK;
+}
+
+// gbp_eval over ALL shards: local sums gathered over the ranks and added in rank order (same bits on every rank)
+static int eval_impl(gbp_ctx* c, gbp_eval_out* o);
+int gbp_eval_global(gbp_ctx* c, gbp_eval_out* o) {
+  if (!c || !o) return GBP_ERR_INVALID;
+  const int rc = guarded(c, "gbp_eval_global", [&] { return eval_impl(c, o); });
+  if (rc != GBP_OK || !c->comm) return rc;
+  const double mine[7] = {o->sum_norm, o->sum_half_sq, (double)o->n_active, (double)o->n_relin, (double)o->n_robust,
+                          (double)o->n_nonfinite, (double)o->n_nonpd};
+  double all[7 * gbp::kCommMaxWorld];
+  COMMCHK(c, c->comm->all_gather_host(mine, all, 7, e_));
+  double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (int r = 0; r < c->world; ++r)
+    for (int i = 0; i < 7; ++i) acc[i] = acc[i] + all[r * 7 + i];
+  o->sum_norm = acc[0]; o->sum_half_sq = acc[1]; o->n_active = (uint64_t)(acc[2] + 0.5); o->n_relin = (uint64_t)(acc[3] + 0.5);
+  o->n_robust = (uint64_t)(acc[4] + 0.5); o->n_nonfinite = (uint64_t)(acc[5] + 0.5); o->n_nonpd = (uint64_t)(acc[6] + 0.5);
   return GBP_OK;
 }
 

@@ -402,6 +402,27 @@ int gbp_eval_host(const gbp_problem* p, const uint32_t* active, const float* mea
   return GBP_OK;
 }
 
+// Contiguous landmark ranges balanced by incident-factor count: bounds[r] = first landmark whose cumulative
+// degree reaches r/world of the factors.  A factor lives with its landmark, so this balances the sweep's work.
+int gbp_landmark_partition(const gbp_problem* p, int world, uint32_t* bounds) {
+  if (!p || !bounds || world < 1) return GBP_ERR_INVALID;
+  std::vector<uint64_t> csum((size_t)p->n_lmks + 1, 0);
+  for (uint32_t e = 0; e < p->n_edges; ++e) {
+    if (p->lmk_id[e] >= p->n_lmks) return GBP_ERR_INVALID;
+    csum[(size_t)p->lmk_id[e] + 1]++;
+  }
+  for (size_t l = 0; l < p->n_lmks; ++l) csum[l + 1] += csum[l];
+  const uint64_t total = csum[p->n_lmks];
+  bounds[0] = 0;
+  for (int r = 1; r < world; ++r) {
+    const uint64_t target = total * (uint64_t)r / (uint64_t)world;
+    const uint32_t b = (uint32_t)(std::lower_bound(csum.begin(), csum.end(), target) - csum.begin());
+    bounds[r] = std::min(std::max(b, bounds[r - 1]), p->n_lmks);
+  }
+  bounds[world] = p->n_lmks;
+  return GBP_OK;
+}
+
 // add_cam_trans_noise / add_cam_rot_noise / add_lmk_noise (dataio.cpp:330-415) with an explicit seed.  The first two
 // cameras anchor the gauge and stay exact (dataio.h:114-119, k = 2).  Draw order: translations, rotations, landmarks.
 int gbp_init_add_noise(uint32_t C, uint32_t L, float tn, float rn_deg, float ltn, uint64_t seed, float* cam, float* lmk) {

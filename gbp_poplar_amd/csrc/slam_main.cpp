@@ -4,14 +4,8 @@
 // damping_count to -15 -> NEW_KEYFRAME, with the usual {WEAKEN_PRIORS?, GBP, READ, eval} body.
 #include "cli_common.hpp"
 
-int main(int argc, char** argv) {
-  cli::Options o;
-  const int pr = cli::parse(argc, argv, /*slam=*/true, o);
-  if (pr) return pr == 1 ? 0 : 1;
-  cli::Problem P;
-  if (cli::load_problem(o, P)) return 1;
+static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
   const uint32_t C = P.bal.n_cams, L = P.bal.n_lmks, E = P.bal.n_edges;
-  if (C < 2) { std::cerr << "slam needs at least two keyframes\n"; return 1; }
 
   std::cout << "SLAM\n";                                        // slam.cpp:586-595
   const unsigned steps = static_cast<unsigned>(o.steps);
@@ -21,13 +15,10 @@ int main(int argc, char** argv) {
   std::cout << "\nNumber of keyframe nodes in the graph: " << C << '\n';
   std::cout << "Number of landmark nodes in the graph: " << L << '\n';
   std::cout << "Number of edges in the graph: " << E << '\n';
-  std::cout << "\nNumber of GPUs: 1\n\nAttaching to GPU device..." << std::endl;
+  std::cout << "\nNumber of GPUs: " << rk.world << "\n\nAttaching to GPU device..." << std::endl;
 
   gbp_ctx* ctx = nullptr;
-  if (gbp_create(&P.prob, nullptr, nullptr, &ctx) != GBP_OK) {
-    std::cout << "Could not find a device\n" << gbp_last_error(nullptr) << "\n";
-    return 255;
-  }
+  if (const int rc = cli::create_rank_ctx(o, P, rk, &ctx)) return rc;
   const auto t0 = std::chrono::steady_clock::now();
   const gbp_state_in in = cli::state_in(P);
   CLI_CHECK(ctx, gbp_upload(ctx, &in));
@@ -39,7 +30,7 @@ int main(int argc, char** argv) {
   po.cam_priors_eta = P.cpe.data(); po.cam_priors_lambda = P.cpl.data();
   po.lmk_priors_eta = P.lpe.data(); po.lmk_priors_lambda = P.lpl.data();
   gbp_eval_out ev{};
-  CLI_CHECK(ctx, gbp_eval(ctx, &ev));
+  CLI_CHECK(ctx, gbp_eval_global(ctx, &ev));
   std::cout << "Initial Reprojection error: " << (float)(ev.sum_norm / (double)ev.n_active) << " Cost " << (float)ev.sum_half_sq << "\n";
 
   const unsigned niters = (C - 1) * (unsigned)o.iters_between_kfs - 1;   // slam.cpp:1013
@@ -73,7 +64,7 @@ int main(int argc, char** argv) {
     }
     CLI_CHECK(ctx, gbp_iterate(ctx, 1));
     if ((i + 1) % (unsigned)o.eval_every == 0 || i + 1 == niters) {
-      CLI_CHECK(ctx, gbp_eval(ctx, &ev));
+      CLI_CHECK(ctx, gbp_eval_global(ctx, &ev));
       std::cout << "Iters " << (unsigned)o.iters_between_kfs * data_counter + iter;
       std::cout << " (since last kf " << iter << ") // Reprojection error " << (float)(ev.sum_norm / (double)ev.n_active);
       std::cout << " // Cost " << (float)ev.sum_half_sq << " // n relins: " << ev.n_relin;
@@ -94,4 +85,15 @@ int main(int argc, char** argv) {
   if (o.profile) cli::write_profile(ctx, "slam", wall, niters);
   gbp_destroy(ctx);
   return 0;
+}
+
+int main(int argc, char** argv) {
+  cli::Options o;
+  const int pr = cli::parse(argc, argv, /*slam=*/true, o);
+  if (pr) return pr == 1 ? 0 : 1;
+  cli::Problem P;
+  if (cli::load_problem(o, P)) return 1;          // host only: the ranks are forked before anything touches HIP
+  if (P.bal.n_cams < 2) { std::cerr << "slam needs at least two keyframes\n"; return 1; }
+  const int world = cli::round_up_pow2(std::max(1, o.gpus));   // slam.cpp:422-425 / ba.cpp:617-621
+  return cli::run_ranks(world, P.bal.n_cams, o.force_sharded, [&](cli::RankCtx& rk) { return run(o, P, rk); });
 }

@@ -136,6 +136,34 @@ class GbpEngine:
     def linearise_factors(self):
         self._chk(self.lib.gbp_linearise_factors(self.h), "gbp_linearise_factors")
 
+    # ---- library-owned exchange (RCCL from the C++ host) ----
+    def comm_unique_id(self):
+        """Rank 0: the 128-byte RCCL id every rank passes to comm_init_rccl (distribute it with your launcher's means)."""
+        buf = C.create_string_buffer(128)
+        rc = self.lib.gbp_comm_unique_id(buf)
+        if rc != 0:
+            raise GbpError("gbp_comm_unique_id: %s (status %d)" % (self.lib.gbp_last_error(None).decode(), rc))
+        return buf.raw
+
+    def comm_init_rccl(self, id128):
+        buf = C.create_string_buffer(bytes(id128), 128)
+        self._chk(self.lib.gbp_comm_init_rccl(self.h, buf), "gbp_comm_init_rccl")
+
+    def comm_transport(self):
+        return self.lib.gbp_comm_transport(self.h).decode()
+
+    def graph_state(self):
+        """1: gbp_iterate replays a captured hipGraph; 0: nothing captured yet; -1: capture failed, direct launches."""
+        return int(self.lib.gbp_graph_state(self.h))
+
+    def comm_barrier(self):
+        self._chk(self.lib.gbp_comm_barrier(self.h), "gbp_comm_barrier")
+
+    def eval_global(self):
+        o = cabi.GbpEvalOut()
+        self._chk(self.lib.gbp_eval_global(self.h, C.byref(o)), "gbp_eval_global")
+        return {k: getattr(o, k) for k, _ in o._fields_}
+
     # ---- raw state for parity tests ----
     def _debug(self, what, na, nb):
         a, b = np.zeros(na, np.float32), np.zeros(nb, np.float32)

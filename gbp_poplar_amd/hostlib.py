@@ -126,6 +126,15 @@ def init_av_depth(cam_id, lmk_id, n_cams, n_lmks, cam_mean, lmk_mean):
     return lmk
 
 
+def landmark_partition(cam_id, lmk_id, n_cams, n_lmks, world):
+    """gbp_landmark_partition: contiguous landmark ranges balanced by factor count -> bounds[world + 1]."""
+    keep = []
+    p = cabi.make_problem(cam_id, lmk_id, n_cams, n_lmks, [0] * 9, keep)
+    bounds = np.zeros(world + 1, np.uint32)
+    _chk(load().gbp_landmark_partition(C.byref(p), int(world), cabi.ptr(bounds, cabi.c_u32p)), "gbp_landmark_partition")
+    return bounds
+
+
 def slam_create_flags(cam_id, lmk_id, n_cams, n_lmks, steps):
     lib = load()
     keep = []

@@ -31,7 +31,8 @@ typedef enum {
   GBP_ERR_HIP = -3,        /* a HIP runtime call failed                    */
   GBP_ERR_STATE = -4,      /* call order violated (e.g. iterate before upload) */
   GBP_ERR_IO = -5,         /* file could not be read (ref: ba.cpp:484-487)  */
-  GBP_ERR_NOMEM = -6       /* host allocation failed (no C++ exception ever crosses this ABI) */
+  GBP_ERR_NOMEM = -6,      /* host allocation failed (no C++ exception ever crosses this ABI) */
+  GBP_ERR_COMM = -7        /* the exchange between ranks failed (RCCL error, a rank died / timed out)  */
 } gbp_status;
 
 typedef struct gbp_ctx gbp_ctx;
@@ -201,6 +202,35 @@ int gbp_iterate_end(gbp_ctx* ctx);     /* camera beliefs = prior + sum_r recv_de
 int gbp_refresh_begin(gbp_ctx* ctx);
 int gbp_refresh_end(gbp_ctx* ctx);
 int gbp_linearise_factors(gbp_ctx* ctx);  /* the factor half of LINEARISE_PROG (after a refresh) */
+
+/* ---- multi-GPU from the C++ host: the exchange owned by the library ---------------------------------------------------
+ * Replaces `--ipus N` (ba.cpp:414-417,617-649) without any Python: one process per GPU, each with a sharded ctx
+ * (gbp_shard).  Once a ctx has a communicator, the plain program list works on it — gbp_linearise, gbp_iterate(n)
+ * (sweep -> local camera partials -> ncclAllGather on a second stream, overlapped with the rank-local landmark beliefs
+ * -> camera combine; captured into a hipGraph like the single-GPU iteration), gbp_weaken_priors, gbp_new_keyframe —
+ * and gbp_eval_global adds the metric sums of all shards in rank order.
+ *
+ * Launchers that fork their ranks (bin/ba --ipus N) share one MAP_SHARED region, created and initialised BEFORE the
+ * ranks start; it carries the rendezvous (RCCL unique id, barrier) and, for ranks that share a GPU (fewer GPUs than
+ * ranks — RCCL refuses duplicate GPUs), the host-staged transport that moves the same buffers through host memory.
+ * transport: 0 = auto (RCCL when every rank has its own GPU, host-staged otherwise), 1 = RCCL, 2 = host-staged.
+ * Launchers with their own rendezvous (torchrun, MPI) pass the 128-byte RCCL id around themselves:
+ * gbp_comm_unique_id on rank 0, gbp_comm_init_rccl on every rank.  All calls are collective over the ranks. */
+#define GBP_COMM_ID_BYTES 128
+int gbp_device_count(void);                                    /* visible GPUs (initialises the HIP runtime)      */
+int gbp_set_device(int device);                                /* the GPU later gbp_create calls of this process use */
+/* contiguous landmark ranges balanced by factor count: bounds[world + 1], shard r = [bounds[r], bounds[r+1]) */
+int gbp_landmark_partition(const gbp_problem* problem, int world, uint32_t* bounds);
+size_t gbp_comm_region_bytes(uint32_t n_cams, int world);
+int gbp_comm_region_init(void* region, size_t bytes, uint32_t n_cams, int world);
+void gbp_comm_region_abort(void* region);                      /* supervisor: a rank died, fail the waiting ones */
+int gbp_comm_init(gbp_ctx* ctx, void* region, int transport);
+int gbp_comm_unique_id(void* id128);
+int gbp_comm_init_rccl(gbp_ctx* ctx, const void* id128);
+const char* gbp_comm_transport(const gbp_ctx* ctx);            /* "rccl", "host-staged" or "none" */
+int gbp_comm_barrier(gbp_ctx* ctx);
+int gbp_graph_state(const gbp_ctx* ctx);                       /* 1 = gbp_iterate replays a captured hipGraph, 0 = not captured (yet), -1 = capture failed: direct launches */
+int gbp_eval_global(gbp_ctx* ctx, gbp_eval_out* out);          /* gbp_eval summed over all shards */
 
 /* ---- measurement / test hooks -------------------------------------------------------------- */
 /* per_stage_events != 0: gbp_iterate launches kernels directly with a hipEvent pair around the

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_functions():
     src = open(os.path.join(ROOT, "include", "gbp_mi355x.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    names = re.findall(r"^\s*(?:const\s+char\s*\*|int|void)\s+(gbp_\w+)\s*\(", src, flags=re.M)
+    names = re.findall(r"^\s*(?:const\s+char\s*\*|int|void|size_t)\s+(gbp_\w+)\s*\(", src, flags=re.M)
     return sorted(set(names))
 
 

@@ -150,3 +150,78 @@ def test_avdepth_flag():
     rows = LINE.findall(out)
     init = float(re.search(r"Initial Reprojection error: (\S+)", out).group(1))
     assert abs(init - 209.343) < 0.01 and 1.40 < float(rows[-1][1]) < 1.45, (init, rows[-1])    # oracle: 209.343 -> 1.423
+
+
+def _oracle_sharded_traj(oracle_mod, oracle_host, name, world, n_iters=None, slam_ibk=None):
+    """The reference-equivalent run in `world`-shard summation order, device conventions (what N ranks compute)."""
+    from gbp_poplar_amd import driver, hostlib
+    bal = oracle_host.bal_read(seq_path(name))
+    opts = driver.Options()
+    K, state, extra = driver.build_inputs(bal, opts, oracle_host, slam=slam_ibk is not None)
+    bounds = hostlib.landmark_partition(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], world)
+    oracle_mod.set_trig_mode(1)
+    try:
+        o = oracle_mod.Oracle(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K)
+        o.set_sum_order(1, bounds)
+        if slam_ibk is None:
+            return driver.run_ba(o, state, opts, n_iters=n_iters)
+        return driver.run_slam(o, oracle_host, bal, state, extra, opts, iters_between_kfs=slam_ibk)
+    finally:
+        oracle_mod.set_trig_mode(0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_ba_ipus_n_runs_one_process_per_rank(world, oracle_mod, oracle_host):
+    """`./ba --ipus N` (ba.cpp:414-417,617-649) from the C++ host: N forked ranks, landmark shards, one all-gather of the
+    camera partials per iteration.  On a one-GPU box the ranks share the GPU, so the library picks the host-staged
+    transport (RCCL refuses duplicate GPUs); the printed trajectory must be the N-shard oracle's: metric to print
+    precision, relinearisation and robust-edge counts exactly, through the relinearising sweeps (17+)."""
+    rc, out, err = run([BA, "--bal_file", seq_path("fr2robot2"), "--n_iters", "24", "--ipus", str(world)])
+    assert rc == 0, err[-2000:]
+    assert "Number of GPUs: %d" % world in out and "Exchange between the %d ranks:" % world in out
+    rows = [m.groups() for m in LINE.finditer(out)]
+    assert len(rows) == 24 and out.count("Weakening priors") == 5 and out.count("Initial Reprojection error") == 1
+    traj = _oracle_sharded_traj(oracle_mod, oracle_host, "fr2robot2", world, n_iters=24)
+    init = float(re.search(r"Initial Reprojection error: (\S+)", out).group(1))
+    assert abs(init - traj[0][1]) <= 2e-5 * traj[0][1]
+    for (it, m, c, nr, nb), (i, mean, cost, n_relin, n_robust) in zip(rows, traj[1:]):
+        assert int(it) == i and abs(float(m) - mean) <= 2e-5 * mean, (i, m, mean)      # 6 printed digits
+        assert int(nr) == n_relin and int(nb) == n_robust, (i, nr, n_relin, nb, n_robust)
+    assert sum(int(r[3]) for r in rows[17:]) > 0
+
+
+@pytest.mark.gpu
+def test_ipus_rounds_up_to_a_power_of_two_and_rccl_needs_distinct_gpus():
+    rc, out, err = run([BA, "--bal_file", seq_path("fr2robot2"), "--n_iters", "2", "--ipus", "3"])
+    assert rc == 0 and "Number of GPUs: 4" in out, err[-1000:]                      # ba.cpp:617-621
+    import torch
+    if torch.cuda.device_count() < 2:
+        rc, out, err = run([BA, "--bal_file", seq_path("fr2robot2"), "--n_iters", "2", "--ipus", "2", "--transport", "rccl"])
+        assert rc != 0 and "share a GPU" in err                                     # loud, not a hang: the supervisor ends all ranks
+
+
+@pytest.mark.gpu
+def test_slam_ipus_2(oracle_mod, oracle_host):
+    """`./slam --ipus 2`: READ_PRIORS / NEW_KEYFRAME on two forked ranks (8 sweeps per keyframe)."""
+    rc, out, err = run([SLAM, "--bal_file", seq_path("fr2robot2"), "--iters_between_kfs", "8", "--ipus", "2"])
+    assert rc == 0, err[-2000:]
+    rows = re.findall(r"Iters (\d+) \(since last kf (\d+)\) // Reprojection error (\S+) // Cost (\S+) // n relins: (\d+) // n robust edges (\d+)", out)
+    assert len(rows) == 19 * 8 - 1 and out.count("Adding keyframe") == 18
+    traj = _oracle_sharded_traj(oracle_mod, oracle_host, "fr2robot2", 2, slam_ibk=8)
+    for (tot, since, m, c, nr, nb), (i, mean, cost, n_relin, n_robust) in zip(rows, traj[1:]):
+        assert abs(float(m) - mean) <= 2e-5 * mean + 1e-5, (i, m, mean)
+        assert int(nr) == n_relin and int(nb) == n_robust, (i, nr, n_relin)
+
+
+@pytest.mark.gpu
+def test_cli_rccl_path_with_one_forked_rank():
+    """--force_sharded 1: the whole multi-GPU code path of the executable — fork before HIP, shard ctx, RCCL unique id
+    through the shared region, librccl dlopen'ed in a process without PyTorch, hipGraph-captured sharded iteration —
+    with a single rank: the printed run equals the plain single-GPU run."""
+    base = [BA, "--bal_file", seq_path("fr2robot2"), "--n_iters", "60", "--eval_every", "20"]
+    rc1, out1, err1 = run(base)
+    rc2, out2, err2 = run(base + ["--force_sharded", "1"])
+    assert rc1 == 0 and rc2 == 0, (err1[-500:], err2[-1500:])
+    assert "Exchange between the 1 ranks: rccl" in out2
+    assert LINE.findall(out1) == LINE.findall(out2) and len(LINE.findall(out1)) == 3

@@ -1226,6 +1226,37 @@ def test_rccl_single_rank_group_overlap_path(chunks):
         dist.destroy_process_group()
 
 
+def test_native_rccl_communicator_single_rank(oracle_mod):
+    """The exchange owned by the C++ library: a sharded ctx with a 1-rank RCCL communicator (gbp_comm_unique_id /
+    gbp_comm_init_rccl; librccl dlopen'ed by the library).  gbp_linearise / gbp_iterate / gbp_weaken_priors then run the
+    sharded sequence — sweep, local partials, ncclAllGather on the second stream overlapped with the landmark beliefs,
+    camera combine — first directly, then replayed from a captured hipGraph: equal to the plain engine bit for bit."""
+    from gbp_poplar_amd import driver, hostlib
+    from gbp_poplar_amd.engine import GbpEngine
+    bal = _bal("fr2robot2")
+    opts = driver.Options()
+    K, state, _ = driver.build_inputs(bal, opts, hostlib)
+    plain = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K)
+    eng = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K, shard=(0, 1, 0, bal["n_lmks"]))
+    eng.comm_init_rccl(eng.comm_unique_id())
+    assert eng.comm_transport() == "rccl"
+    ta = driver.run_ba(plain, state, opts, n_iters=12, eval_every=4)
+    tb = driver.run_ba(eng, state, opts, n_iters=12, eval_every=4)
+    assert ta == tb
+    plain.iterate(45)
+    assert eng.graph_state() == 0
+    eng.iterate(45)                       # 4 replays of the captured 10-iteration graph + 5 direct
+    assert eng.graph_state() == 1         # kernels + ncclAllGather + the two-stream fork/join were captured
+    ra, rb = plain.read(), eng.read()
+    for k in ra:
+        assert np.array_equal(ra[k], rb[k]), k
+    ea, eb = plain.eval(), eng.eval_global()
+    assert ea == eb
+    eng.comm_barrier()
+    tm = eng.timing()
+    assert tm["iterations"] == 12 + 45
+
+
 # ---- BASELINE.json configs 1-3 end to end, bit for bit ---------------------------------------------------------
 
 def _run_ba_recorded(engine, state, opts, n_iters):

@@ -327,3 +327,32 @@ def test_build_inputs_applies_the_init_options():
     d = driver.build_inputs(bal, driver.Options(avdepth_on=True, ltn=0.5, seed=3), hostlib)[1]    # --avdepth_on wins over --ltn
     e = driver.build_inputs(bal, driver.Options(avdepth_on=True), hostlib)[1]
     assert np.array_equal(d["lmk_priors_eta"], e["lmk_priors_eta"]) and not np.array_equal(e["lmk_priors_eta"], base["lmk_priors_eta"])
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_landmark_partition_native_equals_python(world):
+    """gbp_landmark_partition (C++ launcher) and distributed.landmark_partition (Python launcher) must cut the
+    landmarks identically: a shard layout is part of the result (summation order of the camera partials)."""
+    from gbp_poplar_amd.distributed import landmark_partition
+    for bal in (hostlib.bal_read(seq_path("fr2robot2")), hostlib.synth_generate(9, 70, 4, 5)):
+        a = hostlib.landmark_partition(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], world)
+        b = landmark_partition(bal["lmk_id"], bal["n_lmks"], world)
+        assert np.array_equal(a, b) and a[0] == 0 and a[-1] == bal["n_lmks"] and np.all(np.diff(a.astype(np.int64)) >= 0)
+    # more ranks than landmarks with factors: trailing shards are empty, never out of range
+    a = hostlib.landmark_partition(np.array([0, 1], np.uint32), np.array([0, 0], np.uint32), 2, 3, 4)
+    assert a[-1] == 3 and np.all(np.diff(a.astype(np.int64)) >= 0)
+    assert np.array_equal(a, landmark_partition(np.array([0, 0]), 3, 4))
+
+
+def test_comm_region_contract():
+    """The rendezvous region of a forked launcher: size grows with cameras x ranks, init validates its arguments."""
+    import ctypes
+    from gbp_poplar_amd._lib import load
+    lib = load()
+    n1, n2 = lib.gbp_comm_region_bytes(1000, 2), lib.gbp_comm_region_bytes(1000, 8)
+    assert n2 - n1 == 2 * 6 * 1000 * 44 * 4 and n1 > 2 * 2 * 1000 * 44 * 4
+    buf = ctypes.create_string_buffer(n1)
+    assert lib.gbp_comm_region_init(buf, n1, 1000, 2) == 0
+    assert lib.gbp_comm_region_init(buf, n1, 1000, 8) != 0          # too small for 8 ranks
+    assert lib.gbp_comm_region_init(buf, n1, 1000, 0) != 0
+    lib.gbp_comm_region_abort(buf)                                  # supervisor call: must not crash
