@@ -46,7 +46,7 @@ struct gbp_ctx {
   // device memory
   std::vector<DevBuf*> all;
   DevBuf row_cam, lmk_idx, fac, cmsg, mu, lmsg, camb, camp, lmkb, lmkp, rowp, local, d_cam_row_ptr, d_lmk_ptr, cwf, lwf,
-      cscale, lscale, cam_mu, lmk_mu, dK, evalp, hmu_c, hmu_l, d_lmk_fpos, health, tile_perm;
+      cscale, lscale, cam_mu, lmk_mu, dK, evalp, hmu_c, hmu_l, d_lmk_fpos, d_lmk_ix, health, tile_perm;
   DevBuf st_a, st_b;                   // [Ep] scratch of the per-factor state get / set kernels
   std::vector<uint8_t> active_host;    // [Ep] host shadow of the active flags (hoist guard of gbp_new_keyframe)
   bool use_tile_perm = false;
@@ -129,7 +129,7 @@ BeliefArgs belief_args(gbp_ctx* c) {
   b.cam_local = P<float>(c->local); b.gathered = nullptr; b.world = c->world;
   b.camb = P<float>(c->camb); b.cam_mu = P<float4>(c->hmu_c); b.n_cams = c->C;
   b.lmk_prior = P<float4>(c->lmkp); b.lmsg = P<float4>(c->lmsg); b.lmk_ptr = P<uint32_t>(c->d_lmk_ptr);
-  b.lmk_fpos = P<uint32_t>(c->d_lmk_fpos);
+  b.lmk_fpos = P<uint32_t>(c->d_lmk_fpos); b.lmk_ix = P<uint32_t>(c->d_lmk_ix);
   b.lmkb = P<float4>(c->lmkb); b.lmk_mu = P<float4>(c->hmu_l); b.n_lmks = c->L_loc;
   b.partial_only = 0; b.hoist = c->hoist ? 1 : 0; b.roll = 0;
   b.cam0 = 0; b.cam1 = 0;
@@ -342,7 +342,7 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
   const size_t Ep = c->Ep;
   A(c->row_cam, (Ep / kRow) * 4); A(c->lmk_idx, Ep * 4); A(c->fac, Ep * kFacG * 16); A(c->cmsg, Ep * kCmsgG * 16);
   A(c->mu, c->hoist ? 0 : Ep * kMuG * 16);   // literal mu/oldmu tensor: only with per_factor_mu
-  A(c->lmsg, Ep * 64); A(c->d_lmk_fpos, (size_t)c->E_loc * 4);
+  A(c->lmsg, Ep * 64); A(c->d_lmk_fpos, (size_t)c->E_loc * 4); A(c->d_lmk_ix, (size_t)c->L_loc * 64);
   A(c->camb, (size_t)C * kCamRec * 4); A(c->camp, (size_t)C * kCamRec * 4); A(c->local, (size_t)C * kCamRec * 4);
   A(c->lmkb, (size_t)c->L_loc * 64); A(c->lmkp, (size_t)c->L_loc * 64);
   A(c->rowp, (Ep / kRow) * kCamRec * 4);
@@ -368,6 +368,13 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
     for (size_t p = 0; p < Ep; ++p)
       if (c->pos_edge[p] != ~0u) fpos[c->pos_lpos[p]] = (uint32_t)p;
     CK(hipMemcpy(c->d_lmk_fpos.p, fpos.data(), (size_t)c->E_loc * 4, hipMemcpyHostToDevice), "copy lmk_fpos");
+    std::vector<uint32_t> ix((size_t)c->L_loc * 16 + 16, 0u);   // per landmark: degree + positions of its first 15 slots
+    for (uint32_t l = 0; l < c->L_loc; ++l) {
+      const uint32_t s0 = c->lmk_ptr[l], d = c->lmk_ptr[l + 1] - s0;
+      ix[(size_t)l * 16] = d;
+      for (uint32_t k = 0; k < d && k < 15u; ++k) ix[(size_t)l * 16 + 1 + k] = fpos[s0 + k];
+    }
+    CK(hipMemcpy(c->d_lmk_ix.p, ix.data(), (size_t)c->L_loc * 64, hipMemcpyHostToDevice), "copy lmk_ix");
   }
   {
     std::vector<uint32_t> rc_(Ep / kRow);

@@ -83,6 +83,7 @@ struct BeliefArgs {
   float* camb; float4* cam_mu; uint32_t n_cams;
   // landmark part
   const float4* lmk_prior; const float4* lmsg; const uint32_t* lmk_ptr; const uint32_t* lmk_fpos;
+  const uint32_t* lmk_ix;   // [L][16]: degree, device positions of slots 1..15 (one 64-B index record per landmark)
   float4* lmkb; float4* lmk_mu; uint32_t n_lmks;
   // camera range of this launch [cam0, cam1) (0,0 = all) and chunk layout of `gathered` (see k_beliefs)
   uint32_t cam0, cam1;

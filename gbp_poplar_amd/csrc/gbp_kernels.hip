@@ -498,7 +498,7 @@ __global__ __launch_bounds__(256) void k_linearise(const SweepArgs a) {
 // float4 #q of the landmark-message record at device position pos, with the per-factor state that rides in
 // the record's pad slots (3, 13, 14, 15) blanked so that it never enters a belief sum
 GBP_DEV float4 lmsg_piece(const float4* lmsg, uint32_t pos, uint32_t q) {
-  float4 m = lmsg[(size_t)pos * 4 + q];
+  float4 m = lmsg[(size_t)pos * 4 + q];   // default cache policy: a non-temporal hint here costs 4 us (the 128-B line's other half is a neighbour's record)
   if (q == 0) m.w = 0.f;
   if (q == 3) { m.y = 0.f; m.z = 0.f; m.w = 0.f; }
   return m;
@@ -605,31 +605,34 @@ __global__ __launch_bounds__(256) void k_beliefs(const BeliefArgs b) {
   const uint32_t l = t >> 2, q = t & 3;
   const bool live = l < b.n_lmks;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  // LMK_IX[l] = {degree, position of slot 1 .. slot 15} (64 B): ONE load tells the quad where the landmark's records
+  // are, so the whole sum is two dependent round trips (index record -> up to 15 message records in flight) instead
+  // of four (lmk_ptr -> fpos -> 8 records -> tail).  Slots beyond 15 (rare) go through lmk_ptr / lmk_fpos.
+  uint4 ix = make_uint4(0u, 0u, 0u, 0u);
   if (live) {
+    ix = reinterpret_cast<const uint4*>(b.lmk_ix)[(size_t)l * 4 + q];
     acc = b.lmk_prior[(size_t)l * 4 + q];
-    const uint32_t s0 = b.lmk_ptr[l], s1 = b.lmk_ptr[l + 1];
-    uint32_t s = s0;
-    for (; s + 8 <= s1; s += 8) {  // 8 record gathers in flight, adds in slot order
-      uint32_t pos[8];
-      float4 m[8];
-      GBP_UNROLL
-      for (int k = 0; k < 8; ++k) pos[k] = b.lmk_fpos[s + k];
-      GBP_UNROLL
-      for (int k = 0; k < 8; ++k) m[k] = lmsg_piece(b.lmsg, pos[k], q);
-      GBP_UNROLL
-      for (int k = 0; k < 8; ++k) { acc.x = acc.x + m[k].x; acc.y = acc.y + m[k].y; acc.z = acc.z + m[k].z; acc.w = acc.w + m[k].w; }
+  }
+  const uint32_t deg = (uint32_t)__shfl((int)ix.x, 0, 4);
+  {
+    uint32_t pos[15];
+    float4 m[15];
+    GBP_UNROLL
+    for (int k = 0; k < 15; ++k) {   // element k + 1 of the index record sits in lane (k + 1) / 4, component (k + 1) % 4
+      const uint32_t v = ((k + 1) & 3) == 0 ? ix.x : ((k + 1) & 3) == 1 ? ix.y : ((k + 1) & 3) == 2 ? ix.z : ix.w;
+      pos[k] = (uint32_t)__shfl((int)v, (k + 1) >> 2, 4);
     }
-    {
-      uint32_t pos[8];
-      float4 m[8];
-      const uint32_t n = s1 - s;  // < 8
-      GBP_UNROLL
-      for (int k = 0; k < 8; ++k) pos[k] = (uint32_t)k < n ? b.lmk_fpos[s + k] : 0u;
-      GBP_UNROLL
-      for (int k = 0; k < 8; ++k) m[k] = (uint32_t)k < n ? lmsg_piece(b.lmsg, pos[k], q) : make_float4(0.f, 0.f, 0.f, 0.f);
-      GBP_UNROLL
-      for (int k = 0; k < 8; ++k)
-        if ((uint32_t)k < n) { acc.x = acc.x + m[k].x; acc.y = acc.y + m[k].y; acc.z = acc.z + m[k].z; acc.w = acc.w + m[k].w; }
+    GBP_UNROLL
+    for (int k = 0; k < 15; ++k) m[k] = (uint32_t)k < deg ? lmsg_piece(b.lmsg, pos[k], q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    GBP_UNROLL
+    for (int k = 0; k < 15; ++k)     // adds in slot order
+      if ((uint32_t)k < deg) { acc.x = acc.x + m[k].x; acc.y = acc.y + m[k].y; acc.z = acc.z + m[k].z; acc.w = acc.w + m[k].w; }
+  }
+  if (deg > 15u) {
+    const uint32_t s1 = b.lmk_ptr[l + 1];
+    for (uint32_t s = b.lmk_ptr[l] + 15u; s < s1; ++s) {
+      const float4 mm = lmsg_piece(b.lmsg, b.lmk_fpos[s], q);
+      acc.x = acc.x + mm.x; acc.y = acc.y + mm.y; acc.z = acc.z + mm.z; acc.w = acc.w + mm.w;
     }
   }
   if (b.hoist) {
