@@ -70,6 +70,13 @@ struct gbp_ctx {
   int exch_chunks = 1;                 // camera ranges of the pipelined exchange (gbp_set_exchange_chunks)
   std::vector<uint32_t> chunk_start;   // [exch_chunks + 1] camera index where each chunk starts
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+  // gbp_iterate does not block the host: each call is bracketed by an event pair that is read later (gbp_timing, or
+  // when the ring is full), so a caller that evaluates the metric every iteration pays ONE host synchronisation per
+  // iteration (inside gbp_eval), not two
+  struct Span { hipEvent_t a, b; };
+  std::vector<Span> spans;             // recorded, not yet read
+  std::vector<Span> span_pool;         // reusable event pairs
+  void* eval_host = nullptr;           // pinned: per-block metric partials + health counters land here in one copy
   bool profile_stages = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_sweep_ev;  // split-phase profiling: brackets not yet read
   double sweep_ms = 0, belief_ms = 0, total_ms = 0;
@@ -211,6 +218,36 @@ inline void put_state(std::vector<float>& rec, size_t p, const HostState& h) {
   rec[p * 16 + 14] = h.var;
 }
 
+// timing brackets of gbp_iterate calls: read the finished ones without blocking anything that is still queued
+int resolve_spans(gbp_ctx* c, bool wait) {
+  size_t done = 0;
+  for (; done < c->spans.size(); ++done) {
+    const gbp_ctx::Span sp = c->spans[done];
+    if (wait) { if (hipEventSynchronize(sp.b) != hipSuccess) break; }
+    else if (hipEventQuery(sp.b) != hipSuccess) break;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) c->total_ms += ms;
+    c->span_pool.push_back(sp);
+  }
+  c->spans.erase(c->spans.begin(), c->spans.begin() + (long)done);
+  return GBP_OK;
+}
+int span_begin(gbp_ctx* c, gbp_ctx::Span& sp) {
+  if (c->spans.size() >= 64) resolve_spans(c, true);
+  if (!c->span_pool.empty()) { sp = c->span_pool.back(); c->span_pool.pop_back(); }
+  else {
+    HIPCHK(c, hipEventCreate(&sp.a));
+    if (hipError_t e_ = hipEventCreate(&sp.b); e_ != hipSuccess) { (void)hipEventDestroy(sp.a); return fail(c, GBP_ERR_HIP, "hipEventCreate"); }
+  }
+  HIPCHK(c, hipEventRecord(sp.a, c->stream));
+  return GBP_OK;
+}
+int span_end(gbp_ctx* c, const gbp_ctx::Span& sp) {
+  HIPCHK(c, hipEventRecord(sp.b, c->stream));
+  c->spans.push_back(sp);
+  return GBP_OK;
+}
+
 // split-phase profiling: read (and free) the sweep brackets recorded by gbp_iterate_begin
 void drain_sweep_events(gbp_ctx* c) {
   for (auto& pr : c->pending_sweep_ev) {
@@ -264,6 +301,9 @@ void gbp_destroy(gbp_ctx* c) {
   if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
   for (auto& pr : c->pending_sweep_ev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   for (DevBuf* b : c->all) if (b->p) (void)hipFree(b->p);
+  for (auto& v : {&c->spans, &c->span_pool})
+    for (auto& sp : *v) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+  if (c->eval_host) (void)hipHostFree(c->eval_host);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->ev2) (void)hipEventDestroy(c->ev2);
@@ -349,7 +389,7 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
   A(c->d_cam_row_ptr, (size_t)(C + 1) * 4); A(c->d_lmk_ptr, (size_t)(c->L_loc + 1) * 4);
   A(c->cwf, (size_t)C * 4); A(c->lwf, (size_t)c->L_loc * 4); A(c->cscale, (size_t)C * 4); A(c->lscale, (size_t)c->L_loc * 4);
   A(c->cam_mu, (size_t)C * 6 * 4); A(c->lmk_mu, (size_t)c->L_loc * 3 * 4); A(c->dK, 16 * 4);
-  A(c->evalp, sizeof(DeviceEval) * 1024); A(c->health, 16);
+  A(c->evalp, sizeof(DeviceEval) * 1025); A(c->health, 16);
   A(c->hmu_c, (size_t)C * 4 * 16); A(c->hmu_l, (size_t)c->L_loc * 2 * 16);
   A(c->st_a, Ep * 4); A(c->st_b, Ep * 4);
   if (rc != GBP_OK) { g_create_error = c->err; return rc; }
@@ -587,7 +627,8 @@ static int enqueue_sharded_iteration(gbp_ctx* c, const SweepArgs& a) {
 
 static int iterate_sharded(gbp_ctx* c, int n) {
   const SweepArgs a = sweep_args(c);
-  HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+  gbp_ctx::Span sp{};
+  if (int rc = span_begin(c, sp)) return rc;
   int left = n;
   const bool can_graph = c->comm->stream_ordered() && !c->profile_stages && c->prm.graph_unroll > 0 && !c->graph_failed &&
                          c->stream == c->own_stream;
@@ -622,11 +663,8 @@ static int iterate_sharded(gbp_ctx* c, int n) {
   }
   for (; left > 0; --left)
     if (int rc = enqueue_sharded_iteration(c, a)) return rc;
-  HIPCHK(c, hipEventRecord(c->ev3, c->stream));
-  HIPCHK(c, hipEventSynchronize(c->ev3));
-  float ms = 0;
-  HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev3));
-  c->total_ms += ms;
+  if (int rc = span_end(c, sp)) return rc;
+  if (!c->comm->stream_ordered() || c->profile_stages) HIPCHK(c, hipStreamSynchronize(c->stream));
   if (!c->profile_stages) c->timed_iters += (uint64_t)n;    // with profiling the sweep brackets count the iterations
   c->beliefs_valid = true;
   return GBP_OK;
@@ -733,7 +771,8 @@ static int iterate_impl(gbp_ctx* c, int n) {
   if (c->world > 1)
     return fail(c, GBP_ERR_STATE, "sharded ctx without a communicator: gbp_comm_init first, or use gbp_iterate_begin / exchange / gbp_iterate_end");
   const SweepArgs a = sweep_args(c);
-  HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+  gbp_ctx::Span sp{};
+  if (int rc = span_begin(c, sp)) return rc;
   if (c->profile_stages) {
     // Per-stage timing: all n iterations are queued back to back with a hipEvent before / between / after the
     // two kernels, and read after ONE synchronisation, so a bracket holds the kernel (plus the ~1 us
@@ -791,11 +830,7 @@ static int iterate_impl(gbp_ctx* c, int n) {
     for (; left > 0; --left) enqueue_iteration(c, a);
   }
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipEventRecord(c->ev3, c->stream));
-  HIPCHK(c, hipEventSynchronize(c->ev3));
-  float ms = 0;
-  HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev3));
-  c->total_ms += ms;
+  if (int rc = span_end(c, sp)) return rc;
   c->timed_iters += (uint64_t)n;
   c->beliefs_valid = true;
   return GBP_OK;
@@ -925,24 +960,28 @@ static int new_keyframe_impl(gbp_ctx* c, const gbp_kf_update* u) {
 static int eval_impl(gbp_ctx* c, gbp_eval_out* o) {
   if (!c || !o || !c->uploaded) return fail(c, GBP_ERR_STATE, "gbp_eval: upload first");
   std::memset(o, 0, sizeof(*o));
+  // slot 0 of the result buffer holds the two health counters, slots 1..nb the per-block metric partials: everything
+  // comes back in ONE asynchronous copy into pinned memory, followed by the only host synchronisation of the call
+  DeviceEval* slots = P<DeviceEval>(c->evalp);
   launch_means(P<float4>(c->camb), P<float4>(c->lmkb), P<float>(c->cam_mu), P<float>(c->lmk_mu), c->C, c->L_loc,
-               P<unsigned long long>(c->health), /*count_cams=*/c->rank == 0, c->stream);
+               reinterpret_cast<unsigned long long*>(slots), /*count_cams=*/c->rank == 0, c->stream);
   launch_eval(P<uint32_t>(c->row_cam), P<uint32_t>(c->lmk_idx), P<float4>(c->lmsg), P<float4>(c->fac), P<float>(c->cam_mu), P<float>(c->lmk_mu),
-              P<float>(c->dK), c->prm.num_undamped_iters, P<DeviceEval>(c->evalp), c->n_tiles, c->stream);
+              P<float>(c->dK), c->prm.num_undamped_iters, slots + 1, c->n_tiles, c->stream);
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipStreamSynchronize(c->stream));
   const uint32_t nb = eval_blocks(c->n_tiles);
-  std::vector<DeviceEval> part(nb);
-  HIPCHK(c, hipMemcpy(part.data(), c->evalp.p, sizeof(DeviceEval) * nb, hipMemcpyDeviceToHost));
-  for (uint32_t b = 0; b < nb; ++b) {
+  if (!c->eval_host) HIPCHK(c, hipHostMalloc(&c->eval_host, sizeof(DeviceEval) * 1025, hipHostMallocDefault));
+  HIPCHK(c, hipMemcpyAsync(c->eval_host, slots, sizeof(DeviceEval) * (nb + 1), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const DeviceEval* part = static_cast<const DeviceEval*>(c->eval_host);
+  for (uint32_t b = 1; b <= nb; ++b) {
     o->sum_norm += part[b].sum_norm; o->sum_half_sq += part[b].sum_half_sq;
     o->n_active += part[b].n_active; o->n_relin += part[b].n_relin; o->n_robust += part[b].n_robust;
   }
   // non-finite guard (replaces the Poplar FP traps of ba.cpp:888-891) + non-PD belief count;
   // cameras are replicated, so only rank 0 counts them
   {
-    unsigned long long h[2] = {0, 0};
-    HIPCHK(c, hipMemcpy(h, c->health.p, 16, hipMemcpyDeviceToHost));
+    unsigned long long h[2];
+    std::memcpy(h, part, 16);
     o->n_nonfinite = h[0];
     o->n_nonpd = h[1];
   }
@@ -952,6 +991,7 @@ static int eval_impl(gbp_ctx* c, gbp_eval_out* o) {
 int gbp_timing(gbp_ctx* c, gbp_timing_out* t, int reset) {
   if (!c || !t) return GBP_ERR_INVALID;
   drain_sweep_events(c);   // split-phase brackets recorded by gbp_iterate_begin
+  resolve_spans(c, true);  // gbp_iterate brackets still in flight
   t->sweep_ms = c->sweep_ms; t->belief_ms = c->belief_ms; t->total_ms = c->total_ms; t->iterations = c->timed_iters;
   t->algorithmic_bytes_per_iter = 1112ull * c->E_loc + 336ull * c->C + 96ull * c->L_loc;
   t->device_bytes_allocated = c->dev_bytes;

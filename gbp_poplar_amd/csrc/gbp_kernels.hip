@@ -725,27 +725,45 @@ __global__ __launch_bounds__(256) void k_weaken_flags(uint32_t* flag, uint32_t n
 // Metric: util.cpp:74-144.  Variable means by an fp64 partial-pivot solve of the fp32 belief
 // (stands in for Eigen's general inverse), residuals in fp32, sums in fp64.
 // =================================================================================================
+// Every loop has compile-time bounds and every row swap is a select, so the 6 x 7 fp64 tableau lives in registers
+// (no scratch: this kernel sits on the critical path of the per-iteration metric of small graphs).
 template <int N>
 GBP_DEV void solve_pivot(const float* A, int lda, const float* b, float* x) {
   double M[N][N + 1];
+  GBP_UNROLL
   for (int i = 0; i < N; ++i) {
+    GBP_UNROLL
     for (int j = 0; j < N; ++j) M[i][j] = A[i * lda + j];
     M[i][N] = b[i];
   }
+  GBP_UNROLL
   for (int k = 0; k < N; ++k) {
     int piv = k;
     double best = fabs(M[k][k]);
+    GBP_UNROLL
     for (int i = k + 1; i < N; ++i)
       if (fabs(M[i][k]) > best) { best = fabs(M[i][k]); piv = i; }
-    if (piv != k)
-      for (int j = 0; j <= N; ++j) { const double t = M[k][j]; M[k][j] = M[piv][j]; M[piv][j] = t; }
+    GBP_UNROLL
+    for (int i = k + 1; i < N; ++i) {      // swap rows k and piv (at most one i matches)
+      const bool sw = piv == i;
+      GBP_UNROLL
+      for (int j = 0; j <= N; ++j) {
+        const double t = M[k][j];
+        M[k][j] = sw ? M[i][j] : t;
+        M[i][j] = sw ? t : M[i][j];
+      }
+    }
+    GBP_UNROLL
     for (int i = k + 1; i < N; ++i) {
       const double f = M[i][k] / M[k][k];
+      GBP_UNROLL
       for (int j = k; j <= N; ++j) M[i][j] -= f * M[k][j];
     }
   }
+  GBP_UNROLL
   for (int i = N - 1; i >= 0; --i) {
     double s = M[i][N];
+    GBP_UNROLL
     for (int j = i + 1; j < N; ++j) s -= M[i][j] * (double)x[j];
     x[i] = (float)(s / M[i][i]);
   }
@@ -758,13 +776,17 @@ template <int N>
 GBP_DEV bool ldl_pivots_positive(const float* A, int lda) {
   double L[N][N], D[N];
   bool ok = true;
+  GBP_UNROLL
   for (int j = 0; j < N; ++j) {
     double d = A[j * lda + j];
+    GBP_UNROLL
     for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k] * D[k];
     D[j] = d;
     if (!(d > 0.0)) ok = false;
+    GBP_UNROLL
     for (int i = j + 1; i < N; ++i) {
       double v = A[i * lda + j];
+      GBP_UNROLL
       for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k] * D[k];
       L[i][j] = v / d;
     }
@@ -780,6 +802,7 @@ __global__ __launch_bounds__(256) void k_means(const float* __restrict__ camb, c
     float x[6];
     solve_pivot<6>(camb + (size_t)t * kCamRec + 8, 6, camb + (size_t)t * kCamRec, x);
     bool finite = true;
+    GBP_UNROLL
     for (int i = 0; i < 6; ++i) { cam_mu[(size_t)t * 6 + i] = x[i]; finite &= (x[i] - x[i] == 0.f); }
     if (count_cams) {
       if (!finite) atomicAdd(&health[0], 1ull);
@@ -790,6 +813,7 @@ __global__ __launch_bounds__(256) void k_means(const float* __restrict__ camb, c
     float x[3];
     solve_pivot<3>(lmkb + (size_t)l * 16 + 4, 3, lmkb + (size_t)l * 16, x);
     bool finite = true;
+    GBP_UNROLL
     for (int i = 0; i < 3; ++i) { lmk_mu[(size_t)l * 3 + i] = x[i]; finite &= (x[i] - x[i] == 0.f); }
     if (!finite) atomicAdd(&health[0], 1ull);
     if (!ldl_pivots_positive<3>(lmkb + (size_t)l * 16 + 4, 3)) atomicAdd(&health[1], 1ull);
