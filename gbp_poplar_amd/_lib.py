@@ -55,6 +55,7 @@ _SIGS = {
     "gbp_debug_time_sweep": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "gbp_debug_set_factor_potentials": (C.c_int, [C.c_void_p, cabi.c_f32p, cabi.c_f32p]),
     "gbp_debug_math": (C.c_int, [C.c_int, cabi.c_f32p, cabi.c_f32p, C.c_int]),
+    "gbp_debug_math_timed": (C.c_int, [C.c_int, cabi.c_f32p, cabi.c_f32p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "gbp_bal_read_header": (C.c_int, [C.c_char_p, C.POINTER(cabi.GbpBal)]),
     "gbp_bal_read": (C.c_int, [C.c_char_p, C.POINTER(cabi.GbpBal)]),
     "gbp_bal_write": (C.c_int, [C.c_char_p, C.POINTER(cabi.GbpBal)]),

@@ -1216,17 +1216,20 @@ int gbp_eval_global(gbp_ctx* c, gbp_eval_out* o) {
 
 // Device math layer on caller-supplied vectors (test hook, see k_debug_math): HIP vs the reference's own
 // matlib.cpp / bafuncs.cpp outputs, no ctx and no restated vertex layer involved.
-int gbp_debug_math(int op, const float* in, float* out, int n) {
+static int debug_math_run(int op, const float* in, float* out, int n, int reps, double* avg_us) {
   int in_w = 0, out_w = 0;
-  if (!in || !out || n <= 0 || !debug_math_widths(op, &in_w, &out_w))
+  if (!in || !out || n <= 0 || reps < 1 || !debug_math_widths(op, &in_w, &out_w))
     return fail(nullptr, GBP_ERR_INVALID, "gbp_debug_math: bad op / arguments");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     return fail(nullptr, GBP_ERR_NO_DEVICE, "gbp_debug_math: no HIP device (the product has no CPU fallback)");
   float *d_in = nullptr, *d_out = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
   auto done = [&](int rc, const char* what, hipError_t e) {
     if (d_in) (void)hipFree(d_in);
     if (d_out) (void)hipFree(d_out);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
     return rc == GBP_OK ? rc : fail(nullptr, rc, std::string(what) + ": " + hipGetErrorString(e));
   };
   hipError_t e;
@@ -1235,8 +1238,24 @@ int gbp_debug_math(int op, const float* in, float* out, int n) {
   if ((e = hipMemcpy(d_in, in, (size_t)n * in_w * 4, hipMemcpyHostToDevice)) != hipSuccess) return done(GBP_ERR_HIP, "hipMemcpy", e);
   launch_debug_math(op, d_in, d_out, n, nullptr);
   if ((e = hipGetLastError()) != hipSuccess) return done(GBP_ERR_HIP, "k_debug_math", e);
+  if (avg_us) {   // back-to-back launches between two events
+    if ((e = hipEventCreate(&e0)) != hipSuccess || (e = hipEventCreate(&e1)) != hipSuccess) return done(GBP_ERR_HIP, "hipEventCreate", e);
+    (void)hipEventRecord(e0, nullptr);
+    for (int i = 0; i < reps; ++i) launch_debug_math(op, d_in, d_out, n, nullptr);
+    (void)hipEventRecord(e1, nullptr);
+    if ((e = hipEventSynchronize(e1)) != hipSuccess) return done(GBP_ERR_HIP, "hipEventSynchronize", e);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    *avg_us = 1e3 * ms / reps;
+  }
   if ((e = hipMemcpy(out, d_out, (size_t)n * out_w * 4, hipMemcpyDeviceToHost)) != hipSuccess) return done(GBP_ERR_HIP, "hipMemcpy", e);
   return done(GBP_OK, "", hipSuccess);
+}
+
+int gbp_debug_math(int op, const float* in, float* out, int n) { return debug_math_run(op, in, out, n, 1, nullptr); }
+int gbp_debug_math_timed(int op, const float* in, float* out, int n, int reps, double* avg_us) {
+  if (!avg_us) return GBP_ERR_INVALID;
+  return debug_math_run(op, in, out, n, reps, avg_us);
 }
 
 // ---- exported wrappers of the entry points that allocate host memory -----------------------------------------

@@ -1040,15 +1040,105 @@ bool launch_sweep_ablated(const SweepArgs& a, uint32_t n_tiles, int abl, hipStre
 #endif
   return true;
 }
+// =================================================================================================
+// k_inv6_coop: the SUB-WAVE mapping the north star sketches, built for the dominant routine so that it can be measured:
+// 16 lanes (one DPP row) cooperate on ONE 6x6 inverse, operands staged in LDS, lane = output element, every k-loop
+// in the reference's order (so the result is bit-identical to inv6x6_lower / matlib.cpp:180-222).  Four matrices per
+// wavefront instead of 64.  Test + measurement hook (gbp_debug_math op 9, gbp_debug_math_timed): DESIGN.md 2 quotes
+// its timing against the lane-per-matrix routine.
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_inv6_coop(const float* __restrict__ in, float* __restrict__ out, int n) {
+  __shared__ float ws_all[16][64];                          // per 16-lane group: A lower 21 | U 15 | Ui 15
+  const int grp = (blockIdx.x * 256 + threadIdx.x) >> 4;    // matrix handled by this 16-lane group
+  const int t = threadIdx.x & 15;
+  float* ws = ws_all[threadIdx.x >> 4];
+  const bool live = grp < n;
+  const float* A = in + (size_t)(live ? grp : 0) * 36;
+  auto uidx = [](int j, int i) { return 21 + j * 5 - j * (j - 1) / 2 + (i - j - 1); };   // U[j][i], j < i   (15 entries)
+  auto sync = []() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  GBP_UNROLL
+  for (int r = 0; r < 2; ++r) {                             // stage the lower triangle
+    const int e = t + 16 * r;
+    if (e < 21) {
+      int i = 0;
+      while ((i + 1) * (i + 2) / 2 <= e) ++i;
+      const int j = e - i * (i + 1) / 2;
+      ws[e] = A[i * 6 + j];
+    }
+  }
+  sync();
+  float D[6], rD[6];
+  GBP_UNROLL
+  for (int j = 0; j < 6; ++j) {                             // un-pivoted LDL^T, column by column
+    float d = ws[tri(j, j)];
+    GBP_UNROLL
+    for (int k = 0; k < j; ++k) { const float ukj = ws[uidx(k, j)]; d -= ukj * ukj * D[k]; }
+    D[j] = d;
+    rD[j] = 1 / d;
+    const int i = j + 1 + t;                                // lane t owns U[j][j+1+t]
+    if (i < 6) {
+      float u = rD[j] * ws[tri(i, j)];
+      GBP_UNROLL
+      for (int k = 0; k < j; ++k) u -= rD[j] * ws[uidx(k, i)] * ws[uidx(k, j)] * D[k];
+      ws[uidx(j, i)] = u;
+    }
+    sync();
+  }
+  {                                                         // inverse of the unit upper factor: lane t < 5 owns row t
+    float ui[6];
+    GBP_UNROLL
+    for (int k = 0; k < 6; ++k) ui[k] = 0.f;
+    GBP_UNROLL
+    for (int j = 1; j < 6; ++j) {
+      if (t < j) {
+        float acc = 0.f;
+        acc += ws[uidx(t, j)];
+        GBP_UNROLL
+        for (int k = 1; k < j; ++k)
+          if (k > t) acc += ui[k] * ws[uidx(k, j)];
+        ui[j] = acc / -1.f;
+        ws[36 + (uidx(t, j) - 21)] = ui[j];
+      }
+    }
+  }
+  sync();
+  GBP_UNROLL
+  for (int r = 0; r < 3; ++r) {                             // Ainv = (LTinv Dinv) LTinv^T, lane = output element
+    const int e = t + 16 * r;
+    if (e < 36) {
+      const int i = e / 6, j = e - 6 * i;
+      const int k0 = i > j ? i : j;
+      float acc = 0.f;
+      GBP_UNROLL
+      for (int k = 0; k < 6; ++k) {
+        if (k >= k0) {
+          const float w = (k == i) ? rD[k] : ws[36 + (uidx(i, k) - 21)] * rD[k];
+          if (k == j) acc += w;
+          else acc += w * ws[36 + (uidx(j, k) - 21)];
+        }
+      }
+      if (live) out[(size_t)grp * 36 + e] = acc;
+    }
+  }
+}
+
 bool debug_math_widths(int op, int* in_w, int* out_w) {
-  static const int iw[9] = {9, 36, 3, 18, 72, 72, 54, 42, 12}, ow[9] = {9, 36, 9, 20, 18, 18, 36, 6, 3};
-  if (op < 0 || op > 8) return false;
+  static const int iw[10] = {9, 36, 3, 18, 72, 72, 54, 42, 12, 36}, ow[10] = {9, 36, 9, 20, 18, 18, 36, 6, 3, 36};
+  if (op < 0 || op > 9) return false;
   *in_w = iw[op]; *out_w = ow[op];
   return true;
 }
 void launch_debug_math(int op, const float* in, float* out, int n, hipStream_t s) {
   int in_w = 0, out_w = 0;
   if (!debug_math_widths(op, &in_w, &out_w) || n <= 0) return;
+  if (op == 9) {   // 16 lanes per matrix
+    hipLaunchKernelGGL(k_inv6_coop, dim3(((size_t)n * 16 + 255) / 256), dim3(256), 0, s, in, out, n);
+    return;
+  }
   hipLaunchKernelGGL(k_debug_math, dim3((n + 63) / 64), dim3(64), 0, s, op, in, out, n, in_w, out_w);
 }
 void launch_linearise(const SweepArgs& a, uint32_t n_tiles, hipStream_t s) {

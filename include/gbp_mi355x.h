@@ -257,8 +257,12 @@ int gbp_debug_set_factor_potentials(gbp_ctx* ctx, const float* eta9E, const floa
  *   op 2 so3exp 3 -> 9 (bafuncs.cpp:31-55)         op 3 hfunc + Jac: cam6 lmk3 K9 -> hx2 Jkf12 Jlmk6 (bafuncs.cpp:82-213)
  *   op 4 P(6x3) += B(6x6) A(6x3), op 5 P(3x6) += A^T B: A18 B36 P18 -> 18;  op 6 P(6x6) += A A^T: A18 P36 -> 36
  *        (matMul and its transpose modes, matlib.cpp:47-89)
- *   op 7 inf2mean6x6: eta6 Lambda36 -> 6;  op 8 inf2mean3x3: eta3 Lambda9 -> 3 (bafuncs.cpp:2-15)                */
+ *   op 7 inf2mean6x6: eta6 Lambda36 -> 6;  op 8 inf2mean3x3: eta3 Lambda9 -> 3 (bafuncs.cpp:2-15)
+ *   op 9 inv6x6 again, but in the SUB-WAVE mapping: 16 lanes cooperate on one matrix (operands in LDS, lane = output
+ *        element, reference order): 36 -> 36, bit-identical to op 1; exists to be measured against it   */
 int gbp_debug_math(int op, const float* in, float* out, int n);
+/* same, then `reps` back-to-back launches timed with hipEvents: average microseconds per launch */
+int gbp_debug_math_timed(int op, const float* in, float* out, int n, int reps, double* avg_us);
 
 /* ---- host-side helpers of the path's callers (pure CPU, no device needed) ---------------- */
 /* BALProblem::LoadFile (dataio.cpp:17-57).  Two-call pattern: pass NULL arrays to get sizes. */

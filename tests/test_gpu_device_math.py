@@ -84,3 +84,16 @@ def test_hfunc_and_jac_vs_reference():
         den = np.max(np.abs(b), axis=1, keepdims=True).astype(np.float64)
         assert np.max(np.abs(a.astype(np.float64) - b) / den) <= 2e-6
     assert np.all(jk[:, 1] == 0) and np.all(jk[:, 6] == 0)                                       # structural zeros
+
+
+def test_subwave_mapping_of_inv6x6_is_bit_identical():
+    """op 9: the north star's sub-wave mapping (16 lanes per matrix, operands in LDS, lane = output element) built
+    for the dominant routine: bit-identical to the reference's inv6x6 (golden) and to the lane-per-matrix routine on
+    5 000 fresh SPD matrices with ragged tails (n not a multiple of 4, 16 or 64)."""
+    out = _run(9, G["inv6_in"].reshape(-1, 36), 36)
+    assert np.array_equal(out, G["inv6_out"].reshape(-1, 36))
+    rng = np.random.default_rng(5)
+    for n in (1, 3, 17, 4999):
+        a = rng.standard_normal((n, 6, 6))
+        m = (a @ a.transpose(0, 2, 1) + 0.5 * np.eye(6)).astype(np.float32).reshape(n, 36)
+        assert np.array_equal(_run(9, m, 36), _run(1, m, 36)), n
