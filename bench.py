@@ -76,7 +76,10 @@ def parse(argv=None):
     ap.add_argument("--comm", choices=["native", "torch"], default="native",
                     help="N > 1: who runs the all-gather — the C++ library's own RCCL communicator (gbp_comm_init_rccl; "
                          "sharded iteration captured in a hipGraph) or torch.distributed around the split-phase C-ABI")
-    ap.add_argument("--sharded-graph", type=int, default=0, help="--comm torch: capture sharded iterations (kernels + RCCL) in a hipGraph")
+    ap.add_argument("--sharded-graph", type=int, default=None,
+                    help="capture the sharded iteration (kernels + the RCCL all-gather) in a hipGraph.  Default: on for the "
+                         "1-rank diagnostic (--force-sharded, verified on hardware), off for real multi-rank runs, where the "
+                         "capture of a multi-rank collective could not be verified by the build (no multi-GPU node)")
     ap.add_argument("--exchange-chunks", type=int, default=None,
                     help="camera ranges of the pipelined all-gather (default: 1)")
     ap.add_argument("--tile-order", type=int, default=0, help="gbp_params.tile_order: 0 = default, 1 = sequential, 2 = sweep tiles XCD-aware too")
@@ -389,6 +392,10 @@ def main(argv=None):
     K, state, _ = driver.build_inputs(bal, opts, hostlib)
 
     prm = _cabi.GbpParams.defaults(tile_order=a.tile_order)
+    if a.sharded_graph is None:
+        a.sharded_graph = 1 if world == 1 else 0
+    if sharded and a.comm == "native" and not a.sharded_graph:
+        prm.graph_unroll = -1
     comm_error, exchange_kind = None, None
     if not sharded:
         eng = GbpEngine(bal["cam_id"], bal["lmk_id"], C, L, K, params=prm)

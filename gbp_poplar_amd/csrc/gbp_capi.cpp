@@ -323,7 +323,7 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
   c->C = pr->n_cams; c->L = pr->n_lmks; c->E = pr->n_edges;
   std::memcpy(c->K, pr->K, sizeof(c->K));
   if (prm) c->prm = *prm; else gbp_default_params(&c->prm);
-  if (c->prm.graph_unroll <= 0) c->prm.graph_unroll = 10;
+  if (c->prm.graph_unroll == 0) c->prm.graph_unroll = 10;   // < 0: never capture, always direct launches
   c->hoist = c->prm.per_factor_mu == 0;
   c->rank = sh ? sh->rank : 0;
   c->world = sh ? sh->world : 1;
