@@ -430,8 +430,10 @@ def main(argv=None):
     run.linearise()
     ev0 = run_eval()
     warm_start(run, opts, a.warmup)
+    extra_warm = 0
     if getattr(run, "use_graph", False):
-        run.iterate(run.graph_unroll + 3)      # un-timed: triggers the one-off capture of the sharded iteration graph
+        extra_warm = run.graph_unroll + 3
+        run.iterate(extra_warm)                # un-timed: triggers the one-off capture of the sharded iteration graph
 
     def fence():
         run.sync()
@@ -532,7 +534,7 @@ def main(argv=None):
                        "cams": C, "lmks": L, "factors": E, "iters_per_sec": round(ips, 2),
                        "parallelism": "1 GPU, hipGraph x10 iterations" if not sharded else "landmark shards x%d + all_gather(cam partials)" % world,
                        "reproj_rmse_px_initial": round(m0[2], 6), "reproj_rmse_px_final": round(m1[2], 6),
-                       "mean_reproj_px_final": round(m1[0], 6), "iterations_run": a.warmup + a.steps,
+                       "mean_reproj_px_final": round(m1[0], 6), "iterations_run": a.warmup + extra_warm + a.steps,
                        "nonfinite_beliefs": int(ev1["n_nonfinite"]),
                        "exchange_chunks": getattr(run, "chunks", None),
                        "iteration_graph": graph_used, "exchange": exchange_kind, "comm_error": comm_error,

@@ -42,3 +42,43 @@ def test_default_workloads():
     assert bench.workload_name(a1, 1, 1000, 100000, 1000000).startswith("S1 ")
     s = bench.build_stamp(a1)
     assert len(s["source_sha16"]) == 16 and s["workload"] == [1000, 100000, 10, 20200303]
+
+
+def _bench_gpu(*args):
+    import pytest
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cams", "60", "--lmks", "4000", "--steps", "12",
+                        "--warmup", "12", "--profile-steps", "5", "--cpu-seconds", "0", *args],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    return json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("comm", ["native", "torch"])
+def test_bench_sharded_code_path_on_one_gpu(comm):
+    """bench.py --force-sharded: the N > 1 code path (shard ctx, RCCL all-gather, overlap; the library's own communicator
+    or torch.distributed) with one rank on one GPU — same contract fields, same convergence as the plain path."""
+    plain = _bench_gpu("--pmc", "off")
+    out = _bench_gpu("--force-sharded", "--comm", comm, "--sharded-graph", "1" if comm == "native" else "0")
+    assert out["config"]["iterations_run"] == plain["config"]["iterations_run"] == 24
+    assert out["n_gpus"] == 1 and out["steps"] == 12 and out["value"] > 0 and out["higher_is_better"] is True
+    assert out["config"]["comm_error"] is None
+    assert ("native" in out["config"]["exchange"]) == (comm == "native")
+    assert out["config"]["reproj_rmse_px_final"] == plain["config"]["reproj_rmse_px_final"]      # bit-identical runs
+    assert out["roofline"]["avg_launch_us"] > 0 and out["roofline"]["frac_algorithmic"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_live_pmc_traffic():
+    """The default N = 1 bench measures the HBM-side traffic of its kernels itself (two rocprofv3 --pmc child passes)."""
+    out = _bench_gpu()
+    r = out["roofline"]
+    assert r["traffic_source"].startswith("live rocprofv3") and r["traffic"] > 0 and 0 < r["frac"] < 1.0, r
+    assert {k["kernel"] for k in r["kernels"]} == {"k_sweep", "k_beliefs"}
+    assert r["profiled_ms_per_step"] * 1e3 >= 0.9 * (r["avg_launch_us"] + r["belief_kernels_avg_us"])
