@@ -76,7 +76,9 @@ struct gbp_ctx {
   struct Span { hipEvent_t a, b; };
   std::vector<Span> spans;             // recorded, not yet read
   std::vector<Span> span_pool;         // reusable event pairs
-  void* eval_host = nullptr;           // pinned: per-block metric partials + health counters land here in one copy
+  void* eval_host = nullptr;           // pinned + device-mapped: k_eval writes the metric partials + health counters here
+  void* eval_host_dev = nullptr;
+  int eval_parity = 0;
   bool profile_stages = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_sweep_ev;  // split-phase profiling: brackets not yet read
   double sweep_ms = 0, belief_ms = 0, total_ms = 0;
@@ -389,7 +391,7 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
   A(c->d_cam_row_ptr, (size_t)(C + 1) * 4); A(c->d_lmk_ptr, (size_t)(c->L_loc + 1) * 4);
   A(c->cwf, (size_t)C * 4); A(c->lwf, (size_t)c->L_loc * 4); A(c->cscale, (size_t)C * 4); A(c->lscale, (size_t)c->L_loc * 4);
   A(c->cam_mu, (size_t)C * 6 * 4); A(c->lmk_mu, (size_t)c->L_loc * 3 * 4); A(c->dK, 16 * 4);
-  A(c->evalp, sizeof(DeviceEval) * 1025); A(c->health, 16);
+  A(c->evalp, sizeof(DeviceEval) * 16); A(c->health, 32);
   A(c->hmu_c, (size_t)C * 4 * 16); A(c->hmu_l, (size_t)c->L_loc * 2 * 16);
   A(c->st_a, Ep * 4); A(c->st_b, Ep * 4);
   if (rc != GBP_OK) { g_create_error = c->err; return rc; }
@@ -960,17 +962,24 @@ static int new_keyframe_impl(gbp_ctx* c, const gbp_kf_update* u) {
 static int eval_impl(gbp_ctx* c, gbp_eval_out* o) {
   if (!c || !o || !c->uploaded) return fail(c, GBP_ERR_STATE, "gbp_eval: upload first");
   std::memset(o, 0, sizeof(*o));
-  // slot 0 of the result buffer holds the two health counters, slots 1..nb the per-block metric partials: everything
-  // comes back in ONE asynchronous copy into pinned memory, followed by the only host synchronisation of the call
-  DeviceEval* slots = P<DeviceEval>(c->evalp);
+  // The result lands DIRECTLY in pinned, device-mapped host memory: slot 0 = the two health counters, slots 1..nb = the
+  // per-block metric partials, written by k_eval itself — no copy launch, and the one host synchronisation of the call.
+  // The health counters are accumulated with atomics in device memory, double-buffered so that no memset launch is
+  // needed: k_means zeroes the pair the NEXT evaluation will use.
+  if (!c->eval_host) {
+    HIPCHK(c, hipHostMalloc(&c->eval_host, sizeof(DeviceEval) * 1025, hipHostMallocMapped));
+    HIPCHK(c, hipHostGetDevicePointer(&c->eval_host_dev, c->eval_host, 0));
+  }
+  DeviceEval* slots = static_cast<DeviceEval*>(c->eval_host_dev);
+  unsigned long long* h_cur = P<unsigned long long>(c->health) + 2 * (c->eval_parity & 1);
+  unsigned long long* h_next = P<unsigned long long>(c->health) + 2 * ((c->eval_parity + 1) & 1);
+  c->eval_parity ^= 1;
   launch_means(P<float4>(c->camb), P<float4>(c->lmkb), P<float>(c->cam_mu), P<float>(c->lmk_mu), c->C, c->L_loc,
-               reinterpret_cast<unsigned long long*>(slots), /*count_cams=*/c->rank == 0, c->stream);
+               h_cur, h_next, /*count_cams=*/c->rank == 0, c->stream);
   launch_eval(P<uint32_t>(c->row_cam), P<uint32_t>(c->lmk_idx), P<float4>(c->lmsg), P<float4>(c->fac), P<float>(c->cam_mu), P<float>(c->lmk_mu),
-              P<float>(c->dK), c->prm.num_undamped_iters, slots + 1, c->n_tiles, c->stream);
+              P<float>(c->dK), c->prm.num_undamped_iters, slots + 1, h_cur, reinterpret_cast<unsigned long long*>(slots), c->n_tiles, c->stream);
   HIPCHK(c, hipGetLastError());
   const uint32_t nb = eval_blocks(c->n_tiles);
-  if (!c->eval_host) HIPCHK(c, hipHostMalloc(&c->eval_host, sizeof(DeviceEval) * 1025, hipHostMallocDefault));
-  HIPCHK(c, hipMemcpyAsync(c->eval_host, slots, sizeof(DeviceEval) * (nb + 1), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const DeviceEval* part = static_cast<const DeviceEval*>(c->eval_host);
   for (uint32_t b = 1; b <= nb; ++b) {

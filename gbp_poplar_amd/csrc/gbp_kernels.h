@@ -112,11 +112,12 @@ void launch_weaken(float4* prior, const float* scaling, uint32_t* flag, uint32_t
 void launch_state_get(const float4* lmsg, float* damping, int* packed, uint32_t n, hipStream_t s);
 void launch_state_set(float4* lmsg, const int* new_count, const uint32_t* ctl, uint32_t n, hipStream_t s);
 void launch_means(const float4* camb, const float4* lmkb, float* cam_mu, float* lmk_mu, uint32_t n_cams,
-                  uint32_t n_lmks, unsigned long long* health2 /* [0] non-finite means, [1] non-PD beliefs */,
+                  uint32_t n_lmks, unsigned long long* health2 /* [0] non-finite means, [1] non-PD beliefs: zero on entry */,
+                  unsigned long long* health2_next /* zeroed by this launch for the next evaluation */,
                   bool count_cams, hipStream_t s);
 void launch_eval(const uint32_t* row_cam, const uint32_t* lmk_idx, const float4* lmsg, const float4* fac, const float* cam_mu,
-                 const float* lmk_mu, const float* K9_dev, int num_undamped_iters, DeviceEval* partials, uint32_t n_tiles,
-                 hipStream_t s);
+                 const float* lmk_mu, const float* K9_dev, int num_undamped_iters, DeviceEval* partials /* may be mapped host memory */,
+                 const unsigned long long* health2, unsigned long long* health2_out, uint32_t n_tiles, hipStream_t s);
 uint32_t eval_blocks(uint32_t n_tiles);
 bool debug_math_widths(int op, int* in_w, int* out_w);   // floats per vector of k_debug_math's op
 void launch_debug_math(int op, const float* in, float* out, int n, hipStream_t s);  // test hook

@@ -628,11 +628,19 @@ __global__ __launch_bounds__(256) void k_beliefs(const BeliefArgs b) {
     for (int k = 0; k < 15; ++k)     // adds in slot order
       if ((uint32_t)k < deg) { acc.x = acc.x + m[k].x; acc.y = acc.y + m[k].y; acc.z = acc.z + m[k].z; acc.w = acc.w + m[k].w; }
   }
-  if (deg > 15u) {
+  if (deg > 15u) {   // slots 16.. : positions from lmk_fpos, 8 record gathers in flight per round, adds in slot order
     const uint32_t s1 = b.lmk_ptr[l + 1];
-    for (uint32_t s = b.lmk_ptr[l] + 15u; s < s1; ++s) {
-      const float4 mm = lmsg_piece(b.lmsg, b.lmk_fpos[s], q);
-      acc.x = acc.x + mm.x; acc.y = acc.y + mm.y; acc.z = acc.z + mm.z; acc.w = acc.w + mm.w;
+    for (uint32_t s = b.lmk_ptr[l] + 15u; s < s1; s += 8) {
+      uint32_t pos[8];
+      float4 m[8];
+      const uint32_t nleft = s1 - s;
+      GBP_UNROLL
+      for (int k = 0; k < 8; ++k) pos[k] = (uint32_t)k < nleft ? b.lmk_fpos[s + k] : 0u;
+      GBP_UNROLL
+      for (int k = 0; k < 8; ++k) m[k] = (uint32_t)k < nleft ? lmsg_piece(b.lmsg, pos[k], q) : make_float4(0.f, 0.f, 0.f, 0.f);
+      GBP_UNROLL
+      for (int k = 0; k < 8; ++k)
+        if ((uint32_t)k < nleft) { acc.x = acc.x + m[k].x; acc.y = acc.y + m[k].y; acc.z = acc.z + m[k].z; acc.w = acc.w + m[k].w; }
     }
   }
   if (b.hoist) {
@@ -796,8 +804,10 @@ GBP_DEV bool ldl_pivots_positive(const float* A, int lda) {
 
 __global__ __launch_bounds__(256) void k_means(const float* __restrict__ camb, const float* __restrict__ lmkb,
                                                float* __restrict__ cam_mu, float* __restrict__ lmk_mu, uint32_t n_cams,
-                                               uint32_t n_lmks, unsigned long long* health, int count_cams) {
+                                               uint32_t n_lmks, unsigned long long* health, unsigned long long* health_next,
+                                               int count_cams) {
   const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t == 0) { health_next[0] = 0ull; health_next[1] = 0ull; }   // the NEXT evaluation's counters (double-buffered: no memset launch)
   if (t < n_cams) {
     float x[6];
     solve_pivot<6>(camb + (size_t)t * kCamRec + 8, 6, camb + (size_t)t * kCamRec, x);
@@ -829,7 +839,9 @@ uint32_t eval_blocks(uint32_t n_tiles) {
 __global__ __launch_bounds__(256) void k_eval(const uint32_t* __restrict__ row_cam, const uint32_t* __restrict__ lmk_idx,
                                               const float4* __restrict__ lmsg, const float4* __restrict__ fac, const float* __restrict__ cam_mu,
                                               const float* __restrict__ lmk_mu, const float* __restrict__ Kd,
-                                              int num_undamped, DeviceEval* partials, uint32_t n_tiles) {
+                                              int num_undamped, DeviceEval* partials, const unsigned long long* health,
+                                              unsigned long long* health_out, uint32_t n_tiles) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) { health_out[0] = health[0]; health_out[1] = health[1]; }   // k_means has finished (stream order)
   double s_norm = 0, s_half = 0;
   unsigned long long n_act = 0, n_rel = 0, n_rob = 0;
   const uint32_t total = n_tiles * 64;
@@ -1164,16 +1176,15 @@ void launch_state_set(float4* lmsg, const int* new_count, const uint32_t* ctl, u
   hipLaunchKernelGGL(k_state_set, dim3(blocks_for(n)), dim3(256), 0, s, lmsg, new_count, ctl, n);
 }
 void launch_means(const float4* camb, const float4* lmkb, float* cam_mu, float* lmk_mu, uint32_t n_cams, uint32_t n_lmks,
-                  unsigned long long* health2, bool count_cams, hipStream_t s) {
-  (void)hipMemsetAsync(health2, 0, 16, s);
+                  unsigned long long* health2, unsigned long long* health2_next, bool count_cams, hipStream_t s) {
   hipLaunchKernelGGL(k_means, dim3(blocks_for((uint64_t)n_cams + n_lmks)), dim3(256), 0, s, (const float*)camb,
-                     (const float*)lmkb, cam_mu, lmk_mu, n_cams, n_lmks, health2, count_cams ? 1 : 0);
+                     (const float*)lmkb, cam_mu, lmk_mu, n_cams, n_lmks, health2, health2_next, count_cams ? 1 : 0);
 }
 void launch_eval(const uint32_t* row_cam, const uint32_t* lmk_idx, const float4* lmsg, const float4* fac, const float* cam_mu,
-                 const float* lmk_mu, const float* K9_dev, int num_undamped_iters, DeviceEval* partials, uint32_t n_tiles,
-                 hipStream_t s) {
+                 const float* lmk_mu, const float* K9_dev, int num_undamped_iters, DeviceEval* partials,
+                 const unsigned long long* health2, unsigned long long* health2_out, uint32_t n_tiles, hipStream_t s) {
   hipLaunchKernelGGL(k_eval, dim3(eval_blocks(n_tiles)), dim3(256), 0, s, row_cam, lmk_idx, lmsg, fac, cam_mu, lmk_mu, K9_dev,
-                     num_undamped_iters, partials, n_tiles);
+                     num_undamped_iters, partials, health2, health2_out, n_tiles);
 }
 
 }  // namespace gbp
