@@ -25,6 +25,8 @@ _SIGS = {
     "gbp_read_priors": (C.c_int, [C.c_void_p, C.POINTER(cabi.GbpPriorsOut)]),
     "gbp_new_keyframe": (C.c_int, [C.c_void_p, C.POINTER(cabi.GbpKfUpdate)]),
     "gbp_eval": (C.c_int, [C.c_void_p, C.POINTER(cabi.GbpEvalOut)]),
+    "gbp_eval_begin": (C.c_int, [C.c_void_p]),
+    "gbp_eval_end": (C.c_int, [C.c_void_p, C.POINTER(cabi.GbpEvalOut)]),
     "gbp_sync": (C.c_int, [C.c_void_p]),
     "gbp_timing": (C.c_int, [C.c_void_p, C.POINTER(cabi.GbpTimingOut), C.c_int]),
     "gbp_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -31,10 +31,14 @@ static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
   std::cout << "Initial Reprojection error: " << (float)(ev.sum_norm / (double)ev.n_active) << " Cost " << (float)ev.sum_half_sq << "\n";
   std::cout << "Number of iterations: " << o.n_iters << "\n";
 
+  const auto t_loop = std::chrono::steady_clock::now();
+  cli::MetricPipe pipe;
+  pipe.ctx = ctx;
+  pipe.on = !rk.region && !o.verbose;
   unsigned iter = 0;
   for (int i = 0; i < o.n_iters; ++i) {
     if (((iter + 1) % 2 == 0) && (iter < o.steps * 2)) {       // ba.cpp:1003-1006
-      std::cout << "Weakening priors \n";
+      pipe.line("Weakening priors \n");
       CLI_CHECK(ctx, gbp_weaken_priors(ctx));
     }
     // run up to the next host event (prior weakening or read-back) in one call: gbp_iterate(k) replays
@@ -47,11 +51,13 @@ static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
     i += burst - 1;
     iter += burst - 1;
     if ((i + 1) % o.eval_every == 0 || i + 1 == o.n_iters) {
-      CLI_CHECK(ctx, gbp_eval_global(ctx, &ev));
-      std::cout << "Iter " << iter << " // Reprojection error " << (float)(ev.sum_norm / (double)ev.n_active);
-      std::cout << " // Cost " << (float)ev.sum_half_sq << " // n relins: " << ev.n_relin;
-      std::cout << " // n robust edges " << ev.n_robust << "\n";
-      if (ev.n_nonfinite) std::cout << "warning: " << ev.n_nonfinite << " beliefs are non-finite\n";
+      const unsigned it_now = iter;
+      CLI_CHECK(ctx, pipe.submit([it_now](const gbp_eval_out& e) {
+        std::cout << "Iter " << it_now << " // Reprojection error " << (float)(e.sum_norm / (double)e.n_active);
+        std::cout << " // Cost " << (float)e.sum_half_sq << " // n relins: " << e.n_relin;
+        std::cout << " // n robust edges " << e.n_robust << "\n";
+        if (e.n_nonfinite) std::cout << "warning: " << e.n_nonfinite << " beliefs are non-finite\n";
+      }));
       if (o.verbose) {
         CLI_CHECK(ctx, gbp_read(ctx, &rb.out));
         cli::print_verbose(rb);
@@ -59,11 +65,14 @@ static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
     }
     iter += 1;
   }
+  CLI_CHECK(ctx, pipe.flush());
   std::cout << "\n Finished GBP.\n";
-  const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  const auto t_end = std::chrono::steady_clock::now();
+  const double wall = std::chrono::duration<double>(t_end - t0).count();
   gbp_timing_out tm{};
   gbp_timing(ctx, &tm, 0);
-  std::cout << "Total time: " << wall << " s; device time in GBP iterations: " << tm.total_ms << " ms over " << tm.iterations
+  std::cout << "Total time: " << wall << " s (set-up " << std::chrono::duration<double>(t_loop - t0).count() << " s, iteration loop "
+            << std::chrono::duration<double>(t_end - t_loop).count() << " s); device time in GBP iterations: " << tm.total_ms << " ms over " << tm.iterations
             << " iterations (" << (tm.total_ms > 0 ? 1e3 * (double)tm.iterations / tm.total_ms : 0.0) << " iters/s)\n";
   if (o.profile) cli::write_profile(ctx, "ba", wall, o.n_iters);
   gbp_destroy(ctx);

@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <iostream>
 #include <map>
 #include <stdexcept>
@@ -312,6 +313,51 @@ template <class F> int run_ranks(int world, uint32_t n_cams, bool force, F&& bod
   munmap(region, bytes);
   return first_bad;
 }
+
+// The reference's loop prints the metric after every iteration (ba.cpp:1009-1028).  To keep that output without making
+// the GPU wait for the host every iteration, the metric of iteration i is queued (gbp_eval_begin) and printed only after
+// iteration i+1 has been queued too; lines that belong after it ("Weakening priors") are deferred with it, so stdout is
+// byte-identical to the unpipelined loop.  Off for multi-rank runs (the metric needs a gather) and for --v.
+struct MetricPipe {
+  gbp_ctx* ctx = nullptr;
+  bool on = false, pending = false;
+  std::function<void(const gbp_eval_out&)> printer;
+  std::string deferred;
+  void line(const std::string& s) { if (pending) deferred += s; else std::cout << s; }
+  int flush() {
+    if (!pending) return GBP_OK;
+    gbp_eval_out ev{};
+    const int rc = gbp_eval_end(ctx, &ev);
+    pending = false;
+    if (rc != GBP_OK) return rc;
+    printer(ev);
+    std::cout << deferred;
+    deferred.clear();
+    return GBP_OK;
+  }
+  // metric of the current beliefs, printed by `p` — now (pipe off) or once the next submit / flush comes
+  int submit(std::function<void(const gbp_eval_out&)> p) {
+    if (!on) {
+      gbp_eval_out ev{};
+      const int rc = gbp_eval_global(ctx, &ev);
+      if (rc == GBP_OK) p(ev);
+      return rc;
+    }
+    int rc = gbp_eval_begin(ctx);      // queued behind the iteration that was just issued
+    if (rc != GBP_OK) return rc;
+    if (pending) {                     // the previous metric: its kernels finished long ago
+      gbp_eval_out ev{};
+      rc = gbp_eval_end(ctx, &ev);
+      if (rc != GBP_OK) return rc;
+      printer(ev);
+      std::cout << deferred;
+      deferred.clear();
+    }
+    printer = std::move(p);
+    pending = true;
+    return GBP_OK;
+  }
+};
 
 #define CLI_CHECK(ctx, call)                                                              \
   do {                                                                                    \

@@ -78,7 +78,8 @@ struct gbp_ctx {
   std::vector<Span> span_pool;         // reusable event pairs
   void* eval_host = nullptr;           // pinned + device-mapped: k_eval writes the metric partials + health counters here
   void* eval_host_dev = nullptr;
-  int eval_parity = 0;
+  int eval_parity = 0, eval_pending = 0;
+  hipEvent_t eval_ev[2] = {nullptr, nullptr};
   bool profile_stages = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_sweep_ev;  // split-phase profiling: brackets not yet read
   double sweep_ms = 0, belief_ms = 0, total_ms = 0;
@@ -306,6 +307,7 @@ void gbp_destroy(gbp_ctx* c) {
   for (auto& v : {&c->spans, &c->span_pool})
     for (auto& sp : *v) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
   if (c->eval_host) (void)hipHostFree(c->eval_host);
+  for (hipEvent_t e : c->eval_ev) if (e) (void)hipEventDestroy(e);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->ev2) (void)hipEventDestroy(c->ev2);
@@ -959,42 +961,63 @@ static int new_keyframe_impl(gbp_ctx* c, const gbp_kf_update* u) {
 }
 
 // eval_reprojection_error (util.cpp:74-144) + counters (ba.cpp:1011-1020) over the local shard
-static int eval_impl(gbp_ctx* c, gbp_eval_out* o) {
-  if (!c || !o || !c->uploaded) return fail(c, GBP_ERR_STATE, "gbp_eval: upload first");
-  std::memset(o, 0, sizeof(*o));
-  // The result lands DIRECTLY in pinned, device-mapped host memory: slot 0 = the two health counters, slots 1..nb = the
-  // per-block metric partials, written by k_eval itself — no copy launch, and the one host synchronisation of the call.
-  // The health counters are accumulated with atomics in device memory, double-buffered so that no memset launch is
-  // needed: k_means zeroes the pair the NEXT evaluation will use.
+// The metric in two halves, so that a caller printing it every iteration (the reference's default loop) can queue the
+// NEXT GBP iteration before it waits for the previous metric: begin enqueues k_means + k_eval, which write their result
+// DIRECTLY into pinned, device-mapped host memory (slot 0 = the two health counters, slots 1..nb = per-block partials;
+// no copy launch) and records an event; end waits for that event only and sums the partials in block order.  Two
+// evaluations may be in flight (two result areas).  The health counters are accumulated with atomics in device memory,
+// double-buffered so that no memset launch is needed: k_means zeroes the pair the next evaluation will use.
+static int eval_begin_impl(gbp_ctx* c) {
+  if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "gbp_eval: upload first");
+  if (c->eval_pending >= 2) return fail(c, GBP_ERR_STATE, "gbp_eval_begin: two evaluations already in flight, call gbp_eval_end first");
   if (!c->eval_host) {
-    HIPCHK(c, hipHostMalloc(&c->eval_host, sizeof(DeviceEval) * 1025, hipHostMallocMapped));
+    HIPCHK(c, hipHostMalloc(&c->eval_host, sizeof(DeviceEval) * 1025 * 2, hipHostMallocMapped));
     HIPCHK(c, hipHostGetDevicePointer(&c->eval_host_dev, c->eval_host, 0));
+    HIPCHK(c, hipEventCreateWithFlags(&c->eval_ev[0], hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->eval_ev[1], hipEventDisableTiming));
   }
-  DeviceEval* slots = static_cast<DeviceEval*>(c->eval_host_dev);
-  unsigned long long* h_cur = P<unsigned long long>(c->health) + 2 * (c->eval_parity & 1);
-  unsigned long long* h_next = P<unsigned long long>(c->health) + 2 * ((c->eval_parity + 1) & 1);
-  c->eval_parity ^= 1;
+  const int area = c->eval_parity & 1;
+  DeviceEval* slots = static_cast<DeviceEval*>(c->eval_host_dev) + 1025 * area;
+  unsigned long long* h_cur = P<unsigned long long>(c->health) + 2 * area;
+  unsigned long long* h_next = P<unsigned long long>(c->health) + 2 * (area ^ 1);
   launch_means(P<float4>(c->camb), P<float4>(c->lmkb), P<float>(c->cam_mu), P<float>(c->lmk_mu), c->C, c->L_loc,
                h_cur, h_next, /*count_cams=*/c->rank == 0, c->stream);
   launch_eval(P<uint32_t>(c->row_cam), P<uint32_t>(c->lmk_idx), P<float4>(c->lmsg), P<float4>(c->fac), P<float>(c->cam_mu), P<float>(c->lmk_mu),
               P<float>(c->dK), c->prm.num_undamped_iters, slots + 1, h_cur, reinterpret_cast<unsigned long long*>(slots), c->n_tiles, c->stream);
   HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipEventRecord(c->eval_ev[area], c->stream));
+  c->eval_parity ^= 1;
+  c->eval_pending += 1;
+  return GBP_OK;
+}
+
+static int eval_end_impl(gbp_ctx* c, gbp_eval_out* o) {
+  if (!c || !o) return GBP_ERR_INVALID;
+  if (c->eval_pending < 1) return fail(c, GBP_ERR_STATE, "gbp_eval_end: no evaluation in flight");
+  std::memset(o, 0, sizeof(*o));
+  const int area = (c->eval_parity + (c->eval_pending == 2 ? 0 : 1)) & 1;   // the OLDEST pending evaluation
+  HIPCHK(c, hipEventSynchronize(c->eval_ev[area]));
+  c->eval_pending -= 1;
   const uint32_t nb = eval_blocks(c->n_tiles);
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  const DeviceEval* part = static_cast<const DeviceEval*>(c->eval_host);
+  const DeviceEval* part = static_cast<const DeviceEval*>(c->eval_host) + 1025 * area;
   for (uint32_t b = 1; b <= nb; ++b) {
     o->sum_norm += part[b].sum_norm; o->sum_half_sq += part[b].sum_half_sq;
     o->n_active += part[b].n_active; o->n_relin += part[b].n_relin; o->n_robust += part[b].n_robust;
   }
   // non-finite guard (replaces the Poplar FP traps of ba.cpp:888-891) + non-PD belief count;
   // cameras are replicated, so only rank 0 counts them
-  {
-    unsigned long long h[2];
-    std::memcpy(h, part, 16);
-    o->n_nonfinite = h[0];
-    o->n_nonpd = h[1];
-  }
+  unsigned long long h[2];
+  std::memcpy(h, part, 16);
+  o->n_nonfinite = h[0];
+  o->n_nonpd = h[1];
   return GBP_OK;
+}
+
+static int eval_impl(gbp_ctx* c, gbp_eval_out* o) {
+  if (!c || !o || !c->uploaded) return fail(c, GBP_ERR_STATE, "gbp_eval: upload first");
+  if (c->eval_pending) return fail(c, GBP_ERR_STATE, "gbp_eval: finish the evaluations in flight (gbp_eval_end) first");
+  if (int rc = eval_begin_impl(c)) return rc;
+  return eval_end_impl(c, o);
 }
 
 int gbp_timing(gbp_ctx* c, gbp_timing_out* t, int reset) {
@@ -1279,6 +1302,8 @@ int gbp_read(gbp_ctx* c, gbp_state_out* o) { return guarded(c, "gbp_read", [&] {
 int gbp_read_priors(gbp_ctx* c, gbp_priors_out* o) { return guarded(c, "gbp_read_priors", [&] { return read_priors_impl(c, o); }); }
 int gbp_new_keyframe(gbp_ctx* c, const gbp_kf_update* u) { return guarded(c, "gbp_new_keyframe", [&] { return new_keyframe_impl(c, u); }); }
 int gbp_eval(gbp_ctx* c, gbp_eval_out* o) { return guarded(c, "gbp_eval", [&] { return eval_impl(c, o); }); }
+int gbp_eval_begin(gbp_ctx* c) { return guarded(c, "gbp_eval_begin", [&] { return eval_begin_impl(c); }); }
+int gbp_eval_end(gbp_ctx* c, gbp_eval_out* o) { return guarded(c, "gbp_eval_end", [&] { return eval_end_impl(c, o); }); }
 int gbp_debug_get(gbp_ctx* c, int what, float* a, float* b) { return guarded(c, "gbp_debug_get", [&] { return debug_get_impl(c, what, a, b); }); }
 int gbp_debug_set_factor_potentials(gbp_ctx* c, const float* eta9E, const float* lam81E) {
   return guarded(c, "gbp_debug_set_factor_potentials", [&] { return debug_set_factor_potentials_impl(c, eta9E, lam81E); });

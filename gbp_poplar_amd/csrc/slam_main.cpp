@@ -37,8 +37,13 @@ static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
   unsigned iter = 0, data_counter = 0;
   std::cout << "Total number of GBP iterations: " << niters << "\n";
   std::cout << "GBP iterations between sucessive keyframes: " << o.iters_between_kfs << "\n";
+  const auto t_loop = std::chrono::steady_clock::now();
+  cli::MetricPipe pipe;
+  pipe.ctx = ctx;
+  pipe.on = !rk.region && !o.verbose;
   for (unsigned i = 0; i < niters; ++i) {
     if ((i + 1) % (unsigned)o.iters_between_kfs == 0) {         // slam.cpp:1020-1046
+      CLI_CHECK(ctx, pipe.flush());                             // the keyframe logic reads beliefs back: no metric in flight
       iter = 0;
       data_counter += 1;
       int32_t n_new = 0;
@@ -59,16 +64,18 @@ static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
       CLI_CHECK(ctx, gbp_new_keyframe(ctx, &up));
     }
     if (((iter + 1) % 2 == 0) && (iter < o.steps * 2)) {
-      std::cout << "Weakening priors \n";
+      pipe.line("Weakening priors \n");
       CLI_CHECK(ctx, gbp_weaken_priors(ctx));
     }
     CLI_CHECK(ctx, gbp_iterate(ctx, 1));
     if ((i + 1) % (unsigned)o.eval_every == 0 || i + 1 == niters) {
-      CLI_CHECK(ctx, gbp_eval_global(ctx, &ev));
-      std::cout << "Iters " << (unsigned)o.iters_between_kfs * data_counter + iter;
-      std::cout << " (since last kf " << iter << ") // Reprojection error " << (float)(ev.sum_norm / (double)ev.n_active);
-      std::cout << " // Cost " << (float)ev.sum_half_sq << " // n relins: " << ev.n_relin;
-      std::cout << " // n robust edges " << ev.n_robust << "\n";
+      const unsigned total = (unsigned)o.iters_between_kfs * data_counter + iter, since = iter;
+      CLI_CHECK(ctx, pipe.submit([total, since](const gbp_eval_out& e) {
+        std::cout << "Iters " << total;
+        std::cout << " (since last kf " << since << ") // Reprojection error " << (float)(e.sum_norm / (double)e.n_active);
+        std::cout << " // Cost " << (float)e.sum_half_sq << " // n relins: " << e.n_relin;
+        std::cout << " // n robust edges " << e.n_robust << "\n";
+      }));
       if (o.verbose) {
         CLI_CHECK(ctx, gbp_read(ctx, &rb.out));
         cli::print_verbose(rb);
@@ -76,11 +83,14 @@ static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
     }
     iter += 1;
   }
+  CLI_CHECK(ctx, pipe.flush());
   std::cout << "\n Finished GBP.\n";
-  const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  const auto t_end = std::chrono::steady_clock::now();
+  const double wall = std::chrono::duration<double>(t_end - t0).count();
   gbp_timing_out tm{};
   gbp_timing(ctx, &tm, 0);
-  std::cout << "Total time: " << wall << " s; device time in GBP iterations: " << tm.total_ms << " ms over " << tm.iterations
+  std::cout << "Total time: " << wall << " s (set-up " << std::chrono::duration<double>(t_loop - t0).count() << " s, iteration loop "
+            << std::chrono::duration<double>(t_end - t_loop).count() << " s); device time in GBP iterations: " << tm.total_ms << " ms over " << tm.iterations
             << " iterations (" << (tm.total_ms > 0 ? 1e3 * (double)tm.iterations / tm.total_ms : 0.0) << " iters/s)\n";
   if (o.profile) cli::write_profile(ctx, "slam", wall, niters);
   gbp_destroy(ctx);

@@ -93,6 +93,14 @@ class GbpEngine:
         self._chk(self.lib.gbp_eval(self.h, C.byref(o)), "gbp_eval")
         return {k: getattr(o, k) for k, _ in o._fields_}
 
+    def eval_begin(self):
+        self._chk(self.lib.gbp_eval_begin(self.h), "gbp_eval_begin")
+
+    def eval_end(self):
+        o = cabi.GbpEvalOut()
+        self._chk(self.lib.gbp_eval_end(self.h, C.byref(o)), "gbp_eval_end")
+        return {k: getattr(o, k) for k, _ in o._fields_}
+
     def sync(self):
         self._chk(self.lib.gbp_sync(self.h), "gbp_sync")
 

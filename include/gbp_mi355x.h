@@ -174,6 +174,10 @@ int gbp_read(gbp_ctx* ctx, gbp_state_out* out);                /* READ_PROG     
 int gbp_read_priors(gbp_ctx* ctx, gbp_priors_out* out);        /* READ_PRIORS     slam.cpp:913-917 */
 int gbp_new_keyframe(gbp_ctx* ctx, const gbp_kf_update* upd);  /* NEW_KEYFRAME    slam.cpp:919-928 */
 int gbp_eval(gbp_ctx* ctx, gbp_eval_out* out);                 /* util.cpp:74-144 on device (local shard) */
+/* gbp_eval in two halves: begin queues the metric of the CURRENT beliefs, end waits for the oldest queued one.  Up to two
+ * may be in flight, so the loop of ba.cpp:1001-1028 can queue iteration i+1 before it prints the metric of iteration i. */
+int gbp_eval_begin(gbp_ctx* ctx);
+int gbp_eval_end(gbp_ctx* ctx, gbp_eval_out* out);
 int gbp_sync(gbp_ctx* ctx);                                    /* wait for queued device work     */
 int gbp_timing(gbp_ctx* ctx, gbp_timing_out* out, int reset);  /* ba.cpp:980,1056-1058            */
 

@@ -84,6 +84,9 @@ def test_ba_run_matches_oracle(oracle_mod, oracle_host):
     init = re.search(r"Initial Reprojection error: (\S+) Cost (\S+)", out)
     rows = [m.groups() for m in LINE.finditer(out)]
     assert init and len(rows) == 12 and out.count("Weakening priors") == 5 and " Finished GBP." in out
+    # line order of ba.cpp:1001-1028 survives the pipelined metric: Iter 0, "Weakening priors", Iter 1, Iter 2, "Weakening ..."
+    body = [l for l in out.splitlines() if l.startswith(("Iter ", "Weakening"))]
+    assert [l.split(" //")[0] for l in body[:5]] == ["Iter 0", "Weakening priors ", "Iter 1", "Iter 2", "Weakening priors "]
     bal = oracle_host.bal_read(seq_path("fr2robot2"))
     opts = driver.Options()
     K, state, _ = driver.build_inputs(bal, opts, oracle_host)

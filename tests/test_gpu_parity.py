@@ -857,6 +857,40 @@ def test_error_codes_and_call_order():
     assert t["iterations"] == 3 and t["algorithmic_bytes_per_iter"] == 1112 * bal["n_edges"] + 336 * 4 + 96 * 20
 
 
+def test_eval_begin_end_pipelining():
+    """gbp_eval in two halves: up to two metrics in flight while further iterations are queued; results equal the
+    synchronous gbp_eval of the same beliefs (the CLIs print iteration i after queuing iteration i + 1)."""
+    from gbp_poplar_amd import driver, hostlib
+    from gbp_poplar_amd.engine import GbpEngine, GbpError
+    bal = _bal("fr2robot2")
+    K, state, _ = driver.build_inputs(bal, driver.Options(), hostlib)
+    a = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K)
+    b = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K)
+    for e in (a, b):
+        e.upload(state)
+        e.linearise()
+    want, got = [], []
+    for it in range(6):
+        a.iterate(1)
+        want.append(a.eval())
+    b.iterate(1)
+    b.eval_begin()
+    for it in range(1, 6):
+        b.iterate(1)                # queued before the previous metric is collected
+        b.eval_begin()
+        got.append(b.eval_end())
+    with pytest.raises(GbpError, match="in flight"):
+        b.eval()                    # the synchronous call refuses to jump the queue
+    got.append(b.eval_end())
+    assert got == want
+    with pytest.raises(GbpError, match="no evaluation in flight"):
+        b.eval_end()
+    b.eval_begin(); b.eval_begin()
+    with pytest.raises(GbpError, match="two evaluations already in flight"):
+        b.eval_begin()
+    assert b.eval_end() == b.eval_end() == want[-1]
+
+
 def test_health_counters(oracle_mod):
     """A non-PD landmark prior (negative Lambda) must show up in n_nonpd after the belief refresh."""
     from gbp_poplar_amd import driver, hostlib
