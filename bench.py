@@ -77,9 +77,8 @@ def parse(argv=None):
                     help="N > 1: who runs the all-gather — the C++ library's own RCCL communicator (gbp_comm_init_rccl; "
                          "sharded iteration captured in a hipGraph) or torch.distributed around the split-phase C-ABI")
     ap.add_argument("--sharded-graph", type=int, default=None,
-                    help="capture the sharded iteration (kernels + the RCCL all-gather) in a hipGraph.  Default: on for the "
-                         "1-rank diagnostic (--force-sharded, verified on hardware), off for real multi-rank runs, where the "
-                         "capture of a multi-rank collective could not be verified by the build (no multi-GPU node)")
+                    help="capture the sharded iteration (kernels + the RCCL all-gather) in a hipGraph (default off: measured "
+                         "slower than direct launches, 0.191 vs 0.186 ms per iteration on the config-5 shard shape)")
     ap.add_argument("--exchange-chunks", type=int, default=None,
                     help="camera ranges of the pipelined all-gather (default: 1)")
     ap.add_argument("--tile-order", type=int, default=0, help="gbp_params.tile_order: 0 = default, 1 = sequential, 2 = sweep tiles XCD-aware too")
@@ -393,9 +392,9 @@ def main(argv=None):
 
     prm = _cabi.GbpParams.defaults(tile_order=a.tile_order)
     if a.sharded_graph is None:
-        a.sharded_graph = 1 if world == 1 else 0
-    if sharded and a.comm == "native" and not a.sharded_graph:
-        prm.graph_unroll = -1
+        a.sharded_graph = 0
+    if sharded and a.comm == "native":
+        prm.graph_unroll = 10 if a.sharded_graph else -1
     comm_error, exchange_kind = None, None
     if not sharded:
         eng = GbpEngine(bal["cam_id"], bal["lmk_id"], C, L, K, params=prm)

@@ -60,7 +60,8 @@ typedef struct {
   int32_t relin_mode;          /* 0 = accumulate onto the old potential (faithful: matMul is `+=`
                                   and PrepMessageVertex does not zero, gbp_codelets.cpp:285-336);
                                   1 = reset (zero first)                                          */
-  int32_t graph_unroll;        /* GBP iterations captured per hipGraph (>=1); 0 = library default (10); < 0 = never capture */
+  int32_t graph_unroll;        /* GBP iterations captured per hipGraph (>=1); 0 = library default (10 on a single-GPU ctx;
+                                  direct launches on a sharded ctx, where the graph is slower); < 0 = never capture */
   int32_t per_factor_mu;       /* 0 (default): belief means are computed once per variable (bit-identical
                                   to the per-factor recomputation of gbp_codelets.cpp:264-277, requires the
                                   uploaded mu/oldmu to be zero as in ba.cpp:582-583); 1: keep the literal

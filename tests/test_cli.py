@@ -220,7 +220,7 @@ def test_slam_ipus_2(oracle_mod, oracle_host):
 @pytest.mark.gpu
 def test_cli_rccl_path_with_one_forked_rank():
     """--force_sharded 1: the whole multi-GPU code path of the executable — fork before HIP, shard ctx, RCCL unique id
-    through the shared region, librccl dlopen'ed in a process without PyTorch, hipGraph-captured sharded iteration —
+    through the shared region, librccl dlopen'ed in a process without PyTorch, sharded iteration with the overlapped all-gather —
     with a single rank: the printed run equals the plain single-GPU run."""
     base = [BA, "--bal_file", seq_path("fr2robot2"), "--n_iters", "60", "--eval_every", "20"]
     rc1, out1, err1 = run(base)

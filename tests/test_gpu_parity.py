@@ -1271,7 +1271,9 @@ def test_native_rccl_communicator_single_rank(oracle_mod):
     opts = driver.Options()
     K, state, _ = driver.build_inputs(bal, opts, hostlib)
     plain = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K)
-    eng = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K, shard=(0, 1, 0, bal["n_lmks"]))
+    from gbp_poplar_amd import _cabi
+    eng = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K, shard=(0, 1, 0, bal["n_lmks"]),
+                    params=_cabi.GbpParams.defaults(graph_unroll=10))      # the sharded graph is opt-in
     eng.comm_init_rccl(eng.comm_unique_id())
     assert eng.comm_transport() == "rccl"
     ta = driver.run_ba(plain, state, opts, n_iters=12, eval_every=4)
