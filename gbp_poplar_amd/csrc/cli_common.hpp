@@ -300,15 +300,32 @@ template <class F> int run_ranks(int world, uint32_t n_cams, bool force, F&& bod
   }
   int status = 0, left = 0, first_bad = 0;
   for (pid_t p : pid) left += p > 0;
-  while (left > 0) {
-    const pid_t p = wait(&status);
-    if (p < 0) break;
+  auto code_of = [](int st) { return WIFEXITED(st) ? WEXITSTATUS(st) : 128 + (WIFSIGNALED(st) ? WTERMSIG(st) : 0); };
+  auto reap = [&](pid_t p, int st) {
+    for (pid_t& q : pid) if (q == p) q = -1;
     --left;
-    const int code = WIFEXITED(status) ? WEXITSTATUS(status) : 128 + (WIFSIGNALED(status) ? WTERMSIG(status) : 0);
-    if (code != 0 && first_bad == 0) {
-      first_bad = code;
+    if (code_of(st) != 0 && first_bad == 0) {
+      first_bad = code_of(st);
       gbp_comm_region_abort(region);            // the others leave their barriers with an error instead of waiting
     }
+  };
+  while (left > 0 && first_bad == 0) {
+    const pid_t p = wait(&status);
+    if (p < 0) break;
+    reap(p, status);
+  }
+  // a rank failed: the others normally notice at their next barrier; one that is stuck inside a collective whose peer
+  // is gone never will, so after a grace period the remaining ranks are killed
+  for (int waited_ms = 0; left > 0; waited_ms += 20) {
+    const pid_t p = waitpid(-1, &status, WNOHANG);
+    if (p > 0) { reap(p, status); continue; }
+    if (p < 0) break;
+    if (waited_ms >= 5000) {
+      for (pid_t q : pid) if (q > 0) kill(q, SIGKILL);
+      while (left > 0 && (wait(&status)) > 0) --left;
+      break;
+    }
+    usleep(20000);
   }
   munmap(region, bytes);
   return first_bad;

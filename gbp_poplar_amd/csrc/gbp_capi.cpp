@@ -679,7 +679,7 @@ static int iterate_sharded(gbp_ctx* c, int n) {
 }
 
 // LINEARISE_PROG (ba.cpp:890-893): prog_ub, then RelineariseFactorVertex on every factor.
-int gbp_linearise(gbp_ctx* c) {
+static int linearise_impl(gbp_ctx* c) {
   if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "gbp_linearise: upload first");
   if (c->world > 1 && !c->comm)
     return fail(c, GBP_ERR_STATE, "sharded ctx without a communicator: gbp_comm_init first, or use refresh_begin / exchange / refresh_end / linearise_factors");
@@ -1307,6 +1307,7 @@ int gbp_create(const gbp_problem* pr, const gbp_params* prm, const gbp_shard* sh
 int gbp_upload(gbp_ctx* c, const gbp_state_in* in) { return guarded(c, "gbp_upload", [&] { return upload_impl(c, in); }); }
 int gbp_set_exchange_chunks(gbp_ctx* c, int n) { return guarded(c, "gbp_set_exchange_chunks", [&] { return set_exchange_chunks_impl(c, n); }); }
 int gbp_iterate(gbp_ctx* c, int n) { return guarded(c, "gbp_iterate", [&] { return iterate_impl(c, n); }); }
+int gbp_linearise(gbp_ctx* c) { return guarded(c, "gbp_linearise", [&] { return linearise_impl(c); }); }
 int gbp_iterate_begin(gbp_ctx* c) { return guarded(c, "gbp_iterate_begin", [&] { return iterate_begin_impl(c); }); }
 int gbp_read(gbp_ctx* c, gbp_state_out* o) { return guarded(c, "gbp_read", [&] { return read_impl(c, o); }); }
 int gbp_read_priors(gbp_ctx* c, gbp_priors_out* o) { return guarded(c, "gbp_read_priors", [&] { return read_priors_impl(c, o); }); }
