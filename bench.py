@@ -441,6 +441,8 @@ def main(argv=None):
             dist.barrier()
             torch.cuda.synchronize()
 
+    if hasattr(run, "prepare"):
+        run.prepare()      # hipGraph capture + instantiation + upload: one-off, executes no iteration (exactly W warm-up steps ran)
     fence()
     t0 = time.perf_counter()
     run.iterate(a.steps)

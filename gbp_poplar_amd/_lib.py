@@ -20,6 +20,7 @@ _SIGS = {
     "gbp_upload": (C.c_int, [C.c_void_p, C.POINTER(cabi.GbpStateIn)]),
     "gbp_linearise": (C.c_int, [C.c_void_p]),
     "gbp_iterate": (C.c_int, [C.c_void_p, C.c_int]),
+    "gbp_prepare": (C.c_int, [C.c_void_p]),
     "gbp_weaken_priors": (C.c_int, [C.c_void_p]),
     "gbp_read": (C.c_int, [C.c_void_p, C.POINTER(cabi.GbpStateOut)]),
     "gbp_read_priors": (C.c_int, [C.c_void_p, C.POINTER(cabi.GbpPriorsOut)]),

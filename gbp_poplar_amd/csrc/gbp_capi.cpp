@@ -770,6 +770,38 @@ int gbp_iterate_end(gbp_ctx* c) {
   return rc;
 }
 
+// Capture `graph_unroll` single-GPU iterations once (nothing is executed by a capture).  Any failure leaves the stream
+// out of capture mode, drops the partial graph and falls back to direct launches for the life of the ctx (results are
+// identical either way).
+static bool ensure_graph(gbp_ctx* c, const SweepArgs& a) {
+  if (c->graph_exec) return true;
+  if (c->graph_failed || c->prm.graph_unroll <= 0 || c->stream != c->own_stream) return false;
+  hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
+  if (e == hipSuccess) {
+    for (int i = 0; i < c->prm.graph_unroll; ++i) enqueue_iteration(c, a);
+    e = hipStreamEndCapture(c->stream, &c->graph);          // also ends a capture that was invalidated on the way
+    if (e == hipSuccess) e = hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0);
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    drop_graph(c);
+    c->graph_failed = true;
+    return false;
+  }
+  c->graph_iters = c->prm.graph_unroll;
+  return true;
+}
+
+// One-off costs of the multi-iteration path, paid on request instead of inside the first gbp_iterate(n >= graph_unroll):
+// graph capture + instantiation + upload of the executable graph.  Executes no iteration.
+int gbp_prepare(gbp_ctx* c) {
+  if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "gbp_prepare: upload first");
+  if (c->comm || c->world > 1) return GBP_OK;               // sharded iterations run from direct launches by default
+  if (ensure_graph(c, sweep_args(c))) (void)hipGraphUpload(c->graph_exec, c->stream);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return GBP_OK;
+}
+
 // GBP_PROG x n (ba.cpp:895-905) on one GPU: replay of a captured hipGraph of `graph_unroll`
 // iterations, remainder launched directly.
 static int iterate_impl(gbp_ctx* c, int n) {
@@ -811,24 +843,7 @@ static int iterate_impl(gbp_ctx* c, int n) {
   } else {
     int left = n;
     bool use_graph = (c->stream == c->own_stream) && c->prm.graph_unroll > 0 && n >= c->prm.graph_unroll && !c->graph_failed;
-    if (use_graph && !c->graph_exec) {
-      // Capture `graph_unroll` iterations once.  Any failure leaves the stream out of capture mode, drops the partial
-      // graph and falls back to direct launches for the life of the ctx (results are identical either way).
-      hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
-      if (e == hipSuccess) {
-        for (int i = 0; i < c->prm.graph_unroll; ++i) enqueue_iteration(c, a);
-        e = hipStreamEndCapture(c->stream, &c->graph);          // also ends a capture that was invalidated on the way
-        if (e == hipSuccess) e = hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0);
-      }
-      if (e != hipSuccess) {
-        (void)hipGetLastError();
-        drop_graph(c);
-        c->graph_failed = true;
-        use_graph = false;
-      } else {
-        c->graph_iters = c->prm.graph_unroll;
-      }
-    }
+    if (use_graph && !c->graph_exec) use_graph = ensure_graph(c, a);
     if (use_graph) {
       while (left >= c->graph_iters) {
         HIPCHK(c, hipGraphLaunch(c->graph_exec, c->stream));

@@ -57,6 +57,10 @@ class GbpEngine:
     def iterate(self, n=1):
         self._chk(self.lib.gbp_iterate(self.h, int(n)), "gbp_iterate")
 
+    def prepare(self):
+        """Pay the one-off costs of the multi-iteration path now (graph capture, instantiation, upload); runs nothing."""
+        self._chk(self.lib.gbp_prepare(self.h), "gbp_prepare")
+
     def weaken_priors(self):
         self._chk(self.lib.gbp_weaken_priors(self.h), "gbp_weaken_priors")
 

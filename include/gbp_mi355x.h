@@ -170,6 +170,9 @@ const char* gbp_last_error(const gbp_ctx* ctx /*NULL = last create error*/);
 int gbp_upload(gbp_ctx* ctx, const gbp_state_in* in);          /* WRITE_PROG      ba.cpp:868-886  */
 int gbp_linearise(gbp_ctx* ctx);                               /* LINEARISE_PROG  ba.cpp:890-893  */
 int gbp_iterate(gbp_ctx* ctx, int n_iters);                    /* GBP_PROG x n    ba.cpp:895-905  */
+int gbp_prepare(gbp_ctx* ctx);                                 /* optional: pay the one-off costs of gbp_iterate(n >= graph_unroll)
+                                                                  now (hipGraph capture + instantiation + upload; runs nothing) —
+                                                                  what Engine::load does for a Poplar program, ba.cpp:936-937 */
 int gbp_weaken_priors(gbp_ctx* ctx);                           /* WEAKEN_PRIORS   ba.cpp:863-865  */
 int gbp_read(gbp_ctx* ctx, gbp_state_out* out);                /* READ_PROG       ba.cpp:908-916  */
 int gbp_read_priors(gbp_ctx* ctx, gbp_priors_out* out);        /* READ_PRIORS     slam.cpp:913-917 */

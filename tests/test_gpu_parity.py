@@ -323,9 +323,13 @@ def test_graph_replay_equals_direct_launches(oracle_mod):
     b, _, _, _, _ = _setup(bal, oracle_mod)
     a.linearise()
     b.linearise()
+    assert a.graph_state() == 0
+    a.prepare()                          # capture + instantiation + upload, no iteration executed
+    assert a.graph_state() == 1 and a.timing()["iterations"] == 0
     a.iterate(20)
     for _ in range(20):
         b.iterate(1)
+    assert b.graph_state() == 0          # single iterations never capture
     ra, rb = a.read(), b.read()
     for k in ra:
         assert np.array_equal(ra[k], rb[k]), k
