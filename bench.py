@@ -164,7 +164,7 @@ def launch_selftest(a):
 def build_stamp(a):
     """Identifies the kernels + workload a traffic figure belongs to: hash of the device sources and the shapes."""
     h = hashlib.sha256()
-    for f in ("gbp_kernels.hip", "gbp_kernels.h", "gbp_device_math.hpp", "gbp_capi.cpp"):
+    for f in ("gbp_kernels.hip", "gbp_kernels.h", "gbp_device_math.hpp"):
         h.update(open(os.path.join(ROOT, "gbp_poplar_amd", "csrc", f), "rb").read())
     return {"source_sha16": h.hexdigest()[:16], "workload": [a.cams, a.lmks, a.obs, a.seed], "tile_order": a.tile_order}
 

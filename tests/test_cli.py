@@ -174,7 +174,7 @@ def _oracle_sharded_traj(oracle_mod, oracle_host, name, world, n_iters=None, sla
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_ba_ipus_n_runs_one_process_per_rank(world, oracle_mod, oracle_host):
     """`./ba --ipus N` (ba.cpp:414-417,617-649) from the C++ host: N forked ranks, landmark shards, one all-gather of the
     camera partials per iteration.  On a one-GPU box the ranks share the GPU, so the library picks the host-staged
