@@ -90,6 +90,30 @@ int main(int argc, char** argv) {
   for (uint32_t dc = 1; dc + 1 < C; ++dc)
     REQUIRE(gbp_slam_update_flags(&prob, 5, dc, act.data(), lwf.data(), cwf.data(), laf.data(), &n_new) == GBP_OK && n_new >= 0);
 
+  // initialisation options + landmark partition (round 2 additions to the host library)
+  {
+    std::vector<float> cn = camf, ln = lmkf, cn2 = camf, ln2 = lmkf;
+    REQUIRE(gbp_init_add_noise(C, L, 0.05f, 2.f, 0.1f, 7, cn.data(), ln.data()) == GBP_OK);
+    REQUIRE(gbp_init_add_noise(C, L, 0.05f, 2.f, 0.1f, 7, cn2.data(), ln2.data()) == GBP_OK);
+    REQUIRE(cn == cn2 && ln == ln2 && cn != camf);
+    REQUIRE(std::equal(cn.begin(), cn.begin() + 12, camf.begin()));            // cameras 0 and 1 are the gauge anchors
+    std::vector<float> ld = lmkf;
+    REQUIRE(gbp_init_av_depth(&prob, camf.data(), ld.data()) == GBP_OK);
+    REQUIRE(gbp_init_av_depth(&prob, nullptr, ld.data()) == GBP_ERR_INVALID);
+    for (int world : {1, 2, 3, 8, 64}) {
+      std::vector<uint32_t> bounds((size_t)world + 1, 12345u);
+      REQUIRE(gbp_landmark_partition(&prob, world, bounds.data()) == GBP_OK);
+      REQUIRE(bounds.front() == 0 && bounds.back() == L);
+      for (int k = 0; k < world; ++k) REQUIRE(bounds[k] <= bounds[k + 1]);
+    }
+    REQUIRE(gbp_landmark_partition(&prob, 0, nullptr) == GBP_ERR_INVALID);
+    const size_t bytes = gbp_comm_region_bytes(C, 4);
+    std::vector<char> region(bytes);
+    REQUIRE(gbp_comm_region_init(region.data(), bytes, C, 4) == GBP_OK);
+    REQUIRE(gbp_comm_region_init(region.data(), bytes - 1, C, 4) == GBP_ERR_INVALID);
+    gbp_comm_region_abort(region.data());
+  }
+
   // ---- oracle: BA flow with weakening, sharded split-phase flow, read-backs ----
   std::vector<uint32_t> active(E, 1u), cw(C, 5u), lw(L, 5u);
   std::vector<int32_t> count(E, -2);
