@@ -546,6 +546,11 @@ def main(argv=None):
         if cpu:
             out["cpu_baseline"] = cpu
     if dist is not None:
+        # tear the library's communicator down while every rank is still alive and in step (ncclCommDestroy from a
+        # destructor at interpreter exit could wait for a peer that is already gone), then torch's group
+        eng.sync()
+        dist.barrier()
+        eng.close()
         dist.barrier()
         dist.destroy_process_group()
     # The JSON line must be the LAST line on stdout: RCCL prints a version banner through C stdio, which is fully
