@@ -178,10 +178,10 @@ void enqueue_iteration(gbp_ctx* c, const SweepArgs& a) {
 }
 
 // local camera partials only (before an exchange / before a prior-only refresh)
-void enqueue_cam_partials(gbp_ctx* c, float* dst) {
+void enqueue_cam_partials(gbp_ctx* c, float* dst, hipStream_t s = nullptr) {
   BeliefArgs b = belief_args(c);
   b.cam_local = dst; b.partial_only = 1;
-  launch_beliefs(b, true, false, c->stream);
+  launch_beliefs(b, true, false, s ? s : c->stream);
 }
 
 void pack_cam(const float* eta, const float* lam, uint32_t C, std::vector<float>& out) {
@@ -605,11 +605,14 @@ static int enqueue_sharded_iteration(gbp_ctx* c, const SweepArgs& a) {
   } else {
     launch_sweep(a, c->n_tiles, c->hoist, c->stream);
   }
-  enqueue_cam_partials(c, static_cast<float*>(c->send_dev));
+  // The communication stream (highest priority) takes the whole camera side of the exchange — local partial sums, then the
+  // all-gather — right after the sweep; the landmark half of the belief update runs beside it on the main stream.
   const bool ordered = c->comm->stream_ordered();
+  if (!ordered) enqueue_cam_partials(c, static_cast<float*>(c->send_dev));
   if (ordered) {
     HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_fork, 0));
+    enqueue_cam_partials(c, static_cast<float*>(c->send_dev), c->comm_stream);
     COMMCHK(c, c->comm->all_gather(static_cast<const float*>(c->send_dev), static_cast<float*>(c->recv_dev),
                                    (size_t)c->C * kCamRec, c->comm_stream, e_));
     HIPCHK(c, hipEventRecord(c->ev_join, c->comm_stream));
