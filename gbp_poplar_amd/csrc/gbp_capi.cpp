@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <stdexcept>
@@ -60,6 +61,7 @@ struct gbp_ctx {
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int comm_warm = 0;                   // sharded iterations run directly so far (RCCL must have run before a capture)
+  bool comm_single_stream = false;     // all-gather on the main stream, no second queue (default for world <= 2)
   hipStream_t own_stream = nullptr, stream = nullptr;
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
@@ -607,7 +609,7 @@ static int enqueue_sharded_iteration(gbp_ctx* c, const SweepArgs& a) {
   }
   // The communication stream (highest priority) takes the whole camera side of the exchange — local partial sums, then the
   // all-gather — right after the sweep; the landmark half of the belief update runs beside it on the main stream.
-  const bool ordered = c->comm->stream_ordered();
+  const bool ordered = c->comm->stream_ordered() && !c->comm_single_stream;
   if (!ordered) enqueue_cam_partials(c, static_cast<float*>(c->send_dev));
   if (ordered) {
     HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
@@ -623,7 +625,7 @@ static int enqueue_sharded_iteration(gbp_ctx* c, const SweepArgs& a) {
     launch_beliefs(b, false, true, c->stream);
   }
   if (ordered) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
-  else if (int rc = exchange_now(c)) return rc;
+  else if (int rc = exchange_now(c)) return rc;      // same stream (stream-ordered transports: still no host wait)
   {
     BeliefArgs b = belief_args(c);
     b.gathered = static_cast<const float*>(c->recv_dev);
@@ -1183,13 +1185,19 @@ static int debug_set_factor_potentials_impl(gbp_ctx* c, const float* eta9E, cons
 // ---- communicator: the exchange step owned by the library (RCCL over xGMI from the C++ host) ------------------------
 static int comm_attach(gbp_ctx* c, gbp::Comm* comm) {
   c->comm = comm;
+  // A second HSA queue makes every dispatch of the main queue slower (measured: +10 us per sharded iteration on the
+  // config-5 shard shape, 0.183 vs 0.174 ms with a 1-rank communicator), so overlapping the all-gather with the
+  // landmark beliefs (~20 us of cover) only pays once the all-gather itself takes longer than that: 4 ranks and more.
+  // GBP_COMM_SINGLE_STREAM=0/1 overrides the rule (measurements).
+  const char* ss = std::getenv("GBP_COMM_SINGLE_STREAM");
+  c->comm_single_stream = ss ? ss[0] == '1' : c->world <= 2;
   drop_graph(c);
   int rc = GBP_OK;
   if (!c->xsend.p) rc = dev_alloc(c, c->xsend, (size_t)c->C * kCamRec * 4);
   if (rc == GBP_OK && !c->xrecv.p) rc = dev_alloc(c, c->xrecv, (size_t)c->world * c->C * kCamRec * 4);
   if (rc != GBP_OK) return rc;
   c->send_dev = c->xsend.p; c->recv_dev = c->xrecv.p;
-  if (!c->comm_stream) {
+  if (!c->comm_stream && !c->comm_single_stream) {
     // highest priority: the all-gather is issued while the landmark half of k_beliefs fills the GPU; it must not queue
     // behind those blocks (the camera combine of every rank waits for it)
     int least = 0, greatest = 0;

@@ -1264,7 +1264,8 @@ def test_rccl_single_rank_group_overlap_path(chunks):
         dist.destroy_process_group()
 
 
-def test_native_rccl_communicator_single_rank(oracle_mod):
+@pytest.mark.parametrize("single_stream", ["1", "0"])
+def test_native_rccl_communicator_single_rank(single_stream, oracle_mod, monkeypatch):
     """The exchange owned by the C++ library: a sharded ctx with a 1-rank RCCL communicator (gbp_comm_unique_id /
     gbp_comm_init_rccl; librccl dlopen'ed by the library).  gbp_linearise / gbp_iterate / gbp_weaken_priors then run the
     sharded sequence — sweep, local partials, ncclAllGather on the second stream overlapped with the landmark beliefs,
@@ -1276,6 +1277,9 @@ def test_native_rccl_communicator_single_rank(oracle_mod):
     K, state, _ = driver.build_inputs(bal, opts, hostlib)
     plain = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K)
     from gbp_poplar_amd import _cabi
+    # "0": the >= 4-rank configuration (all-gather on a second, high-priority stream beside the landmark beliefs);
+    # "1": the <= 2-rank default (one stream) — read by gbp_comm_init*
+    monkeypatch.setenv("GBP_COMM_SINGLE_STREAM", single_stream)
     eng = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K, shard=(0, 1, 0, bal["n_lmks"]),
                     params=_cabi.GbpParams.defaults(graph_unroll=10))      # the sharded graph is opt-in
     eng.comm_init_rccl(eng.comm_unique_id())
