@@ -1115,6 +1115,20 @@ def test_ba_mp_front_end_single_gpu(capsys):
     assert last and 0.5 < float(last[0].split("Reprojection error ")[1].split(" ")[0]) < 5.0
 
 
+def test_ba_mp_front_end_init_options(capsys):
+    """The initialisation flags of ba.cpp:422-441 in the Python front end: --tn/--rn/--ltn with --seed reproduce, --avdepth_on
+    re-places the landmarks (same host functions as the C++ CLIs: gbp_init_add_noise / gbp_init_av_depth)."""
+    from gbp_poplar_amd import ba_mp
+    outs = []
+    for seed in ("4", "4", "5"):
+        assert ba_mp.main(["--bal_file", seq_path("fr2robot2"), "--n_iters", "12", "--eval_every", "4", "--tn", "0.02", "--rn", "0.5",
+                           "--ltn", "0.02", "--seed", seed]) == 0
+        outs.append([l for l in capsys.readouterr().out.splitlines() if l.startswith(("Initial", "Iter "))])
+    assert outs[0] == outs[1] and outs[0] != outs[2] and len(outs[0]) == 4
+    assert ba_mp.main(["--bal_file", seq_path("fr1xyz"), "--n_iters", "2", "--avdepth_on", "1"]) == 0
+    assert "Initial Reprojection error: 209.34" in capsys.readouterr().out          # the C++ CLI's value (tests/test_cli.py)
+
+
 def test_ba_mp_front_end_slam_mode(capsys):
     """`ba_mp --slam` (what `./slam --ipus N` maps to) on one GPU: keyframes are added and the slam lines printed."""
     from gbp_poplar_amd import ba_mp
