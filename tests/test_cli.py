@@ -228,3 +228,16 @@ def test_cli_rccl_path_with_one_forked_rank():
     assert rc1 == 0 and rc2 == 0, (err1[-500:], err2[-1500:])
     assert "Exchange between the 1 ranks: rccl" in out2
     assert LINE.findall(out1) == LINE.findall(out2) and len(LINE.findall(out1)) == 3
+
+
+@pytest.mark.gpu
+def test_cli_host_staged_transport_with_one_rank_and_bad_transport():
+    """--transport host with a single forked rank (the staging region moves the buffer D2H -> H2D): same run as plain;
+    an unknown transport value is an argument error, not a crash."""
+    base = [BA, "--bal_file", seq_path("fr2robot2"), "--n_iters", "30", "--eval_every", "10"]
+    rc1, out1, _ = run(base)
+    rc2, out2, err2 = run(base + ["--force_sharded", "1", "--transport", "host"])
+    assert rc1 == 0 and rc2 == 0, err2[-1000:]
+    assert "Exchange between the 1 ranks: host-staged" in out2 and LINE.findall(out1) == LINE.findall(out2)
+    rc3, _, err3 = run(base + ["--transport", "carrier-pigeon"])
+    assert rc3 == 1 and "invalid option value" in err3

@@ -853,6 +853,10 @@ def test_error_codes_and_call_order():
         sh.iterate(1)
     with pytest.raises(GbpError, match="exchange buffers not set"):
         sh.iterate_begin()
+    sh.prepare()                                                       # nothing to capture on a sharded ctx: a no-op, not an error
+    with pytest.raises(GbpError, match="gbp_comm_init"):
+        import ctypes
+        sh._chk(sh.lib.gbp_comm_init(sh.h, ctypes.create_string_buffer(4096), 0), "gbp_comm_init")   # not an initialised region
     eng.upload(state)
     eng.linearise()
     eng.iterate(0)                                                     # n = 0 is a no-op
