@@ -223,7 +223,11 @@ int gbp_linearise_factors(gbp_ctx* ctx);  /* the factor half of LINEARISE_PROG (
  * ranks — RCCL refuses duplicate GPUs), the host-staged transport that moves the same buffers through host memory.
  * transport: 0 = auto (RCCL when every rank has its own GPU, host-staged otherwise), 1 = RCCL, 2 = host-staged.
  * Launchers with their own rendezvous (torchrun, MPI) pass the 128-byte RCCL id around themselves:
- * gbp_comm_unique_id on rank 0, gbp_comm_init_rccl on every rank.  All calls are collective over the ranks. */
+ * gbp_comm_unique_id on rank 0, gbp_comm_init_rccl on every rank.  All calls are collective over the ranks.
+ * Scheduling: with 4 ranks or more the camera side of the exchange (local partial sums, all-gather) runs on a second,
+ * highest-priority stream beside the landmark beliefs; with 1 or 2 ranks everything stays on one stream (a second HSA
+ * queue costs more per dispatch than a small all-gather gives back).  Environment GBP_COMM_SINGLE_STREAM=0|1, read by
+ * gbp_comm_init*, overrides the rule (measurements, tests). */
 #define GBP_COMM_ID_BYTES 128
 int gbp_device_count(void);                                    /* visible GPUs (initialises the HIP runtime)      */
 int gbp_set_device(int device);                                /* the GPU later gbp_create calls of this process use */
