@@ -36,7 +36,6 @@ for tag in ("fetch", "write"):
             lines.append("| %s | %s | %d | %.1f |" % (k, c, n, s / n))
         lines.append("")
 # HBM traffic per launch as bench.py derived it from these passes (read side of streaming kernels doubled: gfx950 correction)
-import json
 for f in find("traffic_S1.json"):
     lines += ["## HBM traffic per launch (%s)" % os.path.relpath(f, out_dir), "", "```", open(f).read().strip(), "```", ""]
 for f in find("*bench.json"):

@@ -1,7 +1,5 @@
 """Product host code (csrc/gbp_host.cpp through the C-ABI) against the oracle's independent restatement
 of the same reference functions, plus the synthetic generator's contract and error behaviour."""
-import os
-
 import numpy as np
 import pytest
 
