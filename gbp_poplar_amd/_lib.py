@@ -44,6 +44,7 @@ _SIGS = {
     "gbp_set_device": (C.c_int, [C.c_int]),
     "gbp_landmark_partition": (C.c_int, [C.POINTER(cabi.GbpProblem), C.c_int, cabi.c_u32p]),
     "gbp_comm_region_abort": (None, [C.c_void_p]),
+    "gbp_comm_region_selftest": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "gbp_comm_region_bytes": (C.c_size_t, [C.c_uint32, C.c_int]),
     "gbp_comm_region_init": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint32, C.c_int]),
     "gbp_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),

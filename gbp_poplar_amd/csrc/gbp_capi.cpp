@@ -1228,6 +1228,13 @@ int gbp_comm_region_init(void* region, size_t bytes, uint32_t n_cams, int world)
 
 void gbp_comm_region_abort(void* region) { gbp::comm_region_abort(region); }
 
+int gbp_comm_region_selftest(void* region, int rank, int world, int rounds) {
+  std::string err;
+  const int rc = gbp::comm_region_selftest(region, rank, world, rounds, err);
+  if (rc != 0) return fail(nullptr, GBP_ERR_COMM, "gbp_comm_region_selftest: " + err);
+  return GBP_OK;
+}
+
 int gbp_comm_init(gbp_ctx* c, void* region, int transport) {
   if (!c || !region) return GBP_ERR_INVALID;
   if (c->comm) return fail(c, GBP_ERR_STATE, "gbp_comm_init: the ctx already has a communicator");

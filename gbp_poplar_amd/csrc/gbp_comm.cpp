@@ -239,6 +239,24 @@ void comm_region_abort(void* region) {
   if (h && h->magic == kMagic) h->abort_flag.store(1, std::memory_order_release);
 }
 
+// The cross-process protocol of the region on its own (no device): `rounds` x {gather of two doubles per rank, barrier},
+// every rank checks what it received.  Lets the rendezvous / staging logic be tested on a CPU-only box.
+int comm_region_selftest(void* region, int rank, int world, int rounds, std::string& err) {
+  RegionHeader* h = static_cast<RegionHeader*>(region);
+  if (!h || h->magic != kMagic || (int)h->world != world || rank < 0 || rank >= world) { err = "bad communication region"; return -1; }
+  RegionPeer peer;
+  peer.h = h; peer.world = world;
+  std::vector<double> all((size_t)world * 2);
+  for (int r = 0; r < rounds; ++r) {
+    const double mine[2] = {(double)(rank * 1000 + r), (double)(r - rank)};
+    if (!peer.gather_host(rank, mine, all.data(), 2, err)) return -1;
+    for (int k = 0; k < world; ++k)
+      if (all[(size_t)k * 2] != (double)(k * 1000 + r) || all[(size_t)k * 2 + 1] != (double)(r - k)) { err = "selftest: wrong data from a rank"; return -2; }
+    if (!peer.barrier(err)) return -1;
+  }
+  return 0;
+}
+
 Comm* comm_create_from_region(void* region, int rank, int world, int transport, std::string& err) {
   RegionHeader* h = static_cast<RegionHeader*>(region);
   if (!h || h->magic != kMagic || (int)h->world != world || rank < 0 || rank >= world) { err = "bad communication region"; return nullptr; }

@@ -46,7 +46,8 @@ Comm* comm_create_rccl(const void* id128, int rank, int world, std::string& err)
 // shared rendezvous / staging region (created by the launcher before the ranks start, e.g. mmap MAP_SHARED|MAP_ANONYMOUS)
 size_t comm_region_bytes(uint32_t n_cams, int world);
 int comm_region_init(void* region, size_t bytes, uint32_t n_cams, int world);
-void comm_region_abort(void* region);   // a supervisor saw a rank die: wake every rank waiting in the region with an error
+void comm_region_abort(void* region);
+int comm_region_selftest(void* region, int rank, int world, int rounds, std::string& err);   // protocol check, no device   // a supervisor saw a rank die: wake every rank waiting in the region with an error
 // transport: 0 = auto (RCCL when every rank sits on its own GPU, host-staged otherwise), 1 = RCCL, 2 = host-staged
 Comm* comm_create_from_region(void* region, int rank, int world, int transport, std::string& err);
 

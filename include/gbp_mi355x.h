@@ -236,6 +236,8 @@ int gbp_landmark_partition(const gbp_problem* problem, int world, uint32_t* boun
 size_t gbp_comm_region_bytes(uint32_t n_cams, int world);
 int gbp_comm_region_init(void* region, size_t bytes, uint32_t n_cams, int world);
 void gbp_comm_region_abort(void* region);                      /* supervisor: a rank died, fail the waiting ones */
+/* the region's cross-process protocol alone (gathers + barriers, no device): every rank of `world` calls it; test hook */
+int gbp_comm_region_selftest(void* region, int rank, int world, int rounds);
 int gbp_comm_init(gbp_ctx* ctx, void* region, int transport);
 int gbp_comm_unique_id(void* id128);
 int gbp_comm_init_rccl(gbp_ctx* ctx, const void* id128);
