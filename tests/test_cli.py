@@ -73,6 +73,15 @@ def test_no_device_is_a_loud_failure():
     assert rc != 0 and "Could not find a device" in out                               # ba.cpp:652-655
 
 
+def test_no_device_with_ipus_n_fails_on_every_rank_and_once_on_stdout():
+    """--ipus 4 without a GPU: the four forked ranks all fail, the supervisor returns the failure, only rank 0 printed."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    rc, out, _ = run([BA, "--bal_file", seq_path("fr2robot2"), "--n_iters", "2", "--ipus", "3"])
+    assert rc == 255 and out.count("Could not find a device") == 1 and "Number of GPUs: 4" in out
+
+
 LINE = re.compile(r"Iter (\d+) // Reprojection error (\S+) // Cost (\S+) // n relins: (\d+) // n robust edges (\d+)")
 
 
