@@ -76,6 +76,7 @@ _SIGS = {
     "gbp_slam_initialise_new_kf": (C.c_int, [C.c_uint32] + [cabi.c_f32p] * 4),
     "gbp_eval_host": (C.c_int, [C.POINTER(cabi.GbpProblem), cabi.c_u32p] + [cabi.c_f32p] * 5
                       + [cabi.c_f64p, cabi.c_f64p, C.POINTER(C.c_uint64)]),
+    "gbp_belief_means": (C.c_int, [C.c_uint32, C.c_uint32] + [cabi.c_f32p] * 4 + [cabi.c_f64p, cabi.c_f64p]),
     "gbp_synth_generate": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(cabi.GbpBal),
                                      cabi.c_f64p, cabi.c_f64p]),
 }

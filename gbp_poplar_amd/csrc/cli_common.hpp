@@ -52,6 +52,7 @@ struct Options {
   unsigned long long seed = 0;
   int eval_every = 1;
   int transport = 0;            // --transport: 0 auto, 1 RCCL, 2 host-staged (ranks sharing a GPU)
+  std::string out_file;         // --out_file: write the refined problem (belief means) in the input's format
   bool force_sharded = false;   // --force_sharded: run the multi-rank code path (fork, shard ctx, communicator) with one rank
 };
 
@@ -77,7 +78,8 @@ inline void usage(bool slam) {
                "  --v arg (=0)                   Verbose: print beliefs\n"
                "  --seed arg (=0)                seed of the initialisation noise (0 = from the clock)\n"
                "  --eval_every arg (=1)          read back + evaluate every K iterations\n"
-               "  --transport arg (=auto)        exchange between ranks: auto | rccl | host (ranks sharing one GPU)\n";
+               "  --transport arg (=auto)        exchange between ranks: auto | rccl | host (ranks sharing one GPU)\n"
+               "  --out_file arg                 write the refined cameras / landmarks (belief means) in the input's format\n";
 }
 
 // returns 0 = run, 1 = exit with code 0 (help), 2 = exit with code 1 (error)
@@ -119,6 +121,7 @@ inline int parse(int argc, char** argv, bool slam, Options& o) {
       else if (k == "seed") o.seed = std::stoull(v);
       else if (k == "eval_every") o.eval_every = std::max(1, std::stoi(v));
       else if (k == "force_sharded") o.force_sharded = B(v);
+      else if (k == "out_file") o.out_file = v;
       else if (k == "transport") o.transport = v == "rccl" ? 1 : (v == "host" ? 2 : (v == "auto" ? 0 : std::stoi(v)));
       else { std::cerr << "unrecognised option '--" << k << "'\n"; return 2; }
     }
@@ -224,6 +227,25 @@ inline void print_verbose(const Readback& r) {  // ba.cpp:1030-1051
   for (unsigned i = 0; i < 18; ++i) std::printf("%.12f  ", r.lbl[i]);
   std::cout << '\n';
   std::fflush(stdout);
+}
+
+// --out_file: the solution (belief means) in the format of the input, observations unchanged.  Single-process runs only:
+// a rank of a sharded run holds the landmarks of its own range.
+inline int write_solution(const Options& o, const Problem& P, gbp_ctx* ctx, bool sharded) {
+  if (o.out_file.empty()) return 0;
+  if (sharded) { std::cout << "--out_file is ignored with --ipus N > 1 (each rank holds its own landmark range)\n"; return 0; }
+  const uint32_t C = P.bal.n_cams, L = P.bal.n_lmks;
+  std::vector<float> cbe(6 * (size_t)C), cbl(36 * (size_t)C), lbe(3 * (size_t)L), lbl(9 * (size_t)L);
+  gbp_state_out out{};
+  out.cam_beliefs_eta = cbe.data(); out.cam_beliefs_lambda = cbl.data(); out.lmk_beliefs_eta = lbe.data(); out.lmk_beliefs_lambda = lbl.data();
+  if (gbp_read(ctx, &out) != GBP_OK) { std::cerr << "gbp_read failed: " << gbp_last_error(ctx) << "\n"; return 1; }
+  std::vector<double> cams(6 * (size_t)C), pts(3 * (size_t)L);
+  gbp_belief_means(C, L, cbe.data(), cbl.data(), lbe.data(), lbl.data(), cams.data(), pts.data());
+  gbp_bal res = P.bal;
+  res.cameras = cams.data(); res.points = pts.data();
+  if (gbp_bal_write(o.out_file.c_str(), &res) != GBP_OK) { std::cerr << "ERROR: unable to write " << o.out_file << "\n"; return 1; }
+  std::cout << "Refined problem written to " << o.out_file << "\n";
+  return 0;
 }
 
 // ---- one process per GPU (`--ipus N` / `--gpus N`) -------------------------------------------------------------------

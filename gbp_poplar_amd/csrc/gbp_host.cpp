@@ -402,6 +402,24 @@ int gbp_eval_host(const gbp_problem* p, const uint32_t* active, const float* mea
   return GBP_OK;
 }
 
+// Belief means mu = Lambda^-1 eta of every variable (the solution a caller takes away), with the solve of the metric
+// (util.cpp:103-108 uses Eigen's general inverse; here fp64 partial pivoting).  Variables without information
+// (Lambda = 0: never observed) come out non-finite, like in the reference.
+int gbp_belief_means(uint32_t C, uint32_t L, const float* cbe, const float* cbl, const float* lbe, const float* lbl,
+                     double* cameras, double* points) {
+  if (!cbe || !cbl || !lbe || !lbl || !cameras || !points) return GBP_ERR_INVALID;
+  float mu[6];
+  for (uint32_t c = 0; c < C; ++c) {
+    solve_pivot(cbl + 36ull * c, cbe + 6ull * c, 6, mu);
+    for (int i = 0; i < 6; ++i) cameras[6ull * c + i] = mu[i];
+  }
+  for (uint32_t l = 0; l < L; ++l) {
+    solve_pivot(lbl + 9ull * l, lbe + 3ull * l, 3, mu);
+    for (int i = 0; i < 3; ++i) points[3ull * l + i] = mu[i];
+  }
+  return GBP_OK;
+}
+
 // Contiguous landmark ranges balanced by incident-factor count: bounds[r] = first landmark whose cumulative
 // degree reaches r/world of the factors.  A factor lives with its landmark, so this balances the sweep's work.
 int gbp_landmark_partition(const gbp_problem* p, int world, uint32_t* bounds) {

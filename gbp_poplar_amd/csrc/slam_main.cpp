@@ -93,8 +93,9 @@ static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
             << std::chrono::duration<double>(t_end - t_loop).count() << " s); device time in GBP iterations: " << tm.total_ms << " ms over " << tm.iterations
             << " iterations (" << (tm.total_ms > 0 ? 1e3 * (double)tm.iterations / tm.total_ms : 0.0) << " iters/s)\n";
   if (o.profile) cli::write_profile(ctx, "slam", wall, niters);
+  const int wrc = cli::write_solution(o, P, ctx, rk.region != nullptr);
   gbp_destroy(ctx);
-  return 0;
+  return wrc;
 }
 
 int main(int argc, char** argv) {

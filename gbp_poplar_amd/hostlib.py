@@ -126,6 +126,15 @@ def init_av_depth(cam_id, lmk_id, n_cams, n_lmks, cam_mean, lmk_mean):
     return lmk
 
 
+def belief_means(n_cams, n_lmks, cbe, cbl, lbe, lbl):
+    """gbp_belief_means: (cameras [6C], points [3L]) = Lambda^-1 eta of every variable, float64 arrays."""
+    cams, pts = np.zeros(6 * n_cams, np.float64), np.zeros(3 * n_lmks, np.float64)
+    a = [_f32(x) for x in (cbe, cbl, lbe, lbl)]
+    _chk(load().gbp_belief_means(int(n_cams), int(n_lmks), *[cabi.ptr(x, cabi.c_f32p) for x in a],
+                                 cabi.ptr(cams, cabi.c_f64p), cabi.ptr(pts, cabi.c_f64p)), "gbp_belief_means")
+    return cams, pts
+
+
 def landmark_partition(cam_id, lmk_id, n_cams, n_lmks, world):
     """gbp_landmark_partition: contiguous landmark ranges balanced by factor count -> bounds[world + 1]."""
     keep = []

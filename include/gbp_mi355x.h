@@ -342,6 +342,12 @@ int gbp_eval_host(const gbp_problem* problem, const uint32_t* active_flag, const
                   const float* lmk_beliefs_eta, const float* lmk_beliefs_lambda,
                   double* sum_norm, double* sum_half_sq, uint64_t* n_active);
 
+/* The solution: belief means mu = Lambda^-1 eta of every camera ([6C]: t_cw, axis-angle) and landmark ([3L]) from
+ * read-back beliefs, same solve as the metric (util.cpp:103-108).  With gbp_bal_write this gives `--out_file`: the
+ * refined problem in the input's own format (the reference only prints metrics and keeps the result on the device). */
+int gbp_belief_means(uint32_t n_cams, uint32_t n_lmks, const float* cam_beliefs_eta, const float* cam_beliefs_lambda,
+                     const float* lmk_beliefs_eta, const float* lmk_beliefs_lambda, double* cameras, double* points);
+
 /* Synthetic BAL generator (SURVEY 8d spec; the reference has none).  Fills a caller-allocated
  * gbp_bal with n_edges = n_lmks * obs_per_lmk, edges sorted by (camera, landmark). */
 int gbp_synth_generate(uint32_t n_cams, uint32_t n_lmks, uint32_t obs_per_lmk, uint64_t seed,

@@ -250,3 +250,20 @@ def test_cli_host_staged_transport_with_one_rank_and_bad_transport():
     assert "Exchange between the 1 ranks: host-staged" in out2 and LINE.findall(out1) == LINE.findall(out2)
     rc3, _, err3 = run(base + ["--transport", "carrier-pigeon"])
     assert rc3 == 1 and "invalid option value" in err3
+
+
+@pytest.mark.gpu
+def test_out_file_holds_the_refined_problem(tmp_path):
+    """--out_file: belief means of every variable in the input's own format; feeding it back in starts at the error the
+    first run ended with (the reference keeps its result on the device and only prints metrics)."""
+    from gbp_poplar_amd import hostlib
+    out = str(tmp_path / "refined.txt")
+    rc, o1, err = run([BA, "--bal_file", seq_path("fr2robot2"), "--n_iters", "300", "--eval_every", "100", "--out_file", out])
+    assert rc == 0 and "Refined problem written to" in o1, err[-500:]
+    final = float(LINE.findall(o1)[-1][1])
+    a, b = hostlib.bal_read(seq_path("fr2robot2")), hostlib.bal_read(out)
+    assert np.array_equal(a["cam_id"], b["cam_id"]) and np.array_equal(a["observations"], b["observations"])
+    assert not np.array_equal(a["points"], b["points"]) and np.all(np.isfinite(b["cameras"]))
+    rc, o2, _ = run([BA, "--bal_file", out, "--n_iters", "1"])
+    init2 = float(re.search(r"Initial Reprojection error: (\S+)", o2).group(1))
+    assert rc == 0 and abs(init2 - final) <= 0.02 * final, (init2, final)

@@ -354,3 +354,15 @@ def test_comm_region_contract():
     assert lib.gbp_comm_region_init(buf, n1, 1000, 8) != 0          # too small for 8 ranks
     assert lib.gbp_comm_region_init(buf, n1, 1000, 0) != 0
     lib.gbp_comm_region_abort(buf)                                  # supervisor call: must not crash
+
+
+def test_belief_means_solve_the_information_form():
+    rng = np.random.default_rng(8)
+    C, L = 5, 7
+    cam_mu, lmk_mu = rng.standard_normal((C, 6)), rng.standard_normal((L, 3))
+    a = rng.standard_normal((C, 6, 6)); cl = a @ a.transpose(0, 2, 1) + 6 * np.eye(6)
+    a = rng.standard_normal((L, 3, 3)); ll = a @ a.transpose(0, 2, 1) + 3 * np.eye(3)
+    ce = np.einsum("cij,cj->ci", cl, cam_mu)
+    le = np.einsum("lij,lj->li", ll, lmk_mu)
+    cams, pts = hostlib.belief_means(C, L, ce.ravel(), cl.ravel(), le.ravel(), ll.ravel())
+    assert cams.dtype == np.float64 and np.allclose(cams.reshape(C, 6), cam_mu, atol=2e-5) and np.allclose(pts.reshape(L, 3), lmk_mu, atol=2e-5)
