@@ -319,8 +319,8 @@ def gpu_accuracy_run(bal, K, state, opts, n):
 
 def workload_name(a, world, C, L, E):
     if world == 1:
-        base = "S1" if (a.cams, a.lmks, a.obs) == (1000, 100000, 10) else "synthetic"
-        return "%s synthetic BAL graph: %d cams x %d lmks x %d factors (seed %d)" % (base, C, L, E, a.seed)
+        base = "S1 synthetic" if (a.cams, a.lmks, a.obs) == (1000, 100000, 10) else "synthetic"
+        return "%s BAL graph: %d cams x %d lmks x %d factors (seed %d)" % (base, C, L, E, a.seed)
     fam = "N x S1" if a.weak_s1 else ("BASELINE config 5" if (world, a.cams, a.lmks, a.obs) == (8, 1000, 125000, 10)
                                       else "BASELINE config-5 family")
     return "%s: %d cams x %d lmks x %d factors (seed %d), landmark-sharded over %d GPUs" % (fam, C, L, E, a.seed, world)
@@ -417,7 +417,7 @@ def main(argv=None):
                 eng.comm_init_rccl(bytes(idt.cpu().numpy().tobytes()))
                 run = eng
                 run_eval = eng.eval_global
-                exchange_kind = "native: ncclAllGather issued by libgbp_mi355x.so (C++ host), overlapped with the landmark beliefs"
+                exchange_kind = "native: ncclAllGather issued by libgbp_mi355x.so (C++ host; beside the landmark beliefs from 4 ranks on)"
             except Exception as exc:  # noqa: BLE001 — fall back to the torch.distributed exchange, and say so
                 comm_error = repr(exc)
         if run is None:
