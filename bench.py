@@ -498,6 +498,8 @@ def main(argv=None):
                 "traffic_source": traffic_src, "traffic_error": None if tr_bytes else traffic_err,
                 "avg_launch_us": round(sweep_s * 1e6, 2),
                 "belief_kernels_avg_us": round(belief_s * 1e6, 2) if belief_s is not None else None,
+                "exchange_avg_us": round(tm.get("exchange_ms", 0.0) * 1e3 / a.profile_steps, 2) if sharded and run is eng else None,
+                "exchange_note": "local camera partial sums + all-gather, on the communication stream (beside the landmark beliefs from 4 ranks on)" if sharded and run is eng else None,
                 "profiled_ms_per_step": round(tm["total_ms"] / a.profile_steps, 4) if not sharded else round(prof_wall / a.profile_steps * 1e3, 4),
                 "profiled_note": "direct launches with an event between kernels: sweep + beliefs + two dependent-launch gaps; "
                                  "ms_per_step is the hipGraph replay of the same kernels" if not sharded else

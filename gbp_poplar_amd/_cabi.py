@@ -73,7 +73,7 @@ class GbpEvalOut(C.Structure):
 class GbpTimingOut(C.Structure):
     _fields_ = [("sweep_ms", C.c_double), ("belief_ms", C.c_double), ("total_ms", C.c_double),
                 ("iterations", C.c_uint64), ("algorithmic_bytes_per_iter", C.c_uint64),
-                ("device_bytes_allocated", C.c_uint64)]
+                ("device_bytes_allocated", C.c_uint64), ("exchange_ms", C.c_double)]
 
 
 class GbpBal(C.Structure):

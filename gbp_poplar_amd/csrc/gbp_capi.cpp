@@ -85,7 +85,8 @@ struct gbp_ctx {
   hipEvent_t eval_ev[2] = {nullptr, nullptr};
   bool profile_stages = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_sweep_ev;  // split-phase profiling: brackets not yet read
-  double sweep_ms = 0, belief_ms = 0, total_ms = 0;
+  double sweep_ms = 0, belief_ms = 0, total_ms = 0, exchange_ms = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_exch_ev;     // profiling: brackets of partials + all-gather
   uint64_t timed_iters = 0, dev_bytes = 0;
   std::string err;
 };
@@ -266,6 +267,13 @@ void drain_sweep_events(gbp_ctx* c) {
     (void)hipEventDestroy(pr.second);
   }
   c->pending_sweep_ev.clear();
+  for (auto& pr : c->pending_exch_ev) {
+    float ms = 0;
+    if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) c->exchange_ms += ms;
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
+  c->pending_exch_ev.clear();
 }
 
 // No C++ exception crosses the C-ABI: every entry point that allocates host memory runs inside this guard.
@@ -305,7 +313,8 @@ void gbp_destroy(gbp_ctx* c) {
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
-  for (auto& pr : c->pending_sweep_ev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  for (auto* v : {&c->pending_sweep_ev, &c->pending_exch_ev})
+    for (auto& pr : *v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   for (DevBuf* b : c->all) if (b->p) (void)hipFree(b->p);
   for (auto& v : {&c->spans, &c->span_pool})
     for (auto& sp : *v) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
@@ -610,13 +619,20 @@ static int enqueue_sharded_iteration(gbp_ctx* c, const SweepArgs& a) {
   // The communication stream (highest priority) takes the whole camera side of the exchange — local partial sums, then the
   // all-gather — right after the sweep; the landmark half of the belief update runs beside it on the main stream.
   const bool ordered = c->comm->stream_ordered() && !c->comm_single_stream;
-  if (!ordered) enqueue_cam_partials(c, static_cast<float*>(c->send_dev));
+  hipEvent_t x0 = nullptr, x1 = nullptr;     // profiling: how long the camera side of the exchange takes on its stream
+  if (c->profile_stages && c->comm->stream_ordered()) {
+    HIPCHK(c, hipEventCreate(&x0));
+    if (hipError_t e_ = hipEventCreate(&x1); e_ != hipSuccess) { (void)hipEventDestroy(x0); return fail(c, GBP_ERR_HIP, "hipEventCreate"); }
+    c->pending_exch_ev.emplace_back(x0, x1);
+  }
   if (ordered) {
     HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_fork, 0));
+    if (x0) HIPCHK(c, hipEventRecord(x0, c->comm_stream));
     enqueue_cam_partials(c, static_cast<float*>(c->send_dev), c->comm_stream);
     COMMCHK(c, c->comm->all_gather(static_cast<const float*>(c->send_dev), static_cast<float*>(c->recv_dev),
                                    (size_t)c->C * kCamRec, c->comm_stream, e_));
+    if (x1) HIPCHK(c, hipEventRecord(x1, c->comm_stream));
     HIPCHK(c, hipEventRecord(c->ev_join, c->comm_stream));
   }
   {  // the landmark half needs nothing from other ranks
@@ -624,8 +640,14 @@ static int enqueue_sharded_iteration(gbp_ctx* c, const SweepArgs& a) {
     b.roll = 1;
     launch_beliefs(b, false, true, c->stream);
   }
-  if (ordered) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
-  else if (int rc = exchange_now(c)) return rc;      // same stream (stream-ordered transports: still no host wait)
+  if (ordered) {
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+  } else {                                           // same stream (stream-ordered transports: still no host wait)
+    if (x0) HIPCHK(c, hipEventRecord(x0, c->stream));
+    enqueue_cam_partials(c, static_cast<float*>(c->send_dev));
+    if (int rc = exchange_now(c)) return rc;
+    if (x1) HIPCHK(c, hipEventRecord(x1, c->stream));
+  }
   {
     BeliefArgs b = belief_args(c);
     b.gathered = static_cast<const float*>(c->recv_dev);
@@ -1049,9 +1071,10 @@ int gbp_timing(gbp_ctx* c, gbp_timing_out* t, int reset) {
   drain_sweep_events(c);   // split-phase brackets recorded by gbp_iterate_begin
   resolve_spans(c, true);  // gbp_iterate brackets still in flight
   t->sweep_ms = c->sweep_ms; t->belief_ms = c->belief_ms; t->total_ms = c->total_ms; t->iterations = c->timed_iters;
+  t->exchange_ms = c->exchange_ms;
   t->algorithmic_bytes_per_iter = 1112ull * c->E_loc + 336ull * c->C + 96ull * c->L_loc;
   t->device_bytes_allocated = c->dev_bytes;
-  if (reset) { c->sweep_ms = c->belief_ms = c->total_ms = 0; c->timed_iters = 0; }
+  if (reset) { c->sweep_ms = c->belief_ms = c->total_ms = c->exchange_ms = 0; c->timed_iters = 0; }
   return GBP_OK;
 }
 

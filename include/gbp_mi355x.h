@@ -156,6 +156,8 @@ typedef struct {
   uint64_t iterations;
   uint64_t algorithmic_bytes_per_iter;      /* 1112*E + 336*C + 96*L               */
   uint64_t device_bytes_allocated;
+  double   exchange_ms;                     /* sharded ctx with a communicator, profiling on: accumulated time of the
+                                               camera side of the exchange (local partial sums + all-gather)        */
 } gbp_timing_out;
 
 /* ---- life cycle: graph build + Engine ctor/load (ba.cpp:659-937) -------------------------- */

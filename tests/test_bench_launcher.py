@@ -72,6 +72,8 @@ def test_bench_sharded_code_path_on_one_gpu(comm):
     assert ("native" in out["config"]["exchange"]) == (comm == "native")
     assert out["config"]["reproj_rmse_px_final"] == plain["config"]["reproj_rmse_px_final"]      # bit-identical runs
     assert out["roofline"]["avg_launch_us"] > 0 and out["roofline"]["frac_algorithmic"] > 0
+    if comm == "native":
+        assert out["roofline"]["exchange_avg_us"] > 0          # measured on rank 0: partial sums + all-gather per iteration
 
 
 @pytest.mark.gpu
