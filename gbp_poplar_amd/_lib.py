@@ -6,8 +6,12 @@ import os
 from . import _cabi as cabi
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libgbp_mi355x.so")
+# GBP_LIB: measurement scripts under profiles/ point this at the experiments build (build.py --experiments)
+LIB_PATH = os.environ.get("GBP_LIB") or os.path.join(HERE, "libgbp_mi355x.so")
+# the product sources + the gbp_debug_* hooks of include/gbp_mi355x_debug.h; loaded by tests that look at internal state
+TEST_LIB_PATH = os.environ.get("GBP_LIB") or os.path.join(HERE, "libgbp_mi355x_test.so")
 _lib = None
+_test_lib = None
 
 # every symbol include/gbp_mi355x.h declares (tests/test_cabi_symbols.py parses the header and checks this list)
 _SIGS = {
@@ -55,11 +59,6 @@ _SIGS = {
     "gbp_comm_barrier": (C.c_int, [C.c_void_p]),
     "gbp_eval_global": (C.c_int, [C.c_void_p, C.POINTER(cabi.GbpEvalOut)]),
     "gbp_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
-    "gbp_debug_get": (C.c_int, [C.c_void_p, C.c_int, cabi.c_f32p, cabi.c_f32p]),
-    "gbp_debug_time_sweep": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
-    "gbp_debug_set_factor_potentials": (C.c_int, [C.c_void_p, cabi.c_f32p, cabi.c_f32p]),
-    "gbp_debug_math": (C.c_int, [C.c_int, cabi.c_f32p, cabi.c_f32p, C.c_int]),
-    "gbp_debug_math_timed": (C.c_int, [C.c_int, cabi.c_f32p, cabi.c_f32p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "gbp_bal_read_header": (C.c_int, [C.c_char_p, C.POINTER(cabi.GbpBal)]),
     "gbp_bal_read": (C.c_int, [C.c_char_p, C.POINTER(cabi.GbpBal)]),
     "gbp_bal_write": (C.c_int, [C.c_char_p, C.POINTER(cabi.GbpBal)]),
@@ -81,19 +80,36 @@ _SIGS = {
                                      cabi.c_f64p, cabi.c_f64p]),
 }
 
+# include/gbp_mi355x_debug.h: exported by libgbp_mi355x_test.so only
+_DEBUG_SIGS = {
+    "gbp_debug_get": (C.c_int, [C.c_void_p, C.c_int, cabi.c_f32p, cabi.c_f32p]),
+    "gbp_debug_time_sweep": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "gbp_debug_set_factor_potentials": (C.c_int, [C.c_void_p, cabi.c_f32p, cabi.c_f32p]),
+    "gbp_debug_math": (C.c_int, [C.c_int, cabi.c_f32p, cabi.c_f32p, C.c_int]),
+    "gbp_debug_math_timed": (C.c_int, [C.c_int, cabi.c_f32p, cabi.c_f32p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+}
+
 
 def symbols():
     return sorted(_SIGS)
 
 
-def load():
-    global _lib
-    if _lib is not None:
+def debug_symbols():
+    return sorted(_DEBUG_SIGS)
+
+
+def load(hooks=False):
+    """The product library (hooks=False) or the test-hooks build of the same sources (hooks=True)."""
+    global _lib, _test_lib
+    if hooks and _test_lib is not None:
+        return _test_lib
+    if not hooks and _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = TEST_LIB_PATH if hooks else LIB_PATH
+    if not os.path.exists(path):
         raise RuntimeError(
             "native library %s is missing — build it with `python -m gbp_poplar_amd.build` "
-            "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+            "(hipcc, gfx950). There is no CPU fallback." % path)
     # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 and dlopens it by path, so
     # if this library (linked against /opt/rocm's copy) initialised the GPU first, a later `import torch`
     # would bring up a second runtime that finds "No HIP GPUs".  Loading torch's runtime first makes our
@@ -104,10 +120,19 @@ def load():
             torch.cuda.is_available()
         except ImportError:
             pass
-    lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in _SIGS.items():
+    lib = C.CDLL(path)
+    sigs = dict(_SIGS)
+    if hooks:
+        sigs.update(_DEBUG_SIGS)
+    for name, (res, args) in sigs.items():
         fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
+    if lib.gbp_abi_version() != cabi.GBP_ABI_VERSION:
+        raise RuntimeError("%s has ABI version %d, these bindings were written for %d — rebuild (python -m gbp_poplar_amd.build)"
+                           % (path, lib.gbp_abi_version(), cabi.GBP_ABI_VERSION))
+    if hooks:
+        _test_lib = lib
+    else:
+        _lib = lib
     return lib

@@ -1,6 +1,11 @@
 """Build recipe of the native library (in-tree, gfx950 only).
 
-    python -m gbp_poplar_amd.build        -> gbp_poplar_amd/libgbp_mi355x.so  (+ bin/ba, bin/slam, bin/bal_convert)
+    python -m gbp_poplar_amd.build        -> gbp_poplar_amd/libgbp_mi355x.so       the product (+ bin/ba, bin/slam, bin/bal_convert)
+                                             gbp_poplar_amd/libgbp_mi355x_test.so  the same sources + the test hooks of
+                                                                                   include/gbp_mi355x_debug.h (tests/ only)
+    python -m gbp_poplar_amd.build --experiments
+                                          -> gbp_poplar_amd/libgbp_mi355x_exp.so   + timing ablations / mapping experiments
+                                                                                   (profiles/*.py only)
 
 hipcc cross-compiles for gfx950 without a GPU.  -ffp-contract=off: results are compared
 bit-for-bit with the CPU oracle, so no FMA contraction on either side.
@@ -13,6 +18,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgbp_mi355x.so")
+TEST_LIB = os.path.join(HERE, "libgbp_mi355x_test.so")  # + gbp_debug_* (include/gbp_mi355x_debug.h): what tests/ load for stage-level checks
+EXP_LIB = os.path.join(HERE, "libgbp_mi355x_exp.so")    # + timing ablations and mapping experiments (profiles/*.py only)
 BIN = os.path.join(HERE, "bin")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function"]
@@ -34,15 +41,27 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    cc = hipcc()
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "gbp_mi355x.h")]
-    if force or _stale(LIB, deps):
+def _deps():
+    inc = os.path.join(HERE, "..", "include")
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(inc, f) for f in os.listdir(inc)]
+
+
+def _build_lib(target, defines, force, verbose):
+    if force or _stale(target, _deps()):
         extra = os.environ.get("GBP_EXTRA_HIPFLAGS", "").split()     # experiments only (e.g. -DGBP_FAC_TEMPORAL)
-        cmd = [cc, "-shared", "-o", LIB] + FLAGS + extra + ["-x", "hip"] + [os.path.join(CSRC, s) for s in LIB_SRCS] + ["-ldl"]
+        cmd = [hipcc(), "-shared", "-o", target] + FLAGS + defines + extra + ["-x", "hip"] + \
+              [os.path.join(CSRC, s) for s in LIB_SRCS] + ["-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+    return target
+
+
+def build(force=False, verbose=False, test_hooks=True):
+    deps = _deps()
+    _build_lib(LIB, [], force, verbose)
+    if test_hooks:
+        _build_lib(TEST_LIB, ["-DGBP_BUILD_TEST_HOOKS"], force, verbose)
     os.makedirs(BIN, exist_ok=True)
     for name, src in CLI_SRCS.items():
         path = os.path.join(CSRC, src)
@@ -57,5 +76,13 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_experiments(force=False, verbose=False):
+    """The measurement build: the product sources + test hooks + the ablated / experimental kernel instantiations.
+    Loaded only by profiles/*.py (GBP_LIB)."""
+    return _build_lib(EXP_LIB, ["-DGBP_BUILD_ABLATIONS", "-DGBP_BUILD_EXPERIMENTS", "-DGBP_BUILD_TEST_HOOKS"], force, verbose)
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--experiments" in sys.argv:
+        print(build_experiments(force="--force" in sys.argv, verbose=True))

@@ -16,6 +16,7 @@
 
 #include <chrono>
 #include <cmath>
+#include <cerrno>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -307,9 +308,10 @@ template <class F> int run_ranks(int world, uint32_t n_cams, bool force, F&& bod
   std::cout.flush();
   std::fflush(nullptr);
   std::vector<pid_t> pid((size_t)world, -1);
+  bool fork_failed = false;
   for (int r = 0; r < world; ++r) {
     pid[r] = fork();
-    if (pid[r] < 0) { std::cerr << "fork failed\n"; gbp_comm_region_abort(region); break; }
+    if (pid[r] < 0) { std::cerr << "fork failed\n"; gbp_comm_region_abort(region); fork_failed = true; break; }
     if (pid[r] == 0) {
       rk.rank = r; rk.world = world; rk.region = region;
       if (r != 0 && !std::freopen("/dev/null", "w", stdout)) std::_Exit(1);     // rank 0 prints (ba.cpp:996,1026-1028)
@@ -320,7 +322,7 @@ template <class F> int run_ranks(int world, uint32_t n_cams, bool force, F&& bod
       std::_Exit(rc);
     }
   }
-  int status = 0, left = 0, first_bad = 0;
+  int status = 0, left = 0, first_bad = fork_failed ? 1 : 0;   // a run that could not start all its ranks never exits 0
   for (pid_t p : pid) left += p > 0;
   auto code_of = [](int st) { return WIFEXITED(st) ? WEXITSTATUS(st) : 128 + (WIFSIGNALED(st) ? WTERMSIG(st) : 0); };
   auto reap = [&](pid_t p, int st) {
@@ -333,7 +335,10 @@ template <class F> int run_ranks(int world, uint32_t n_cams, bool force, F&& bod
   };
   while (left > 0 && first_bad == 0) {
     const pid_t p = wait(&status);
-    if (p < 0) break;
+    if (p < 0) {
+      if (errno == EINTR) continue;            // a signal is not a failed rank
+      break;
+    }
     reap(p, status);
   }
   // a rank failed: the others normally notice at their next barrier; one that is stuck inside a collective whose peer

@@ -7,6 +7,9 @@
 // into device order, builds the tile-coalesced arrays the kernels stream, and records the launch
 // sequence of one iteration as a hipGraph.
 #include "../../include/gbp_mi355x.h"
+#ifdef GBP_BUILD_TEST_HOOKS
+#include "../../include/gbp_mi355x_debug.h"
+#endif
 #include "gbp_comm.hpp"
 #include "gbp_kernels.h"
 
@@ -1085,6 +1088,7 @@ int gbp_set_profiling(gbp_ctx* c, int per_stage_events) {
   return GBP_OK;
 }
 
+#ifdef GBP_BUILD_TEST_HOOKS   // ---- test hooks (include/gbp_mi355x_debug.h): only in libgbp_mi355x_test.so ----
 // Raw internal state in the reference's tensor layouts, for stage-level parity tests.
 //   what = 0: factor_potentials_eta [9E] + factor_potentials_lambda [81E] = [cc36|cl18|lc18|ll9] (ba.cpp:93-96)
 //   what = 1: factor->camera messages as stored: eta [6E] + Lambda [36E] (lower triangle; upper = 0)
@@ -1165,7 +1169,7 @@ int gbp_debug_time_sweep(gbp_ctx* c, int ablation, int reps, double* avg_us) {
   const SweepArgs a = sweep_args(c);
   bool built = true;
   auto one = [&]() {
-    if (ablation >= 100) {  // 100: k_beliefs, 101: camera part only, 102: landmark part only
+    if (ablation >= 100 && ablation <= 102) {  // 100: k_beliefs, 101: camera part only, 102: landmark part only
       BeliefArgs b = belief_args(c);
       launch_beliefs(b, ablation != 102, ablation != 101, c->stream);
     } else {
@@ -1204,6 +1208,8 @@ static int debug_set_factor_potentials_impl(gbp_ctx* c, const float* eta9E, cons
   HIPCHK(c, hipMemcpy(c->fac.p, f.data(), f.size() * 4, hipMemcpyHostToDevice));
   return GBP_OK;
 }
+
+#endif  // GBP_BUILD_TEST_HOOKS
 
 // ---- communicator: the exchange step owned by the library (RCCL over xGMI from the C++ host) ------------------------
 static int comm_attach(gbp_ctx* c, gbp::Comm* comm) {
@@ -1312,6 +1318,7 @@ int gbp_eval_global(gbp_ctx* c, gbp_eval_out* o) {
   return GBP_OK;
 }
 
+#ifdef GBP_BUILD_TEST_HOOKS
 // Device math layer on caller-supplied vectors (test hook, see k_debug_math): HIP vs the reference's own
 // matlib.cpp / bafuncs.cpp outputs, no ctx and no restated vertex layer involved.
 static int debug_math_run(int op, const float* in, float* out, int n, int reps, double* avg_us) {
@@ -1356,6 +1363,8 @@ int gbp_debug_math_timed(int op, const float* in, float* out, int n, int reps, d
   return debug_math_run(op, in, out, n, reps, avg_us);
 }
 
+#endif  // GBP_BUILD_TEST_HOOKS
+
 // ---- exported wrappers of the entry points that allocate host memory -----------------------------------------
 int gbp_create(const gbp_problem* pr, const gbp_params* prm, const gbp_shard* sh, gbp_ctx** out) {
   return guarded(nullptr, "gbp_create", [&] { return create_impl(pr, prm, sh, out); });
@@ -1371,9 +1380,11 @@ int gbp_new_keyframe(gbp_ctx* c, const gbp_kf_update* u) { return guarded(c, "gb
 int gbp_eval(gbp_ctx* c, gbp_eval_out* o) { return guarded(c, "gbp_eval", [&] { return eval_impl(c, o); }); }
 int gbp_eval_begin(gbp_ctx* c) { return guarded(c, "gbp_eval_begin", [&] { return eval_begin_impl(c); }); }
 int gbp_eval_end(gbp_ctx* c, gbp_eval_out* o) { return guarded(c, "gbp_eval_end", [&] { return eval_end_impl(c, o); }); }
+#ifdef GBP_BUILD_TEST_HOOKS
 int gbp_debug_get(gbp_ctx* c, int what, float* a, float* b) { return guarded(c, "gbp_debug_get", [&] { return debug_get_impl(c, what, a, b); }); }
 int gbp_debug_set_factor_potentials(gbp_ctx* c, const float* eta9E, const float* lam81E) {
   return guarded(c, "gbp_debug_set_factor_potentials", [&] { return debug_set_factor_potentials_impl(c, eta9E, lam81E); });
 }
+#endif  // GBP_BUILD_TEST_HOOKS
 
 }  // extern "C"

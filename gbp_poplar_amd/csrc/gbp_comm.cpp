@@ -34,15 +34,28 @@ RcclApi& rccl() {
   tried = true;
   // Inside a PyTorch process torch's own librccl (loaded as "librccl.so") is already there: reuse it, two RCCL
   // runtimes in one process would each bring their own bootstrap and HIP state.
+  // GBP_RCCL_LIB names the library explicitly: then ONLY that path is tried (no silent substitute).
   const char* env = std::getenv("GBP_RCCL_LIB");
   void* h = nullptr;
-  if (env && *env) h = dlopen(env, RTLD_NOW | RTLD_LOCAL);
-  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
-  if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
-  for (const char* name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"})
-    if (!h) h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+  std::string tried_names;
+  auto open = [&](const char* name, int flags) {
+    if (h) return;
+    (void)dlerror();
+    h = dlopen(name, flags);
+    if (!h && !(flags & RTLD_NOLOAD)) {
+      const char* de = dlerror();     // read ONCE: the call clears the message
+      tried_names += std::string(tried_names.empty() ? "" : "; ") + name + ": " + (de ? de : "?");
+    }
+  };
+  if (env && *env) {
+    open(env, RTLD_NOW | RTLD_LOCAL);
+  } else {
+    open("librccl.so", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+    open("librccl.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+    for (const char* name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) open(name, RTLD_NOW | RTLD_LOCAL);
+  }
   if (!h) {
-    api.error = std::string("librccl not found (dlopen: ") + (dlerror() ? dlerror() : "?") + ")";
+    api.error = "librccl not found (dlopen: " + tried_names + ")";
     return api;
   }
   api.handle = h;

@@ -89,6 +89,7 @@ GBP_DEV void inv6x6_lower(const float (&A)[21], float (&Ainv)[36]) {
 // dropped; "0 + x" is kept (acc starts at 0.f) because 0 + (-0) = +0 in the reference too.
 
 // reference ba/bafuncs.cpp:31-55 — Rodrigues, identity if theta <= 1e-6.
+template <bool FAST_TRIG = false>   // FAST_TRIG: timing experiments only (hardware sin/cos approximations)
 GBP_DEV void so3exp(const float (&v)[3], float (&R)[9]) {
   const float theta = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
   GBP_UNROLL
@@ -97,7 +98,7 @@ GBP_DEV void so3exp(const float (&v)[3], float (&R)[9]) {
     // sin/cos are taken correctly rounded (fp64 evaluation rounded once to fp32): the reference's
     // own std::sin/std::cos resolve to whatever libm its target ships (Poplar's on the IPU), so no
     // libm is "the" reference; a correctly rounded value is the one every good libm approximates.
-    const float s = (float)sin((double)theta), c = (float)cos((double)theta);
+    const float s = FAST_TRIG ? __sinf(theta) : (float)sin((double)theta), c = FAST_TRIG ? __cosf(theta) : (float)cos((double)theta);
     const float H[9] = {0.f, -v[2], v[1], v[2], 0.f, -v[0], -v[1], v[0], 0.f};
     const float a = s / theta;
     const float b = (1 - c) / (theta * theta);
@@ -126,10 +127,11 @@ struct Lin {
   float hx[2];
 };
 
+template <bool FAST_TRIG = false>
 GBP_DEV void jac_hfunc(const float (&cam)[6], const float (&lmk)[3], const float (&K)[9], Lin& o) {
   float R[9];
   const float v[3] = {cam[3], cam[4], cam[5]};
-  so3exp(v, R);
+  so3exp<FAST_TRIG>(v, R);
   float yc[3];
   GBP_UNROLL
   for (int i = 0; i < 3; ++i) {

@@ -97,10 +97,11 @@ GBP_DEV void belief_means(const float (&cb)[44], const float (&lb)[16], float (&
 
 // Shared body of gbp_codelets.cpp:90-168 and :294-373 on the packed FAC record: accumulate
 // J^T J / J^T (J x0 + z - h(x0)) onto the potential, Huber-rescale.  Returns the robust flag.
+template <int ABL = 0>   // ABL: timing experiments only (256 = hardware sin/cos, 512 = reciprocal multiply for the Huber rescale)
 GBP_DEV bool relin_core(float (&fac)[56], const float (&x0c)[6], const float (&x0l)[3], const float (&K)[9],
                         float var, float nstds) {
   Lin L;
-  jac_hfunc(x0c, x0l, K, L);
+  jac_hfunc<(ABL & 256) != 0>(x0c, x0l, K, L);
   GBP_UNROLL
   for (int i = 0; i < 6; ++i) {
     GBP_UNROLL
@@ -158,6 +159,12 @@ GBP_DEV bool relin_core(float (&fac)[56], const float (&x0c)[6], const float (&x
   if (robust) {
     const double den = 2 * ((double)(nstds * sqrtf(var) * err) - 0.5 * (double)nstds * (double)nstds * (double)var);
     mvar = (float)((double)(var * err * err) / den);
+  }
+  if (ABL & 512) {
+    const float rm = 1 / mvar;
+    GBP_UNROLL
+    for (int i = 0; i < 54; ++i) fac[i] *= rm;
+    return robust;
   }
   GBP_UNROLL
   for (int i = 0; i < 54; ++i) fac[i] /= mvar;
@@ -294,8 +301,15 @@ __global__ __launch_bounds__(64 * kWpb) void k_sweep(const SweepArgs a) {
     const float dmu = sqrtf(d2);
     mu[9] = dmu;
     relin = (dmu < a.hp.dmu_threshold) && (count > a.hp.min_linear_iters - a.hp.num_undamped_iters);
+    if (ABL & 64) relin = false;    // timing experiments: no lane / every lane relinearises
+    if (ABL & 128) relin = true;
     if (relin) {
-      if (HOIST) {  // linearisation point = the hoisted means (rare path: loaded only here)
+      if (HOIST && (ABL & 1024)) {  // timing experiment: linearisation point without the dependent loads
+        GBP_UNROLL
+        for (int i = 0; i < 6; ++i) x0c[i] = cb[i] + 0.5f;
+        GBP_UNROLL
+        for (int i = 0; i < 3; ++i) x0l[i] = lb[i] + 0.5f;
+      } else if (HOIST) {  // linearisation point = the hoisted means (rare path: loaded only here)
         const float4 m0 = a.cam_mu[(size_t)cam_i * 4], m1 = a.cam_mu[(size_t)cam_i * 4 + 1];
         const float4 l0 = a.lmk_mu[(size_t)lmk_i * 2];
         x0c[0] = m0.x; x0c[1] = m0.y; x0c[2] = m0.z; x0c[3] = m0.w; x0c[4] = m1.x; x0c[5] = m1.y;
@@ -307,7 +321,7 @@ __global__ __launch_bounds__(64 * kWpb) void k_sweep(const SweepArgs a) {
         GBP_UNROLL
         for (int i = 0; i < 54; ++i) fac[i] = 0.f;
       }
-      const bool robust = relin_core(fac, x0c, x0l, K, var, a.hp.nstds);
+      const bool robust = relin_core<ABL>(fac, x0c, x0l, K, var, a.hp.nstds);
       flags = robust ? (flags | kFlagRobust) : (flags & ~kFlagRobust);
     }
 
@@ -455,7 +469,7 @@ __global__ __launch_bounds__(64 * kWpb) void k_sweep(const SweepArgs a) {
   }
   if (active) {
     if (!HOIST) store_tile<kMuG>(a.mu, tile, lane, mu);
-    if (relin) store_tile<kFacG>(a.fac, tile, lane, fac);
+    if (relin && !(ABL & 2048)) store_tile<kFacG>(a.fac, tile, lane, fac);
   }
 }
 
@@ -914,6 +928,7 @@ __global__ __launch_bounds__(256) void k_eval(const uint32_t* __restrict__ row_c
   }
 }
 
+#ifdef GBP_BUILD_TEST_HOOKS
 // =================================================================================================
 // k_debug_math: the device math layer (gbp_device_math.hpp) on caller-supplied vectors, one lane per
 // vector — lets a test compare HIP directly with the reference's own matlib.cpp / bafuncs.cpp outputs
@@ -1021,6 +1036,8 @@ __global__ __launch_bounds__(64) void k_debug_math(int op, const float* __restri
   }
 }
 
+#endif  // GBP_BUILD_TEST_HOOKS
+
 // =================================================================================================
 // launchers
 // =================================================================================================
@@ -1053,11 +1070,16 @@ bool launch_sweep_ablated(const SweepArgs& a, uint32_t n_tiles, int abl, hipStre
     case 7: hipLaunchKernelGGL((k_sweep<true, 7>), g, b, 0, s, a); break;
     case 16: hipLaunchKernelGGL((k_sweep<true, 16>), g, b, 0, s, a); break;
     case 32: hipLaunchKernelGGL((k_sweep<true, 32>), g, b, 0, s, a); break;
+#define GBP_ABL_CASE(N) case N: hipLaunchKernelGGL((k_sweep<true, N>), g, b, 0, s, a); break;
+    GBP_ABL_CASE(64) GBP_ABL_CASE(128) GBP_ABL_CASE(128 + 256) GBP_ABL_CASE(128 + 512) GBP_ABL_CASE(128 + 1024)
+    GBP_ABL_CASE(128 + 2048) GBP_ABL_CASE(128 + 256 + 512 + 1024 + 2048) GBP_ABL_CASE(128 + 256 + 512)
+#undef GBP_ABL_CASE
     default: hipLaunchKernelGGL((k_sweep<true, 0>), g, b, 0, s, a); break;
   }
 #endif
   return true;
 }
+#ifdef GBP_BUILD_TEST_HOOKS
 // =================================================================================================
 // k_inv6_coop: the SUB-WAVE mapping the north star sketches, built for the dominant routine so that it can be measured:
 // 16 lanes (one DPP row) cooperate on ONE 6x6 inverse, operands staged in LDS, lane = output element, every k-loop
@@ -1159,6 +1181,7 @@ void launch_debug_math(int op, const float* in, float* out, int n, hipStream_t s
   }
   hipLaunchKernelGGL(k_debug_math, dim3((n + 63) / 64), dim3(64), 0, s, op, in, out, n, in_w, out_w);
 }
+#endif  // GBP_BUILD_TEST_HOOKS
 void launch_linearise(const SweepArgs& a, uint32_t n_tiles, hipStream_t s) {
   hipLaunchKernelGGL(k_linearise, dim3(n_tiles / 4), dim3(256), 0, s, a);
 }

@@ -14,8 +14,11 @@ class GbpError(RuntimeError):
 
 
 class GbpEngine:
-    def __init__(self, cam_id, lmk_id, n_cams, n_lmks, K9, params=None, shard=None):
-        self.lib = load()
+    def __init__(self, cam_id, lmk_id, n_cams, n_lmks, K9, params=None, shard=None, hooks=False):
+        """hooks=True loads libgbp_mi355x_test.so — the product sources + the gbp_debug_* test hooks
+        (include/gbp_mi355x_debug.h) — instead of the product library; only tests and profiles/ ask for it."""
+        self.hooks = bool(hooks)
+        self.lib = load(hooks=self.hooks)
         self._keep = []
         self.problem = cabi.make_problem(cam_id, lmk_id, n_cams, n_lmks, K9, self._keep)
         self.C, self.L, self.E = int(n_cams), int(n_lmks), int(self.problem.n_edges)
@@ -177,7 +180,12 @@ class GbpEngine:
         return {k: getattr(o, k) for k, _ in o._fields_}
 
     # ---- raw state for parity tests ----
+    def _need_hooks(self):
+        if not self.hooks:
+            raise GbpError("internal state is reachable only through the test-hooks build: GbpEngine(..., hooks=True)")
+
     def _debug(self, what, na, nb):
+        self._need_hooks()
         a, b = np.zeros(na, np.float32), np.zeros(nb, np.float32)
         self._chk(self.lib.gbp_debug_get(self.h, what, cabi.ptr(a, cabi.c_f32p), cabi.ptr(b, cabi.c_f32p)),
                   "gbp_debug_get")
@@ -187,6 +195,7 @@ class GbpEngine:
         return self._debug(0, 9 * self.E, 81 * self.E)
 
     def set_factor_potentials(self, eta, lam):
+        self._need_hooks()
         eta, lam = np.ascontiguousarray(eta, np.float32), np.ascontiguousarray(lam, np.float32)
         self._chk(self.lib.gbp_debug_set_factor_potentials(self.h, cabi.ptr(eta, cabi.c_f32p), cabi.ptr(lam, cabi.c_f32p)),
                   "gbp_debug_set_factor_potentials")

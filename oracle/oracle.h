@@ -11,7 +11,7 @@
  *
  * Pin status (details in DESIGN.md "Oracle"):
  *   - dense-math layer (matlib.cpp, bafuncs.cpp): pinned bit-for-bit against the reference's own
- *     code compiled here (oracle/_ref, ref_adapter.cpp);
+ *     code compiled here (ref_adapter.cpp, built out of tree by `make ref`);
  *   - vertex classes + schedule: gbp_codelets.cpp / ba.cpp need the Poplar SDK (absent) and are
  *     NOT built; pinned against the reference-run known answers recorded in BASELINE.md
  *     (metric trajectory of the reference's vertex code on fr1xyz / fr2robot2, incl. the chaotic

@@ -5,8 +5,9 @@ reported baseline.  The product package (gbp_poplar_amd) never imports this modu
 
 Two builds of the same vertex/schedule restatement (oracle_gbp.c):
   variant "restatement": oracle/_build/liboracle.so  — dense math from oracle_math.c (travels)
-  variant "ref"        : oracle/_ref/liboracle_ref.so — dense math is the reference's own
-                         matlib.cpp / bafuncs.cpp compiled in the build container
+  variant "ref"        : $TMPDIR/gbp_oracle_ref/liboracle_ref.so — dense math is the reference's own
+                         matlib.cpp / bafuncs.cpp compiled in the build container, OUTSIDE the repository:
+                         nothing made from the reference's sources sits in the work tree or travels to the GPU box
 """
 import ctypes as C
 import os
@@ -22,13 +23,18 @@ from gbp_poplar_amd import _cabi as cabi  # noqa: E402  (struct declarations onl
 _LIBS = {}
 
 
+def ref_dir():
+    """Where `make -C oracle ref` puts the reference-math builds (out of tree; GBP_ORACLE_REF_DIR overrides)."""
+    return os.environ.get("GBP_ORACLE_REF_DIR") or os.path.join(os.environ.get("TMPDIR") or "/tmp", "gbp_oracle_ref")
+
+
 def lib_path(variant="restatement"):
     if variant == "restatement":
         return os.path.join(_HERE, "_build", "liboracle.so")
     if variant == "ref":
-        return os.path.join(_HERE, "_ref", "liboracle_ref.so")
+        return os.path.join(ref_dir(), "liboracle_ref.so")
     if variant == "ref_math":
-        return os.path.join(_HERE, "_ref", "libref_math.so")
+        return os.path.join(ref_dir(), "libref_math.so")
     raise ValueError(variant)
 
 
@@ -38,7 +44,7 @@ def build(ref=None):
     if ref is None:
         ref = os.path.isdir("/root/reference/ba")
     if ref:
-        subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+        subprocess.check_call(["make", "-s", "-C", _HERE, "ref", "REFOUT=" + ref_dir()])
 
 
 def have(variant):

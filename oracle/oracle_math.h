@@ -4,7 +4,7 @@
  * ba/bafuncs.cpp), as a C interface with two interchangeable implementations:
  *   oracle_math.c     our CPU restatement (travels with the repo, used on the GPU box)
  *   ref_adapter.cpp   thin wrappers that call the reference's own templates, compiled from
- *                     /root/reference where they lie into oracle/_ref/ (this container only)
+ *                     /root/reference where they lie, out of tree (make ref; this container only)
  * tests/test_oracle_math.py checks the two bit-for-bit.
  *
  * All matrices are row-major fp32.  Like the reference's matMul, products ACCUMULATE into the

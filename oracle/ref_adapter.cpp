@@ -1,8 +1,8 @@
 // ref_adapter.cpp — TEST INFRASTRUCTURE ONLY, built in the survey/build container only.
 //
 // Implements the om_* interface of oracle_math.h by calling the REFERENCE's own templates,
-// compiled from the sources where they lie (no copy is made into this repository; the output goes
-// to oracle/_ref/, which is git-ignored).  matlib.cpp and bafuncs.cpp are self-contained
+// compiled from the sources where they lie (no copy is made into this repository; the objects go to
+// $TMPDIR/gbp_oracle_ref, OUTSIDE the repository, so they never travel with a snapshot of it).  matlib.cpp and bafuncs.cpp are self-contained
 // header-style C++ (they need only <cmath>), so this is g++ on the reference's own files —
 // no stand-in headers.  gbp_codelets.cpp (the Poplar vertex classes) is NOT built: it needs
 // <poplar/Vertex.hpp>, which the image lacks, so it is restated in oracle_gbp.c instead.

@@ -16,7 +16,7 @@ NL = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
 bal = hostlib.synth_generate(NC, NL, 10, 20200303)
 opts = driver.Options()
 K, state, _ = driver.build_inputs(bal, opts, hostlib)
-eng = GbpEngine(bal["cam_id"], bal["lmk_id"], NC, NL, K)
+eng = GbpEngine(bal["cam_id"], bal["lmk_id"], NC, NL, K, hooks=True)
 eng.upload(state)
 eng.linearise()
 for it in range(20):

@@ -1,0 +1,99 @@
+// exp_gridbarrier.hip — what does a device-wide barrier cost on MI355X (8 XCDs, private L2s)?
+//
+// Floor of a persistent (one launch, many iterations) GBP kernel for small graphs: every iteration needs two
+// grid-wide hand-offs (messages -> beliefs -> messages) through memory that another XCD wrote.
+//   build:  hipcc -O3 --offload-arch=gfx950 -o profiles/_bin/exp_gridbarrier profiles/exp_gridbarrier.hip
+//   run:    profiles/_bin/exp_gridbarrier            (prints one table)
+// Each "round" = every block writes 1 KiB per wave, release, barrier, acquire, reads the 1 KiB of the NEXT block's wave
+// (written on another XCD under round-robin placement) and checks it.  Variants:
+//   flat     one monotonically increasing counter, agent-scope atomics, every wave's lane 0 polls it
+//   mono1    the same, only thread 0 of the block arrives / polls, __syncthreads around it
+//   launch   the same rounds as separate kernel launches (what a hipGraph replays), for comparison
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+__device__ __forceinline__ void grid_barrier(unsigned* counter, unsigned target, bool one_per_block) {
+  if (one_per_block) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __atomic_thread_fence(__ATOMIC_RELEASE);   // agent scope: L2 write-back so that other XCDs see this block's stores
+      __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (unsigned spin = 0; __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && spin < (1u << 22); ++spin)
+        __builtin_amdgcn_s_sleep(1);             // bounded: a scheduling surprise must not hang the box
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
+    __syncthreads();
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  } else {
+    if ((threadIdx.x & 63) == 0) {
+      __atomic_thread_fence(__ATOMIC_RELEASE);
+      __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (unsigned spin = 0; __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && spin < (1u << 22); ++spin)
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  }
+}
+
+template <int MODE>   // 0 flat (per wave), 1 one thread per block, 2 no barrier at all (one round per launch)
+__global__ void k_rounds(float4* buf, unsigned* counter, unsigned* errors, int rounds, int round0) {
+  const unsigned nwaves = gridDim.x * (blockDim.x >> 6);
+  const unsigned wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const unsigned arrivals = MODE == 1 ? gridDim.x : nwaves;
+  unsigned bad = 0;
+  for (int r = 0; r < rounds; ++r) {
+    const int rr = round0 + r;
+    float4* mine = buf + ((size_t)(rr & 1) * nwaves + wave) * 64;
+    mine[lane] = make_float4((float)rr, (float)wave, (float)lane, 1.f);
+    if (MODE != 2) grid_barrier(counter, (unsigned)(r + 1) * arrivals, MODE == 1);
+    if (MODE != 2) {
+      const unsigned other = (wave + (blockDim.x >> 6)) % nwaves;   // a wave of the next block: another XCD
+      const float4 v = buf[((size_t)(rr & 1) * nwaves + other) * 64 + lane];
+      if (v.x != (float)rr || v.y != (float)other || v.z != (float)lane) ++bad;
+    }
+  }
+  if (bad) atomicAdd(errors, bad);
+}
+
+int main() {
+  unsigned *counter, *errors;
+  float4* buf;
+  CK(hipMalloc(&counter, 64));
+  CK(hipMalloc(&errors, 64));
+  CK(hipMalloc(&buf, 2 * 4096 * 64 * sizeof(float4)));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  hipStream_t s;
+  CK(hipStreamCreate(&s));
+  const int rounds = 2000;
+  printf("| blocks x threads | waves | flat: us/round | one-thread-per-block: us/round | separate launches: us/round | errors |\n|---|---|---|---|---|---|\n");
+  const int cfgs[][2] = {{14, 256}, {51, 256}, {128, 256}, {256, 256}, {512, 256}, {56, 64}, {202, 64}, {512, 64}, {1024, 64}};
+  for (auto& cfg : cfgs) {
+    const int nb = cfg[0], nt = cfg[1];
+    double us[3];
+    unsigned herr = 0;
+    CK(hipMemset(errors, 0, 4));
+    for (int mode = 0; mode < 3; ++mode) {
+      for (int rep = 0; rep < 2; ++rep) {   // rep 0 = warm-up
+        CK(hipMemsetAsync(counter, 0, 4, s));
+        CK(hipEventRecord(e0, s));
+        if (mode == 0) hipLaunchKernelGGL(k_rounds<0>, dim3(nb), dim3(nt), 0, s, buf, counter, errors, rounds, 0);
+        else if (mode == 1) hipLaunchKernelGGL(k_rounds<1>, dim3(nb), dim3(nt), 0, s, buf, counter, errors, rounds, 0);
+        else for (int r = 0; r < rounds; ++r) hipLaunchKernelGGL(k_rounds<2>, dim3(nb), dim3(nt), 0, s, buf, counter, errors, 1, r);
+        CK(hipEventRecord(e1, s));
+        CK(hipEventSynchronize(e1));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        us[mode] = 1e3 * ms / rounds;
+      }
+    }
+    CK(hipMemcpy(&herr, errors, 4, hipMemcpyDeviceToHost));
+    printf("| %d x %d | %d | %.2f | %.2f | %.2f | %u |\n", nb, nt, nb * nt / 64, us[0], us[1], us[2], herr);
+  }
+  return 0;
+}

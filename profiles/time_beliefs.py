@@ -10,7 +10,7 @@ cams, lmks = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (100
 bal = hostlib.synth_generate(cams, lmks, 10, 20200303)
 opts = driver.Options()
 K, state, _ = driver.build_inputs(bal, opts, hostlib)
-eng = GbpEngine(bal["cam_id"], bal["lmk_id"], cams, lmks, K)
+eng = GbpEngine(bal["cam_id"], bal["lmk_id"], cams, lmks, K, hooks=True)
 eng.upload(state)
 eng.linearise()
 eng.iterate(12)

@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from gbp_poplar_amd import _cabi as cabi
 from gbp_poplar_amd._lib import load
-lib = load()
+lib = load(hooks=True)
 rng = np.random.default_rng(1)
 print("| matrices | lane per matrix (us) | 16 lanes per matrix (us) | ratio |")
 print("|---|---|---|---|")

@@ -3,7 +3,7 @@
 /root/reference exists):   python tests/golden/make_golden.py
 
 Sources of truth:
-  * variant "ref": oracle/_ref/liboracle_ref.so — the vertex/schedule restatement linked against the
+  * variant "ref": $TMPDIR/gbp_oracle_ref/liboracle_ref.so (out of tree) — the vertex/schedule restatement linked against the
     REFERENCE's own matlib.cpp / bafuncs.cpp (compiled where they lie).  Everything tagged `ref_` below
     comes from it (literal std::sin/std::cos, ascending slot-order sums).
   * `dev_` entries: the same restatement in the device's arithmetic conventions (correctly rounded trig,
@@ -184,7 +184,7 @@ def trajectories():
 
 def main():
     if not orc.have("ref"):
-        raise SystemExit("oracle/_ref is missing: run `make -C oracle ref` in the build container first")
+        raise SystemExit("the reference-math build is missing: run `make -C oracle ref` in the build container first")
     ref = orc.load("ref")
     assert ref.om_impl_name() == b"reference"
     if sys.argv[1:] == ["vertex"]:          # only (re)write the vertex-level fixture

@@ -9,8 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_functions():
-    src = open(os.path.join(ROOT, "include", "gbp_mi355x.h")).read()
+def declared_functions(header="gbp_mi355x.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     names = re.findall(r"^\s*(?:const\s+char\s*\*|int|void|size_t)\s+(gbp_\w+)\s*\(", src, flags=re.M)
     return sorted(set(names))
@@ -32,7 +32,33 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "libgbp_mi355x.so does not export %s" % n
     assert sorted(_lib.symbols()) == names, set(names) ^ set(_lib.symbols())
-    assert lib.gbp_abi_version() == 1
+    assert lib.gbp_abi_version() == 2
+
+
+def _exported(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], stdout=subprocess.PIPE, text=True, check=True).stdout
+    return {l.split()[-1] for l in out.splitlines() if l.strip()}
+
+
+def test_product_library_exports_no_test_hooks():
+    """The default build carries the program list, the host helpers and gbp_comm_* — no gbp_debug_* entry point and
+    none of the test-only kernels."""
+    from gbp_poplar_amd import _lib
+    sym = _exported(_lib.LIB_PATH)
+    assert not [s for s in sym if "gbp_debug" in s], [s for s in sym if "gbp_debug" in s]
+    assert not [s for s in sym if "k_debug_math" in s or "k_inv6_coop" in s]
+    exported_api = {s for s in sym if s.startswith("gbp_")}
+    assert exported_api == set(declared_functions()), exported_api ^ set(declared_functions())
+
+
+def test_test_hooks_library_exports_the_debug_header():
+    from gbp_poplar_amd import _lib
+    lib = _lib.load(hooks=True)
+    names = declared_functions("gbp_mi355x_debug.h")
+    assert names == sorted(_lib.debug_symbols()) and len(names) == 5
+    for n in names + declared_functions():
+        assert hasattr(lib, n), "libgbp_mi355x_test.so does not export %s" % n
 
 
 def test_struct_sizes_match_the_header():

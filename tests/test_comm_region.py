@@ -66,3 +66,25 @@ def test_wrong_world_is_refused():
     assert lib.gbp_comm_region_init(buf, n, 10, 2) == 0
     assert lib.gbp_comm_region_selftest(buf, 0, 3, 1) != 0               # region was made for 2 ranks
     assert lib.gbp_comm_region_selftest(buf, 2, 2, 1) != 0               # rank out of range
+
+
+def test_missing_rccl_library_is_reported_not_crashed():
+    """with librccl unloadable, gbp_comm_unique_id (needs no device) returns GBP_ERR_COMM and a message naming
+    the path and the loader's reason — it used to dereference a NULL dlerror() and crash.  GBP_RCCL_LIB is a strict
+    override: only that path is tried."""
+    import subprocess
+    import sys
+    code = ("import ctypes, os, sys\n"
+            "sys.path.insert(0, %r)\n"
+            "from gbp_poplar_amd._lib import load\n"
+            "lib = load()\n"
+            "buf = ctypes.create_string_buffer(128)\n"
+            "rc = lib.gbp_comm_unique_id(buf)\n"
+            "rc2 = lib.gbp_comm_unique_id(buf)\n"          # the cached failure path
+            "print(rc, rc2, lib.gbp_last_error(None).decode())\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GBP_NO_TORCH="1", GBP_RCCL_LIB="/nonexistent/dir/librccl-missing.so")
+    p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rc, rc2, msg = p.stdout.strip().split(" ", 2)
+    assert (rc, rc2) == ("-7", "-7"), p.stdout
+    assert "librccl not found" in msg and "/nonexistent/dir/librccl-missing.so" in msg and "No such file" in msg, msg

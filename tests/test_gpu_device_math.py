@@ -1,7 +1,7 @@
 """HIP device math vs the REFERENCE's own matlib.cpp / bafuncs.cpp — no restated layer in between.
 
 tests/golden/math_vectors.npz holds inputs and the outputs of the reference's templates compiled here
-(oracle/ref_adapter.cpp -> oracle/_ref, generator tests/golden/make_golden.py).  gbp_debug_math runs the routines of
+(oracle/ref_adapter.cpp -> `make -C oracle ref`, out of tree; generator tests/golden/make_golden.py).  gbp_debug_math runs the routines of
 csrc/gbp_device_math.hpp — the ones k_sweep / k_linearise / k_beliefs are built from — on the GPU, one lane per vector.
 
 Bars: everything without a transcendental is BIT-EXACT (matMul modes, inv3x3, inv6x6, inf2mean).  so3exp / hfunc / Jac
@@ -22,7 +22,7 @@ G = np.load(os.path.join(os.path.dirname(__file__), "golden", "math_vectors.npz"
 def _run(op, inp, out_w):
     from gbp_poplar_amd import _cabi as cabi
     from gbp_poplar_amd._lib import load
-    lib = load()
+    lib = load(hooks=True)      # gbp_debug_math lives in the test-hooks build of the same sources
     inp = np.ascontiguousarray(inp, np.float32)
     n = inp.shape[0]
     out = np.zeros((n, out_w), np.float32)

@@ -140,7 +140,7 @@ def test_vertex_known_answers_bit_for_bit():
             orc.set_trig_mode(0)
 
 
-@pytest.mark.skipif(not orc.have("ref"), reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.skipif(not orc.have("ref"), reason="reference-math build absent (make -C oracle ref; needs /root/reference)")
 def test_long_chaotic_trajectory_equals_reference_math_build():
     """fr1xyz is chaotic in fp32 (ulp differences blow up within ~25 sweeps): 200 sweeps with
     relinearisations staying bit-identical means the restated math layer IS the reference's."""

@@ -1,9 +1,9 @@
 """Pins of the oracle's dense-math layer (reference ba/matlib.cpp + ba/bafuncs.cpp).
 
 1. against the committed golden vectors (tests/golden/math_vectors.npz, produced by the REFERENCE's own
-   code through oracle/_ref, see tests/golden/make_golden.py) — runs everywhere, bit for bit;
-2. against the reference code itself when oracle/_ref/libref_math.so is present (build container, and on
-   the GPU box if the built .so travelled) on fresh random inputs — bit for bit."""
+   code through the out-of-tree reference build, see tests/golden/make_golden.py) — runs everywhere, bit for bit;
+2. against the reference code itself when the out-of-tree reference build ($TMPDIR/gbp_oracle_ref/libref_math.so)
+   is present (build container only — it never travels to the GPU box) on fresh random inputs — bit for bit."""
 import os
 
 import numpy as np
@@ -60,7 +60,7 @@ def test_golden_vectors_are_sane():
     assert np.all(G["jac_kf"][:, 1] == 0) and np.all(G["jac_kf"][:, 6] == 0)
 
 
-@pytest.mark.skipif(not orc.have("ref_math"), reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.skipif(not orc.have("ref_math"), reason="reference-math build absent (make -C oracle ref; needs /root/reference)")
 def test_restatement_equals_reference_code_on_fresh_inputs():
     ref, mine = orc.load("ref_math"), orc.load("restatement")
     assert ref.om_impl_name() == b"reference"

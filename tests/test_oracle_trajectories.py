@@ -1,5 +1,5 @@
 """The travelling oracle (oracle/_build, restated math) against tests/golden/trajectories.npz, which the
-reference-math build (oracle/_ref: the reference's own matlib.cpp / bafuncs.cpp) produced in the literal conventions.
+reference-math build (`make -C oracle ref`, out of tree: the reference's own matlib.cpp / bafuncs.cpp) produced in the literal conventions.
 The two math layers are bit-identical (tests/test_oracle_math.py), so whole chaotic trajectories must coincide."""
 import os
 
