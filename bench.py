@@ -33,6 +33,12 @@ roofline (dominant kernel k_sweep; `kernels` carries the same figures for k_beli
                                 (rank 0, N = 1) in child processes before the parent touches the GPU; a stamped
                                 profiles/traffic_S1.json is used only if the live passes fail and its stamp matches.
   frac                          achieved_traffic / peak — the physically meaningful HBM fraction (headline).
+  N > 1 (and --force-sharded)   the PMC passes run on rank 0's SHARD SHAPE — the same generator with all C = 1000 N cameras
+                                and one rank's share of the landmarks, one process, before rank 0 touches its GPU — so the
+                                line of every N carries a measured roofline.frac; beside it exchange_avg_us (local camera
+                                partial sums + all-gather per iteration, rank 0) and the fastest / slowest rank's step time.
+                                A native-communicator failure ends the run non-zero on every rank (no silent downgrade to
+                                the torch.distributed exchange; `--comm torch` asks for that one explicitly).
 """
 import argparse
 import glob
@@ -161,12 +167,19 @@ def launch_selftest(a):
 
 # ---- HBM traffic from rocprofv3 PMC passes ----------------------------------------------------------------------
 
-def build_stamp(a):
+def pmc_shape(a, world):
+    """(cameras, landmarks) of the graph the PMC child runs: S1 itself at N = 1; at N > 1 one rank's shard shape —
+    every camera of the global graph, one rank's share of the landmarks, drawn by the same generator."""
+    return a.cams * world, a.lmks
+
+
+def build_stamp(a, world=1):
     """Identifies the kernels + workload a traffic figure belongs to: hash of the device sources and the shapes."""
     h = hashlib.sha256()
     for f in ("gbp_kernels.hip", "gbp_kernels.h", "gbp_device_math.hpp"):
         h.update(open(os.path.join(ROOT, "gbp_poplar_amd", "csrc", f), "rb").read())
-    return {"source_sha16": h.hexdigest()[:16], "workload": [a.cams, a.lmks, a.obs, a.seed], "tile_order": a.tile_order}
+    cams, lmks = pmc_shape(a, world)
+    return {"source_sha16": h.hexdigest()[:16], "workload": [cams, lmks, a.obs, a.seed], "tile_order": a.tile_order}
 
 
 def parse_pmc_csv(directory, counter):
@@ -186,7 +199,7 @@ def parse_pmc_csv(directory, counter):
     return {k: (s / n, n) for k, (n, s) in agg.items() if n}
 
 
-def measure_traffic_live(a, keep_dir=None):
+def measure_traffic_live(a, keep_dir=None, world=1):
     """Two rocprofv3 passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE: the TCC slots do not hold both) over a short run of
     the same workload in child processes.  Returns {"k_sweep": {...}, "k_beliefs": {...}} or None."""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
@@ -194,8 +207,16 @@ def measure_traffic_live(a, keep_dir=None):
         return None, "rocprofv3 not found"
     tmp = os.path.abspath(keep_dir) if keep_dir else tempfile.mkdtemp(prefix="gbp_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
-    child = ["python3", os.path.abspath(__file__), "--pmc-child", "--steps", "4", "--warmup", "12", "--cams", str(a.cams),
-             "--lmks", str(a.lmks), "--obs", str(a.obs), "--seed", str(a.seed), "--tile-order", str(a.tile_order)]
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT",
+              "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)           # the child is a plain single-process run on this rank's GPU
+    if "LOCAL_RANK" in os.environ:
+        env.setdefault("HIP_VISIBLE_DEVICES", os.environ["LOCAL_RANK"])
+    cams, lmks = pmc_shape(a, world)
+    # the program after `--` is the interpreter binary itself (no PATH lookup, no shim script: a re-exec behind
+    # rocprofv3 --pmc is refused on this pool)
+    child = [os.path.realpath(sys.executable), os.path.abspath(__file__), "--pmc-child", "--steps", "4", "--warmup", "12",
+             "--cams", str(cams), "--lmks", str(lmks), "--obs", str(a.obs), "--seed", str(a.seed), "--tile-order", str(a.tile_order)]
     vals = {}
     try:
         for counter, tag in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
@@ -347,14 +368,17 @@ def main(argv=None):
     # ---- HBM traffic of the kernels: live PMC passes in child processes, BEFORE this process touches the GPU ----
     traffic, traffic_src, traffic_err = None, None, None
     s1_like = world == 1 and not a.force_sharded
-    if rank == 0 and s1_like and a.profile_steps > 0 and a.pmc == "live":
-        traffic, traffic_err = measure_traffic_live(a, keep_dir=a.keep_pmc)
+    if rank == 0 and a.profile_steps > 0 and a.pmc == "live":
+        traffic, traffic_err = measure_traffic_live(a, keep_dir=a.keep_pmc, world=world)
         if traffic and a.save_traffic:
-            json.dump({"stamp": build_stamp(a), "kernels": traffic,
+            json.dump({"stamp": build_stamp(a, world), "kernels": traffic,
                        "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (KB per dispatch, mean); "
                                "read side of the streaming kernels doubled (gfx950 correction, MI355X_MICROARCH.md HBM)"},
                       open(a.save_traffic, "w"), indent=1)
-        traffic_src = "live rocprofv3 --pmc passes of this run's build and workload" if traffic else None
+        if traffic:
+            traffic_src = ("live rocprofv3 --pmc passes of this run's build and workload" if s1_like else
+                           "live rocprofv3 --pmc passes of this build on rank 0's shard shape (%d cameras x %d landmarks, one process)"
+                           % pmc_shape(a, world))
     if rank == 0 and s1_like and traffic is None and a.pmc in ("live", "file"):
         tpath = os.path.join(ROOT, "profiles", "traffic_S1.json")
         try:
@@ -406,25 +430,35 @@ def main(argv=None):
         eng = GbpEngine(bal["cam_id"], bal["lmk_id"], C, L, K, params=prm,
                         shard=(rank, world, int(bounds[rank]), int(bounds[rank + 1])))
         e_local = int(((bal["lmk_id"] >= bounds[rank]) & (bal["lmk_id"] < bounds[rank + 1])).sum())
-        run = None
         if a.comm == "native":
-            # the exchange lives in the C++ library: rank 0 draws the RCCL id, torch.distributed only carries it around
+            # the exchange lives in the C++ library: rank 0 draws the RCCL id, torch.distributed only carries it around.
+            # A failure on ANY rank ends the run non-zero on EVERY rank: a per-rank fallback would mix two different
+            # collectives (hang) or report a torch-exchange number under the native label.
             try:
                 idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
                 if rank == 0:
                     idt.copy_(torch.frombuffer(bytearray(eng.comm_unique_id()), dtype=torch.uint8))
                 dist.broadcast(idt, src=0)
                 eng.comm_init_rccl(bytes(idt.cpu().numpy().tobytes()))
-                run = eng
-                run_eval = eng.eval_global
-                exchange_kind = "native: ncclAllGather issued by libgbp_mi355x.so (C++ host; beside the landmark beliefs from 4 ranks on)"
-            except Exception as exc:  # noqa: BLE001 — fall back to the torch.distributed exchange, and say so
+            except Exception as exc:  # noqa: BLE001
                 comm_error = repr(exc)
-        if run is None:
+            ok = torch.tensor([0 if comm_error else 1], dtype=torch.int32, device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                sys.stderr.write("bench.py: the library's RCCL communicator could not be set up on rank %d: %s\n"
+                                 "(no fallback: rerun with --comm torch for the torch.distributed exchange)\n"
+                                 % (rank, comm_error or "failed on another rank"))
+                dist.barrier()
+                dist.destroy_process_group()
+                return 4
+            run = eng
+            run_eval = eng.eval_global
+            exchange_kind = "native: ncclAllGather issued by libgbp_mi355x.so (C++ host; beside the landmark beliefs from 4 ranks on)"
+        else:
             run = ShardedGbp(eng, C, rank, world, dist=dist, device="cuda", always_collective=a.force_sharded,
                              use_graph=bool(a.sharded_graph), chunks=a.exchange_chunks)
             run_eval = run.eval
-            exchange_kind = "torch.distributed all_gather_into_tensor around the split-phase C-ABI"
+            exchange_kind = "torch.distributed all_gather_into_tensor around the split-phase C-ABI (--comm torch)"
     run.upload(state)
     run.linearise()
     ev0 = run_eval()
@@ -448,10 +482,13 @@ def main(argv=None):
     run.iterate(a.steps)
     fence()
     dt = time.perf_counter() - t0
+    rank_dt = [dt]
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        allt = torch.zeros(world, dtype=torch.float64, device="cuda")
+        dist.all_gather_into_tensor(allt, t)
+        rank_dt = [float(x) for x in allt.cpu().tolist()]
+        dt = max(rank_dt)                                   # the contract: MAX over ranks
     ev1 = run_eval()
 
     # ---- roofline of the dominant kernel (k_sweep), measured live with hipEvents on its stream ----
@@ -504,6 +541,7 @@ def main(argv=None):
                 "profiled_note": "direct launches with an event between kernels: sweep + beliefs + two dependent-launch gaps; "
                                  "ms_per_step is the hipGraph replay of the same kernels" if not sharded else
                                  "split-phase iterations (sweep, partials, all-gather, combine), wall clock per iteration",
+                "rank_step_ms_min": round(min(rank_dt) / a.steps * 1e3, 4), "rank_step_ms_max": round(max(rank_dt) / a.steps * 1e3, 4),
                 "measured_on": "rank 0" if world > 1 else "the GPU"}
         if not sharded:
             kb = (traffic or {}).get("k_beliefs")

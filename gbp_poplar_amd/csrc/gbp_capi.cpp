@@ -342,6 +342,7 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
   c->C = pr->n_cams; c->L = pr->n_lmks; c->E = pr->n_edges;
   std::memcpy(c->K, pr->K, sizeof(c->K));
   if (prm) c->prm = *prm; else gbp_default_params(&c->prm);
+  if (const char* gu = std::getenv("GBP_GRAPH_UNROLL")) c->prm.graph_unroll = std::atoi(gu);   // measurements: callers that pass no params (the CLIs)
   c->sharded_graph = c->prm.graph_unroll > 0;                // a sharded iteration is captured only on explicit request
   if (c->prm.graph_unroll == 0) c->prm.graph_unroll = 10;   // < 0: never capture, always direct launches
   c->hoist = c->prm.per_factor_mu == 0;

@@ -19,19 +19,39 @@ namespace gbpdev {
 GBP_DEV constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }
 GBP_DEV constexpr int trisym(int i, int j) { return i >= j ? tri(i, j) : tri(j, i); }
 
-// reference ba/matlib.cpp:143-161 — cofactor inverse, nine IEEE divisions by det.
+// v[i] / m for N values and ONE divisor, each quotient the correctly rounded IEEE fp32 quotient (bit for bit what
+// `v[i] / m` gives), through one fp64 reciprocal: q = (float)((double)v * (1.0 / (double)m)).
+// Why it is exact: the product carries a relative error <= 2^-52 (two fp64 roundings).  A quotient of two 24-bit
+// significands is never a midpoint of two fp32 numbers and lies at least 2^-49 (relative) away from the nearest one
+// (|X 2^(24+s) - (2k+1) M| >= 1 for integers X, M < 2^24), so the fp64 value and the exact quotient sit on the same
+// side of every fp32 rounding boundary and round alike.  Zeros, infinities and NaNs behave like the division.  The
+// bound needs a NORMAL fp32 result: a quotient that is subnormal (or underflows to zero from a non-zero numerator)
+// raises `redo` and the whole set is divided the slow way.  An fp32 IEEE division costs 11 instructions, five of them
+// quarter-rate; this costs 3 full-rate ones per value (measured in situ on fr1xyz: 29.9 -> 26.4 us per iteration for
+// the 54 divisions of the Huber rescale alone, profiles/r03_small_graphs.md).
+template <int N>
+GBP_DEV void div_shared(const float (&v)[N], float m, float (&q)[N]) {
+  const double r = 1.0 / (double)m;
+  bool redo = false;
+  GBP_UNROLL
+  for (int i = 0; i < N; ++i) {
+    q[i] = (float)((double)v[i] * r);
+    redo |= (__builtin_fabsf(q[i]) < 1.17549435e-38f) != (v[i] == 0.f);
+  }
+  if (redo) {
+    GBP_UNROLL
+    for (int i = 0; i < N; ++i) q[i] = v[i] / m;
+  }
+}
+
+// reference ba/matlib.cpp:143-161 — cofactor inverse, nine IEEE divisions by det (div_shared: same bits).
 GBP_DEV void inv3x3(const float (&M)[9], float (&inv)[9]) {
   const float det = M[0] * (M[4] * M[8] - M[7] * M[5]) - M[1] * (M[3] * M[8] - M[5] * M[6]) +
                     M[2] * (M[3] * M[7] - M[4] * M[6]);
-  inv[0] = (M[4] * M[8] - M[7] * M[5]) / det;
-  inv[1] = (M[2] * M[7] - M[1] * M[8]) / det;
-  inv[2] = (M[1] * M[5] - M[2] * M[4]) / det;
-  inv[3] = (M[5] * M[6] - M[3] * M[8]) / det;
-  inv[4] = (M[0] * M[8] - M[2] * M[6]) / det;
-  inv[5] = (M[3] * M[2] - M[0] * M[5]) / det;
-  inv[6] = (M[3] * M[7] - M[6] * M[4]) / det;
-  inv[7] = (M[6] * M[1] - M[0] * M[7]) / det;
-  inv[8] = (M[0] * M[4] - M[3] * M[1]) / det;
+  const float cof[9] = {M[4] * M[8] - M[7] * M[5], M[2] * M[7] - M[1] * M[8], M[1] * M[5] - M[2] * M[4],
+                        M[5] * M[6] - M[3] * M[8], M[0] * M[8] - M[2] * M[6], M[3] * M[2] - M[0] * M[5],
+                        M[3] * M[7] - M[6] * M[4], M[6] * M[1] - M[0] * M[7], M[0] * M[4] - M[3] * M[1]};
+  div_shared(cof, det, inv);
 }
 
 // reference ba/matlib.cpp:180-222 — un-pivoted LDL^T of the LOWER triangle (packed, 21 entries),
@@ -141,13 +161,19 @@ GBP_DEV void jac_hfunc(const float (&cam)[6], const float (&lmk)[3], const float
     acc += cam[i];  // T(i,3) * 1.0
     yc[i] = acc;
   }
-  o.hx[0] = K[0] * (yc[0] / yc[2]) + K[2];
-  o.hx[1] = K[4] * (yc[1] / yc[2]) + K[5];
-
-  const float jp00 = K[0] / yc[2];
-  const float jp02 = -(K[0] * yc[0]) / (yc[2] * yc[2]);
-  const float jp11 = K[4] / yc[2];
-  const float jp12 = -(K[4] * yc[1]) / (yc[2] * yc[2]);
+  // six divisions by two divisors (bafuncs.cpp:96-99,150-160): yc[2] and yc[2]^2
+  const float nz[4] = {yc[0], yc[1], K[0], K[4]};
+  float qz[4];
+  div_shared(nz, yc[2], qz);
+  o.hx[0] = K[0] * qz[0] + K[2];
+  o.hx[1] = K[4] * qz[1] + K[5];
+  const float nzz[2] = {-(K[0] * yc[0]), -(K[4] * yc[1])};
+  float qzz[2];
+  div_shared(nzz, yc[2] * yc[2], qzz);
+  const float jp00 = qz[2];
+  const float jp02 = qzz[0];
+  const float jp11 = qz[3];
+  const float jp12 = qzz[1];
   // Jlmk = J_proj * R  (J_proj has structural zeros at (0,1) and (1,0))
   GBP_UNROLL
   for (int j = 0; j < 3; ++j) {
@@ -193,6 +219,7 @@ GBP_DEV void jac_hfunc(const float (&cam)[6], const float (&lmk)[3], const float
   float den = 0.f;
   GBP_UNROLL
   for (int i = 0; i < 3; ++i) den += v[i] * v[i];
+  float ndR[9];
   GBP_UNROLL
   for (int i = 0; i < 3; ++i) {
     GBP_UNROLL
@@ -200,9 +227,10 @@ GBP_DEV void jac_hfunc(const float (&cam)[6], const float (&lmk)[3], const float
       float a = 0.f;
       GBP_UNROLL
       for (int k = 0; k < 3; ++k) a += Ry[i * 3 + k] * num[k * 3 + j];
-      dR[i * 3 + j] = -a / den;
+      ndR[i * 3 + j] = -a;
     }
   }
+  div_shared(ndR, den, dR);
   GBP_UNROLL
   for (int j = 0; j < 3; ++j) {
     float a0 = 0.f, a1 = 0.f;

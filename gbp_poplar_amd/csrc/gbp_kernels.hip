@@ -14,6 +14,7 @@
 // 6x6/3x3 algebra (no MFMA: the blocks are tiny and chains are serial) hides under the loads.
 // fp32 throughout, compiled with -ffp-contract=off so results are bit-comparable with the oracle.
 #include "gbp_kernels.h"
+#include <cstdlib>
 #include "gbp_device_math.hpp"
 
 namespace gbp {
@@ -166,104 +167,32 @@ GBP_DEV bool relin_core(float (&fac)[56], const float (&x0c)[6], const float (&x
     for (int i = 0; i < 54; ++i) fac[i] *= rm;
     return robust;
   }
-  GBP_UNROLL
-  for (int i = 0; i < 54; ++i) fac[i] /= mvar;
+  {  // 54 divisions by one divisor (gbp_codelets.cpp:142-168, 343-373): exact through one fp64 reciprocal
+    float num[54], quo[54];
+    GBP_UNROLL
+    for (int i = 0; i < 54; ++i) num[i] = fac[i];
+    div_shared(num, mvar, quo);
+    GBP_UNROLL
+    for (int i = 0; i < 54; ++i) fac[i] = quo[i];
+  }
   return robust;
 }
 
-}  // namespace
-
-// =================================================================================================
-// k_sweep: one lane = one factor.
-// =================================================================================================
-// HOIST = true: the belief means are per-VARIABLE quantities (inf2mean of the camera / landmark belief,
-// gbp_codelets.cpp:264-265) that the reference recomputes in every incident factor.  The belief kernels
-// compute them once per variable; dmu^2 = ((((((0+t0)+..+t5) + u0) + u1) + u2) splits into a per-camera
-// prefix S_c (CAMB slot 6) and three per-landmark terms u (LMKB slots 3,13,14), evaluated with the same
-// fp32 operations in the same order, so the result is bit-identical while the per-factor MU stream and
-// two of the five small inverses disappear from the sweep.  HOIST = false keeps the literal per-factor
-// mu/oldmu tensors (needed only if a caller uploads non-zero oldmu).
-// ABL != 0 builds timing-only ablations of the same instruction stream (gbp_debug_time_sweep; results are
-// garbage): 1 = no landmark-message stream, 2 = no landmark-belief gather, 4 = no arithmetic (pass-through),
-// 16 / 32 = no landmark-message load / store.
-#ifndef GBP_SWEEP_WPB
-#define GBP_SWEEP_WPB 4      // wavefronts per workgroup of the sweep (1, 2 or 4; the waves of a workgroup share nothing)
-#endif
-constexpr int kWpb = GBP_SWEEP_WPB;
-template <bool HOIST, int ABL = 0>
-__global__ __launch_bounds__(64 * kWpb) void k_sweep(const SweepArgs a) {
-  const uint32_t wslot = (blockIdx.x + a.block0 * (4 / kWpb)) * kWpb + (threadIdx.x >> 6);
-  const uint32_t tile = a.tile_perm ? (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tile_perm[wslot]) : wslot;
-  const uint32_t lane = threadIdx.x & 63, p = tile * 64 + lane;
-
-  const uint32_t cam_i = a.row_cam[p >> 4];
-  const uint32_t lmk_i = __builtin_nontemporal_load(a.lmk_idx + p);
-
-  float fac[56], cm[28], mu[12], lm[16], cb[44], lb[16];
-  load_tile<kFacG>(a.fac, tile, lane, fac);
-  load_tile<kCmsgG>(a.cmsg, tile, lane, cm);
-  if (!HOIST) load_tile<kMuG>(a.mu, tile, lane, mu);
-  // Landmark messages live as 64-byte records in DEVICE (camera-major) order: the wave's 64 records are one
-  // contiguous 4 KiB block, moved with four coalesced 1 KiB accesses and transposed through a wave-private
-  // LDS staging area.  Piece q of record r sits at float4 slot r*4 + (q ^ swz(r)), swz(r) = ((r>>2)&3) ^ (r&2):
-  // a permutation inside each 64-B record, so the tile-order accesses (whole records) and the record-order
-  // accesses (one piece per lane) are both bank-conflict-free for ds_read_b128 (16-lane groups, 64 banks)
-  // and ds_write_b128 (8-lane groups, 32 banks).  k_beliefs gathers the records of a landmark by position
-  // (random 64-B READS are ~2.3x cheaper than random 64-B writes, profiles/ablate_sweep.py).
-  __shared__ float4 lm_stage[kWpb][64 * 4];
-  float4* stage = lm_stage[threadIdx.x >> 6];
-  const uint32_t rec_t = lane >> 2;                                   // record handled in tile order (+16k)
-  const uint32_t swz_own = ((lane >> 2) & 3u) ^ (lane & 2u);          // swizzle of the lane's own record
-  float4* lm_tile = a.lmsg + (size_t)tile * 256;
-  if (ABL & (1 | 16)) {  // 16 = no LMSG load (store stays), 32 = no LMSG store (load stays)
-    GBP_UNROLL
-    for (int i = 0; i < 16; ++i) lm[i] = 0.f;
-    lm[13] = __int_as_float((int)((5u << 3) | kFlagActive));
-    lm[14] = 4.f;
-  } else {
-    GBP_UNROLL
-    for (int k = 0; k < 4; ++k) {
-      const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(lm_tile) + k * 64 + lane);
-      const uint32_t r = k * 16 + rec_t;
-      stage[r * 4 + ((lane & 3u) ^ (((r >> 2) & 3u) ^ (r & 2u)))] = make_float4(v.x, v.y, v.z, v.w);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    GBP_UNROLL
-    for (int q = 0; q < 4; ++q) {
-      const float4 v = stage[lane * 4 + ((uint32_t)q ^ swz_own)];
-      lm[4 * q] = v.x; lm[4 * q + 1] = v.y; lm[4 * q + 2] = v.z; lm[4 * q + 3] = v.w;
-    }
-  }
-  load_rec<kCamRec4>(a.camb + (size_t)cam_i * kCamRec4, cb);
-  if (ABL & 2) {
-    GBP_UNROLL
-    for (int i = 0; i < 16; ++i) lb[i] = (i == 4 || i == 8 || i == 12) ? 1.f : 0.f;
-  } else {
-    load_rec<kLmkRec4>(a.lmkb + (size_t)lmk_i * kLmkRec4, lb);
-  }
-  // per-factor scalar state rides in the pad slots of the landmark-message record (read and rewritten
-  // every sweep anyway): [3] damping, [13] (damping_count << 3) | flags, [14] measurement variance
-  float damping = lm[3];
-  const int packed = __float_as_int(lm[13]);
-  int count = packed >> 3;
-  uint32_t flags = (uint32_t)packed & 7u;
-  const float var = lm[14];
-  const bool active = (flags & kFlagActive) != 0;
-
-  float K[9];
-  GBP_UNROLL
-  for (int i = 0; i < 9; ++i) K[i] = a.K[i];
-
-  float oc_eta[6], oc_lam[36], ol[16];
+// One factor's share of a sweep on register state: PrepMessageVertex + the four Compute*Message*Vertex classes
+// (gbp_codelets.cpp:215-710).  Shared by k_sweep (state streamed from HBM every launch) and k_persist (state kept in
+// registers across iterations).  `means(x0c, x0l)` supplies the hoisted linearisation point when a lane relinearises.
+template <bool HOIST, int ABL, class Means>
+GBP_DEV void factor_update(float (&fac)[56], const float (&cm)[28], float (&mu)[12], const float (&lm)[16], const float (&cb)[44],
+                           const float (&lb)[16], const float (&K)[9], const Hyper& hp, float& damping, int& count, uint32_t& flags,
+                           const float var, const bool active, float (&oc_eta)[6], float (&oc_lam)[36], float (&ol)[16], bool& relin,
+                           Means&& means) {
   GBP_UNROLL
   for (int i = 0; i < 6; ++i) oc_eta[i] = 0.f;
   GBP_UNROLL
   for (int i = 0; i < 36; ++i) oc_lam[i] = 0.f;
   GBP_UNROLL
   for (int i = 0; i < 16; ++i) ol[i] = 0.f;
-  bool relin = false;
+  relin = false;
 
   if (ABL & 4) {  // keep every load alive, no algebra
     GBP_UNROLL
@@ -275,7 +204,7 @@ __global__ __launch_bounds__(64 * kWpb) void k_sweep(const SweepArgs a) {
   }
   if (active && !(ABL & 4)) {
     // ---- PrepMessageVertex, gbp_codelets.cpp:241-378 ----
-    if (0 == count) damping = a.hp.maxeta_damping;
+    if (0 == count) damping = hp.maxeta_damping;
     count += 1;
     float x0c[6], x0l[3];
     float d2;
@@ -300,7 +229,7 @@ __global__ __launch_bounds__(64 * kWpb) void k_sweep(const SweepArgs a) {
     }
     const float dmu = sqrtf(d2);
     mu[9] = dmu;
-    relin = (dmu < a.hp.dmu_threshold) && (count > a.hp.min_linear_iters - a.hp.num_undamped_iters);
+    relin = (dmu < hp.dmu_threshold) && (count > hp.min_linear_iters - hp.num_undamped_iters);
     if (ABL & 64) relin = false;    // timing experiments: no lane / every lane relinearises
     if (ABL & 128) relin = true;
     if (relin) {
@@ -310,18 +239,15 @@ __global__ __launch_bounds__(64 * kWpb) void k_sweep(const SweepArgs a) {
         GBP_UNROLL
         for (int i = 0; i < 3; ++i) x0l[i] = lb[i] + 0.5f;
       } else if (HOIST) {  // linearisation point = the hoisted means (rare path: loaded only here)
-        const float4 m0 = a.cam_mu[(size_t)cam_i * 4], m1 = a.cam_mu[(size_t)cam_i * 4 + 1];
-        const float4 l0 = a.lmk_mu[(size_t)lmk_i * 2];
-        x0c[0] = m0.x; x0c[1] = m0.y; x0c[2] = m0.z; x0c[3] = m0.w; x0c[4] = m1.x; x0c[5] = m1.y;
-        x0l[0] = l0.x; x0l[1] = l0.y; x0l[2] = l0.z;
+        means(x0c, x0l);
       }
       damping = 0.f;
-      count = -a.hp.num_undamped_iters;
-      if (a.hp.relin_mode == 1) {
+      count = -hp.num_undamped_iters;
+      if (hp.relin_mode == 1) {
         GBP_UNROLL
         for (int i = 0; i < 54; ++i) fac[i] = 0.f;
       }
-      const bool robust = relin_core<ABL>(fac, x0c, x0l, K, var, a.hp.nstds);
+      const bool robust = relin_core<ABL>(fac, x0c, x0l, K, var, hp.nstds);
       flags = robust ? (flags | kFlagRobust) : (flags & ~kFlagRobust);
     }
 
@@ -421,6 +347,102 @@ __global__ __launch_bounds__(64 * kWpb) void k_sweep(const SweepArgs a) {
       }
     }
   }
+}
+
+}  // namespace
+
+// =================================================================================================
+// k_sweep: one lane = one factor.
+// =================================================================================================
+// HOIST = true: the belief means are per-VARIABLE quantities (inf2mean of the camera / landmark belief,
+// gbp_codelets.cpp:264-265) that the reference recomputes in every incident factor.  The belief kernels
+// compute them once per variable; dmu^2 = ((((((0+t0)+..+t5) + u0) + u1) + u2) splits into a per-camera
+// prefix S_c (CAMB slot 6) and three per-landmark terms u (LMKB slots 3,13,14), evaluated with the same
+// fp32 operations in the same order, so the result is bit-identical while the per-factor MU stream and
+// two of the five small inverses disappear from the sweep.  HOIST = false keeps the literal per-factor
+// mu/oldmu tensors (needed only if a caller uploads non-zero oldmu).
+// ABL != 0 builds timing-only ablations of the same instruction stream (gbp_debug_time_sweep; results are
+// garbage): 1 = no landmark-message stream, 2 = no landmark-belief gather, 4 = no arithmetic (pass-through),
+// 16 / 32 = no landmark-message load / store.
+#ifndef GBP_SWEEP_WPB
+#define GBP_SWEEP_WPB 4      // wavefronts per workgroup of the sweep (1, 2 or 4; the waves of a workgroup share nothing)
+#endif
+constexpr int kWpb = GBP_SWEEP_WPB;
+template <bool HOIST, int ABL = 0>
+__global__ __launch_bounds__(64 * kWpb) void k_sweep(const SweepArgs a) {
+  const uint32_t wslot = (blockIdx.x + a.block0 * (4 / kWpb)) * kWpb + (threadIdx.x >> 6);
+  const uint32_t tile = a.tile_perm ? (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tile_perm[wslot]) : wslot;
+  const uint32_t lane = threadIdx.x & 63, p = tile * 64 + lane;
+
+  const uint32_t cam_i = a.row_cam[p >> 4];
+  const uint32_t lmk_i = __builtin_nontemporal_load(a.lmk_idx + p);
+
+  float fac[56], cm[28], mu[12], lm[16], cb[44], lb[16];
+  load_tile<kFacG>(a.fac, tile, lane, fac);
+  load_tile<kCmsgG>(a.cmsg, tile, lane, cm);
+  if (!HOIST) load_tile<kMuG>(a.mu, tile, lane, mu);
+  // Landmark messages live as 64-byte records in DEVICE (camera-major) order: the wave's 64 records are one
+  // contiguous 4 KiB block, moved with four coalesced 1 KiB accesses and transposed through a wave-private
+  // LDS staging area.  Piece q of record r sits at float4 slot r*4 + (q ^ swz(r)), swz(r) = ((r>>2)&3) ^ (r&2):
+  // a permutation inside each 64-B record, so the tile-order accesses (whole records) and the record-order
+  // accesses (one piece per lane) are both bank-conflict-free for ds_read_b128 (16-lane groups, 64 banks)
+  // and ds_write_b128 (8-lane groups, 32 banks).  k_beliefs gathers the records of a landmark by position
+  // (random 64-B READS are ~2.3x cheaper than random 64-B writes, profiles/ablate_sweep.py).
+  __shared__ float4 lm_stage[kWpb][64 * 4];
+  float4* stage = lm_stage[threadIdx.x >> 6];
+  const uint32_t rec_t = lane >> 2;                                   // record handled in tile order (+16k)
+  const uint32_t swz_own = ((lane >> 2) & 3u) ^ (lane & 2u);          // swizzle of the lane's own record
+  float4* lm_tile = a.lmsg + (size_t)tile * 256;
+  if (ABL & (1 | 16)) {  // 16 = no LMSG load (store stays), 32 = no LMSG store (load stays)
+    GBP_UNROLL
+    for (int i = 0; i < 16; ++i) lm[i] = 0.f;
+    lm[13] = __int_as_float((int)((5u << 3) | kFlagActive));
+    lm[14] = 4.f;
+  } else {
+    GBP_UNROLL
+    for (int k = 0; k < 4; ++k) {
+      const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(lm_tile) + k * 64 + lane);
+      const uint32_t r = k * 16 + rec_t;
+      stage[r * 4 + ((lane & 3u) ^ (((r >> 2) & 3u) ^ (r & 2u)))] = make_float4(v.x, v.y, v.z, v.w);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    GBP_UNROLL
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = stage[lane * 4 + ((uint32_t)q ^ swz_own)];
+      lm[4 * q] = v.x; lm[4 * q + 1] = v.y; lm[4 * q + 2] = v.z; lm[4 * q + 3] = v.w;
+    }
+  }
+  load_rec<kCamRec4>(a.camb + (size_t)cam_i * kCamRec4, cb);
+  if (ABL & 2) {
+    GBP_UNROLL
+    for (int i = 0; i < 16; ++i) lb[i] = (i == 4 || i == 8 || i == 12) ? 1.f : 0.f;
+  } else {
+    load_rec<kLmkRec4>(a.lmkb + (size_t)lmk_i * kLmkRec4, lb);
+  }
+  // per-factor scalar state rides in the pad slots of the landmark-message record (read and rewritten
+  // every sweep anyway): [3] damping, [13] (damping_count << 3) | flags, [14] measurement variance
+  float damping = lm[3];
+  const int packed = __float_as_int(lm[13]);
+  int count = packed >> 3;
+  uint32_t flags = (uint32_t)packed & 7u;
+  const float var = lm[14];
+  const bool active = (flags & kFlagActive) != 0;
+
+  float K[9];
+  GBP_UNROLL
+  for (int i = 0; i < 9; ++i) K[i] = a.K[i];
+
+  float oc_eta[6], oc_lam[36], ol[16];
+  bool relin;
+  factor_update<HOIST, ABL>(fac, cm, mu, lm, cb, lb, K, a.hp, damping, count, flags, var, active, oc_eta, oc_lam, ol, relin,
+                            [&](float (&x0c)[6], float (&x0l)[3]) {   // rare path: the hoisted means are loaded only by relinearising lanes
+                              const float4 m0 = a.cam_mu[(size_t)cam_i * 4], m1 = a.cam_mu[(size_t)cam_i * 4 + 1];
+                              const float4 l0 = a.lmk_mu[(size_t)lmk_i * 2];
+                              x0c[0] = m0.x; x0c[1] = m0.y; x0c[2] = m0.z; x0c[3] = m0.w; x0c[4] = m1.x; x0c[5] = m1.y;
+                              x0l[0] = l0.x; x0l[1] = l0.y; x0l[2] = l0.z;
+                            });
 
   // ---- outputs --------------------------------------------------------------------------------
   ol[3] = damping;
@@ -1051,6 +1073,18 @@ void launch_sweep_blocks(SweepArgs a, uint32_t block0, uint32_t block1, bool hoi
   if (block1 <= block0) return;
   a.block0 = block0;
   const dim3 g((block1 - block0) * (4 / kWpb)), b(64 * kWpb);
+#ifdef GBP_BUILD_ABLATIONS   // experiments build only: GBP_SWEEP_ABL swaps an ablated instantiation into the REAL iteration flow
+  static const int env_abl = std::getenv("GBP_SWEEP_ABL") ? std::atoi(std::getenv("GBP_SWEEP_ABL")) : 0;
+  if (env_abl && hoist) {
+    switch (env_abl) {
+#define GBP_ABL_CASE(N) case N: hipLaunchKernelGGL((k_sweep<true, N>), g, b, 0, s, a); return;
+      GBP_ABL_CASE(64) GBP_ABL_CASE(256) GBP_ABL_CASE(512) GBP_ABL_CASE(1024) GBP_ABL_CASE(2048) GBP_ABL_CASE(256 + 512)
+      GBP_ABL_CASE(256 + 512 + 1024 + 2048)
+#undef GBP_ABL_CASE
+      default: break;
+    }
+  }
+#endif
   if (hoist) hipLaunchKernelGGL(k_sweep<true>, g, b, 0, s, a);
   else hipLaunchKernelGGL(k_sweep<false>, g, b, 0, s, a);
 }

@@ -39,7 +39,43 @@ __device__ __forceinline__ void grid_barrier(unsigned* counter, unsigned target,
   }
 }
 
-template <int MODE>   // 0 flat (per wave), 1 one thread per block, 2 no barrier at all (one round per launch)
+// hierarchical: 8 group counters (block b -> group b & 7, each on its own 128-B line) + one top counter bumped by the last
+// arrival of every group; one thread per block arrives and polls.  counter layout: [g * 32] groups, [8 * 32] top.
+__device__ __forceinline__ void grid_barrier_tree(unsigned* counter, unsigned epoch, unsigned nblocks) {
+  __atomic_thread_fence(__ATOMIC_RELEASE);     // every wave: its own stores out to memory (agent scope)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned g = blockIdx.x & 7u, ngroups = nblocks < 8u ? nblocks : 8u;
+    const unsigned n_g = (nblocks - g + 7u) / 8u;
+    const unsigned old = __hip_atomic_fetch_add(counter + g * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1u == epoch * n_g) __hip_atomic_fetch_add(counter + 8 * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (unsigned spin = 0; __hip_atomic_load(counter + 8 * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch * ngroups && spin < (1u << 22); ++spin)
+      __builtin_amdgcn_s_sleep(1);
+  }
+  __syncthreads();
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+}
+
+// flags: no read-modify-write at all.  Block b stores the epoch into flag[b]; the first wave of every block polls ALL
+// flags (lane i reads flag[i], flag[i + 64], ...) until every one has reached the epoch.
+__device__ __forceinline__ void grid_barrier_flags(unsigned* flags, unsigned epoch, unsigned nblocks) {
+  __atomic_thread_fence(__ATOMIC_RELEASE);
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    if (threadIdx.x == 0) __hip_atomic_store(flags + blockIdx.x, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (unsigned spin = 0; spin < (1u << 22); ++spin) {
+      bool ok = true;
+      for (unsigned i = threadIdx.x; i < nblocks; i += 64)
+        ok = ok && __hip_atomic_load(flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= epoch;
+      if (__all(ok)) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  __syncthreads();
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+}
+
+template <int MODE>   // 0 flat (per wave), 1 one thread per block, 2 no barrier at all (one round per launch), 3 tree, 4 flags
 __global__ void k_rounds(float4* buf, unsigned* counter, unsigned* errors, int rounds, int round0) {
   const unsigned nwaves = gridDim.x * (blockDim.x >> 6);
   const unsigned wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -49,7 +85,9 @@ __global__ void k_rounds(float4* buf, unsigned* counter, unsigned* errors, int r
     const int rr = round0 + r;
     float4* mine = buf + ((size_t)(rr & 1) * nwaves + wave) * 64;
     mine[lane] = make_float4((float)rr, (float)wave, (float)lane, 1.f);
-    if (MODE != 2) grid_barrier(counter, (unsigned)(r + 1) * arrivals, MODE == 1);
+    if (MODE == 3) grid_barrier_tree(counter, (unsigned)(r + 1), gridDim.x);
+    else if (MODE == 4) grid_barrier_flags(counter, (unsigned)(r + 1), gridDim.x);
+    else if (MODE != 2) grid_barrier(counter, (unsigned)(r + 1) * arrivals, MODE == 1);
     if (MODE != 2) {
       const unsigned other = (wave + (blockDim.x >> 6)) % nwaves;   // a wave of the next block: another XCD
       const float4 v = buf[((size_t)(rr & 1) * nwaves + other) * 64 + lane];
@@ -62,7 +100,7 @@ __global__ void k_rounds(float4* buf, unsigned* counter, unsigned* errors, int r
 int main() {
   unsigned *counter, *errors;
   float4* buf;
-  CK(hipMalloc(&counter, 64));
+  CK(hipMalloc(&counter, 16384));
   CK(hipMalloc(&errors, 64));
   CK(hipMalloc(&buf, 2 * 4096 * 64 * sizeof(float4)));
   hipEvent_t e0, e1;
@@ -71,20 +109,22 @@ int main() {
   hipStream_t s;
   CK(hipStreamCreate(&s));
   const int rounds = 2000;
-  printf("| blocks x threads | waves | flat: us/round | one-thread-per-block: us/round | separate launches: us/round | errors |\n|---|---|---|---|---|---|\n");
-  const int cfgs[][2] = {{14, 256}, {51, 256}, {128, 256}, {256, 256}, {512, 256}, {56, 64}, {202, 64}, {512, 64}, {1024, 64}};
+  printf("| blocks x threads | waves | flat: us/round | one-thread-per-block: us/round | separate launches: us/round | tree (8 groups): us/round | flags (no RMW): us/round | errors |\n|---|---|---|---|---|---|---|---|\n");
+  const int cfgs[][2] = {{14, 256}, {19, 256}, {51, 256}, {128, 256}, {256, 256}, {512, 256}, {56, 64}, {202, 64}, {1024, 64}};
   for (auto& cfg : cfgs) {
     const int nb = cfg[0], nt = cfg[1];
-    double us[3];
+    double us[5];
     unsigned herr = 0;
     CK(hipMemset(errors, 0, 4));
-    for (int mode = 0; mode < 3; ++mode) {
+    for (int mode = 0; mode < 5; ++mode) {
       for (int rep = 0; rep < 2; ++rep) {   // rep 0 = warm-up
-        CK(hipMemsetAsync(counter, 0, 4, s));
+        CK(hipMemsetAsync(counter, 0, 16384, s));
         CK(hipEventRecord(e0, s));
         if (mode == 0) hipLaunchKernelGGL(k_rounds<0>, dim3(nb), dim3(nt), 0, s, buf, counter, errors, rounds, 0);
         else if (mode == 1) hipLaunchKernelGGL(k_rounds<1>, dim3(nb), dim3(nt), 0, s, buf, counter, errors, rounds, 0);
-        else for (int r = 0; r < rounds; ++r) hipLaunchKernelGGL(k_rounds<2>, dim3(nb), dim3(nt), 0, s, buf, counter, errors, 1, r);
+        else if (mode == 2) for (int r = 0; r < rounds; ++r) hipLaunchKernelGGL(k_rounds<2>, dim3(nb), dim3(nt), 0, s, buf, counter, errors, 1, r);
+        else if (mode == 3) hipLaunchKernelGGL(k_rounds<3>, dim3(nb), dim3(nt), 0, s, buf, counter, errors, rounds, 0);
+        else hipLaunchKernelGGL(k_rounds<4>, dim3(nb), dim3(nt), 0, s, buf, counter, errors, rounds, 0);
         CK(hipEventRecord(e1, s));
         CK(hipEventSynchronize(e1));
         float ms = 0;
@@ -93,7 +133,7 @@ int main() {
       }
     }
     CK(hipMemcpy(&herr, errors, 4, hipMemcpyDeviceToHost));
-    printf("| %d x %d | %d | %.2f | %.2f | %.2f | %u |\n", nb, nt, nb * nt / 64, us[0], us[1], us[2], herr);
+    printf("| %d x %d | %d | %.2f | %.2f | %.2f | %.2f | %.2f | %u |\n", nb, nt, nb * nt / 64, us[0], us[1], us[2], us[3], us[4], herr);
   }
   return 0;
 }

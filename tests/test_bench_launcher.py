@@ -42,6 +42,8 @@ def test_default_workloads():
     assert bench.workload_name(a1, 1, 1000, 100000, 1000000).startswith("S1 ")
     s = bench.build_stamp(a1)
     assert len(s["source_sha16"]) == 16 and s["workload"] == [1000, 100000, 10, 20200303]
+    assert bench.pmc_shape(a8, 8) == (8000, 125000)                   # the PMC child of an N > 1 run: rank 0's shard shape
+    assert bench.build_stamp(a8, 8)["workload"] == [8000, 125000, 10, 20200303]
 
 
 def _bench_gpu(*args):
@@ -65,7 +67,7 @@ def test_bench_sharded_code_path_on_one_gpu(comm):
     """bench.py --force-sharded: the N > 1 code path (shard ctx, RCCL all-gather, overlap; the library's own communicator
     or torch.distributed) with one rank on one GPU — same contract fields, same convergence as the plain path."""
     plain = _bench_gpu("--pmc", "off")
-    out = _bench_gpu("--force-sharded", "--comm", comm, "--sharded-graph", "1" if comm == "native" else "0")
+    out = _bench_gpu("--force-sharded", "--comm", comm, "--sharded-graph", "1" if comm == "native" else "0", "--pmc", "off")
     assert out["config"]["iterations_run"] == plain["config"]["iterations_run"] == 24
     assert out["n_gpus"] == 1 and out["steps"] == 12 and out["value"] > 0 and out["higher_is_better"] is True
     assert out["config"]["comm_error"] is None
@@ -84,3 +86,32 @@ def test_bench_live_pmc_traffic():
     assert r["traffic_source"].startswith("live rocprofv3") and r["traffic"] > 0 and 0 < r["frac"] < 1.0, r
     assert {k["kernel"] for k in r["kernels"]} == {"k_sweep", "k_beliefs"}
     assert r["profiled_ms_per_step"] * 1e3 >= 0.9 * (r["avg_launch_us"] + r["belief_kernels_avg_us"])
+
+
+@pytest.mark.gpu
+def test_bench_sharded_line_is_complete_on_the_config5_shard_shape():
+    """the line an N > 1 run prints must carry a MEASURED roofline.frac (PMC passes on rank 0's shard
+    shape), the exchange time and the per-rank step times — checked here with one rank on the per-GPU shard of BASELINE
+    config 5 (8 000 cameras x 125 000 landmarks x 1.25 M factors), the library's own communicator."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-sharded", "--cams", "8000", "--lmks", "125000", "--steps", "20",
+                        "--warmup", "5", "--cpu-seconds", "0"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+    r = out["roofline"]
+    assert out["config"]["comm_error"] is None and "native" in out["config"]["exchange"]
+    assert r["traffic"] and 0.3 < r["frac"] < 1.0, r
+    assert "shard shape" in r["traffic_source"]
+    assert r["exchange_avg_us"] > 0 and r["rank_step_ms_max"] >= r["rank_step_ms_min"] > 0
+    assert out["config"]["factors"] == 1250000 and out["steps"] == 20
+
+
+@pytest.mark.gpu
+def test_bench_native_communicator_failure_is_fatal():
+    """No silent downgrade: with the library's RCCL unloadable, `--comm native` (the default) exits non-zero and prints no
+    result line; `--comm torch` is the explicit way to measure the torch.distributed exchange."""
+    env = dict(os.environ, GBP_RCCL_LIB="/nonexistent/librccl-missing.so")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-sharded", "--cams", "60", "--lmks", "1500", "--steps", "4", "--warmup", "2",
+                        "--cpu-seconds", "0", "--pmc", "off", "--profile-steps", "0"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 4, (p.returncode, p.stderr[-2000:])
+    assert "could not be set up" in p.stderr and not [l for l in p.stdout.splitlines() if l.startswith("{")]
