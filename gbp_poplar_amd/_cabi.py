@@ -24,7 +24,7 @@ class GbpParams(C.Structure):
     _fields_ = [("maxeta_damping", C.c_float), ("num_undamped_iters", C.c_int32),
                 ("dmu_threshold", C.c_float), ("min_linear_iters", C.c_int32),
                 ("nstds", C.c_float), ("relin_mode", C.c_int32), ("graph_unroll", C.c_int32),
-                ("per_factor_mu", C.c_int32), ("tile_order", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("per_factor_mu", C.c_int32), ("tile_order", C.c_int32), ("persistent", C.c_int32), ("reserved", C.c_int32 * 2)]
 
     @classmethod
     def defaults(cls, **kw):

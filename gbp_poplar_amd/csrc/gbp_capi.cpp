@@ -87,6 +87,13 @@ struct gbp_ctx {
   int eval_parity = 0, eval_pending = 0;
   hipEvent_t eval_ev[2] = {nullptr, nullptr};
   bool profile_stages = false;
+  // k_persist (small graphs): n iterations in one launch
+  bool persist_ok = false;             // the graph is eligible and co-resident on this GPU
+  DevBuf psync;                        // barrier words
+  DevBuf ptrace;                       // experiments build: per-phase time stamps of k_persist (gbp_debug_persist_trace)
+  void* pstatus_host = nullptr;        // pinned + device-mapped: raised by the kernel if a barrier gave up
+  void* pstatus_dev = nullptr;
+  uint64_t persist_launches = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_sweep_ev;  // split-phase profiling: brackets not yet read
   double sweep_ms = 0, belief_ms = 0, total_ms = 0, exchange_ms = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_exch_ev;     // profiling: brackets of partials + all-gather
@@ -322,6 +329,7 @@ void gbp_destroy(gbp_ctx* c) {
   for (auto& v : {&c->spans, &c->span_pool})
     for (auto& sp : *v) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
   if (c->eval_host) (void)hipHostFree(c->eval_host);
+  if (c->pstatus_host) (void)hipHostFree(c->pstatus_host);
   for (hipEvent_t e : c->eval_ev) if (e) (void)hipEventDestroy(e);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -475,6 +483,32 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
     c->use_tile_perm = rc == GBP_OK;
   }
   if (rc != GBP_OK) return rc;
+  // ---- persistent iteration kernel: only where every workgroup of the graph is resident at once ----
+  {
+    const char* pe = std::getenv("GBP_PERSIST");                     // measurements: -1 / 0 / 1 like gbp_params.persistent
+    const int mode = pe ? std::atoi(pe) : c->prm.persistent;
+    const uint32_t nb = persist_blocks(c->n_tiles, c->C, c->L_loc);
+    // measured (profiles/r03_small_graphs.md): the shipped sequences (14 - 52 workgroups, relinearising in every sweep) run
+    // 1.26 - 1.45x faster in k_persist; converging synthetic graphs break even at ~40 workgroups and lose beyond
+    const uint32_t auto_limit = 56;
+    if (mode >= 0 && !sh && c->hoist && !c->use_tile_perm && nb <= (mode > 0 ? 1u << 30 : auto_limit)) {
+      const int resident = persist_max_resident_blocks();
+      if (resident > 0 && nb <= (uint32_t)resident) {
+        rc = dev_alloc(c, c->psync, kPersistSyncWords * sizeof(unsigned));
+        if (rc == GBP_OK) {
+          CK(hipHostMalloc(&c->pstatus_host, 64, hipHostMallocMapped), "hipHostMalloc");
+          if (rc == GBP_OK) {
+            std::memset(c->pstatus_host, 0, 64);
+            CK(hipHostGetDevicePointer(&c->pstatus_dev, c->pstatus_host, 0), "hipHostGetDevicePointer");
+          }
+        } else {
+          g_create_error = c->err;
+        }
+        c->persist_ok = rc == GBP_OK;
+      }
+    }
+    if (rc != GBP_OK) return rc;
+  }
   owner.p = nullptr;
   *out = c;
   return GBP_OK;
@@ -496,6 +530,8 @@ int gbp_set_exchange_buffers(gbp_ctx* c, void* send_dev, void* recv_dev) {
 int gbp_sync(gbp_ctx* c) {
   if (!c) return GBP_ERR_INVALID;
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->pstatus_host && *static_cast<volatile unsigned*>(c->pstatus_host) != 0u)
+    return fail(c, GBP_ERR_HIP, "k_persist: a device-wide barrier timed out (workgroups not co-resident); results are invalid");
   return GBP_OK;
 }
 
@@ -828,6 +864,7 @@ static bool ensure_graph(gbp_ctx* c, const SweepArgs& a) {
 int gbp_prepare(gbp_ctx* c) {
   if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "gbp_prepare: upload first");
   if (c->comm || c->world > 1) return GBP_OK;               // sharded iterations run from direct launches by default
+  if (c->persist_ok) return GBP_OK;                         // multi-iteration bursts run inside k_persist: nothing to capture
   if (ensure_graph(c, sweep_args(c))) (void)hipGraphUpload(c->graph_exec, c->stream);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return GBP_OK;
@@ -871,6 +908,23 @@ static int iterate_impl(gbp_ctx* c, int n) {
       HIPCHK(c, hipEventElapsedTime(&b_ms, ev[2 * i + 1], ev[2 * i + 2]));
       c->sweep_ms += a_ms; c->belief_ms += b_ms;
     }
+  } else if (c->persist_ok && n >= 2) {
+    // small graph: the whole burst in one launch (k_persist).  The barrier words are zeroed in stream order first.
+    if (*static_cast<volatile unsigned*>(c->pstatus_host) != 0u)
+      return fail(c, GBP_ERR_HIP, "k_persist: a device-wide barrier timed out in an earlier launch (workgroups not co-resident)");
+    HIPCHK(c, hipMemsetAsync(c->psync.p, 0, kPersistSyncWords * sizeof(unsigned), c->stream));
+    PersistArgs A;
+    A.s = a;
+    A.b = belief_args(c);
+    A.b.roll = 1;
+    A.n_tiles = c->n_tiles;
+    A.n_lmk_groups = 0;
+    A.n_iters = n;
+    A.sync = P<unsigned>(c->psync);
+    A.status = static_cast<unsigned*>(c->pstatus_dev);
+    A.trace = static_cast<unsigned long long*>(c->ptrace.p);      // NULL outside the experiments build
+    launch_persist(A, c->stream);
+    c->persist_launches += 1;
   } else {
     int left = n;
     bool use_graph = (c->stream == c->own_stream) && c->prm.graph_unroll > 0 && n >= c->prm.graph_unroll && !c->graph_failed;
@@ -902,7 +956,7 @@ int gbp_weaken_priors(gbp_ctx* c) {
 // READ_PROG (ba.cpp:908-916)
 static int read_impl(gbp_ctx* c, gbp_state_out* o) {
   if (!c || !o) return GBP_ERR_INVALID;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (int rc = gbp_sync(c)) return rc;
   if (o->cam_beliefs_eta || o->cam_beliefs_lambda) {
     std::vector<float> rec((size_t)c->C * kCamRec);
     HIPCHK(c, hipMemcpy(rec.data(), c->camb.p, rec.size() * 4, hipMemcpyDeviceToHost));
@@ -1048,6 +1102,8 @@ static int eval_end_impl(gbp_ctx* c, gbp_eval_out* o) {
   const int area = (c->eval_parity + (c->eval_pending == 2 ? 0 : 1)) & 1;   // the OLDEST pending evaluation
   HIPCHK(c, hipEventSynchronize(c->eval_ev[area]));
   c->eval_pending -= 1;
+  if (c->pstatus_host && *static_cast<volatile unsigned*>(c->pstatus_host) != 0u)
+    return fail(c, GBP_ERR_HIP, "k_persist: a device-wide barrier timed out (workgroups not co-resident); results are invalid");
   const uint32_t nb = eval_blocks(c->n_tiles);
   const DeviceEval* part = static_cast<const DeviceEval*>(c->eval_host) + 1025 * area;
   for (uint32_t b = 1; b <= nb; ++b) {
@@ -1189,6 +1245,33 @@ int gbp_debug_time_sweep(gbp_ctx* c, int ablation, int reps, double* avg_us) {
   return GBP_OK;
 }
 
+#ifdef GBP_BUILD_EXPERIMENTS
+// arm (out == NULL) / read the [waves][16] stamps of the relinearisation path written by the last launch
+int gbp_debug_ticks(gbp_ctx* c, unsigned long long* out, int waves) {
+  static void* dev = nullptr;
+  if (!c) return GBP_ERR_INVALID;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (!dev) HIPCHK(c, hipMalloc(&dev, 4096 * 16 * 8));
+  if (!out) { HIPCHK(c, hipMemset(dev, 0, 4096 * 16 * 8)); debug_tick_buf(static_cast<unsigned long long*>(dev)); }
+  else { HIPCHK(c, hipMemcpy(out, dev, (size_t)waves * 16 * 8, hipMemcpyDeviceToHost)); debug_tick_buf(nullptr); }
+  return GBP_OK;
+}
+int gbp_debug_div_redo(unsigned long long* out4, int reset) { debug_div_redo(out4, reset != 0); return GBP_OK; }
+// Per-phase wall-clock stamps (100 MHz ticks) of the first 16 iterations of the NEXT k_persist launches:
+// out[wave][iteration][8] = {iteration start, sweep done, barrier 1 passed, beliefs done, barrier 2 passed, sweep loads arrived, factor update done, wave had a relinearising lane}.  Call once to
+// arm (out = NULL), run gbp_iterate(n), call again with `out` to read.  Returns the number of waves.
+int gbp_debug_persist_trace(gbp_ctx* c, unsigned long long* out, int cap_waves) {
+  if (!c || !c->persist_ok) return GBP_ERR_STATE;
+  const int waves = (int)persist_blocks(c->n_tiles, c->C, c->L_loc) * 4;
+  const size_t bytes = (size_t)waves * kPersistTraceIters * 8 * sizeof(unsigned long long);
+  if (!c->ptrace.p) { if (int rc = dev_alloc(c, c->ptrace, bytes)) return rc; }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (out) HIPCHK(c, hipMemcpy(out, c->ptrace.p, std::min(bytes, (size_t)cap_waves * kPersistTraceIters * 8 * sizeof(unsigned long long)), hipMemcpyDeviceToHost));
+  else HIPCHK(c, hipMemset(c->ptrace.p, 0, bytes));
+  return waves;
+}
+#endif
+
 // Inverse of gbp_debug_get(what = 0): overwrite the factor potentials (lower triangles of the
 // symmetric blocks and Lambda_cl are taken; Lambda_lc is implied).  Test hook only.
 static int debug_set_factor_potentials_impl(gbp_ctx* c, const float* eta9E, const float* lam81E) {
@@ -1290,7 +1373,7 @@ int gbp_comm_init_rccl(gbp_ctx* c, const void* id128) {
   return comm_attach(c, comm);
 }
 
-int gbp_graph_state(const gbp_ctx* c) { return !c ? 0 : (c->graph_exec ? 1 : (c->graph_failed ? -1 : 0)); }
+int gbp_graph_state(const gbp_ctx* c) { return !c ? 0 : (c->persist_ok ? 2 : (c->graph_exec ? 1 : (c->graph_failed ? -1 : 0))); }
 
 const char* gbp_comm_transport(const gbp_ctx* c) { return (c && c->comm) ? c->comm->name() : "none"; }
 

@@ -29,6 +29,13 @@ GBP_DEV constexpr int trisym(int i, int j) { return i >= j ? tri(i, j) : tri(j, 
 // raises `redo` and the whole set is divided the slow way.  An fp32 IEEE division costs 11 instructions, five of them
 // quarter-rate; this costs 3 full-rate ones per value (measured in situ on fr1xyz: 29.9 -> 26.4 us per iteration for
 // the 54 divisions of the Huber rescale alone, profiles/r03_small_graphs.md).
+#ifdef GBP_BUILD_EXPERIMENTS
+__device__ unsigned long long g_div_redo[4];
+__device__ unsigned long long* g_tick_buf;     // [wave][16] wall-clock stamps inside the relinearisation path (last iteration wins)
+#define GBP_TICK(slot) do { if (g_tick_buf) g_tick_buf[(size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (slot)] = wall_clock64(); } while (0)
+#else
+#define GBP_TICK(slot) do { } while (0)
+#endif
 template <int N>
 GBP_DEV void div_shared(const float (&v)[N], float m, float (&q)[N]) {
   const double r = 1.0 / (double)m;
@@ -39,6 +46,9 @@ GBP_DEV void div_shared(const float (&v)[N], float m, float (&q)[N]) {
     redo |= (__builtin_fabsf(q[i]) < 1.17549435e-38f) != (v[i] == 0.f);
   }
   if (redo) {
+#ifdef GBP_BUILD_EXPERIMENTS
+    atomicAdd(&g_div_redo[N == 54 ? 0 : N == 9 ? 1 : 2], 1ull);   // how often does the slow path run? (profiles/persist_trace.py)
+#endif
     GBP_UNROLL
     for (int i = 0; i < N; ++i) q[i] = v[i] / m;
   }
@@ -151,7 +161,9 @@ template <bool FAST_TRIG = false>
 GBP_DEV void jac_hfunc(const float (&cam)[6], const float (&lmk)[3], const float (&K)[9], Lin& o) {
   float R[9];
   const float v[3] = {cam[3], cam[4], cam[5]};
+  GBP_TICK(1);
   so3exp<FAST_TRIG>(v, R);
+  GBP_TICK(2);
   float yc[3];
   GBP_UNROLL
   for (int i = 0; i < 3; ++i) {

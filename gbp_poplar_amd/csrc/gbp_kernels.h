@@ -98,6 +98,23 @@ struct BeliefArgs {
   int roll;                  // end of an iteration: "means used by the last sweep" := current means, then recompute
 };
 
+// k_persist: n GBP iterations in ONE launch for graphs small enough that every workgroup is resident at once
+// (the launch-bound configs: fr1xyz = 51 workgroups).  Wave w sweeps tile w (per-factor state stays in registers across
+// iterations), a device-wide barrier, wave w then owns camera w or a group of 16 landmarks in the belief update
+// (its index records and priors stay in registers), a second barrier.
+struct PersistArgs {
+  SweepArgs s;
+  BeliefArgs b;
+  uint32_t n_tiles;        // sweep tiles = waves with a phase-A role
+  uint32_t n_lmk_groups;   // ceil(L / 16): waves [C, C + n_lmk_groups) own 16 landmarks each in phase B
+  int n_iters;
+  unsigned* sync;          // [kPersistSyncWords] barrier words, zero on entry
+  unsigned* status;        // host-mapped: set to 1 if a barrier gave up waiting (a workgroup was not resident)
+  unsigned long long* trace;  // experiments build only (else NULL): [wave][iteration < kPersistTraceIters][8] wall-clock ticks
+};
+constexpr int kPersistTraceIters = 16;
+constexpr int kPersistSyncWords = 16 * 32;
+
 struct DeviceEval {  // per-block partials, summed on the host in block order
   double sum_norm, sum_half_sq;
   unsigned long long n_active, n_relin, n_robust, pad;
@@ -108,6 +125,9 @@ void launch_sweep_blocks(SweepArgs a, uint32_t block0, uint32_t block1, bool hoi
 bool launch_sweep_ablated(const SweepArgs& a, uint32_t n_tiles, int abl, hipStream_t s);  // timing experiments; false = not built in
 void launch_linearise(const SweepArgs& a, uint32_t n_tiles, hipStream_t s);
 void launch_beliefs(BeliefArgs b, bool do_cam, bool do_lmk, hipStream_t s);
+uint32_t persist_blocks(uint32_t n_tiles, uint32_t n_cams, uint32_t n_lmks);   // workgroups k_persist needs for a graph
+int persist_max_resident_blocks();                                            // how many of them this GPU keeps resident at once
+void launch_persist(PersistArgs a, hipStream_t s);
 void launch_weaken(float4* prior, const float* scaling, uint32_t* flag, uint32_t n, int rec4, hipStream_t s);
 void launch_state_get(const float4* lmsg, float* damping, int* packed, uint32_t n, hipStream_t s);
 void launch_state_set(float4* lmsg, const int* new_count, const uint32_t* ctl, uint32_t n, hipStream_t s);
@@ -119,6 +139,8 @@ void launch_eval(const uint32_t* row_cam, const uint32_t* lmk_idx, const float4*
                  const float* lmk_mu, const float* K9_dev, int num_undamped_iters, DeviceEval* partials /* may be mapped host memory */,
                  const unsigned long long* health2, unsigned long long* health2_out, uint32_t n_tiles, hipStream_t s);
 uint32_t eval_blocks(uint32_t n_tiles);
+void debug_div_redo(unsigned long long* out4, bool reset);
+void debug_tick_buf(unsigned long long* dev_buf);             // experiments build: stamps inside the relinearisation path   // experiments build: slow-path counts of div_shared
 bool debug_math_widths(int op, int* in_w, int* out_w);   // floats per vector of k_debug_math's op
 void launch_debug_math(int op, const float* in, float* out, int n, hipStream_t s);  // test hook
 

@@ -102,7 +102,9 @@ template <int ABL = 0>   // ABL: timing experiments only (256 = hardware sin/cos
 GBP_DEV bool relin_core(float (&fac)[56], const float (&x0c)[6], const float (&x0l)[3], const float (&K)[9],
                         float var, float nstds) {
   Lin L;
+  GBP_TICK(0);
   jac_hfunc<(ABL & 256) != 0>(x0c, x0l, K, L);
+  GBP_TICK(3);
   GBP_UNROLL
   for (int i = 0; i < 6; ++i) {
     GBP_UNROLL
@@ -153,6 +155,7 @@ GBP_DEV bool relin_core(float (&fac)[56], const float (&x0c)[6], const float (&x
     for (int k = 0; k < 2; ++k) acc += (i < 6 ? L.Jkf[k * 6 + i] : L.Jl[k * 3 + (i - 6)]) * buf[k];
     fac[i] = acc;
   }
+  GBP_TICK(4);
   // Huber (gbp_codelets.cpp:135-141): the 0.5 literal makes the denominator a double expression
   const float err = sqrtf((L.hx[0] - z0) * (L.hx[0] - z0) + (L.hx[1] - z1) * (L.hx[1] - z1));
   float mvar = var;
@@ -167,6 +170,7 @@ GBP_DEV bool relin_core(float (&fac)[56], const float (&x0c)[6], const float (&x
     for (int i = 0; i < 54; ++i) fac[i] *= rm;
     return robust;
   }
+  GBP_TICK(5);
   {  // 54 divisions by one divisor (gbp_codelets.cpp:142-168, 343-373): exact through one fp64 reciprocal
     float num[54], quo[54];
     GBP_UNROLL
@@ -175,6 +179,7 @@ GBP_DEV bool relin_core(float (&fac)[56], const float (&x0c)[6], const float (&x
     GBP_UNROLL
     for (int i = 0; i < 54; ++i) fac[i] = quo[i];
   }
+  GBP_TICK(6);
   return robust;
 }
 
@@ -721,6 +726,384 @@ __global__ __launch_bounds__(256) void k_beliefs(const BeliefArgs b) {
   if (live) b.lmkb[(size_t)l * 4 + q] = acc;
 }
 
+// =================================================================================================
+// k_persist: n iterations of {k_sweep; k_beliefs} in ONE launch, for graphs whose workgroups are all resident at once.
+//
+// A graph of a few thousand factors (BASELINE configs 1-3: fr1xyz = 204 wavefronts on 1 024 SIMDs) is bound by what
+// happens BETWEEN its kernels: a dependent launch costs ~3.5 us on this stack and every kernel starts with cold L2s
+// (profiles/r03_small_graphs.md), while the arithmetic of a whole iteration is ~10 us.  Here the iteration loop lives
+// inside the kernel:
+//   phase A  wave w sweeps tile w with factor_update() — the same per-lane arithmetic as k_sweep; the factor's
+//            potential and both of its messages stay in REGISTERS across iterations (FAC / CMSG are written back once,
+//            after the last iteration); the landmark-message tile and the row sums go to memory for phase B;
+//   barrier  device-wide (grid_sync below);
+//   phase B  wave w owns camera w, or 16 landmarks (4 lanes each) — the arithmetic of k_beliefs; row pointers, the
+//            landmark index record and the priors stay in registers, so the phase is ONE round of loads;
+//   barrier  (not after the last iteration).
+// Results are bit-identical to the two-kernel path (same per-lane operations in the same order); every array the other
+// kernels and the C-ABI read (FAC, CMSG, LMSG, ROWP, CAMB, LMKB, the hoisted means, cam_local) is left exactly as n
+// launches of k_sweep + k_beliefs leave it.  Hoisted means only (gbp_params.per_factor_mu = 0), single-GPU ctx only.
+// =================================================================================================
+// Device-wide hand-off without cache maintenance.  The 8 XCDs have private, mutually incoherent L2s; the textbook grid
+// barrier (release: write the L2 back, acquire: invalidate it) costs 5.5 us for 51 workgroups on this chip — more than
+// the 3.7 us of a kernel boundary (profiles/r03_small_graphs.md).  Instead every access to the arrays that cross waves
+// inside the launch (LMSG, ROWP, CAMB, LMKB, the hoisted means) is an agent-scope relaxed atomic: stores are written
+// through to memory, loads are re-fetched (global_load/store_dwordx2 ... sc1), so the barrier itself only has to wait for
+// this wave's stores (s_waitcnt vmcnt(0)), meet the workgroup, and count one arrival per workgroup: 1.4 us for 51
+// workgroups.  The counter only grows (epoch e expects e * n arrivals); the host zeroes it before the launch.  The wait
+// is bounded: if a workgroup were not resident (the launcher checks occupancy, so it is) the kernel raises *status and
+// carries on instead of hanging the GPU.
+GBP_DEV float4 ld4_xw(const float4* p) {      // "cross-wave" load: never served from a stale L1 / L2 line
+  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+  const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return make_float4(__uint_as_float((unsigned)a), __uint_as_float((unsigned)(a >> 32)), __uint_as_float((unsigned)b),
+                     __uint_as_float((unsigned)(b >> 32)));
+}
+GBP_DEV void st4_xw(float4* p, const float4 v) {
+  unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
+  __hip_atomic_store(q, (unsigned long long)__float_as_uint(v.x) | ((unsigned long long)__float_as_uint(v.y) << 32), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(q + 1, (unsigned long long)__float_as_uint(v.z) | ((unsigned long long)__float_as_uint(v.w) << 32), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+GBP_DEV float ld1_xw(const float* p) {
+  return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+GBP_DEV void st1_xw(float* p, const float v) {
+  __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int G>
+GBP_DEV void load_rec_xw(const float4* rec, float (&out)[G * 4]) {
+  GBP_UNROLL
+  for (int g = 0; g < G; ++g) {
+    const float4 v = ld4_xw(rec + g);
+    out[4 * g] = v.x; out[4 * g + 1] = v.y; out[4 * g + 2] = v.z; out[4 * g + 3] = v.w;
+  }
+}
+GBP_DEV float4 lmsg_piece_xw(const float4* lmsg, uint32_t pos, uint32_t q) {
+  float4 m = ld4_xw(lmsg + (size_t)pos * 4 + q);
+  if (q == 0) m.w = 0.f;
+  if (q == 3) { m.y = 0.f; m.z = 0.f; m.w = 0.f; }
+  return m;
+}
+
+GBP_DEV void grid_sync(unsigned* sync, unsigned epoch, unsigned nblocks, unsigned* status) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's write-through stores have been acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spin = 0;
+    while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch * nblocks) {
+      if (++spin > (1u << 24)) { *status = 1u; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  __syncthreads();
+}
+
+template <int ABL = 0>   // ABL: timing experiments only (see k_sweep)
+__global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
+  const SweepArgs& a = A.s;
+  const BeliefArgs& b = A.b;
+  const uint32_t wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t w = blockIdx.x * 4 + wib;                    // wave of the grid
+  __shared__ float4 lm_stage[4][64 * 4];
+  __shared__ float sh[4][48];
+  float4* stage = lm_stage[wib];
+
+  // ---- phase-A role: sweep tile w.  State that only this lane ever touches lives in registers for the whole launch.
+  const bool has_tile = w < A.n_tiles;
+  const uint32_t tile = has_tile ? w : 0u, p = tile * 64 + lane;
+  const uint32_t rec_t = lane >> 2, swz_own = ((lane >> 2) & 3u) ^ (lane & 2u);
+  float4* lm_tile = a.lmsg + (size_t)tile * 256;
+  float fac[56], cm[28], lm[16];
+  uint32_t cam_i = 0, lmk_i = 0;
+  bool fac_dirty = false;
+  if (has_tile) {
+    cam_i = a.row_cam[p >> 4];
+    lmk_i = a.lmk_idx[p];
+    load_tile<kFacG, false>(a.fac, tile, lane, fac);
+    load_tile<kCmsgG, false>(a.cmsg, tile, lane, cm);
+    GBP_UNROLL
+    for (int k = 0; k < 4; ++k) {   // the wave's 64 landmark-message records: coalesced, transposed through LDS (see k_sweep)
+      const uint32_t r = k * 16 + rec_t;
+      stage[r * 4 + ((lane & 3u) ^ (((r >> 2) & 3u) ^ (r & 2u)))] = ld4_xw(lm_tile + k * 64 + lane);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    GBP_UNROLL
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = stage[lane * 4 + ((uint32_t)q ^ swz_own)];
+      lm[4 * q] = v.x; lm[4 * q + 1] = v.y; lm[4 * q + 2] = v.z; lm[4 * q + 3] = v.w;
+    }
+  }
+  float K[9];
+  GBP_UNROLL
+  for (int i = 0; i < 9; ++i) K[i] = a.K[i];
+  const float4* cb_rec = a.camb + (size_t)cam_i * kCamRec4;      // loop-invariant addresses: phase A is ONE round of loads
+  const float4* lb_rec = a.lmkb + (size_t)lmk_i * kLmkRec4;
+  const float4* cmu_rec = a.cam_mu + (size_t)cam_i * 4;
+  const float4* lmu_rec = a.lmk_mu + (size_t)lmk_i * 2;
+
+  // ---- phase-B role: camera w (lanes 0..43 = the record), or landmarks 16 (w - C) .. + 15 (4 lanes each)
+  const bool cam_wave = w < b.n_cams;
+  const bool lmk_wave = !cam_wave && (w - b.n_cams) < A.n_lmk_groups;
+  const uint32_t cj = lane;                                   // camera role: element of the 44-float record
+  const bool cam_live = cam_wave && cj < (uint32_t)kCamRec;
+  uint32_t r0 = 0, r1 = 0;
+  float cam_prior_j = 0.f;
+  float4 cam_cur0 = make_float4(0.f, 0.f, 0.f, 0.f), cam_cur1 = cam_cur0;   // mean of the belief the next sweep consumes
+  if (cam_wave) {
+    r0 = b.cam_row_ptr[w]; r1 = b.cam_row_ptr[w + 1];
+    if (cam_live) cam_prior_j = b.cam_prior[(size_t)w * kCamRec + cj];
+    cam_cur0 = b.cam_mu[(size_t)w * 4]; cam_cur1 = b.cam_mu[(size_t)w * 4 + 1];
+  }
+  const uint32_t l = lmk_wave ? (w - b.n_cams) * 16 + (lane >> 2) : 0u, q4 = lane & 3;
+  const bool lmk_live = lmk_wave && l < b.n_lmks;
+  uint4 ix = make_uint4(0u, 0u, 0u, 0u);
+  float4 lmk_prior4 = make_float4(0.f, 0.f, 0.f, 0.f), lmk_cur = lmk_prior4;
+  uint32_t lp0 = 0, lp1 = 0;
+  if (lmk_live) {
+    ix = reinterpret_cast<const uint4*>(b.lmk_ix)[(size_t)l * 4 + q4];
+    lmk_prior4 = b.lmk_prior[(size_t)l * 4 + q4];
+    lmk_cur = b.lmk_mu[(size_t)l * 2];
+    lp0 = b.lmk_ptr[l]; lp1 = b.lmk_ptr[l + 1];
+  }
+  const uint32_t deg = (uint32_t)__shfl((int)ix.x, 0, 4);
+  uint32_t pos[15];
+  GBP_UNROLL
+  for (int k = 0; k < 15; ++k) {   // element k + 1 of the index record sits in lane (k + 1) / 4, component (k + 1) % 4
+    const uint32_t v = ((k + 1) & 3) == 0 ? ix.x : ((k + 1) & 3) == 1 ? ix.y : ((k + 1) & 3) == 2 ? ix.z : ix.w;
+    pos[k] = (uint32_t)__shfl((int)v, (k + 1) >> 2, 4);
+  }
+
+#ifdef GBP_BUILD_EXPERIMENTS   // per-phase wall-clock stamps of the first iterations (profiles/persist_trace.py)
+#define GBP_TRACE(slot) if (A.trace && it < kPersistTraceIters && lane == 0) A.trace[((size_t)w * kPersistTraceIters + it) * 8 + (slot)] = wall_clock64()
+#else
+#define GBP_TRACE(slot)
+#endif
+  // slots 16 .. 30 of a landmark (fr1xyz: up to 30 factors per landmark): positions fetched ONCE, so that phase B stays a
+  // single round of loads; slots beyond 30 go through lmk_fpos every iteration
+  uint32_t pos2[15];
+  GBP_UNROLL
+  for (int k = 0; k < 15; ++k) pos2[k] = (lmk_live && 15u + (uint32_t)k < deg) ? b.lmk_fpos[lp0 + 15u + (uint32_t)k] : 0u;
+
+  unsigned epoch = 0;
+  for (int it = 0; it < A.n_iters; ++it) {
+    GBP_TRACE(0);
+    // ================= phase A: the sweep of this wave's tile =================
+    if (has_tile) {
+      float cb[44], lb[16], mu[12];
+      // the linearisation point of a relinearising lane is fetched with the beliefs (one round of loads per phase)
+      const float4 l0 = ld4_xw(lmu_rec);
+      const float4 m0 = ld4_xw(cmu_rec), m1 = ld4_xw(cmu_rec + 1);
+      load_rec_xw<kLmkRec4>(lb_rec, lb);
+      load_rec_xw<kCamRec4>(cb_rec, cb);
+#ifdef GBP_BUILD_EXPERIMENTS
+      if (A.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); GBP_TRACE(5); }
+#endif
+      float damping = lm[3];
+      const int packed = __float_as_int(lm[13]);
+      int count = packed >> 3;
+      uint32_t flags = (uint32_t)packed & 7u;
+      const float var = lm[14];
+      const bool active = (flags & kFlagActive) != 0;
+      float oc_eta[6], oc_lam[36], ol[16];
+      bool relin;
+      factor_update<true, ABL>(fac, cm, mu, lm, cb, lb, K, a.hp, damping, count, flags, var, active, oc_eta, oc_lam, ol, relin,
+                             [&](float (&x0c)[6], float (&x0l)[3]) {
+                               x0c[0] = m0.x; x0c[1] = m0.y; x0c[2] = m0.z; x0c[3] = m0.w; x0c[4] = m1.x; x0c[5] = m1.y;
+                               x0l[0] = l0.x; x0l[1] = l0.y; x0l[2] = l0.z;
+                             });
+      fac_dirty = fac_dirty || (active && relin);
+#ifdef GBP_BUILD_EXPERIMENTS
+      if (A.trace) {
+        GBP_TRACE(6);
+        const unsigned long long any_relin = __ballot(active && relin);
+        // relinearising lanes | XCC_ID << 8 | HW_ID << 16  (hwreg 20 = XCC_ID, hwreg 4 = HW_ID: simd [5:4], cu [11:8], sh [12], se [15:13])
+        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20), hwid = __builtin_amdgcn_s_getreg((15 << 11) | 4);
+        if (it < kPersistTraceIters && lane == 0)
+          A.trace[((size_t)w * kPersistTraceIters + it) * 8 + 7] = (unsigned long long)__popcll(any_relin) | ((unsigned long long)xcc << 8) | ((unsigned long long)hwid << 16);
+      }
+#endif
+      ol[3] = damping;
+      ol[13] = __int_as_float((int)(((uint32_t)count << 3) | flags));
+      ol[14] = var;
+      // the wave's landmark messages go to memory (phase B gathers them by position); this lane keeps its own copy
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      GBP_UNROLL
+      for (int q = 0; q < 4; ++q)
+        stage[lane * 4 + ((uint32_t)q ^ swz_own)] = make_float4(ol[4 * q], ol[4 * q + 1], ol[4 * q + 2], ol[4 * q + 3]);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      GBP_UNROLL
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t r = k * 16 + rec_t;
+        st4_xw(lm_tile + k * 64 + lane, stage[r * 4 + ((lane & 3u) ^ (((r >> 2) & 3u) ^ (r & 2u)))]);
+      }
+      GBP_UNROLL
+      for (int i = 0; i < 16; ++i) lm[i] = ol[i];
+      GBP_UNROLL
+      for (int i = 0; i < 6; ++i) cm[i] = oc_eta[i];
+      GBP_UNROLL
+      for (int i = 0; i < 6; ++i) {
+        GBP_UNROLL
+        for (int j = 0; j <= i; ++j) cm[6 + tri(i, j)] = oc_lam[i * 6 + j];
+      }
+      cm[27] = 0.f;
+      {  // camera half of the belief reduction: per-row tree sums, as in k_sweep
+        float rs[44];
+        GBP_UNROLL
+        for (int i = 0; i < 6; ++i) rs[i] = row16_sum(oc_eta[i]);
+        rs[6] = 0.f; rs[7] = 0.f;
+        GBP_UNROLL
+        for (int i = 0; i < 36; ++i) rs[8 + i] = row16_sum(oc_lam[i]);
+        if ((lane & 15) == 0) {
+          float4* rp = a.rowp + (size_t)(p >> 4) * kCamRec4;
+          GBP_UNROLL
+          for (int g = 0; g < kCamRec4; ++g) st4_xw(rp + g, make_float4(rs[4 * g], rs[4 * g + 1], rs[4 * g + 2], rs[4 * g + 3]));
+        }
+      }
+    }
+    GBP_TRACE(1);
+    grid_sync(A.sync, ++epoch, gridDim.x, A.status);
+    GBP_TRACE(2);
+
+    // ================= phase B: the belief update (arithmetic of k_beliefs, roll = 1) =================
+    if (cam_wave) {
+      float acc = 0.f;
+      if (cam_live && r1 > r0) {
+        const float* row = b.rowp + (size_t)r0 * kCamRec + cj;
+        acc = ld1_xw(row);
+        uint32_t r = 1;
+        const uint32_t n = r1 - r0;
+        for (; r + 16 <= n; r += 16) {
+          float v[16];
+          GBP_UNROLL
+          for (int k = 0; k < 16; ++k) v[k] = ld1_xw(row + (size_t)(r + k) * kCamRec);
+          GBP_UNROLL
+          for (int k = 0; k < 16; ++k) acc = acc + v[k];
+        }
+        {  // tail (< 16 rows): the loads are UNCONDITIONAL (row index clamped, value dropped) — a conditional atomic load
+           // becomes a branch with its own wait, i.e. one memory round trip per row
+          float v[16];
+          const uint32_t m = n - r;
+          GBP_UNROLL
+          for (int k = 0; k < 16; ++k) v[k] = ld1_xw(row + (size_t)((uint32_t)k < m ? r + k : n - 1) * kCamRec);
+          GBP_UNROLL
+          for (int k = 0; k < 16; ++k)
+            if ((uint32_t)k < m) acc = acc + v[k];
+        }
+      }
+      if (cam_live) {
+        b.cam_local[(size_t)w * kCamRec + cj] = acc;
+        sh[wib][cj] = cam_prior_j + acc;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (lane == 0) {
+        float cb[44], x0c[6];
+        GBP_UNROLL
+        for (int i = 0; i < 44; ++i) cb[i] = sh[wib][i];
+        cam_mean(cb, x0c);
+        float4* mu = b.cam_mu + (size_t)w * 4;  // [0,1] = means of the current belief, [2,3] = means the last sweep used
+        st4_xw(mu + 2, cam_cur0); st4_xw(mu + 3, cam_cur1);
+        const float used[6] = {cam_cur0.x, cam_cur0.y, cam_cur0.z, cam_cur0.w, cam_cur1.x, cam_cur1.y};
+        float S = 0.f;
+        GBP_UNROLL
+        for (int i = 0; i < 6; ++i) S += (used[i] - x0c[i]) * (used[i] - x0c[i]);
+        cam_cur0 = make_float4(x0c[0], x0c[1], x0c[2], x0c[3]);
+        cam_cur1 = make_float4(x0c[4], x0c[5], 0.f, 0.f);
+        st4_xw(mu, cam_cur0); st4_xw(mu + 1, cam_cur1);
+        sh[wib][6] = S;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (cam_live) st1_xw(b.camb + (size_t)w * kCamRec + cj, sh[wib][cj]);
+    } else if (lmk_wave) {
+      float4 acc = lmk_prior4;
+      {
+        float4 m[15];
+        GBP_UNROLL
+        for (int k = 0; k < 15; ++k) m[k] = lmsg_piece_xw(b.lmsg, pos[k], q4);   // unconditional: unused slots hold position 0
+        GBP_UNROLL
+        for (int k = 0; k < 15; ++k)     // adds in slot order
+          if ((uint32_t)k < deg) { acc.x = acc.x + m[k].x; acc.y = acc.y + m[k].y; acc.z = acc.z + m[k].z; acc.w = acc.w + m[k].w; }
+      }
+      if (__any(deg > 15u)) {
+        float4 m[15];
+        GBP_UNROLL
+        for (int k = 0; k < 15; ++k) m[k] = lmsg_piece_xw(b.lmsg, pos2[k], q4);
+        GBP_UNROLL
+        for (int k = 0; k < 15; ++k)
+          if (15u + (uint32_t)k < deg) { acc.x = acc.x + m[k].x; acc.y = acc.y + m[k].y; acc.z = acc.z + m[k].z; acc.w = acc.w + m[k].w; }
+      }
+      if (deg > 30u) {
+        for (uint32_t s = lp0 + 30u; s < lp1; s += 8) {
+          uint32_t ps[8];
+          float4 m[8];
+          const uint32_t nleft = lp1 - s;
+          GBP_UNROLL
+          for (int k = 0; k < 8; ++k) ps[k] = (uint32_t)k < nleft ? b.lmk_fpos[s + k] : 0u;
+          GBP_UNROLL
+          for (int k = 0; k < 8; ++k) m[k] = lmsg_piece_xw(b.lmsg, ps[k], q4);
+          GBP_UNROLL
+          for (int k = 0; k < 8; ++k)
+            if ((uint32_t)k < nleft) { acc.x = acc.x + m[k].x; acc.y = acc.y + m[k].y; acc.z = acc.z + m[k].z; acc.w = acc.w + m[k].w; }
+        }
+      }
+      float rec[16];
+      GBP_UNROLL
+      for (int k = 0; k < 4; ++k) {
+        rec[4 * k] = __shfl(acc.x, k, 4); rec[4 * k + 1] = __shfl(acc.y, k, 4);
+        rec[4 * k + 2] = __shfl(acc.z, k, 4); rec[4 * k + 3] = __shfl(acc.w, k, 4);
+      }
+      float u[3] = {0.f, 0.f, 0.f};
+      if (lmk_live && q4 == 0) {
+        float B[9], S3[9], x0l[3];
+        GBP_UNROLL
+        for (int i = 0; i < 9; ++i) B[i] = rec[4 + i];
+        inv3x3(B, S3);
+        GBP_UNROLL
+        for (int i = 0; i < 3; ++i) {
+          float a2 = 0.f;
+          GBP_UNROLL
+          for (int k = 0; k < 3; ++k) a2 += S3[i * 3 + k] * rec[k];
+          x0l[i] = a2;
+        }
+        float4* mu = b.lmk_mu + (size_t)l * 2;  // [0] = mean of the current belief, [1] = mean the last sweep used
+        const float4 used = lmk_cur;
+        st4_xw(mu + 1, used);
+        u[0] = (used.x - x0l[0]) * (used.x - x0l[0]);
+        u[1] = (used.y - x0l[1]) * (used.y - x0l[1]);
+        u[2] = (used.z - x0l[2]) * (used.z - x0l[2]);
+        lmk_cur = make_float4(x0l[0], x0l[1], x0l[2], 0.f);
+        st4_xw(mu, lmk_cur);
+      }
+      const float u0 = __shfl(u[0], 0, 4), u1 = __shfl(u[1], 0, 4), u2 = __shfl(u[2], 0, 4);
+      if (q4 == 0) acc.w = u0;                       // record slot 3
+      if (q4 == 3) { acc.y = u1; acc.z = u2; }       // record slots 13, 14
+      if (lmk_live) st4_xw(b.lmkb + (size_t)l * 4 + q4, acc);
+    }
+    GBP_TRACE(3);
+    if (it + 1 < A.n_iters) grid_sync(A.sync, ++epoch, gridDim.x, A.status);
+    GBP_TRACE(4);
+  }
+#undef GBP_TRACE
+
+  // ---- what stayed in registers goes back to its arrays ----
+  if (has_tile) {
+    store_tile<kCmsgG, false>(a.cmsg, tile, lane, cm);
+    if (fac_dirty) store_tile<kFacG, false>(a.fac, tile, lane, fac);
+  }
+}
+
 // Per-factor scalar state (damping, damping_count, flags: pad slots 3 / 13 of the LMSG record) <-> compact
 // per-position arrays, so that READ_PROG's damping / damping_count / robust_flag streams (ba.cpp:912-914) and
 // NEW_KEYFRAME's damping_count / active_flag streams (slam.cpp:920,926) move 8 bytes per factor over PCIe instead of the
@@ -1200,6 +1583,13 @@ __global__ __launch_bounds__(256) void k_inv6_coop(const float* __restrict__ in,
   }
 }
 
+#ifdef GBP_BUILD_EXPERIMENTS
+void debug_tick_buf(unsigned long long* dev_buf) { (void)hipMemcpyToSymbol(HIP_SYMBOL(gbpdev::g_tick_buf), &dev_buf, sizeof(dev_buf)); }
+void debug_div_redo(unsigned long long* out4, bool reset) {
+  (void)hipMemcpyFromSymbol(out4, HIP_SYMBOL(gbpdev::g_div_redo), 4 * sizeof(unsigned long long));
+  if (reset) { const unsigned long long z[4] = {0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(gbpdev::g_div_redo), z, sizeof(z)); }
+}
+#endif
 bool debug_math_widths(int op, int* in_w, int* out_w) {
   static const int iw[10] = {9, 36, 3, 18, 72, 72, 54, 42, 12, 36}, ow[10] = {9, 36, 9, 20, 18, 18, 36, 6, 3, 36};
   if (op < 0 || op > 9) return false;
@@ -1227,6 +1617,29 @@ void launch_beliefs(BeliefArgs b, bool do_cam, bool do_lmk, hipStream_t s) {
   b.lmk_blocks = lmk_blocks;
   if (b.cam_blocks + lmk_blocks == 0) return;
   hipLaunchKernelGGL(k_beliefs, dim3(b.cam_blocks + lmk_blocks), dim3(256), 0, s, b);
+}
+uint32_t persist_blocks(uint32_t n_tiles, uint32_t n_cams, uint32_t n_lmks) {
+  const uint64_t waves_b = (uint64_t)n_cams + ((uint64_t)n_lmks + 15) / 16;
+  const uint64_t waves = waves_b > n_tiles ? waves_b : n_tiles;
+  return (uint32_t)((waves + 3) / 4);
+}
+int persist_max_resident_blocks() {
+  int dev = 0, per_cu = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_persist<0>, 256, 0) != hipSuccess) return 0;
+  return per_cu * prop.multiProcessorCount;
+}
+void launch_persist(PersistArgs A, hipStream_t s) {
+  A.n_lmk_groups = (A.b.n_lmks + 15) / 16;
+  const uint32_t nb = persist_blocks(A.n_tiles, A.b.n_cams, A.b.n_lmks);
+#ifdef GBP_BUILD_ABLATIONS
+  static const int env_abl = std::getenv("GBP_PERSIST_ABL") ? std::atoi(std::getenv("GBP_PERSIST_ABL")) : 0;
+  if (env_abl == 256) { hipLaunchKernelGGL(k_persist<256>, dim3(nb), dim3(256), 0, s, A); return; }
+  if (env_abl == 64) { hipLaunchKernelGGL(k_persist<64>, dim3(nb), dim3(256), 0, s, A); return; }
+  if (env_abl == 768) { hipLaunchKernelGGL(k_persist<768>, dim3(nb), dim3(256), 0, s, A); return; }
+#endif
+  hipLaunchKernelGGL(k_persist<0>, dim3(nb), dim3(256), 0, s, A);
 }
 void launch_weaken(float4* prior, const float* scaling, uint32_t* flag, uint32_t n, int rec4, hipStream_t s) {
   hipLaunchKernelGGL(k_weaken, dim3(blocks_for((uint64_t)n * rec4)), dim3(256), 0, s, prior, scaling, flag, n, rec4);

@@ -94,12 +94,20 @@ def run_ba(engine, state, opts, n_iters=None, eval_every=1, log=None):
     traj.append((-1, m[0], m[1], int(ev["n_relin"]), int(ev["n_robust"])))
     if log:
         log("Initial Reprojection error: %.6f Cost %.6f" % (m[0], m[1]))
-    for it in range(n_iters):
+    it = 0
+    while it < n_iters:
         if ((it + 1) % 2 == 0) and (it < opts.steps * 2):                   # ba.cpp:1003-1006
             if log:
                 log("Weakening priors ")
             engine.weaken_priors()
-        engine.iterate(1)
+        # up to the next host event (prior weakening, metric read-back, end) in ONE call, like csrc/ba_main.cpp: the
+        # engine then runs the burst without leaving the device (hipGraph replay, or k_persist on small graphs)
+        burst = 1
+        while (it + burst < n_iters and not (eval_every and (it + burst) % eval_every == 0)
+               and not (((it + burst + 1) % 2 == 0) and (it + burst < opts.steps * 2))):
+            burst += 1
+        engine.iterate(burst)
+        it += burst - 1
         if eval_every and ((it + 1) % eval_every == 0 or it == n_iters - 1):
             ev = engine.eval()
             m = metric(ev)
@@ -107,6 +115,7 @@ def run_ba(engine, state, opts, n_iters=None, eval_every=1, log=None):
             if log:
                 log("Iter %d // Reprojection error %.6f // Cost %.6f // n relins: %d // n robust edges %d"
                     % (it, m[0], m[1], ev["n_relin"], ev["n_robust"]))
+        it += 1
     return traj
 
 
@@ -130,7 +139,8 @@ def run_slam(engine, host, bal, state, extra, opts, iters_between_kfs=None, max_
     if max_iters is not None:
         niters = min(niters, max_iters)
     it, data_counter = 0, 0
-    for i in range(niters):
+    i = 0
+    while i < niters:
         if (i + 1) % ibk == 0:                                              # slam.cpp:1020-1046
             it = 0
             data_counter += 1
@@ -148,7 +158,13 @@ def run_slam(engine, host, bal, state, extra, opts, iters_between_kfs=None, max_
                 log("Adding keyframe %d, %d new landmarks" % (data_counter + 1, n_new))
         if ((it + 1) % 2 == 0) and (it < opts.steps * 2):
             engine.weaken_priors()
-        engine.iterate(1)
+        burst = 1                       # up to the next keyframe / prior weakening / read-back in one call
+        while (i + burst < niters and (i + burst + 1) % ibk != 0 and not (eval_every and (i + burst) % eval_every == 0)
+               and not (((it + burst + 1) % 2 == 0) and (it + burst < opts.steps * 2))):
+            burst += 1
+        engine.iterate(burst)
+        i += burst - 1
+        it += burst - 1
         if eval_every and ((i + 1) % eval_every == 0 or i == niters - 1):
             ev = engine.eval()
             m = metric(ev)
@@ -157,4 +173,5 @@ def run_slam(engine, host, bal, state, extra, opts, iters_between_kfs=None, max_
                 log("Iters %d (since last kf %d) // Reprojection error %.6f // Cost %.6f // n relins: %d // n robust edges %d"
                     % (ibk * data_counter + it, it, m[0], m[1], ev["n_relin"], ev["n_robust"]))
         it += 1
+        i += 1
     return traj

@@ -168,7 +168,8 @@ class GbpEngine:
         return self.lib.gbp_comm_transport(self.h).decode()
 
     def graph_state(self):
-        """1: gbp_iterate replays a captured hipGraph; 0: nothing captured yet; -1: capture failed, direct launches."""
+        """2: bursts run inside the persistent kernel (small graph); 1: gbp_iterate replays a captured hipGraph;
+        0: nothing captured yet; -1: capture failed, direct launches."""
         return int(self.lib.gbp_graph_state(self.h))
 
     def comm_barrier(self):

@@ -75,7 +75,12 @@ typedef struct {
                                   1 = everything sequential;
                                   2 = as 0, and each XCD also sweeps the tiles of one landmark range (11 % less fabric
                                       traffic, slightly slower: kept for measurements)                              */
-  int32_t reserved[3];
+  int32_t persistent;          /* gbp_iterate(n >= 2) on a graph small enough that all of its workgroups are resident at once
+                                  (BASELINE configs 1-3) runs the n iterations inside ONE kernel launch (k_persist: per-factor
+                                  state in registers, device-wide barriers instead of kernel boundaries; identical results):
+                                  0 (default) = automatically up to 56 workgroups (14 336 factor positions), 1 = whenever the graph is
+                                  co-resident, -1 = never.  Single-GPU ctx with hoisted means only. */
+  int32_t reserved[2];
 } gbp_params;
 
 /* Landmark shard of a multi-GPU run (one process per GPU).  The global problem is passed to
@@ -247,7 +252,7 @@ int gbp_comm_unique_id(void* id128);
 int gbp_comm_init_rccl(gbp_ctx* ctx, const void* id128);
 const char* gbp_comm_transport(const gbp_ctx* ctx);            /* "rccl", "host-staged" or "none" */
 int gbp_comm_barrier(gbp_ctx* ctx);
-int gbp_graph_state(const gbp_ctx* ctx);                       /* 1 = gbp_iterate replays a captured hipGraph, 0 = not captured (yet), -1 = capture failed: direct launches */
+int gbp_graph_state(const gbp_ctx* ctx);                       /* 2 = bursts run inside the persistent kernel (small graph), 1 = gbp_iterate replays a captured hipGraph, 0 = not captured (yet), -1 = capture failed: direct launches */
 int gbp_eval_global(gbp_ctx* ctx, gbp_eval_out* out);          /* gbp_eval summed over all shards */
 
 /* ---- measurement ---------------------------------------------------------------------------- */

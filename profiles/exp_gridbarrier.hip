@@ -75,6 +75,35 @@ __device__ __forceinline__ void grid_barrier_flags(unsigned* flags, unsigned epo
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
 }
 
+// light: no L2 write-back / invalidate at all.  The exchanged DATA is written and read with agent-scope relaxed
+// atomics (64-bit: global_store/load_dwordx2 sc1 — write-through / re-fetched per access), so the barrier only has to
+// wait for the stores of the workgroup (s_waitcnt vmcnt(0) + s_barrier), then one arrival per workgroup on one counter.
+__device__ __forceinline__ void grid_barrier_light(unsigned* counter, unsigned target) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's write-through stores have been acknowledged
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (unsigned spin = 0; __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && spin < (1u << 22); ++spin)
+      __builtin_amdgcn_s_sleep(1);
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__device__ __forceinline__ void grid_barrier_agent(unsigned* counter, unsigned target) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // buffer_wbl2 sc1: agent scope, not the system-scope default of __atomic_thread_fence
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (unsigned spin = 0; __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && spin < (1u << 22); ++spin)
+      __builtin_amdgcn_s_sleep(1);
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
 template <int MODE>   // 0 flat (per wave), 1 one thread per block, 2 no barrier at all (one round per launch), 3 tree, 4 flags
 __global__ void k_rounds(float4* buf, unsigned* counter, unsigned* errors, int rounds, int round0) {
   const unsigned nwaves = gridDim.x * (blockDim.x >> 6);
@@ -84,13 +113,29 @@ __global__ void k_rounds(float4* buf, unsigned* counter, unsigned* errors, int r
   for (int r = 0; r < rounds; ++r) {
     const int rr = round0 + r;
     float4* mine = buf + ((size_t)(rr & 1) * nwaves + wave) * 64;
+    if (MODE == 5) {
+      unsigned long long* m64 = reinterpret_cast<unsigned long long*>(mine + lane);
+      const float2 lo = make_float2((float)rr, (float)wave), hi = make_float2((float)lane, 1.f);
+      __hip_atomic_store(m64, *reinterpret_cast<const unsigned long long*>(&lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(m64 + 1, *reinterpret_cast<const unsigned long long*>(&hi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else
     mine[lane] = make_float4((float)rr, (float)wave, (float)lane, 1.f);
-    if (MODE == 3) grid_barrier_tree(counter, (unsigned)(r + 1), gridDim.x);
+    if (MODE == 5) grid_barrier_light(counter, (unsigned)(r + 1) * gridDim.x);
+    else if (MODE == 6) grid_barrier_agent(counter, (unsigned)(r + 1) * gridDim.x);
+    else if (MODE == 3) grid_barrier_tree(counter, (unsigned)(r + 1), gridDim.x);
     else if (MODE == 4) grid_barrier_flags(counter, (unsigned)(r + 1), gridDim.x);
     else if (MODE != 2) grid_barrier(counter, (unsigned)(r + 1) * arrivals, MODE == 1);
     if (MODE != 2) {
       const unsigned other = (wave + (blockDim.x >> 6)) % nwaves;   // a wave of the next block: another XCD
-      const float4 v = buf[((size_t)(rr & 1) * nwaves + other) * 64 + lane];
+      float4 v;
+      if (MODE == 5) {
+        const unsigned long long* o64 = reinterpret_cast<const unsigned long long*>(buf + ((size_t)(rr & 1) * nwaves + other) * 64 + lane);
+        const unsigned long long a0 = __hip_atomic_load(o64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long a1 = __hip_atomic_load(o64 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float2 lo = *reinterpret_cast<const float2*>(&a0), hi = *reinterpret_cast<const float2*>(&a1);
+        v = make_float4(lo.x, lo.y, hi.x, hi.y);
+      } else
+      v = buf[((size_t)(rr & 1) * nwaves + other) * 64 + lane];
       if (v.x != (float)rr || v.y != (float)other || v.z != (float)lane) ++bad;
     }
   }
@@ -109,14 +154,14 @@ int main() {
   hipStream_t s;
   CK(hipStreamCreate(&s));
   const int rounds = 2000;
-  printf("| blocks x threads | waves | flat: us/round | one-thread-per-block: us/round | separate launches: us/round | tree (8 groups): us/round | flags (no RMW): us/round | errors |\n|---|---|---|---|---|---|---|---|\n");
+  printf("| blocks x threads | waves | flat: us/round | one-thread-per-block: us/round | separate launches: us/round | tree (8 groups): us/round | flags (no RMW): us/round | light (sc1 data, no L2 flush): us/round | one thread per block, agent-scope fences: us/round | errors |\n|---|---|---|---|---|---|---|---|---|---|\n");
   const int cfgs[][2] = {{14, 256}, {19, 256}, {51, 256}, {128, 256}, {256, 256}, {512, 256}, {56, 64}, {202, 64}, {1024, 64}};
   for (auto& cfg : cfgs) {
     const int nb = cfg[0], nt = cfg[1];
-    double us[5];
+    double us[7];
     unsigned herr = 0;
     CK(hipMemset(errors, 0, 4));
-    for (int mode = 0; mode < 5; ++mode) {
+    for (int mode = 0; mode < 7; ++mode) {
       for (int rep = 0; rep < 2; ++rep) {   // rep 0 = warm-up
         CK(hipMemsetAsync(counter, 0, 16384, s));
         CK(hipEventRecord(e0, s));
@@ -124,7 +169,9 @@ int main() {
         else if (mode == 1) hipLaunchKernelGGL(k_rounds<1>, dim3(nb), dim3(nt), 0, s, buf, counter, errors, rounds, 0);
         else if (mode == 2) for (int r = 0; r < rounds; ++r) hipLaunchKernelGGL(k_rounds<2>, dim3(nb), dim3(nt), 0, s, buf, counter, errors, 1, r);
         else if (mode == 3) hipLaunchKernelGGL(k_rounds<3>, dim3(nb), dim3(nt), 0, s, buf, counter, errors, rounds, 0);
-        else hipLaunchKernelGGL(k_rounds<4>, dim3(nb), dim3(nt), 0, s, buf, counter, errors, rounds, 0);
+        else if (mode == 4) hipLaunchKernelGGL(k_rounds<4>, dim3(nb), dim3(nt), 0, s, buf, counter, errors, rounds, 0);
+        else if (mode == 5) hipLaunchKernelGGL(k_rounds<5>, dim3(nb), dim3(nt), 0, s, buf, counter, errors, rounds, 0);
+        else hipLaunchKernelGGL(k_rounds<6>, dim3(nb), dim3(nt), 0, s, buf, counter, errors, rounds, 0);
         CK(hipEventRecord(e1, s));
         CK(hipEventSynchronize(e1));
         float ms = 0;
@@ -133,7 +180,7 @@ int main() {
       }
     }
     CK(hipMemcpy(&herr, errors, 4, hipMemcpyDeviceToHost));
-    printf("| %d x %d | %d | %.2f | %.2f | %.2f | %.2f | %.2f | %u |\n", nb, nt, nb * nt / 64, us[0], us[1], us[2], us[3], us[4], herr);
+    printf("| %d x %d | %d | %.2f | %.2f | %.2f | %.2f | %.2f | %.2f | %.2f | %u |\n", nb, nt, nb * nt / 64, us[0], us[1], us[2], us[3], us[4], us[5], us[6], herr);
   }
   return 0;
 }

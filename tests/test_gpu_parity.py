@@ -15,7 +15,7 @@ from tests.conftest import per_var_rel, rel_err, seq_path, small_synth
 pytestmark = pytest.mark.gpu
 
 
-def _setup(bal, oracle_mod, slam=False, sum_order=1, per_factor_mu=0, hooks=True):
+def _setup(bal, oracle_mod, slam=False, sum_order=1, per_factor_mu=0, hooks=True, **engine_params):
     """hooks=True: the engine runs libgbp_mi355x_test.so (the product sources + the gbp_debug_* hooks), so that
     messages, potentials and mu can be compared; hooks=False: the product library itself (whole-run tests)."""
     from gbp_poplar_amd import _cabi, driver, hostlib
@@ -23,7 +23,7 @@ def _setup(bal, oracle_mod, slam=False, sum_order=1, per_factor_mu=0, hooks=True
     opts = driver.Options()
     K, state, extra = driver.build_inputs(bal, opts, hostlib, slam=slam)
     eng = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K,
-                    params=_cabi.GbpParams.defaults(per_factor_mu=per_factor_mu), hooks=hooks)
+                    params=_cabi.GbpParams.defaults(per_factor_mu=per_factor_mu, **engine_params), hooks=hooks)
     orc = oracle_mod.Oracle(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K)
     orc.set_sum_order(sum_order)
     eng.upload(state)
@@ -326,8 +326,8 @@ def test_inactive_factors_and_ragged_degrees(oracle_mod):
 def test_graph_replay_equals_direct_launches(oracle_mod):
     """gbp_iterate(20) (hipGraph replay, unroll 10) == 20 x gbp_iterate(1) (direct launches), bit for bit."""
     bal = _bal("fr2robot2")
-    a, _, _, state, _ = _setup(bal, oracle_mod)
-    b, _, _, _, _ = _setup(bal, oracle_mod)
+    a, _, _, state, _ = _setup(bal, oracle_mod, persistent=-1)      # small graph: keep it off the persistent kernel
+    b, _, _, _, _ = _setup(bal, oracle_mod, persistent=-1)
     a.linearise()
     b.linearise()
     assert a.graph_state() == 0
@@ -340,6 +340,109 @@ def test_graph_replay_equals_direct_launches(oracle_mod):
     ra, rb = a.read(), b.read()
     for k in ra:
         assert np.array_equal(ra[k], rb[k]), k
+
+
+# ---- k_persist: the iteration loop inside one kernel launch (small graphs) ---------------------------------------
+
+def _full_snapshot(eng):
+    d = _gpu_snapshot(eng)
+    d["mu"] = eng.mu()[0]                  # the hoisted means the last sweep used, per factor
+    return d
+
+
+@pytest.mark.parametrize("name", ["fr2robot2", "fr1xyz", "ragged"])
+def test_persistent_kernel_equals_two_kernel_path(name, oracle_mod):
+    """gbp_iterate(n) through k_persist (sweep + device-wide barrier + beliefs + barrier, n times in ONE launch, per-factor
+    state in registers) leaves EVERY tensor — beliefs, both message sets, potentials, per-factor scalars, hoisted means —
+    bit for bit as n x (k_sweep, k_beliefs) do: the ./ba flow with bursts of odd lengths, relinearisations included,
+    on the two shipped small sequences and on a ragged synthetic graph (hub landmark of degree > 15, inactive factors,
+    cameras with one row, waves with a belief role but no sweep tile)."""
+    from gbp_poplar_amd import _cabi, driver, hostlib
+    from gbp_poplar_amd.engine import GbpEngine
+    opts = driver.Options()
+    kw = {}
+    if name == "ragged":
+        rng = np.random.default_rng(11)
+        C, L, E = 9, 700, 1500                       # few factors, many landmarks: more belief waves than sweep tiles
+        cam_id = np.sort(rng.integers(0, C, E)).astype(np.uint32)
+        lmk_id = rng.integers(0, L, E).astype(np.uint32)
+        lmk_id[rng.random(E) < 0.03] = 5             # hub landmark: degree > 15 (slots beyond the index record)
+        cam_id[:C] = np.arange(C)
+        bal = _tiny_problem(list(cam_id), list(lmk_id), C, L, seed=3)
+        opts.undamped_start = 2
+        kw = dict(dmu_threshold=0.05, min_linear_iters=3, num_undamped_iters=2)
+    else:
+        bal = _bal(name)
+    K, state, _ = driver.build_inputs(bal, opts, hostlib)
+    if name == "ragged":
+        state["active_flag"] = (np.random.default_rng(5).random(bal["n_edges"]) < 0.9).astype(np.uint32)
+    engs = [GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K, hooks=True,
+                      params=_cabi.GbpParams.defaults(persistent=mode, **kw)) for mode in (1, -1)]
+    assert engs[0].graph_state() == 2 and engs[1].graph_state() != 2
+    n_relin = 0
+    for e in engs:
+        e.upload(state)
+        e.linearise()
+    it = 0
+    for burst in (1, 1, 2, 3, 5, 7, 2, 37, 64, 3, 100):       # ba.cpp:1001-1008: weaken priors before iterations 1,3,5,7,9
+        for e in engs:
+            left = burst
+            i = it
+            while left > 0:
+                if (i + 1) % 2 == 0 and i < 10:
+                    e.weaken_priors()
+                k = 1
+                while k < left and not ((i + k + 1) % 2 == 0 and i + k < 10):
+                    k += 1
+                e.iterate(k)
+                i += k
+                left -= k
+        it += burst
+        sa, sb = _full_snapshot(engs[0]), _full_snapshot(engs[1])
+        for k in sa:
+            assert np.array_equal(sa[k], sb[k], equal_nan=True), (name, it, k)
+        ea, eb = engs[0].eval(), engs[1].eval()
+        assert ea == eb, (it, ea, eb)
+        n_relin += ea["n_relin"]
+    assert n_relin > 0 and engs[0].timing()["iterations"] == it
+
+
+def test_persistent_kernel_full_run_vs_oracle(oracle_mod):
+    """`./ba fr1xyz --eval_every 100` as the CLI issues it (bursts of up to 100 iterations inside k_persist), 600 sweeps
+    of the chaotic sequence: every belief equal to the CPU oracle's, bit for bit."""
+    from gbp_poplar_amd import driver
+    oracle_mod.set_trig_mode(1)
+    try:
+        eng, orc, opts, state, _ = _setup(_bal("fr1xyz"), oracle_mod, sum_order=1, hooks=False, persistent=1)
+        assert eng.graph_state() == 2
+        tg = driver.run_ba(eng, state, opts, n_iters=600, eval_every=100)
+        to = driver.run_ba(orc, state, opts, n_iters=600, eval_every=100)
+    finally:
+        oracle_mod.set_trig_mode(0)
+    g, o = eng.read(), orc.read()
+    for k in g:
+        assert np.array_equal(g[k], o[k]), k
+    assert [t[0] for t in tg] == [t[0] for t in to] and [t[3:] for t in tg] == [t[3:] for t in to]
+
+
+def test_persistent_kernel_is_chosen_by_size():
+    """Automatic selection (gbp_params.persistent = 0): the shipped sequences run in k_persist, S1-sized graphs do not;
+    a sharded ctx and per_factor_mu = 1 never do."""
+    from gbp_poplar_amd import _cabi, driver, hostlib
+    from gbp_poplar_amd.engine import GbpEngine
+    for name, want in (("fr1xyz", 2), ("fr2robot2", 2)):
+        bal = _bal(name)
+        K, state, _ = driver.build_inputs(bal, driver.Options(), hostlib)
+        assert GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K).graph_state() == want
+        assert GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K,
+                         params=_cabi.GbpParams.defaults(per_factor_mu=1)).graph_state() == 0
+        assert GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K,
+                         shard=(0, 1, 0, bal["n_lmks"])).graph_state() == 0
+    bal = small_synth(n_cams=200, n_lmks=20000, obs=10, seed=1)        # 200 000 factors: 782 workgroups
+    K, state, _ = driver.build_inputs(bal, driver.Options(), hostlib)
+    assert GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K).graph_state() == 0
+    assert GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K,
+                     params=_cabi.GbpParams.defaults(persistent=1)).graph_state() == 0      # not co-resident: refused
 
 
 # ---- committed golden fixtures (tests/golden/*.npz, produced with the REFERENCE's math layer) ----------------

@@ -21,13 +21,20 @@ class EvalAt:
             setattr(self, name, getattr(engine, name))
 
     def iterate(self, n=1):
-        for _ in range(n):
-            self.e.iterate(1)
-            if self.i in self.wanted:
+        """A burst of n iterations, split only where a metric is wanted (so that the engine sees real bursts:
+        hipGraph replay / k_persist on the GPU)."""
+        left = int(n)
+        while left > 0:
+            k = 1
+            while k < left and (self.i + k - 1) not in self.wanted:
+                k += 1
+            self.e.iterate(k)
+            self.i += k
+            left -= k
+            if (self.i - 1) in self.wanted:
                 ev = self.e.eval()
                 m = driver.metric(ev)
-                self.rows.append((self.i, m[0], m[1], m[2], ev["n_relin"], ev["n_robust"], ev["n_active"]))
-            self.i += 1
+                self.rows.append((self.i - 1, m[0], m[1], m[2], ev["n_relin"], ev["n_robust"], ev["n_active"]))
 
     def array(self):
         return np.array(self.rows, dtype=np.float64)
