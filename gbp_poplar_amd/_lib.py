@@ -10,8 +10,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GBP_LIB") or os.path.join(HERE, "libgbp_mi355x.so")
 # the product sources + the gbp_debug_* hooks of include/gbp_mi355x_debug.h; loaded by tests that look at internal state
 TEST_LIB_PATH = os.environ.get("GBP_LIB") or os.path.join(HERE, "libgbp_mi355x_test.so")
+EXP_LIB_PATH = os.path.join(HERE, "libgbp_mi355x_exp.so")    # build.py --experiments: + ablations / mapping experiments
 _lib = None
 _test_lib = None
+_exp_lib = None
 
 # every symbol include/gbp_mi355x.h declares (tests/test_cabi_symbols.py parses the header and checks this list)
 _SIGS = {
@@ -100,12 +102,15 @@ def debug_symbols():
 
 def load(hooks=False):
     """The product library (hooks=False) or the test-hooks build of the same sources (hooks=True)."""
-    global _lib, _test_lib
-    if hooks and _test_lib is not None:
+    global _lib, _test_lib, _exp_lib
+    if hooks == "exp":               # the experiments build (mapping experiments: tests/test_gpu_experiments.py, profiles/)
+        if _exp_lib is not None:
+            return _exp_lib
+    elif hooks and _test_lib is not None:
         return _test_lib
-    if not hooks and _lib is not None:
+    elif not hooks and _lib is not None:
         return _lib
-    path = TEST_LIB_PATH if hooks else LIB_PATH
+    path = EXP_LIB_PATH if hooks == "exp" else (TEST_LIB_PATH if hooks else LIB_PATH)
     if not os.path.exists(path):
         raise RuntimeError(
             "native library %s is missing — build it with `python -m gbp_poplar_amd.build` "
@@ -131,7 +136,9 @@ def load(hooks=False):
     if lib.gbp_abi_version() != cabi.GBP_ABI_VERSION:
         raise RuntimeError("%s has ABI version %d, these bindings were written for %d — rebuild (python -m gbp_poplar_amd.build)"
                            % (path, lib.gbp_abi_version(), cabi.GBP_ABI_VERSION))
-    if hooks:
+    if hooks == "exp":
+        _exp_lib = lib
+    elif hooks:
         _test_lib = lib
     else:
         _lib = lib

@@ -137,6 +137,7 @@ SweepArgs sweep_args(gbp_ctx* c) {
   a.hp.dmu_threshold = c->prm.dmu_threshold; a.hp.min_linear_iters = c->prm.min_linear_iters;
   a.hp.nstds = c->prm.nstds; a.hp.relin_mode = c->prm.relin_mode;
   a.block0 = 0;
+  a.variant = c->prm.reserved[0];      // read by the experiments build only
   a.tile_perm = c->use_tile_perm ? P<uint32_t>(c->tile_perm) : nullptr;
   return a;
 }
@@ -675,16 +676,25 @@ static int enqueue_sharded_iteration(gbp_ctx* c, const SweepArgs& a) {
     if (x1) HIPCHK(c, hipEventRecord(x1, c->comm_stream));
     HIPCHK(c, hipEventRecord(c->ev_join, c->comm_stream));
   }
-  {  // the landmark half needs nothing from other ranks
-    BeliefArgs b = belief_args(c);
-    b.roll = 1;
-    launch_beliefs(b, false, true, c->stream);
-  }
   if (ordered) {
+    {  // the landmark half needs nothing from other ranks: it runs beside the all-gather
+      BeliefArgs b = belief_args(c);
+      b.roll = 1;
+      launch_beliefs(b, false, true, c->stream);
+    }
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
-  } else {                                           // same stream (stream-ordered transports: still no host wait)
+  } else {
+    // ONE stream: the local camera partial sums ride in the launch of the landmark half (camera blocks write send_dev and
+    // leave, landmark blocks do the rank-local belief update), so an iteration is sweep -> beliefs -> all-gather -> combine:
+    // three kernels and one collective.  Still no host wait with a stream-ordered transport.
+    {
+      BeliefArgs b = belief_args(c);
+      b.cam_local = static_cast<float*>(c->send_dev);
+      b.partial_only = 1;
+      b.roll = 1;
+      launch_beliefs(b, true, true, c->stream);
+    }
     if (x0) HIPCHK(c, hipEventRecord(x0, c->stream));
-    enqueue_cam_partials(c, static_cast<float*>(c->send_dev));
     if (int rc = exchange_now(c)) return rc;
     if (x1) HIPCHK(c, hipEventRecord(x1, c->stream));
   }
@@ -908,7 +918,7 @@ static int iterate_impl(gbp_ctx* c, int n) {
       HIPCHK(c, hipEventElapsedTime(&b_ms, ev[2 * i + 1], ev[2 * i + 2]));
       c->sweep_ms += a_ms; c->belief_ms += b_ms;
     }
-  } else if (c->persist_ok && n >= 2) {
+  } else if (c->persist_ok && n >= 2) {   // a single iteration is as fast from two launches (measured)
     // small graph: the whole burst in one launch (k_persist).  The barrier words are zeroed in stream order first.
     if (*static_cast<volatile unsigned*>(c->pstatus_host) != 0u)
       return fail(c, GBP_ERR_HIP, "k_persist: a device-wide barrier timed out in an earlier launch (workgroups not co-resident)");
@@ -1226,9 +1236,10 @@ int gbp_debug_time_sweep(gbp_ctx* c, int ablation, int reps, double* avg_us) {
   const SweepArgs a = sweep_args(c);
   bool built = true;
   auto one = [&]() {
-    if (ablation >= 100 && ablation <= 102) {  // 100: k_beliefs, 101: camera part only, 102: landmark part only
-      BeliefArgs b = belief_args(c);
-      launch_beliefs(b, ablation != 102, ablation != 101, c->stream);
+    if (ablation >= 100 && ablation <= 104) {  // 100: k_beliefs, 101: camera part only, 102: landmark part only,
+      BeliefArgs b = belief_args(c);           // 103 / 104 (experiments build): landmark part with a streaming / an index-free gather
+      b.abl = ablation == 103 ? 1 : ablation == 104 ? 2 : 0;
+      launch_beliefs(b, ablation != 102 && ablation < 103, ablation != 101, c->stream);
     } else {
       built = launch_sweep_ablated(a, c->n_tiles, ablation, c->stream) && built;
     }

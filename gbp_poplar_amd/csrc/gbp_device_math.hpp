@@ -68,20 +68,22 @@ GBP_DEV void inv3x3(const float (&M)[9], float (&inv)[9]) {
 // D^-1, inverse of the unit upper factor (matlib.cpp:163-178), Ainv = (LT^-1 D^-1) LT^-T.
 // All 36 entries of Ainv are produced separately: (a*d)*b and (b*d)*a round differently, so the
 // reference's result is not bit-symmetric.
-GBP_DEV void inv6x6_lower(const float (&A)[21], float (&Ainv)[36]) {
-  float D[6], rD[6];
+// The factorisation part: D^-1 and the inverse of the unit upper factor.  `A(i, j)`, i >= j, supplies the lower triangle
+// (an array, or straight from LDS where registers are scarce).
+template <class AF>
+GBP_DEV void ldl6_lower(AF&& A, float (&rD)[6], float (&Ui)[6][6]) {
+  float D[6];
   float U[6][6];   // U[j][i], i > j : LT(j,i)
-  float Ui[6][6];  // Ui[i][j], j > i : LTinv(i,j)
   GBP_UNROLL
   for (int j = 0; j < 6; ++j) {
-    float d = A[tri(j, j)];
+    float d = A(j, j);
     GBP_UNROLL
     for (int k = 0; k < j; ++k) d -= U[k][j] * U[k][j] * D[k];
     D[j] = d;
     rD[j] = 1 / d;
     GBP_UNROLL
     for (int i = j + 1; i < 6; ++i) {
-      float u = rD[j] * A[tri(i, j)];
+      float u = rD[j] * A(i, j);
       GBP_UNROLL
       for (int k = 0; k < j; ++k) u -= rD[j] * U[k][i] * U[k][j] * D[k];
       U[j][i] = u;
@@ -95,23 +97,44 @@ GBP_DEV void inv6x6_lower(const float (&A)[21], float (&Ainv)[36]) {
       acc += U[i][j];  // k = i: LTinv(i,i) * LT(i,j) = 1 * LT(i,j)
       GBP_UNROLL
       for (int k = i + 1; k < j; ++k) acc += Ui[i][k] * U[k][j];
-      Ui[i][j] = acc / -1.f;
+      Ui[i][j] = acc / -1.f;   // Ui[i][j], j > i : LTinv(i,j)
     }
   }
+}
+// entry (i, j) of Ainv = (LT^-1 D^-1) LT^-T from the factors
+GBP_DEV float inv6_entry(const float (&rD)[6], const float (&Ui)[6][6], int i, int j) {
+  const int k0 = i > j ? i : j;
+  float acc = 0.f;
+  GBP_UNROLL
+  for (int k = 0; k < 6; ++k) {
+    if (k < k0) continue;
+    const float w = (k == i) ? rD[k] : Ui[i][k] * rD[k];  // (LTinv Dinv)(i,k); LTinv(i,i) = 1
+    const float b = (k == j) ? 1.f : Ui[j][k];            // LTinv(j,k)
+    acc += (k == j) ? w : w * b;
+  }
+  return acc;
+}
+GBP_DEV void inv6x6_lower(const float (&A)[21], float (&Ainv)[36]) {
+  float rD[6], Ui[6][6];
+  ldl6_lower([&](int i, int j) { return A[tri(i, j)]; }, rD, Ui);
   GBP_UNROLL
   for (int i = 0; i < 6; ++i) {
     GBP_UNROLL
-    for (int j = 0; j < 6; ++j) {
-      const int k0 = i > j ? i : j;
-      float acc = 0.f;
-      GBP_UNROLL
-      for (int k = k0; k < 6; ++k) {
-        const float w = (k == i) ? rD[k] : Ui[i][k] * rD[k];  // (LTinv Dinv)(i,k); LTinv(i,i) = 1
-        const float b = (k == j) ? 1.f : Ui[j][k];            // LTinv(j,k)
-        acc += (k == j) ? w : w * b;
-      }
-      Ainv[i * 6 + j] = acc;
-    }
+    for (int j = 0; j < 6; ++j) Ainv[i * 6 + j] = inv6_entry(rD, Ui, i, j);
+  }
+}
+// inf2mean6x6 (bafuncs.cpp:2-9) without materialising the inverse: x = A^-1 eta, every entry of A^-1 and every partial sum
+// evaluated exactly as inv6x6_lower + the row-times-vector loop do (fewer live registers: used by the belief kernels).
+template <class AF, class EF>
+GBP_DEV void solve6_lower(AF&& A, EF&& eta, float (&x)[6]) {
+  float rD[6], Ui[6][6];
+  ldl6_lower(A, rD, Ui);
+  GBP_UNROLL
+  for (int i = 0; i < 6; ++i) {
+    float acc = 0.f;
+    GBP_UNROLL
+    for (int k = 0; k < 6; ++k) acc += inv6_entry(rD, Ui, i, k) * eta(k);
+    x[i] = acc;
   }
 }
 

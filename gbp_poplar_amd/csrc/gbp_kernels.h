@@ -66,6 +66,7 @@ struct SweepArgs {
   float K[9];
   Hyper hp;
   uint32_t block0;           // first 256-factor block of this launch (pieces of a sweep: pipelined exchange)
+  int variant;               // experiments build only: 1 = k_sweep_coop16 (16 lanes per factor) instead of k_sweep
   const uint32_t* tile_perm; // [n_tiles] or NULL (default): wave slot (4 * block + wave) -> tile.  Optional XCD-aware
                              // order (gbp_params.tile_order = 2): workgroups are dealt round-robin over the 8 XCDs, the
                              // table hands every XCD the tiles of one landmark range so that its private L2 holds that
@@ -96,6 +97,8 @@ struct BeliefArgs {
   int partial_only;          // camera part writes cam_local only (multi-GPU: before the exchange)
   int hoist;                 // compute per-variable means + dmu^2 pieces
   int roll;                  // end of an iteration: "means used by the last sweep" := current means, then recompute
+  int abl;                   // experiments build only (timing, results are garbage): 1 = message records read in landmark-major
+                             // order (what a streaming gather would cost), 2 = random positions WITHOUT the index-record load
 };
 
 // k_persist: n GBP iterations in ONE launch for graphs small enough that every workgroup is resident at once

@@ -373,8 +373,8 @@ GBP_DEV void factor_update(float (&fac)[56], const float (&cm)[28], float (&mu)[
 #define GBP_SWEEP_WPB 4      // wavefronts per workgroup of the sweep (1, 2 or 4; the waves of a workgroup share nothing)
 #endif
 constexpr int kWpb = GBP_SWEEP_WPB;
-template <bool HOIST, int ABL = 0>
-__global__ __launch_bounds__(64 * kWpb) void k_sweep(const SweepArgs a) {
+template <bool HOIST, int ABL>
+GBP_DEV void sweep_tile(const SweepArgs& a) {
   const uint32_t wslot = (blockIdx.x + a.block0 * (4 / kWpb)) * kWpb + (threadIdx.x >> 6);
   const uint32_t tile = a.tile_perm ? (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tile_perm[wslot]) : wslot;
   const uint32_t lane = threadIdx.x & 63, p = tile * 64 + lane;
@@ -500,6 +500,299 @@ __global__ __launch_bounds__(64 * kWpb) void k_sweep(const SweepArgs a) {
   }
 }
 
+template <bool HOIST, int ABL = 0>
+__global__ __launch_bounds__(64 * kWpb) void k_sweep(const SweepArgs a) { sweep_tile<HOIST, ABL>(a); }
+
+#ifdef GBP_BUILD_EXPERIMENTS
+// Mapping experiment (profiles/time_mapping.py): the SAME sweep forced to three wavefronts per SIMD
+// (<= 168 VGPRs): what a third wave buys against what the spills cost.
+__global__ __launch_bounds__(64 * kWpb) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_sweep_w3(const SweepArgs a) { sweep_tile<true, 0>(a); }
+#endif
+
+#ifdef GBP_BUILD_EXPERIMENTS
+// =================================================================================================
+// k_sweep_coop16 — the sweep in the NORTH STAR's sub-wave mapping, built so that it can be measured against the product
+// kernel (profiles/time_mapping.py): 16 lanes (one DPP row) cooperate on ONE factor, the factor's blocks
+// (potential, both messages, both beliefs) are staged in LDS, every product / inverse is evaluated with lane = output
+// element in the reference's k order, the 6x6 inverse is the cooperative LDL^T of k_inv6_coop.  One wavefront = 4
+// factors, one workgroup = 16 factors = one camera row (its 44 row sums are a tree over the 16 factors, same order as
+// row16_sum).  Functionally complete and bit-identical to k_sweep (a relinearising factor runs relin_core on lane 0 of
+// its group); experiments build only.
+// =================================================================================================
+namespace coop {
+constexpr int kF = 0, kCm = 56, kLm = 84, kCb = 100, kLb = 144, kWs = 160;          // LDS floats of one factor
+constexpr int kAp = kWs, kU = kWs + 21, kUi = kWs + 36, kAinv = kWs + 51, kG = kWs + 87, kEd = kWs + 105, kBp = kWs + 111, kBi = kWs + 120,
+              kG2 = kWs + 129, kEl = kWs + 147, kOut = kWs + 150 /* ol 16 | oc_eta 6 | oc_lam 36 */, kStride = kWs + 150 + 58 + 2;   // 370 floats
+GBP_DEV void sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// cooperative un-pivoted LDL^T inverse of the packed lower triangle at w[kAp..] -> w[kAinv..] (36), lane t of 16
+GBP_DEV void inv6(float* w, int t) {
+  auto uidx = [](int j, int i) { return kU + j * 5 - j * (j - 1) / 2 + (i - j - 1); };   // U[j][i], j < i   (15 entries)
+  float D[6], rD[6];
+  GBP_UNROLL
+  for (int j = 0; j < 6; ++j) {
+    float d = w[kAp + tri(j, j)];
+    GBP_UNROLL
+    for (int k = 0; k < j; ++k) { const float ukj = w[uidx(k, j)]; d -= ukj * ukj * D[k]; }
+    D[j] = d;
+    rD[j] = 1 / d;
+    const int i = j + 1 + t;
+    if (i < 6) {
+      float u = rD[j] * w[kAp + tri(i, j)];
+      GBP_UNROLL
+      for (int k = 0; k < j; ++k) u -= rD[j] * w[uidx(k, i)] * w[uidx(k, j)] * D[k];
+      w[uidx(j, i)] = u;
+    }
+    sync();
+  }
+  {
+    float ui[6];
+    GBP_UNROLL
+    for (int k = 0; k < 6; ++k) ui[k] = 0.f;
+    GBP_UNROLL
+    for (int j = 1; j < 6; ++j) {
+      if (t < j) {
+        float acc = 0.f;
+        acc += w[uidx(t, j)];
+        GBP_UNROLL
+        for (int k = 1; k < j; ++k)
+          if (k > t) acc += ui[k] * w[uidx(k, j)];
+        ui[j] = acc / -1.f;
+        w[kUi + (uidx(t, j) - kU)] = ui[j];
+      }
+    }
+  }
+  sync();
+  GBP_UNROLL
+  for (int r = 0; r < 3; ++r) {
+    const int e = t + 16 * r;
+    if (e < 36) {
+      const int i = e / 6, j = e - 6 * i;
+      const int k0 = i > j ? i : j;
+      float acc = 0.f;
+      GBP_UNROLL
+      for (int k = 0; k < 6; ++k) {
+        if (k >= k0) {
+          const float ww = (k == i) ? rD[k] : w[kUi + (uidx(i, k) - kU)] * rD[k];
+          if (k == j) acc += ww;
+          else acc += ww * w[kUi + (uidx(j, k) - kU)];
+        }
+      }
+      w[kAinv + e] = acc;
+    }
+  }
+  sync();
+}
+}  // namespace coop
+
+__global__ __launch_bounds__(256) void k_sweep_coop16(const SweepArgs a) {
+  using namespace coop;
+  __shared__ float lds[16][kStride];
+  const uint32_t f = threadIdx.x >> 4, t = threadIdx.x & 15;        // factor of the workgroup, lane of the factor
+  const uint32_t p = blockIdx.x * 16 + f, tile = p >> 6, lt = p & 63;
+  float* w = lds[f];
+  const uint32_t cam_i = a.row_cam[p >> 4], lmk_i = a.lmk_idx[p];
+  // ---- stage the factor's 160 input floats: 40 float4 over 16 lanes ----
+  GBP_UNROLL
+  for (int r = 0; r < 3; ++r) {
+    const int i = (int)t + 16 * r;
+    float4 v;
+    int dst = -1;
+    if (i < 14) { v = a.fac[((size_t)tile * kFacG + i) * 64 + lt]; dst = kF + 4 * i; }
+    else if (i < 21) { v = a.cmsg[((size_t)tile * kCmsgG + (i - 14)) * 64 + lt]; dst = kCm + 4 * (i - 14); }
+    else if (i < 25) { v = a.lmsg[(size_t)p * 4 + (i - 21)]; dst = kLm + 4 * (i - 21); }
+    else if (i < 36) { v = a.camb[(size_t)cam_i * kCamRec4 + (i - 25)]; dst = kCb + 4 * (i - 25); }
+    else if (i < 40) { v = a.lmkb[(size_t)lmk_i * kLmkRec4 + (i - 36)]; dst = kLb + 4 * (i - 36); }
+    if (dst >= 0) { w[dst] = v.x; w[dst + 1] = v.y; w[dst + 2] = v.z; w[dst + 3] = v.w; }
+  }
+  sync();
+  const float* fac = w + kF; const float* cm = w + kCm; const float* lm = w + kLm; const float* cb = w + kCb; const float* lb = w + kLb;
+  float damping = lm[3];
+  const int packed = __float_as_int(lm[13]);
+  int count = packed >> 3;
+  uint32_t flags = (uint32_t)packed & 7u;
+  const float var = lm[14];
+  const bool active = (flags & kFlagActive) != 0;
+  bool relin = false;
+  float* out = w + kOut;               // ol[0..15] | oc_eta[16..21] | oc_lam[22..57]
+  GBP_UNROLL
+  for (int r = 0; r < 4; ++r) { const int e = (int)t + 16 * r; if (e < 58) out[e] = 0.f; }
+  if (active) {    // uniform over the 16 lanes of a factor
+    if (0 == count) damping = a.hp.maxeta_damping;
+    count += 1;
+    float d2 = cb[6];
+    d2 += lb[3];
+    d2 += lb[13];
+    d2 += lb[14];
+    const float dmu = sqrtf(d2);
+    relin = (dmu < a.hp.dmu_threshold) && (count > a.hp.min_linear_iters - a.hp.num_undamped_iters);
+    if (relin) {
+      damping = 0.f;
+      count = -a.hp.num_undamped_iters;
+      if (t == 0) {                    // the rare path stays on one lane: relin_core as the product kernel runs it
+        float fr[56], x0c[6], x0l[3], K[9];
+        GBP_UNROLL
+        for (int i = 0; i < 56; ++i) fr[i] = fac[i];
+        GBP_UNROLL
+        for (int i = 0; i < 9; ++i) K[i] = a.K[i];
+        const float4 m0 = a.cam_mu[(size_t)cam_i * 4], m1 = a.cam_mu[(size_t)cam_i * 4 + 1];
+        const float4 l0 = a.lmk_mu[(size_t)lmk_i * 2];
+        x0c[0] = m0.x; x0c[1] = m0.y; x0c[2] = m0.z; x0c[3] = m0.w; x0c[4] = m1.x; x0c[5] = m1.y;
+        x0l[0] = l0.x; x0l[1] = l0.y; x0l[2] = l0.z;
+        if (a.hp.relin_mode == 1) {
+          GBP_UNROLL
+          for (int i = 0; i < 54; ++i) fr[i] = 0.f;
+        }
+        const bool robust = relin_core<0>(fr, x0c, x0l, K, var, a.hp.nstds);
+        GBP_UNROLL
+        for (int i = 0; i < 54; ++i) w[kF + i] = fr[i];
+        w[kStride - 1] = robust ? 1.f : 0.f;
+      }
+      sync();
+      flags = w[kStride - 1] != 0.f ? (flags | kFlagRobust) : (flags & ~kFlagRobust);
+    }
+    const float omd = 1 - damping;
+    // ---- factor -> landmark message (gbp_codelets.cpp:503-562, 664-709) ----
+    GBP_UNROLL
+    for (int r = 0; r < 2; ++r) {
+      const int e = (int)t + 16 * r;
+      if (e < 21) {
+        int i = 0;
+        while ((i + 1) * (i + 2) / 2 <= e) ++i;
+        const int j = e - i * (i + 1) / 2;
+        float v = fac[9 + e] + cb[8 + i * 6 + j];
+        w[kAp + e] = v - cm[6 + e];
+      }
+    }
+    if (t < 6) { const float v = fac[t] + cb[t]; w[kEd + t] = v - cm[t]; }
+    sync();
+    inv6(w, (int)t);
+    GBP_UNROLL
+    for (int r = 0; r < 2; ++r) {
+      const int e = (int)t + 16 * r;
+      if (e < 18) {
+        const int i = e / 6, j = e - 6 * i;
+        float acc = 0.f;
+        GBP_UNROLL
+        for (int k = 0; k < 6; ++k) acc += fac[30 + k * 3 + i] * w[kAinv + k * 6 + j];
+        w[kG + e] = acc;
+      }
+    }
+    sync();
+    if (t < 3) {
+      float s = 0.f;
+      GBP_UNROLL
+      for (int k = 0; k < 6; ++k) s += w[kG + t * 6 + k] * w[kEd + k];
+      const float h = fac[6 + t] - s;
+      out[t] = h * omd + lm[t] * damping;
+    } else if (t < 12) {
+      const int e = (int)t - 3, i = e / 3, j = e - 3 * i;
+      float tt = 0.f;
+      GBP_UNROLL
+      for (int k = 0; k < 6; ++k) tt += w[kG + i * 6 + k] * fac[30 + k * 3 + j];
+      out[4 + e] = fac[48 + trisym(i, j)] - tt;
+    }
+    // ---- factor -> camera message (gbp_codelets.cpp:411-471, 592-637) ----
+    if (t < 9) {
+      const int i = (int)t / 3, j = (int)t - 3 * i;
+      const float v = fac[48 + trisym(i, j)] + lb[4 + t];
+      w[kBp + t] = v - lm[4 + t];
+    }
+    if (t < 3) { const float v = fac[6 + t] + lb[t]; w[kEl + t] = v - lm[t]; }
+    sync();
+    {
+      float M[9], I[9];
+      GBP_UNROLL
+      for (int i = 0; i < 9; ++i) M[i] = w[kBp + i];
+      inv3x3(M, I);                    // 50 operations: every lane runs it, lane t < 9 keeps entry t
+      if (t < 9) {
+        float v = I[0];
+        GBP_UNROLL
+        for (int i = 1; i < 9; ++i) v = ((int)t == i) ? I[i] : v;
+        w[kBi + t] = v;
+      }
+    }
+    sync();
+    GBP_UNROLL
+    for (int r = 0; r < 2; ++r) {
+      const int e = (int)t + 16 * r;
+      if (e < 18) {
+        const int i = e / 3, j = e - 3 * i;
+        float acc = 0.f;
+        GBP_UNROLL
+        for (int k = 0; k < 3; ++k) acc += fac[30 + i * 3 + k] * w[kBi + k * 3 + j];
+        w[kG2 + e] = acc;
+      }
+    }
+    sync();
+    if (t < 6) {
+      float s = 0.f;
+      GBP_UNROLL
+      for (int k = 0; k < 3; ++k) s += w[kG2 + t * 3 + k] * w[kEl + k];
+      const float h = fac[t] - s;
+      out[16 + t] = h * omd + cm[t] * damping;
+    }
+    GBP_UNROLL
+    for (int r = 0; r < 3; ++r) {
+      const int e = (int)t + 16 * r;
+      if (e < 36) {
+        const int i = e / 6, j = e - 6 * i;
+        float tt = 0.f;
+        GBP_UNROLL
+        for (int k = 0; k < 3; ++k) tt += w[kG2 + i * 3 + k] * fac[30 + j * 3 + k];
+        out[22 + e] = fac[9 + trisym(i, j)] - tt;
+      }
+    }
+  }
+  if (t == 0) {
+    out[3] = damping;
+    out[13] = __int_as_float((int)(((uint32_t)count << 3) | flags));
+    out[14] = var;
+  }
+  sync();
+  // ---- stores: landmark-message record (64 B), camera message (7 groups of the tile layout), potential if relinearised ----
+  if (t < 4) a.lmsg[(size_t)p * 4 + t] = make_float4(out[4 * t], out[4 * t + 1], out[4 * t + 2], out[4 * t + 3]);
+  if (t < 7) {
+    float c4[4];
+    GBP_UNROLL
+    for (int q = 0; q < 4; ++q) {
+      const int e = 4 * (int)t + q;            // cmo[e]: eta 0..5, lower triangle 6..26, pad
+      float v = 0.f;
+      if (e < 6) v = out[16 + e];
+      else if (e < 27) {
+        const int m = e - 6;
+        int i = 0;
+        while ((i + 1) * (i + 2) / 2 <= m) ++i;
+        const int j = m - i * (i + 1) / 2;
+        v = out[22 + i * 6 + j];
+      }
+      c4[q] = v;
+    }
+    a.cmsg[((size_t)tile * kCmsgG + t) * 64 + lt] = make_float4(c4[0], c4[1], c4[2], c4[3]);
+  }
+  if (active && relin && t < 14) a.fac[((size_t)tile * kFacG + t) * 64 + lt] = make_float4(w[kF + 4 * t], w[kF + 4 * t + 1], w[kF + 4 * t + 2], w[kF + 4 * t + 3]);
+  // ---- row sums over the 16 factors of the workgroup (= one camera row): the tree of row16_sum ----
+  __syncthreads();
+  if (threadIdx.x < 44) {
+    const int j = (int)threadIdx.x;
+    float r = 0.f;
+    if (j != 6 && j != 7) {
+      const int src = j < 6 ? kOut + 16 + j : kOut + 22 + (j - 8);
+      float x[16];
+      GBP_UNROLL
+      for (int q = 0; q < 16; ++q) x[q] = lds[q][src];
+      const float q0 = (x[0] + x[1]) + (x[2] + x[3]), q1 = (x[6] + x[7]) + (x[4] + x[5]);     // operand order of the DPP steps of lane 0 / lane 15
+      const float q2 = (x[8] + x[9]) + (x[10] + x[11]), q3 = (x[15] + x[14]) + (x[13] + x[12]);
+      r = (q0 + q1) + (q3 + q2);
+    }
+    reinterpret_cast<float*>(a.rowp)[(size_t)blockIdx.x * kCamRec + j] = r;
+  }
+}
+#endif  // GBP_BUILD_EXPERIMENTS
+
 // =================================================================================================
 // k_linearise: RelineariseFactorVertex on every factor (no active_flag test in the reference).
 // =================================================================================================
@@ -545,24 +838,17 @@ GBP_DEV float4 lmsg_piece(const float4* lmsg, uint32_t pos, uint32_t q) {
   return m;
 }
 
-GBP_DEV void cam_mean(const float (&cb)[44], float (&x0c)[6]) {
-  float Al[21], S6[36];
-  GBP_UNROLL
-  for (int i = 0; i < 6; ++i) {
-    GBP_UNROLL
-    for (int j = 0; j <= i; ++j) Al[tri(i, j)] = cb[8 + i * 6 + j];
-  }
-  inv6x6_lower(Al, S6);
-  GBP_UNROLL
-  for (int i = 0; i < 6; ++i) {
-    float acc = 0.f;
-    GBP_UNROLL
-    for (int k = 0; k < 6; ++k) acc += S6[i * 6 + k] * cb[k];
-    x0c[i] = acc;
-  }
+// mean of a camera belief record (44 floats, in registers or in LDS): inf2mean6x6 (bafuncs.cpp:2-9)
+template <class REC>
+GBP_DEV void cam_mean(REC&& cb, float (&x0c)[6]) {
+  solve6_lower([&](int i, int j) { return cb[8 + i * 6 + j]; }, [&](int k) { return cb[k]; }, x0c);
 }
 
+#ifdef GBP_BELIEFS_WAVES   // occupancy experiment (profiles/r03_beliefs.md): -DGBP_BELIEFS_WAVES=7|8 through GBP_EXTRA_HIPFLAGS
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GBP_BELIEFS_WAVES, GBP_BELIEFS_WAVES))) void k_beliefs(const BeliefArgs b) {
+#else
 __global__ __launch_bounds__(256) void k_beliefs(const BeliefArgs b) {
+#endif
   __shared__ float sh[4][48];
   if (blockIdx.x < b.cam_blocks) {
     const uint32_t w = threadIdx.x >> 6, j = threadIdx.x & 63;
@@ -618,10 +904,8 @@ __global__ __launch_bounds__(256) void k_beliefs(const BeliefArgs b) {
     if (b.hoist && w == 0 && j < 4) {
       const uint32_t cj = b.cam0 + blockIdx.x * 4 + j;
       if (cj < b.cam1) {
-        float cb[44], x0c[6];
-        GBP_UNROLL
-        for (int i = 0; i < 44; ++i) cb[i] = sh[j][i];
-        cam_mean(cb, x0c);
+        float x0c[6];
+        cam_mean(sh[j], x0c);                    // operands straight from LDS: the 44-float copy cost 14 VGPRs of occupancy
         float4* mu = b.cam_mu + (size_t)cj * 4;  // [0,1] = means of the current belief, [2,3] = means the last sweep used
         float4 u0 = mu[2], u1 = mu[3];
         if (b.roll) { u0 = mu[0]; u1 = mu[1]; mu[2] = u0; mu[3] = u1; }
@@ -660,20 +944,36 @@ __global__ __launch_bounds__(256) void k_beliefs(const BeliefArgs b) {
     ix = reinterpret_cast<const uint4*>(b.lmk_ix)[(size_t)l * 4 + q];
     acc = b.lmk_prior[(size_t)l * 4 + q];
   }
+#ifdef GBP_BUILD_EXPERIMENTS
+  if (b.abl == 2) ix = make_uint4(live ? 10u : 0u, 0u, 0u, 0u);   // degree without waiting for the record (S1: 10 everywhere)
+#endif
   const uint32_t deg = (uint32_t)__shfl((int)ix.x, 0, 4);
   {
-    uint32_t pos[15];
-    float4 m[15];
-    GBP_UNROLL
-    for (int k = 0; k < 15; ++k) {   // element k + 1 of the index record sits in lane (k + 1) / 4, component (k + 1) % 4
+    // element k + 1 of the index record sits in lane (k + 1) / 4, component (k + 1) % 4 of the quad
+    auto slot_pos = [&](int k) -> uint32_t {
       const uint32_t v = ((k + 1) & 3) == 0 ? ix.x : ((k + 1) & 3) == 1 ? ix.y : ((k + 1) & 3) == 2 ? ix.z : ix.w;
-      pos[k] = (uint32_t)__shfl((int)v, (k + 1) >> 2, 4);
-    }
+      uint32_t pk = (uint32_t)__shfl((int)v, (k + 1) >> 2, 4);
+#ifdef GBP_BUILD_EXPERIMENTS   // timing only: where would the kernel be with a streaming / an index-free gather?
+      if (b.abl == 1) pk = b.lmk_ptr[0] + l * 10u + (uint32_t)k;
+      if (b.abl == 2) pk = (uint32_t)(((uint64_t)(l * 10u + (uint32_t)k) * 2654435761ull) % ((uint64_t)b.n_lmks * 10u));
+#endif
+      return pk;
+    };
+    // Ten gathers in flight, then (only where a landmark of the wave has more than ten factors) the other five: 40
+    // instead of 60 staging registers (S1: k_beliefs 20.4 -> 18.8 us; profiles/r03_beliefs.md).
+    float4 m[10];
     GBP_UNROLL
-    for (int k = 0; k < 15; ++k) m[k] = (uint32_t)k < deg ? lmsg_piece(b.lmsg, pos[k], q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < 10; ++k) m[k] = (uint32_t)k < deg ? lmsg_piece(b.lmsg, slot_pos(k), q) : make_float4(0.f, 0.f, 0.f, 0.f);
     GBP_UNROLL
-    for (int k = 0; k < 15; ++k)     // adds in slot order
+    for (int k = 0; k < 10; ++k)     // adds in slot order
       if ((uint32_t)k < deg) { acc.x = acc.x + m[k].x; acc.y = acc.y + m[k].y; acc.z = acc.z + m[k].z; acc.w = acc.w + m[k].w; }
+    if (__any(deg > 10u)) {
+      GBP_UNROLL
+      for (int k = 10; k < 15; ++k) m[k - 10] = (uint32_t)k < deg ? lmsg_piece(b.lmsg, slot_pos(k), q) : make_float4(0.f, 0.f, 0.f, 0.f);
+      GBP_UNROLL
+      for (int k = 10; k < 15; ++k)
+        if ((uint32_t)k < deg) { acc.x = acc.x + m[k - 10].x; acc.y = acc.y + m[k - 10].y; acc.z = acc.z + m[k - 10].z; acc.w = acc.w + m[k - 10].w; }
+    }
   }
   if (deg > 15u) {   // slots 16.. : positions from lmk_fpos, 8 record gathers in flight per round, adds in slot order
     const uint32_t s1 = b.lmk_ptr[l + 1];
@@ -1456,6 +1756,12 @@ void launch_sweep_blocks(SweepArgs a, uint32_t block0, uint32_t block1, bool hoi
   if (block1 <= block0) return;
   a.block0 = block0;
   const dim3 g((block1 - block0) * (4 / kWpb)), b(64 * kWpb);
+#ifdef GBP_BUILD_EXPERIMENTS
+  if (a.variant == 1 && hoist) {   // gbp_params.reserved[0] = 1: the sub-wave mapping (mapping experiments, parity test)
+    hipLaunchKernelGGL(k_sweep_coop16, dim3((block1 - block0) * 16), dim3(256), 0, s, a);   // needs block0 == 0 (whole sweeps only)
+    return;
+  }
+#endif
 #ifdef GBP_BUILD_ABLATIONS   // experiments build only: GBP_SWEEP_ABL swaps an ablated instantiation into the REAL iteration flow
   static const int env_abl = std::getenv("GBP_SWEEP_ABL") ? std::atoi(std::getenv("GBP_SWEEP_ABL")) : 0;
   if (env_abl && hoist) {
@@ -1491,6 +1797,10 @@ bool launch_sweep_ablated(const SweepArgs& a, uint32_t n_tiles, int abl, hipStre
     GBP_ABL_CASE(64) GBP_ABL_CASE(128) GBP_ABL_CASE(128 + 256) GBP_ABL_CASE(128 + 512) GBP_ABL_CASE(128 + 1024)
     GBP_ABL_CASE(128 + 2048) GBP_ABL_CASE(128 + 256 + 512 + 1024 + 2048) GBP_ABL_CASE(128 + 256 + 512)
 #undef GBP_ABL_CASE
+#ifdef GBP_BUILD_EXPERIMENTS
+    case 3000: hipLaunchKernelGGL(k_sweep_w3, g, b, 0, s, a); break;       // the product sweep at 3 waves / SIMD
+    case 3001: hipLaunchKernelGGL(k_sweep_coop16, dim3(n_tiles * 4), dim3(256), 0, s, a); break;   // 16 lanes per factor
+#endif
     default: hipLaunchKernelGGL((k_sweep<true, 0>), g, b, 0, s, a); break;
   }
 #endif

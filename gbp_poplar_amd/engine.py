@@ -17,7 +17,7 @@ class GbpEngine:
     def __init__(self, cam_id, lmk_id, n_cams, n_lmks, K9, params=None, shard=None, hooks=False):
         """hooks=True loads libgbp_mi355x_test.so — the product sources + the gbp_debug_* test hooks
         (include/gbp_mi355x_debug.h) — instead of the product library; only tests and profiles/ ask for it."""
-        self.hooks = bool(hooks)
+        self.hooks = hooks if hooks == "exp" else bool(hooks)     # "exp": the experiments build (has the hooks too)
         self.lib = load(hooks=self.hooks)
         self._keep = []
         self.problem = cabi.make_problem(cam_id, lmk_id, n_cams, n_lmks, K9, self._keep)

@@ -11,6 +11,7 @@ ARGS="--steps 5 --warmup 12 --cpu-seconds 0 --profile-steps 0"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY --output-format csv -d $OUT/sq -o sq -- python3 $REPO/bench.py $ARGS > /dev/null 2> $OUT/sq.log
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $OUT/tcc -o tcc -- python3 $REPO/bench.py $ARGS > /dev/null 2> $OUT/tcc.log
 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum --output-format csv -d $OUT/ea -o ea -- python3 $REPO/bench.py $ARGS > /dev/null 2> $OUT/ea.log
+rocprofv3 --pmc TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_RD_UNCACHED_32B_sum --output-format csv -d $OUT/ea2 -o ea2 -- python3 $REPO/bench.py $ARGS > /dev/null 2> $OUT/ea2.log
 python3 - <<PY
 import csv, glob, os
 out = "$OUT"

@@ -4,6 +4,7 @@ import ctypes as C
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("GBP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gbp_poplar_amd", "libgbp_mi355x_exp.so"))
 from gbp_poplar_amd import driver, hostlib
 from gbp_poplar_amd.engine import GbpEngine
 cams, lmks = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1000, 100000)
@@ -14,7 +15,9 @@ eng = GbpEngine(bal["cam_id"], bal["lmk_id"], cams, lmks, K, hooks=True)
 eng.upload(state)
 eng.linearise()
 eng.iterate(12)
-for abl, name in ((100, "k_beliefs"), (101, "camera part"), (102, "landmark part")):
+for abl, name in ((100, "k_beliefs"), (101, "camera part"), (102, "landmark part"),
+                  (103, "landmark part, records read in landmark-major order (streaming gather; experiments build)"),
+                  (104, "landmark part, random records WITHOUT the index-record load (experiments build)")):
     us = C.c_double()
     rc = eng.lib.gbp_debug_time_sweep(eng.h, abl, 50, C.byref(us))
     print("%-14s %8.2f us  rc=%d" % (name, us.value, rc))
