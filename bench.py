@@ -239,9 +239,10 @@ def measure_traffic_live(a, keep_dir=None, world=1):
             continue
         f_kb, n = vals["fetch"][k]
         w_kb, _ = vals["write"][k]
-        # k_sweep / k_relin read wide coalesced streams (counted at 1/2 on gfx950 -> doubled); k_beliefs reads 64-B records
-        # at random: one request per record, uncalibrated, reported uncorrected with the doubled figure as upper bound
-        mult = 1.0 if k == "k_beliefs" else 2.0
+        # FETCH_SIZE = fabric read requests x 64 B, but the requests are 128-B line fills (gfx950 correction of the guide):
+        # doubled for the streaming kernels AND for k_beliefs — its counters show no 32-B request (TCC_EA0_RDREQ_32B = 0)
+        # and 0.69 M requests for 1.0 M 64-B records, i.e. one fill brings both halves of a line (profiles/r03_beliefs.md)
+        mult = 2.0
         out[k] = {"fetch_kb": f_kb, "write_kb": w_kb, "dispatches": n,
                   "hbm_bytes_per_launch": int((mult * f_kb + w_kb) * 1024),
                   "hbm_bytes_upper_bound": int((2.0 * f_kb + w_kb) * 1024)}
@@ -554,7 +555,7 @@ def main(argv=None):
                  "traffic_upper_bound": kb["hbm_bytes_upper_bound"] if kb else None,
                  "frac": round(kb["hbm_bytes_per_launch"] / belief_s / 1e9 / HBM_PEAK_GBS, 4) if kb else None,
                  "algorithmic_bytes": bel_algo,
-                 "note": "random 64-B record gathers: FETCH_SIZE taken uncorrected (one request per record), doubled figure as upper bound"}]
+                 "note": "64-B record gathers served by 128-B line fills: read side doubled like the streaming kernels (profiles/r03_beliefs.md)"}]
 
     cpu = None
     if rank == 0 and world == 1 and a.cpu_seconds > 0:

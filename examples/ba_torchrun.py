@@ -1,8 +1,10 @@
-"""Multi-GPU front end with the `ba` / `slam` flag sets: what `./ba --ipus N` and `./slam --ipus N` (reference
-ba/ba.cpp:414-417,617-649, ba/slam.cpp:422-425) map to.
+"""EXAMPLE, not the product path: a caller that brings its OWN collective (torch.distributed) around the split-phase
+C-ABI (gbp_iterate_begin / gbp_iterate_local / gbp_iterate_end, gbp_poplar_amd/distributed.py), with the `ba` / `slam` flag
+sets.  The product's multi-GPU path is `bin/ba --ipus N` / `bin/slam --ipus N`: one forked process per GPU, the exchange
+owned by the C++ library (csrc/gbp_comm.cpp, RCCL).
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-           -m gbp_poplar_amd.ba_mp --bal_file F [--n_iters K] [--eval_every E] [... the ba flags]
+           examples/ba_torchrun.py --bal_file F [--n_iters K] [--eval_every E] [... the ba flags]
 
 One process per GPU; landmarks are sharded over the ranks (gbp_poplar_amd.distributed), rank 0 prints the
 same lines as `./ba` (ba.cpp:996,1004,1026-1028) or, with `--slam`, as `./slam` (slam.cpp:1073-1076; keyframes
@@ -13,9 +15,11 @@ import os
 import sys
 import time
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
 
 def main(argv=None):
-    ap = argparse.ArgumentParser(prog="ba_mp")
+    ap = argparse.ArgumentParser(prog="ba_torchrun")
     ap.add_argument("--bal_file", required=True)
     ap.add_argument("--n_iters", type=int, default=1500)
     ap.add_argument("--reproj_meas_var", type=float, default=4.0)
@@ -48,9 +52,9 @@ def main(argv=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    from . import driver, hostlib
-    from .distributed import ShardedGbp, landmark_partition
-    from .engine import GbpEngine
+    from gbp_poplar_amd import driver, hostlib
+    from gbp_poplar_amd.distributed import ShardedGbp, landmark_partition
+    from gbp_poplar_amd.engine import GbpEngine
 
     log = print if rank == 0 else (lambda *x: None)
     try:

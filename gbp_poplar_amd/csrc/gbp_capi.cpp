@@ -489,9 +489,9 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
     const char* pe = std::getenv("GBP_PERSIST");                     // measurements: -1 / 0 / 1 like gbp_params.persistent
     const int mode = pe ? std::atoi(pe) : c->prm.persistent;
     const uint32_t nb = persist_blocks(c->n_tiles, c->C, c->L_loc);
-    // measured (profiles/r03_small_graphs.md): the shipped sequences (14 - 52 workgroups, relinearising in every sweep) run
-    // 1.26 - 1.45x faster in k_persist; converging synthetic graphs break even at ~40 workgroups and lose beyond
-    const uint32_t auto_limit = 56;
+    // measured (profiles/r03_small_graphs.md): the shipped sequences (19 - 61 workgroups, relinearising in every sweep) run
+    // 1.26 - 1.45x faster in k_persist; converging synthetic graphs break even at ~40 workgroups (0.95x at 63)
+    const uint32_t auto_limit = 64;
     if (mode >= 0 && !sh && c->hoist && !c->use_tile_perm && nb <= (mode > 0 ? 1u << 30 : auto_limit)) {
       const int resident = persist_max_resident_blocks();
       if (resident > 0 && nb <= (uint32_t)resident) {

@@ -1,4 +1,14 @@
-"""Landmark-sharded multi-GPU GBP: one process per GPU, torch.distributed (RCCL over xGMI) for the
+"""The split-phase C-ABI (gbp_iterate_begin / _local / _end) driven by a CALLER-OWNED collective — test harness and
+example, not the product's multi-GPU path.
+
+The product path is the library-owned exchange: `bin/ba --ipus N` / `bin/slam --ipus N` and bench.py fork / launch one
+process per GPU, csrc/gbp_comm.cpp issues the RCCL all-gather inside gbp_iterate (ONE exchange
+path).  This module stays because (a) the CPU suite exercises the sharding logic on 2 gloo ranks through it with an
+oracle-backed engine (tests/test_distributed_gloo.py), (b) the GPU suite emulates N shards on one GPU with it
+(dist=None: the "exchange" is a copy), (c) it documents what a caller with its own collective (torch.distributed, MPI)
+has to do — examples/ba_torchrun.py.
+
+Landmark-sharded multi-GPU GBP: one process per GPU, torch.distributed (RCCL over xGMI) for the
 single exchange step of an iteration.
 
 Replaces the reference's `--ipus N` (ba.cpp:414-417,617-623: one Poplar graph spread over N x 1216

@@ -4,7 +4,7 @@
 # Pass 2: the bench's own live PMC passes (FETCH_SIZE / WRITE_SIZE in separate rocprofv3 runs, MI355X_MICROARCH.md HBM:
 #         the TCC slots do not hold both; FETCH_SIZE reads 1/2 of wide coalesced streams on gfx950), CSVs kept.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT

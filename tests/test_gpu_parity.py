@@ -36,6 +36,16 @@ def _golden(name):
     return np.load(os.path.join(os.path.dirname(__file__), "golden", name))
 
 
+def _example(name):
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", name + ".py")
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def _bal(name):
     from gbp_poplar_amd import hostlib
     return hostlib.bal_read(seq_path(name))
@@ -1220,8 +1230,8 @@ def test_config5_at_size_eight_shards_on_one_gpu(oracle_mod):
 
 
 def test_ba_mp_front_end_single_gpu(capsys):
-    """`python -m gbp_poplar_amd.ba_mp` (the --ipus/--gpus N front end) on one GPU prints the ba lines and converges."""
-    from gbp_poplar_amd import ba_mp
+    """examples/ba_torchrun.py (a caller with its own collective around the split-phase C-ABI) on one GPU prints the ba lines and converges."""
+    ba_mp = _example("ba_torchrun")
     rc = ba_mp.main(["--bal_file", seq_path("fr2robot2"), "--n_iters", "40", "--eval_every", "10"])
     out = capsys.readouterr().out
     assert rc == 0 and "Initial Reprojection error: 39.8638" in out and out.count("Weakening priors") == 5
@@ -1232,7 +1242,7 @@ def test_ba_mp_front_end_single_gpu(capsys):
 def test_ba_mp_front_end_init_options(capsys):
     """The initialisation flags of ba.cpp:422-441 in the Python front end: --tn/--rn/--ltn with --seed reproduce, --avdepth_on
     re-places the landmarks (same host functions as the C++ CLIs: gbp_init_add_noise / gbp_init_av_depth)."""
-    from gbp_poplar_amd import ba_mp
+    ba_mp = _example("ba_torchrun")
     outs = []
     for seed in ("4", "4", "5"):
         assert ba_mp.main(["--bal_file", seq_path("fr2robot2"), "--n_iters", "12", "--eval_every", "4", "--tn", "0.02", "--rn", "0.5",
@@ -1245,7 +1255,7 @@ def test_ba_mp_front_end_init_options(capsys):
 
 def test_ba_mp_front_end_slam_mode(capsys):
     """`ba_mp --slam` (what `./slam --ipus N` maps to) on one GPU: keyframes are added and the slam lines printed."""
-    from gbp_poplar_amd import ba_mp
+    ba_mp = _example("ba_torchrun")
     rc = ba_mp.main(["--bal_file", seq_path("fr2robot2"), "--slam", "--iters_between_kfs", "20", "--eval_every", "19"])
     out = capsys.readouterr().out
     assert rc == 0 and "Initial Reprojection error: 32.7526" in out          # BASELINE.md: two keyframes active
