@@ -111,6 +111,8 @@ struct PersistArgs {
   uint32_t n_tiles;        // sweep tiles = waves with a phase-A role
   uint32_t n_lmk_groups;   // ceil(L / 16): waves [C, C + n_lmk_groups) own 16 landmarks each in phase B
   int n_iters;
+  uint32_t spread;         // the grid is `spread` times larger than the work and only every spread-th workgroup works (4: see launch_persist)
+  uint32_t n_work_blocks;  // working workgroups (== gridDim.x unless spread)
   unsigned* sync;          // [kPersistSyncWords] barrier words, zero on entry
   unsigned* status;        // host-mapped: set to 1 if a barrier gave up waiting (a workgroup was not resident)
   unsigned long long* trace;  // experiments build only (else NULL): [wave][iteration < kPersistTraceIters][8] wall-clock ticks

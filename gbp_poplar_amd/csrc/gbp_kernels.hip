@@ -1107,7 +1107,20 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
   const SweepArgs& a = A.s;
   const BeliefArgs& b = A.b;
   const uint32_t wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const uint32_t w = blockIdx.x * 4 + wib;                    // wave of the grid
+  // placement (profiles/r03_small_graphs.md): the grid is `spread` times larger than the work; filler workgroups leave at once.
+  // spread > 0: workgroup b works iff b % spread == 0;  spread < 0 (s = -spread): iff (b / 8) % s == 0 (every XCD keeps working,
+  // every s-th dispatch slot inside an XCD)
+  uint32_t bid = blockIdx.x, nblk = gridDim.x;
+  if ((int)A.spread > 1) {
+    if (blockIdx.x % A.spread) return;
+    bid = blockIdx.x / A.spread; nblk = gridDim.x / A.spread;
+  } else if ((int)A.spread < -1) {
+    const uint32_t sp = (uint32_t)(-(int)A.spread), slot = blockIdx.x >> 3;
+    if (slot % sp) return;
+    bid = (slot / sp) * 8 + (blockIdx.x & 7u); nblk = A.n_work_blocks;
+    if (bid >= nblk) return;
+  }
+  const uint32_t w = bid * 4 + wib;                           // wave of the grid
   __shared__ float4 lm_stage[4][64 * 4];
   __shared__ float sh[4][48];
   float4* stage = lm_stage[wib];
@@ -1270,7 +1283,7 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
       }
     }
     GBP_TRACE(1);
-    grid_sync(A.sync, ++epoch, gridDim.x, A.status);
+    grid_sync(A.sync, ++epoch, nblk, A.status);
     GBP_TRACE(2);
 
     // ================= phase B: the belief update (arithmetic of k_beliefs, roll = 1) =================
@@ -1392,7 +1405,7 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
       if (lmk_live) st4_xw(b.lmkb + (size_t)l * 4 + q4, acc);
     }
     GBP_TRACE(3);
-    if (it + 1 < A.n_iters) grid_sync(A.sync, ++epoch, gridDim.x, A.status);
+    if (it + 1 < A.n_iters) grid_sync(A.sync, ++epoch, nblk, A.status);
     GBP_TRACE(4);
   }
 #undef GBP_TRACE
@@ -1943,13 +1956,29 @@ int persist_max_resident_blocks() {
 void launch_persist(PersistArgs A, hipStream_t s) {
   A.n_lmk_groups = (A.b.n_lmks + 15) / 16;
   const uint32_t nb = persist_blocks(A.n_tiles, A.b.n_cams, A.b.n_lmks);
+  // Placement: the grid is 4x the work and only every 4th workgroup works (the fillers leave at once).  Measured
+  // (profiles/persist_placement.py, profiles/r03_small_graphs.md): with the working workgroups in consecutive dispatch slots a
+  // few of them — always all four waves of a workgroup, on a CU next to another working CU — run their fp64-heavy sections
+  // 2-2.7x slower and set the barrier-to-barrier time; every 2nd or 4th slot removes those outliers (fr1xyz 22.0 -> 19.3 us
+  // per iteration in the traced build), every 3rd does not.
+  // Workgroup b runs on XCD b % 8 (round-robin dispatch), so every spread-th workgroup lands on 8 / spread XCDs of 32 CUs:
+  // the working workgroups stay co-resident (one per CU: 340 registers per lane) only while nb <= 32 * 8 / spread.
+  int spread = nb <= 64 ? 4 : nb <= 128 ? 2 : 1;
+  A.n_work_blocks = nb;
 #ifdef GBP_BUILD_ABLATIONS
+  static const int env_spread = std::getenv("GBP_PERSIST_SPREAD") ? std::atoi(std::getenv("GBP_PERSIST_SPREAD")) : 0;
+  if (env_spread) spread = env_spread;      // placement study: the caller keeps nb within what the chosen placement can hold
   static const int env_abl = std::getenv("GBP_PERSIST_ABL") ? std::atoi(std::getenv("GBP_PERSIST_ABL")) : 0;
-  if (env_abl == 256) { hipLaunchKernelGGL(k_persist<256>, dim3(nb), dim3(256), 0, s, A); return; }
-  if (env_abl == 64) { hipLaunchKernelGGL(k_persist<64>, dim3(nb), dim3(256), 0, s, A); return; }
-  if (env_abl == 768) { hipLaunchKernelGGL(k_persist<768>, dim3(nb), dim3(256), 0, s, A); return; }
+  if (env_abl) {
+    A.spread = 1;
+    if (env_abl == 256) { hipLaunchKernelGGL(k_persist<256>, dim3(nb), dim3(256), 0, s, A); return; }
+    if (env_abl == 64) { hipLaunchKernelGGL(k_persist<64>, dim3(nb), dim3(256), 0, s, A); return; }
+    if (env_abl == 768) { hipLaunchKernelGGL(k_persist<768>, dim3(nb), dim3(256), 0, s, A); return; }
+  }
 #endif
-  hipLaunchKernelGGL(k_persist<0>, dim3(nb), dim3(256), 0, s, A);
+  A.spread = (uint32_t)spread;
+  const uint32_t grid = spread > 1 ? nb * (uint32_t)spread : spread < -1 ? ((nb + 7) / 8) * (uint32_t)(-spread) * 8 : nb;
+  hipLaunchKernelGGL(k_persist<0>, dim3(grid), dim3(256), 0, s, A);
 }
 void launch_weaken(float4* prior, const float* scaling, uint32_t* flag, uint32_t n, int rec4, hipStream_t s) {
   hipLaunchKernelGGL(k_weaken, dim3(blocks_for((uint64_t)n * rec4)), dim3(256), 0, s, prior, scaling, flag, n, rec4);

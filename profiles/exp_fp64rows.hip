@@ -8,10 +8,10 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 template <int OP>
-__global__ void k_chain(float* out, unsigned long long mask, int n) {
+__global__ void k_chain(float* out, unsigned long long mask, int n, float x0 = 1.0f) {
   const unsigned lane = threadIdx.x & 63;
-  float x = 1.0f + lane * 1e-3f;
-  double d = 1.0 + lane * 1e-3;
+  float x = x0 * (1.0f + lane * 1e-3f);
+  double d = (double)x0 * (1.0 + lane * 1e-3);
   if ((mask >> lane) & 1ull) {
     for (int i = 0; i < n; ++i) {
       if (OP == 0) {          // div_shared's body: cvt, mul, cvt
@@ -29,12 +29,12 @@ __global__ void k_chain(float* out, unsigned long long mask, int n) {
       }
     }
   }
-  out[blockIdx.x * 64 + lane] = x + (float)d;
+  out[blockIdx.x * blockDim.x + threadIdx.x] = x + (float)d;
 }
 
 int main() {
   float* out;
-  CK(hipMalloc(&out, 64 * 64 * 4));
+  CK(hipMalloc(&out, 64 * 512 * 4));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
@@ -51,10 +51,53 @@ int main() {
       float ms = 0;
       for (int rep = 0; rep < 2; ++rep) {
         CK(hipEventRecord(e0, nullptr));
-        if (op == 0) hipLaunchKernelGGL(k_chain<0>, dim3(64), dim3(64), 0, nullptr, out, mk.m, n);
-        if (op == 1) hipLaunchKernelGGL(k_chain<1>, dim3(64), dim3(64), 0, nullptr, out, mk.m, n);
-        if (op == 2) hipLaunchKernelGGL(k_chain<2>, dim3(64), dim3(64), 0, nullptr, out, mk.m, n);
-        if (op == 3) hipLaunchKernelGGL(k_chain<3>, dim3(64), dim3(64), 0, nullptr, out, mk.m, n);
+        if (op == 0) hipLaunchKernelGGL(k_chain<0>, dim3(64), dim3(64), 0, nullptr, out, mk.m, n, 1.0f);
+        if (op == 1) hipLaunchKernelGGL(k_chain<1>, dim3(64), dim3(64), 0, nullptr, out, mk.m, n, 1.0f);
+        if (op == 2) hipLaunchKernelGGL(k_chain<2>, dim3(64), dim3(64), 0, nullptr, out, mk.m, n, 1.0f);
+        if (op == 3) hipLaunchKernelGGL(k_chain<3>, dim3(64), dim3(64), 0, nullptr, out, mk.m, n, 1.0f);
+        CK(hipEventRecord(e1, nullptr));
+        CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+      }
+      printf(" %.2f ns |", 1e6 * ms / ((double)n * 16 * 3));
+    }
+    printf("\n");
+  }
+  // ---- does a CU share its fp64 / conversion / transcendental pipe between its four SIMDs?  1, 2, 4 wavefronts per
+  // workgroup (one per SIMD), all 64 lanes active, 64 workgroups: ns per instruction of one wave ----
+  printf("\n| waves per workgroup (one per SIMD) | %s | %s | %s | %s |\n|---|---|---|---|---|\n", ops[0], ops[1], ops[2], ops[3]);
+  for (int wpb = 1; wpb <= 8; wpb *= 2) {
+    printf("| %d |", wpb);
+    for (int op = 0; op < 4; ++op) {
+      float ms = 0;
+      for (int rep = 0; rep < 2; ++rep) {
+        CK(hipEventRecord(e0, nullptr));
+        if (op == 0) hipLaunchKernelGGL(k_chain<0>, dim3(64), dim3(64 * wpb), 0, nullptr, out, ~0ull, n, 1.0f);
+        if (op == 1) hipLaunchKernelGGL(k_chain<1>, dim3(64), dim3(64 * wpb), 0, nullptr, out, ~0ull, n, 1.0f);
+        if (op == 2) hipLaunchKernelGGL(k_chain<2>, dim3(64), dim3(64 * wpb), 0, nullptr, out, ~0ull, n, 1.0f);
+        if (op == 3) hipLaunchKernelGGL(k_chain<3>, dim3(64), dim3(64 * wpb), 0, nullptr, out, ~0ull, n, 1.0f);
+        CK(hipEventRecord(e1, nullptr));
+        CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+      }
+      printf(" %.2f ns |", 1e6 * ms / ((double)n * 16 * 3));
+    }
+    printf("\n");
+  }
+  // ---- data dependence: the same chains on normal, fp32-subnormal, zero, infinite and NaN operands (all 64 lanes) ----
+  printf("\n| operand | %s | %s | %s | %s |\n|---|---|---|---|---|\n", ops[0], ops[1], ops[2], ops[3]);
+  struct { const char* name; float v; } vals[] = {{"1.0", 1.0f}, {"1e-20", 1e-20f}, {"1e-40 (fp32 subnormal)", 1e-40f}, {"0", 0.f},
+                                                  {"inf", __builtin_inff()}, {"NaN", __builtin_nanf("")}};
+  for (auto& vv : vals) {
+    printf("| %s |", vv.name);
+    for (int op = 0; op < 4; ++op) {
+      float ms = 0;
+      for (int rep = 0; rep < 2; ++rep) {
+        CK(hipEventRecord(e0, nullptr));
+        if (op == 0) hipLaunchKernelGGL(k_chain<0>, dim3(64), dim3(64), 0, nullptr, out, ~0ull, n, vv.v);
+        if (op == 1) hipLaunchKernelGGL(k_chain<1>, dim3(64), dim3(64), 0, nullptr, out, ~0ull, n, vv.v);
+        if (op == 2) hipLaunchKernelGGL(k_chain<2>, dim3(64), dim3(64), 0, nullptr, out, ~0ull, n, vv.v);
+        if (op == 3) hipLaunchKernelGGL(k_chain<3>, dim3(64), dim3(64), 0, nullptr, out, ~0ull, n, vv.v);
         CK(hipEventRecord(e1, nullptr));
         CK(hipEventSynchronize(e1));
         CK(hipEventElapsedTime(&ms, e0, e1));

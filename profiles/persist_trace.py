@@ -108,3 +108,5 @@ print("relinearisation sections of the 6 slowest and 3 median waves of the last 
 for i in list(order[:6]) + list(order[len(order) // 2 - 1: len(order) // 2 + 2]):
     w = int(idx_ok[i])
     print("  wave %3d: %s | %.2f | %s" % (w, " ".join("%.2f" % x for x in dd[i]), tot[i], place[w]))
+if os.environ.get("GBP_TRACE_PLACEMENT"):
+    print("block -> placement:", "; ".join("%d: %s" % (b, place[4 * b].replace(" simd%d" % ((hwid[4 * b] >> 4) & 3), "")) for b in range(min(waves // 4, 64))))
