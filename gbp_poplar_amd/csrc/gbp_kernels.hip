@@ -1095,7 +1095,13 @@ GBP_DEV void grid_sync(unsigned* sync, unsigned epoch, unsigned nblocks, unsigne
     __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned spin = 0;
     while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch * nblocks) {
-      if (++spin > (1u << 24)) { *status = 1u; break; }
+      // bounded wait (~1 s), and once ONE workgroup has given up every other one leaves its barriers at once (sync[32] is
+      // the abort word): a launch that can never complete ends in seconds with *status raised, it does not hang the GPU
+      if ((++spin & 1023u) == 0u && (spin > (1u << 23) || __hip_atomic_load(sync + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+        __hip_atomic_store(sync + 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *status = 1u;
+        break;
+      }
       __builtin_amdgcn_s_sleep(1);
     }
   }
