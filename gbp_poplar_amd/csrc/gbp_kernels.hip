@@ -1177,7 +1177,9 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
   if (cam_wave) {
     r0 = b.cam_row_ptr[w]; r1 = b.cam_row_ptr[w + 1];
     if (cam_live) cam_prior_j = b.cam_prior[(size_t)w * kCamRec + cj];
-    cam_cur0 = b.cam_mu[(size_t)w * 4]; cam_cur1 = b.cam_mu[(size_t)w * 4 + 1];
+    // (sc1 like EVERY access of this launch to an array that crosses waves: a plain load could leave a copy in this XCD's L2
+    // that goes stale when another XCD rewrites the neighbouring half of the 128-B line)
+    cam_cur0 = ld4_xw(b.cam_mu + (size_t)w * 4); cam_cur1 = ld4_xw(b.cam_mu + (size_t)w * 4 + 1);
   }
   const uint32_t l = lmk_wave ? (w - b.n_cams) * 16 + (lane >> 2) : 0u, q4 = lane & 3;
   const bool lmk_live = lmk_wave && l < b.n_lmks;
@@ -1187,7 +1189,7 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
   if (lmk_live) {
     ix = reinterpret_cast<const uint4*>(b.lmk_ix)[(size_t)l * 4 + q4];
     lmk_prior4 = b.lmk_prior[(size_t)l * 4 + q4];
-    lmk_cur = b.lmk_mu[(size_t)l * 2];
+    lmk_cur = ld4_xw(b.lmk_mu + (size_t)l * 2);
     lp0 = b.lmk_ptr[l]; lp1 = b.lmk_ptr[l + 1];
   }
   const uint32_t deg = (uint32_t)__shfl((int)ix.x, 0, 4);
@@ -1665,6 +1667,7 @@ __global__ __launch_bounds__(256) void k_eval(const uint32_t* __restrict__ row_c
 //   op 5 P(3x6) += A^T B            in A18 B36 P18  out 18    matMul transposeA, matlib.cpp:57-66
 //   op 6 P(6x6) += A A^T            in A18 P36      out 36    matMul transposeB, matlib.cpp:67-76
 //   op 7 inf2mean6x6 in eta6 L36  out 6 ; op 8 inf2mean3x3 in eta3 L9 out 3   bafuncs.cpp:2-15
+//   op 10 div_shared  in x9 m1     out 9      (gbp_device_math.hpp: IEEE quotients through one fp64 reciprocal)
 // =================================================================================================
 __global__ __launch_bounds__(64) void k_debug_math(int op, const float* __restrict__ in, float* __restrict__ out, int n,
                                                    int in_w, int out_w) {
@@ -1757,6 +1760,13 @@ __global__ __launch_bounds__(64) void k_debug_math(int op, const float* __restri
     belief_means(cb, lb, x0c, x0l);
     if (op == 7) { GBP_UNROLL for (int i = 0; i < 6; ++i) y[i] = x0c[i]; }
     else { GBP_UNROLL for (int i = 0; i < 3; ++i) y[i] = x0l[i]; }
+  } else if (op == 10) {   // div_shared: 9 numerators, one divisor -> 9 quotients (must equal IEEE x / m bit for bit)
+    float num[9], quo[9];
+    GBP_UNROLL
+    for (int i = 0; i < 9; ++i) num[i] = x[i];
+    div_shared(num, x[9], quo);
+    GBP_UNROLL
+    for (int i = 0; i < 9; ++i) y[i] = quo[i];
   }
 }
 
@@ -1920,8 +1930,8 @@ void debug_div_redo(unsigned long long* out4, bool reset) {
 }
 #endif
 bool debug_math_widths(int op, int* in_w, int* out_w) {
-  static const int iw[10] = {9, 36, 3, 18, 72, 72, 54, 42, 12, 36}, ow[10] = {9, 36, 9, 20, 18, 18, 36, 6, 3, 36};
-  if (op < 0 || op > 9) return false;
+  static const int iw[11] = {9, 36, 3, 18, 72, 72, 54, 42, 12, 36, 10}, ow[11] = {9, 36, 9, 20, 18, 18, 36, 6, 3, 36, 9};
+  if (op < 0 || op > 10) return false;
   *in_w = iw[op]; *out_w = ow[op];
   return true;
 }

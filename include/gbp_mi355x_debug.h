@@ -32,7 +32,9 @@ int gbp_debug_set_factor_potentials(gbp_ctx* ctx, const float* eta9E, const floa
  *        (matMul and its transpose modes, matlib.cpp:47-89)
  *   op 7 inf2mean6x6: eta6 Lambda36 -> 6;  op 8 inf2mean3x3: eta3 Lambda9 -> 3 (bafuncs.cpp:2-15)
  *   op 9 inv6x6 again, but in the SUB-WAVE mapping: 16 lanes cooperate on one matrix (operands in LDS, lane = output
- *        element, reference order): 36 -> 36, bit-identical to op 1; exists to be measured against it   */
+ *        element, reference order): 36 -> 36, bit-identical to op 1; exists to be measured against it
+ *   op 10 div_shared: x9 m1 -> 9 quotients x[i] / m — the shared-reciprocal division of gbp_device_math.hpp, which must equal
+ *        the IEEE fp32 division bit for bit (tests/test_gpu_device_math.py)                                             */
 int gbp_debug_math(int op, const float* in, float* out, int n);
 /* same, then `reps` back-to-back launches timed with hipEvents: average microseconds per launch */
 int gbp_debug_math_timed(int op, const float* in, float* out, int n, int reps, double* avg_us);

@@ -97,3 +97,39 @@ def test_subwave_mapping_of_inv6x6_is_bit_identical():
         a = rng.standard_normal((n, 6, 6))
         m = (a @ a.transpose(0, 2, 1) + 0.5 * np.eye(6)).astype(np.float32).reshape(n, 36)
         assert np.array_equal(_run(9, m, 36), _run(1, m, 36)), n
+
+
+def test_shared_reciprocal_division_is_the_ieee_division():
+    """div_shared (one fp64 reciprocal per divisor, 3 instructions per quotient) against numpy's IEEE fp32 division, bit for
+    bit: 2 M random pairs over the whole exponent range, quotients engineered to sit next to fp32 rounding midpoints,
+    divisors with all-ones / all-zeros significands, powers of two, zeros, infinities, NaNs and the subnormal range (where
+    the fast path must hand over to the slow one)."""
+    rng = np.random.default_rng(12)
+    cases = []
+    n = 200000
+    # (a) random significands, moderate exponents (the regime of the potentials)
+    cases.append((rng.standard_normal((n, 9)).astype(np.float32) * np.float32(1e3), (rng.random(n).astype(np.float32) + np.float32(0.1)) * np.float32(8)))
+    # (b) random bit patterns: every exponent, subnormals, infs, NaNs
+    cases.append((rng.integers(0, 2 ** 32, (n, 9), dtype=np.uint64).astype(np.uint32).view(np.float32),
+                  rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32)))
+    # (c) quotients next to midpoints: x = fl(m * (q +- half an ulp of q)) for random q, m
+    m = (rng.random(n).astype(np.float32) + np.float32(1.0)) * np.float32(3.0)
+    q = (rng.random((n, 9)).astype(np.float32) + np.float32(1.0))
+    half = np.spacing(q) * np.float32(0.5)
+    x = ((q.astype(np.float64) + half.astype(np.float64) * rng.choice([-1.0, 1.0], (n, 9))) * m[:, None].astype(np.float64)).astype(np.float32)
+    cases.append((x, m))
+    # (d) special divisors: significand all ones / all zeros, powers of two, tiny, huge
+    special = np.array([1.0, 2.0, 0.5, np.float32(2.0) - np.spacing(np.float32(1.0)), np.float32(1.0) + np.spacing(np.float32(1.0)), 3.0,
+                        1e-30, 1e30, 1e-38, 3e38, 1e-45, 0.0, -0.0, np.inf, -np.inf, np.nan, -7.0, 4.0], np.float32)
+    xs = np.concatenate([special, rng.standard_normal(200).astype(np.float32), np.float32(1e-38) * rng.standard_normal(50).astype(np.float32),
+                         np.float32(1e-44) * np.arange(1, 20, dtype=np.float32)])
+    xs = np.resize(xs, (len(xs) + 8) // 9 * 9).reshape(-1, 9)
+    for mm in special:
+        cases.append((xs, np.full(xs.shape[0], mm, np.float32)))
+    with np.errstate(all="ignore"):
+        for x, m in cases:
+            x, m = np.ascontiguousarray(x, np.float32), np.ascontiguousarray(m, np.float32)
+            out = _run(10, np.concatenate([x, m[:, None]], axis=1), 9)
+            ref = x / m[:, None]
+            same = (out.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(out) & np.isnan(ref))
+            assert same.all(), (x[~same][:4], np.broadcast_to(m[:, None], x.shape)[~same][:4], out[~same][:4], ref[~same][:4])
