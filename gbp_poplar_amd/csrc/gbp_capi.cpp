@@ -505,7 +505,11 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
         } else {
           g_create_error = c->err;
         }
-        c->persist_ok = rc == GBP_OK;
+        // the occupancy query says the workgroups fit; the probe checks that THIS device's dispatcher really keeps them
+        // resident together under the placement k_persist uses (three barriers, no work): a failure costs ~1 s once and
+        // leaves the ctx on the two-kernel path
+        c->persist_ok = rc == GBP_OK && persist_probe(c->n_tiles, c->C, c->L_loc, P<unsigned>(c->psync), static_cast<unsigned*>(c->pstatus_dev),
+                                                      static_cast<volatile unsigned*>(c->pstatus_host), c->stream);
       }
     }
     if (rc != GBP_OK) return rc;

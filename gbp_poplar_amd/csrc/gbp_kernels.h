@@ -133,6 +133,9 @@ void launch_beliefs(BeliefArgs b, bool do_cam, bool do_lmk, hipStream_t s);
 uint32_t persist_blocks(uint32_t n_tiles, uint32_t n_cams, uint32_t n_lmks);   // workgroups k_persist needs for a graph
 int persist_max_resident_blocks();                                            // how many of them this GPU keeps resident at once
 void launch_persist(PersistArgs a, hipStream_t s);
+// runs the placement + barriers of k_persist for this graph once (blocking); false = the workgroups are not co-resident here
+bool persist_probe(uint32_t n_tiles, uint32_t n_cams, uint32_t n_lmks, unsigned* sync, unsigned* status_dev, volatile unsigned* status_host,
+                   hipStream_t s);
 void launch_weaken(float4* prior, const float* scaling, uint32_t* flag, uint32_t n, int rec4, hipStream_t s);
 void launch_state_get(const float4* lmsg, float* damping, int* packed, uint32_t n, hipStream_t s);
 void launch_state_set(float4* lmsg, const int* new_count, const uint32_t* ctl, uint32_t n, hipStream_t s);

@@ -1957,6 +1957,37 @@ void launch_beliefs(BeliefArgs b, bool do_cam, bool do_lmk, hipStream_t s) {
   if (b.cam_blocks + lmk_blocks == 0) return;
   hipLaunchKernelGGL(k_beliefs, dim3(b.cam_blocks + lmk_blocks), dim3(256), 0, s, b);
 }
+// The placement of k_persist without its work: the same grid, the same filler rule, three barriers.  gbp_create runs it
+// once: if the working workgroups of this graph are NOT all resident at once on this device (another partition mode, another
+// dispatch order than workgroup b -> XCD b mod 8) the barrier gives up, *status is raised and the ctx stays on the
+// two-kernel path — found at creation, in milliseconds, not in the middle of a run.
+__global__ __launch_bounds__(256) void k_persist_probe(unsigned* sync, unsigned* status, uint32_t spread, uint32_t n_work_blocks) {
+  // same register footprint class as k_persist is not needed for the residency question that matters here (which CUs the
+  // working workgroups may use); one workgroup per CU is enforced by asking for the LDS a CU can give only once
+  extern __shared__ float probe_lds[];
+  if (threadIdx.x == 0) probe_lds[0] = 0.f;
+  if ((int)spread > 1 && blockIdx.x % spread) return;
+  const uint32_t nblk = (int)spread > 1 ? gridDim.x / spread : gridDim.x;
+  (void)n_work_blocks;
+  for (unsigned e = 1; e <= 3; ++e) grid_sync(sync, e, nblk, status);
+}
+
+static int persist_spread(uint32_t nb) { return nb <= 64 ? 4 : nb <= 128 ? 2 : 1; }
+
+bool persist_probe(uint32_t n_tiles, uint32_t n_cams, uint32_t n_lmks, unsigned* sync, unsigned* status_dev, volatile unsigned* status_host,
+                   hipStream_t s) {
+  const uint32_t nb = persist_blocks(n_tiles, n_cams, n_lmks);
+  const int spread = persist_spread(nb);
+  if (hipMemsetAsync(sync, 0, kPersistSyncWords * sizeof(unsigned), s) != hipSuccess) return false;
+  // 96 KiB of dynamic LDS per workgroup: at most ONE workgroup per CU (160 KiB), like k_persist's 340 registers per lane
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_persist_probe), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) return false;
+  hipLaunchKernelGGL(k_persist_probe, dim3(nb * (uint32_t)spread), dim3(256), 96 * 1024, s, sync, status_dev, (uint32_t)spread, nb);
+  if (hipStreamSynchronize(s) != hipSuccess) return false;
+  const bool ok = *status_host == 0u;
+  *status_host = 0u;
+  return ok;
+}
+
 uint32_t persist_blocks(uint32_t n_tiles, uint32_t n_cams, uint32_t n_lmks) {
   const uint64_t waves_b = (uint64_t)n_cams + ((uint64_t)n_lmks + 15) / 16;
   const uint64_t waves = waves_b > n_tiles ? waves_b : n_tiles;
@@ -1979,7 +2010,7 @@ void launch_persist(PersistArgs A, hipStream_t s) {
   // per iteration in the traced build), every 3rd does not.
   // Workgroup b runs on XCD b % 8 (round-robin dispatch), so every spread-th workgroup lands on 8 / spread XCDs of 32 CUs:
   // the working workgroups stay co-resident (one per CU: 340 registers per lane) only while nb <= 32 * 8 / spread.
-  int spread = nb <= 64 ? 4 : nb <= 128 ? 2 : 1;
+  int spread = persist_spread(nb);
   A.n_work_blocks = nb;
 #ifdef GBP_BUILD_ABLATIONS
   static const int env_spread = std::getenv("GBP_PERSIST_SPREAD") ? std::atoi(std::getenv("GBP_PERSIST_SPREAD")) : 0;
