@@ -490,8 +490,8 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
     const int mode = pe ? std::atoi(pe) : c->prm.persistent;
     const uint32_t nb = persist_blocks(c->n_tiles, c->C, c->L_loc);
     // measured (profiles/r03_small_graphs.md): the shipped sequences (19 - 61 workgroups, relinearising in every sweep) run
-    // 1.26 - 1.45x faster in k_persist; converging synthetic graphs break even at ~40 workgroups (0.95x at 63)
-    const uint32_t auto_limit = 64;
+    // 1.55 - 1.82x faster in k_persist; converging synthetic graphs 1.21x at 63 workgroups, break even at 125
+    const uint32_t auto_limit = 96;
     if (mode >= 0 && !sh && c->hoist && !c->use_tile_perm && nb <= (mode > 0 ? 1u << 30 : auto_limit)) {
       const int resident = persist_max_resident_blocks();
       if (resident > 0 && nb <= (uint32_t)resident) {

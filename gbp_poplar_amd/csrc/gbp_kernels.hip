@@ -1053,36 +1053,38 @@ __global__ __launch_bounds__(256) void k_beliefs(const BeliefArgs b) {
 // workgroups.  The counter only grows (epoch e expects e * n arrivals); the host zeroes it before the launch.  The wait
 // is bounded: if a workgroup were not resident (the launcher checks occupancy, so it is) the kernel raises *status and
 // carries on instead of hanging the GPU.
-GBP_DEV float4 ld4_xw(const float4* p) {      // "cross-wave" load: never served from a stale L1 / L2 line
-  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
-  const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return make_float4(__uint_as_float((unsigned)a), __uint_as_float((unsigned)(a >> 32)), __uint_as_float((unsigned)b),
-                     __uint_as_float((unsigned)(b >> 32)));
-}
-GBP_DEV void st4_xw(float4* p, const float4 v) {
-  unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
-  __hip_atomic_store(q, (unsigned long long)__float_as_uint(v.x) | ((unsigned long long)__float_as_uint(v.y) << 32), __ATOMIC_RELAXED,
-                     __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(q + 1, (unsigned long long)__float_as_uint(v.z) | ((unsigned long long)__float_as_uint(v.w) << 32), __ATOMIC_RELAXED,
-                     __HIP_MEMORY_SCOPE_AGENT);
-}
-GBP_DEV float ld1_xw(const float* p) {
-  return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-GBP_DEV void st1_xw(float* p, const float v) {
-  __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+// An array that crosses waves inside the launch ("xw"): every access is sc1 — through a buffer descriptor, because the
+// buffer intrinsics give 16-byte sc1 accesses the compiler tracks (agent-scope atomics stop at 8 bytes, and 8-byte accesses
+// move at 0.54-0.70x the 16-byte rate, MI355X_MICROARCH.md).  Offsets are 32-bit: arrays below 4 GiB, which the size limit of
+// k_persist guarantees by a factor of a thousand.
+struct XwBuf {
+  __amdgpu_buffer_rsrc_t r;
+  GBP_DEV explicit XwBuf(const void* base) : r(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000)) {}
+  static constexpr int kSc1 = 16;        // cache-policy bit of the gfx94x / gfx950 buffer instructions
+  GBP_DEV float4 ld4(uint32_t i4) const {   // float4 #i4 of the array
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(i4 * 16u), 0, kSc1);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+  }
+  GBP_DEV void st4(uint32_t i4, const float4 v) const {
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const v4u x = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(x, r, (int)(i4 * 16u), 0, kSc1);
+  }
+  // (the b32 intrinsics are typed unsigned: bit casts, not value conversions)
+  GBP_DEV float ld1(uint32_t i) const { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)(i * 4u), 0, kSc1)); }
+  GBP_DEV void st1(uint32_t i, const float v) const { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)(i * 4u), 0, kSc1); }
+};
 template <int G>
-GBP_DEV void load_rec_xw(const float4* rec, float (&out)[G * 4]) {
+GBP_DEV void load_rec_xw(const XwBuf& buf, uint32_t i4, float (&out)[G * 4]) {
   GBP_UNROLL
   for (int g = 0; g < G; ++g) {
-    const float4 v = ld4_xw(rec + g);
+    const float4 v = buf.ld4(i4 + (uint32_t)g);
     out[4 * g] = v.x; out[4 * g + 1] = v.y; out[4 * g + 2] = v.z; out[4 * g + 3] = v.w;
   }
 }
-GBP_DEV float4 lmsg_piece_xw(const float4* lmsg, uint32_t pos, uint32_t q) {
-  float4 m = ld4_xw(lmsg + (size_t)pos * 4 + q);
+GBP_DEV float4 lmsg_piece_xw(const XwBuf& lmsg, uint32_t pos, uint32_t q) {
+  float4 m = lmsg.ld4(pos * 4u + q);
   if (q == 0) m.w = 0.f;
   if (q == 3) { m.y = 0.f; m.z = 0.f; m.w = 0.f; }
   return m;
@@ -1130,12 +1132,13 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
   __shared__ float4 lm_stage[4][64 * 4];
   __shared__ float sh[4][48];
   float4* stage = lm_stage[wib];
+  const XwBuf X_lmsg(a.lmsg), X_rowp(a.rowp), X_camb(a.camb), X_lmkb(a.lmkb), X_cmu(a.cam_mu), X_lmu(a.lmk_mu);
 
   // ---- phase-A role: sweep tile w.  State that only this lane ever touches lives in registers for the whole launch.
   const bool has_tile = w < A.n_tiles;
   const uint32_t tile = has_tile ? w : 0u, p = tile * 64 + lane;
   const uint32_t rec_t = lane >> 2, swz_own = ((lane >> 2) & 3u) ^ (lane & 2u);
-  float4* lm_tile = a.lmsg + (size_t)tile * 256;
+  const uint32_t lm_tile4 = tile * 256u;                        // first float4 of the wave's 64 landmark-message records
   float fac[56], cm[28], lm[16];
   uint32_t cam_i = 0, lmk_i = 0;
   bool fac_dirty = false;
@@ -1147,7 +1150,7 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
     GBP_UNROLL
     for (int k = 0; k < 4; ++k) {   // the wave's 64 landmark-message records: coalesced, transposed through LDS (see k_sweep)
       const uint32_t r = k * 16 + rec_t;
-      stage[r * 4 + ((lane & 3u) ^ (((r >> 2) & 3u) ^ (r & 2u)))] = ld4_xw(lm_tile + k * 64 + lane);
+      stage[r * 4 + ((lane & 3u) ^ (((r >> 2) & 3u) ^ (r & 2u)))] = X_lmsg.ld4(lm_tile4 + (uint32_t)k * 64u + lane);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1161,10 +1164,8 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
   float K[9];
   GBP_UNROLL
   for (int i = 0; i < 9; ++i) K[i] = a.K[i];
-  const float4* cb_rec = a.camb + (size_t)cam_i * kCamRec4;      // loop-invariant addresses: phase A is ONE round of loads
-  const float4* lb_rec = a.lmkb + (size_t)lmk_i * kLmkRec4;
-  const float4* cmu_rec = a.cam_mu + (size_t)cam_i * 4;
-  const float4* lmu_rec = a.lmk_mu + (size_t)lmk_i * 2;
+  const uint32_t cb_rec4 = cam_i * (uint32_t)kCamRec4, lb_rec4 = lmk_i * (uint32_t)kLmkRec4;   // loop-invariant: phase A is ONE round of loads
+  const uint32_t cmu_rec4 = cam_i * 4u, lmu_rec4 = lmk_i * 2u;
 
   // ---- phase-B role: camera w (lanes 0..43 = the record), or landmarks 16 (w - C) .. + 15 (4 lanes each)
   const bool cam_wave = w < b.n_cams;
@@ -1179,7 +1180,7 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
     if (cam_live) cam_prior_j = b.cam_prior[(size_t)w * kCamRec + cj];
     // (sc1 like EVERY access of this launch to an array that crosses waves: a plain load could leave a copy in this XCD's L2
     // that goes stale when another XCD rewrites the neighbouring half of the 128-B line)
-    cam_cur0 = ld4_xw(b.cam_mu + (size_t)w * 4); cam_cur1 = ld4_xw(b.cam_mu + (size_t)w * 4 + 1);
+    cam_cur0 = X_cmu.ld4(w * 4u); cam_cur1 = X_cmu.ld4(w * 4u + 1u);
   }
   const uint32_t l = lmk_wave ? (w - b.n_cams) * 16 + (lane >> 2) : 0u, q4 = lane & 3;
   const bool lmk_live = lmk_wave && l < b.n_lmks;
@@ -1189,7 +1190,7 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
   if (lmk_live) {
     ix = reinterpret_cast<const uint4*>(b.lmk_ix)[(size_t)l * 4 + q4];
     lmk_prior4 = b.lmk_prior[(size_t)l * 4 + q4];
-    lmk_cur = ld4_xw(b.lmk_mu + (size_t)l * 2);
+    lmk_cur = X_lmu.ld4(l * 2u);
     lp0 = b.lmk_ptr[l]; lp1 = b.lmk_ptr[l + 1];
   }
   const uint32_t deg = (uint32_t)__shfl((int)ix.x, 0, 4);
@@ -1218,10 +1219,10 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
     if (has_tile) {
       float cb[44], lb[16], mu[12];
       // the linearisation point of a relinearising lane is fetched with the beliefs (one round of loads per phase)
-      const float4 l0 = ld4_xw(lmu_rec);
-      const float4 m0 = ld4_xw(cmu_rec), m1 = ld4_xw(cmu_rec + 1);
-      load_rec_xw<kLmkRec4>(lb_rec, lb);
-      load_rec_xw<kCamRec4>(cb_rec, cb);
+      const float4 l0 = X_lmu.ld4(lmu_rec4);
+      const float4 m0 = X_cmu.ld4(cmu_rec4), m1 = X_cmu.ld4(cmu_rec4 + 1u);
+      load_rec_xw<kLmkRec4>(X_lmkb, lb_rec4, lb);
+      load_rec_xw<kCamRec4>(X_camb, cb_rec4, cb);
 #ifdef GBP_BUILD_EXPERIMENTS
       if (A.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); GBP_TRACE(5); }
 #endif
@@ -1264,7 +1265,7 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
       GBP_UNROLL
       for (int k = 0; k < 4; ++k) {
         const uint32_t r = k * 16 + rec_t;
-        st4_xw(lm_tile + k * 64 + lane, stage[r * 4 + ((lane & 3u) ^ (((r >> 2) & 3u) ^ (r & 2u)))]);
+        X_lmsg.st4(lm_tile4 + (uint32_t)k * 64u + lane, stage[r * 4 + ((lane & 3u) ^ (((r >> 2) & 3u) ^ (r & 2u)))]);
       }
       GBP_UNROLL
       for (int i = 0; i < 16; ++i) lm[i] = ol[i];
@@ -1284,9 +1285,9 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
         GBP_UNROLL
         for (int i = 0; i < 36; ++i) rs[8 + i] = row16_sum(oc_lam[i]);
         if ((lane & 15) == 0) {
-          float4* rp = a.rowp + (size_t)(p >> 4) * kCamRec4;
+          const uint32_t rp4 = (p >> 4) * (uint32_t)kCamRec4;
           GBP_UNROLL
-          for (int g = 0; g < kCamRec4; ++g) st4_xw(rp + g, make_float4(rs[4 * g], rs[4 * g + 1], rs[4 * g + 2], rs[4 * g + 3]));
+          for (int g = 0; g < kCamRec4; ++g) X_rowp.st4(rp4 + (uint32_t)g, make_float4(rs[4 * g], rs[4 * g + 1], rs[4 * g + 2], rs[4 * g + 3]));
         }
       }
     }
@@ -1298,14 +1299,14 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
     if (cam_wave) {
       float acc = 0.f;
       if (cam_live && r1 > r0) {
-        const float* row = b.rowp + (size_t)r0 * kCamRec + cj;
-        acc = ld1_xw(row);
+        const uint32_t row = r0 * (uint32_t)kCamRec + cj;           // float index into ROWP
+        acc = X_rowp.ld1(row);
         uint32_t r = 1;
         const uint32_t n = r1 - r0;
         for (; r + 16 <= n; r += 16) {
           float v[16];
           GBP_UNROLL
-          for (int k = 0; k < 16; ++k) v[k] = ld1_xw(row + (size_t)(r + k) * kCamRec);
+          for (int k = 0; k < 16; ++k) v[k] = X_rowp.ld1(row + (r + (uint32_t)k) * (uint32_t)kCamRec);
           GBP_UNROLL
           for (int k = 0; k < 16; ++k) acc = acc + v[k];
         }
@@ -1314,7 +1315,7 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
           float v[16];
           const uint32_t m = n - r;
           GBP_UNROLL
-          for (int k = 0; k < 16; ++k) v[k] = ld1_xw(row + (size_t)((uint32_t)k < m ? r + k : n - 1) * kCamRec);
+          for (int k = 0; k < 16; ++k) v[k] = X_rowp.ld1(row + ((uint32_t)k < m ? r + (uint32_t)k : n - 1u) * (uint32_t)kCamRec);
           GBP_UNROLL
           for (int k = 0; k < 16; ++k)
             if ((uint32_t)k < m) acc = acc + v[k];
@@ -1332,27 +1333,27 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
         GBP_UNROLL
         for (int i = 0; i < 44; ++i) cb[i] = sh[wib][i];
         cam_mean(cb, x0c);
-        float4* mu = b.cam_mu + (size_t)w * 4;  // [0,1] = means of the current belief, [2,3] = means the last sweep used
-        st4_xw(mu + 2, cam_cur0); st4_xw(mu + 3, cam_cur1);
+        const uint32_t mu4 = w * 4u;            // [0,1] = means of the current belief, [2,3] = means the last sweep used
+        X_cmu.st4(mu4 + 2u, cam_cur0); X_cmu.st4(mu4 + 3u, cam_cur1);
         const float used[6] = {cam_cur0.x, cam_cur0.y, cam_cur0.z, cam_cur0.w, cam_cur1.x, cam_cur1.y};
         float S = 0.f;
         GBP_UNROLL
         for (int i = 0; i < 6; ++i) S += (used[i] - x0c[i]) * (used[i] - x0c[i]);
         cam_cur0 = make_float4(x0c[0], x0c[1], x0c[2], x0c[3]);
         cam_cur1 = make_float4(x0c[4], x0c[5], 0.f, 0.f);
-        st4_xw(mu, cam_cur0); st4_xw(mu + 1, cam_cur1);
+        X_cmu.st4(mu4, cam_cur0); X_cmu.st4(mu4 + 1u, cam_cur1);
         sh[wib][6] = S;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (cam_live) st1_xw(b.camb + (size_t)w * kCamRec + cj, sh[wib][cj]);
+      if (cam_live) X_camb.st1(w * (uint32_t)kCamRec + cj, sh[wib][cj]);
     } else if (lmk_wave) {
       float4 acc = lmk_prior4;
       {
         float4 m[15];
         GBP_UNROLL
-        for (int k = 0; k < 15; ++k) m[k] = lmsg_piece_xw(b.lmsg, pos[k], q4);   // unconditional: unused slots hold position 0
+        for (int k = 0; k < 15; ++k) m[k] = lmsg_piece_xw(X_lmsg, pos[k], q4);   // unconditional: unused slots hold position 0
         GBP_UNROLL
         for (int k = 0; k < 15; ++k)     // adds in slot order
           if ((uint32_t)k < deg) { acc.x = acc.x + m[k].x; acc.y = acc.y + m[k].y; acc.z = acc.z + m[k].z; acc.w = acc.w + m[k].w; }
@@ -1360,7 +1361,7 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
       if (__any(deg > 15u)) {
         float4 m[15];
         GBP_UNROLL
-        for (int k = 0; k < 15; ++k) m[k] = lmsg_piece_xw(b.lmsg, pos2[k], q4);
+        for (int k = 0; k < 15; ++k) m[k] = lmsg_piece_xw(X_lmsg, pos2[k], q4);
         GBP_UNROLL
         for (int k = 0; k < 15; ++k)
           if (15u + (uint32_t)k < deg) { acc.x = acc.x + m[k].x; acc.y = acc.y + m[k].y; acc.z = acc.z + m[k].z; acc.w = acc.w + m[k].w; }
@@ -1373,7 +1374,7 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
           GBP_UNROLL
           for (int k = 0; k < 8; ++k) ps[k] = (uint32_t)k < nleft ? b.lmk_fpos[s + k] : 0u;
           GBP_UNROLL
-          for (int k = 0; k < 8; ++k) m[k] = lmsg_piece_xw(b.lmsg, ps[k], q4);
+          for (int k = 0; k < 8; ++k) m[k] = lmsg_piece_xw(X_lmsg, ps[k], q4);
           GBP_UNROLL
           for (int k = 0; k < 8; ++k)
             if ((uint32_t)k < nleft) { acc.x = acc.x + m[k].x; acc.y = acc.y + m[k].y; acc.z = acc.z + m[k].z; acc.w = acc.w + m[k].w; }
@@ -1398,19 +1399,19 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
           for (int k = 0; k < 3; ++k) a2 += S3[i * 3 + k] * rec[k];
           x0l[i] = a2;
         }
-        float4* mu = b.lmk_mu + (size_t)l * 2;  // [0] = mean of the current belief, [1] = mean the last sweep used
+        const uint32_t mu4 = l * 2u;            // [0] = mean of the current belief, [1] = mean the last sweep used
         const float4 used = lmk_cur;
-        st4_xw(mu + 1, used);
+        X_lmu.st4(mu4 + 1u, used);
         u[0] = (used.x - x0l[0]) * (used.x - x0l[0]);
         u[1] = (used.y - x0l[1]) * (used.y - x0l[1]);
         u[2] = (used.z - x0l[2]) * (used.z - x0l[2]);
         lmk_cur = make_float4(x0l[0], x0l[1], x0l[2], 0.f);
-        st4_xw(mu, lmk_cur);
+        X_lmu.st4(mu4, lmk_cur);
       }
       const float u0 = __shfl(u[0], 0, 4), u1 = __shfl(u[1], 0, 4), u2 = __shfl(u[2], 0, 4);
       if (q4 == 0) acc.w = u0;                       // record slot 3
       if (q4 == 3) { acc.y = u1; acc.z = u2; }       // record slots 13, 14
-      if (lmk_live) st4_xw(b.lmkb + (size_t)l * 4 + q4, acc);
+      if (lmk_live) X_lmkb.st4(l * 4u + q4, acc);
     }
     GBP_TRACE(3);
     if (it + 1 < A.n_iters) grid_sync(A.sync, ++epoch, nblk, A.status);

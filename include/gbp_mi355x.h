@@ -78,7 +78,7 @@ typedef struct {
   int32_t persistent;          /* gbp_iterate(n >= 2) on a graph small enough that all of its workgroups are resident at once
                                   (BASELINE configs 1-3) runs the n iterations inside ONE kernel launch (k_persist: per-factor
                                   state in registers, device-wide barriers instead of kernel boundaries; identical results):
-                                  0 (default) = automatically up to 64 workgroups (16 384 factor positions: all shipped sequences), 1 = whenever the graph is
+                                  0 (default) = automatically up to 96 workgroups (24 576 factor positions; all shipped sequences need <= 61), 1 = whenever the graph is
                                   co-resident, -1 = never.  Single-GPU ctx with hoisted means only. */
   int32_t reserved[2];
 } gbp_params;
