@@ -47,17 +47,18 @@ static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
     while (i + burst < o.n_iters && (i + burst) % o.eval_every != 0 &&
            !(((iter + burst + 1) % 2 == 0) && (iter + burst < o.steps * 2)))
       ++burst;
-    CLI_CHECK(ctx, gbp_iterate(ctx, burst));
+    const bool eval_now = (i + burst) % o.eval_every == 0 || i + burst == o.n_iters;
+    if (!eval_now) CLI_CHECK(ctx, gbp_iterate(ctx, burst));
     i += burst - 1;
     iter += burst - 1;
-    if ((i + 1) % o.eval_every == 0 || i + 1 == o.n_iters) {
+    if (eval_now) {
       const unsigned it_now = iter;
       CLI_CHECK(ctx, pipe.submit([it_now](const gbp_eval_out& e) {
         std::cout << "Iter " << it_now << " // Reprojection error " << (float)(e.sum_norm / (double)e.n_active);
         std::cout << " // Cost " << (float)e.sum_half_sq << " // n relins: " << e.n_relin;
         std::cout << " // n robust edges " << e.n_robust << "\n";
         if (e.n_nonfinite) std::cout << "warning: " << e.n_nonfinite << " beliefs are non-finite\n";
-      }));
+      }, burst));                      // the burst and its metric in one call
       if (o.verbose) {
         CLI_CHECK(ctx, gbp_read(ctx, &rb.out));
         cli::print_verbose(rb);

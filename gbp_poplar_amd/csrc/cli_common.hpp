@@ -379,15 +379,18 @@ struct MetricPipe {
     deferred.clear();
     return GBP_OK;
   }
-  // metric of the current beliefs, printed by `p` — now (pipe off) or once the next submit / flush comes
-  int submit(std::function<void(const gbp_eval_out&)> p) {
+  // metric of the current beliefs, printed by `p` — now (pipe off) or once the next submit / flush comes.
+  // iterate_first > 0: that many GBP iterations are issued first, in the SAME call as the metric (gbp_iterate_eval: one
+  // launch for both on graphs that run in the persistent kernel).
+  int submit(std::function<void(const gbp_eval_out&)> p, int iterate_first = 0) {
     if (!on) {
+      if (iterate_first > 0) { const int rc = gbp_iterate(ctx, iterate_first); if (rc != GBP_OK) return rc; }
       gbp_eval_out ev{};
       const int rc = gbp_eval_global(ctx, &ev);
       if (rc == GBP_OK) p(ev);
       return rc;
     }
-    int rc = gbp_eval_begin(ctx);      // queued behind the iteration that was just issued
+    int rc = iterate_first > 0 ? gbp_iterate_eval(ctx, iterate_first) : gbp_eval_begin(ctx);   // the metric is queued behind the iterations
     if (rc != GBP_OK) return rc;
     if (pending) {                     // the previous metric: its kernels finished long ago
       gbp_eval_out ev{};

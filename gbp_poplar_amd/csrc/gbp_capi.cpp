@@ -94,6 +94,7 @@ struct gbp_ctx {
   void* pstatus_host = nullptr;        // pinned + device-mapped: raised by the kernel if a barrier gave up
   void* pstatus_dev = nullptr;
   uint64_t persist_launches = 0;
+  unsigned persist_epoch_base = 0;     // arrivals the barrier counter has seen so far (it keeps counting across launches)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_sweep_ev;  // split-phase profiling: brackets not yet read
   double sweep_ms = 0, belief_ms = 0, total_ms = 0, exchange_ms = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_exch_ev;     // profiling: brackets of partials + all-gather
@@ -510,6 +511,7 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
         // leaves the ctx on the two-kernel path
         c->persist_ok = rc == GBP_OK && persist_probe(c->n_tiles, c->C, c->L_loc, P<unsigned>(c->psync), static_cast<unsigned*>(c->pstatus_dev),
                                                       static_cast<volatile unsigned*>(c->pstatus_host), c->stream);
+        if (c->persist_ok) CK(hipMemset(c->psync.p, 0, kPersistSyncWords * sizeof(unsigned)), "hipMemset");   // counter back to 0 after the probe
       }
     }
     if (rc != GBP_OK) return rc;
@@ -884,6 +886,30 @@ int gbp_prepare(gbp_ctx* c) {
   return GBP_OK;
 }
 
+// n iterations inside ONE k_persist launch (+ the metric phases when `ev` is given).  The barrier counter keeps counting
+// across the launches of a ctx (no memset per launch): the host tracks how many arrivals it has seen.
+static int launch_persist_burst(gbp_ctx* c, const SweepArgs& a, int n, const PersistEval* ev) {
+  if (*static_cast<volatile unsigned*>(c->pstatus_host) != 0u)
+    return fail(c, GBP_ERR_HIP, "k_persist: a device-wide barrier timed out in an earlier launch (workgroups not co-resident)");
+  PersistArgs A{};
+  A.s = a;
+  A.b = belief_args(c);
+  A.b.roll = 1;
+  A.n_tiles = c->n_tiles;
+  A.n_iters = n;
+  A.sync = P<unsigned>(c->psync);
+  A.status = static_cast<unsigned*>(c->pstatus_dev);
+  A.trace = static_cast<unsigned long long*>(c->ptrace.p);      // NULL outside the experiments build
+  A.epoch_base = c->persist_epoch_base;
+  if (ev) A.ev = *ev;
+  launch_persist(A, c->stream);
+  HIPCHK(c, hipGetLastError());
+  const unsigned nb = persist_blocks(c->n_tiles, c->C, c->L_loc);
+  c->persist_epoch_base += nb * (unsigned)(2 * n - 1 + (ev ? 1 : 0));
+  c->persist_launches += 1;
+  return GBP_OK;
+}
+
 // GBP_PROG x n (ba.cpp:895-905) on one GPU: replay of a captured hipGraph of `graph_unroll`
 // iterations, remainder launched directly.
 static int iterate_impl(gbp_ctx* c, int n) {
@@ -923,22 +949,8 @@ static int iterate_impl(gbp_ctx* c, int n) {
       c->sweep_ms += a_ms; c->belief_ms += b_ms;
     }
   } else if (c->persist_ok && n >= 2) {   // a single iteration is as fast from two launches (measured)
-    // small graph: the whole burst in one launch (k_persist).  The barrier words are zeroed in stream order first.
-    if (*static_cast<volatile unsigned*>(c->pstatus_host) != 0u)
-      return fail(c, GBP_ERR_HIP, "k_persist: a device-wide barrier timed out in an earlier launch (workgroups not co-resident)");
-    HIPCHK(c, hipMemsetAsync(c->psync.p, 0, kPersistSyncWords * sizeof(unsigned), c->stream));
-    PersistArgs A;
-    A.s = a;
-    A.b = belief_args(c);
-    A.b.roll = 1;
-    A.n_tiles = c->n_tiles;
-    A.n_lmk_groups = 0;
-    A.n_iters = n;
-    A.sync = P<unsigned>(c->psync);
-    A.status = static_cast<unsigned*>(c->pstatus_dev);
-    A.trace = static_cast<unsigned long long*>(c->ptrace.p);      // NULL outside the experiments build
-    launch_persist(A, c->stream);
-    c->persist_launches += 1;
+    // small graph: the whole burst in one launch (k_persist)
+    if (int rc = launch_persist_burst(c, a, n, nullptr)) return rc;
   } else {
     int left = n;
     bool use_graph = (c->stream == c->own_stream) && c->prm.graph_unroll > 0 && n >= c->prm.graph_unroll && !c->graph_failed;
@@ -1138,6 +1150,46 @@ static int eval_impl(gbp_ctx* c, gbp_eval_out* o) {
   if (c->eval_pending) return fail(c, GBP_ERR_STATE, "gbp_eval: finish the evaluations in flight (gbp_eval_end) first");
   if (int rc = eval_begin_impl(c)) return rc;
   return eval_end_impl(c, o);
+}
+
+// gbp_iterate(n) followed by gbp_eval_begin() in one call.  On a graph that runs in k_persist the metric rides in the same
+// launch (two more phases after the last belief update: what k_means and k_eval compute, bit for bit) — the reference's
+// default loop prints the metric after EVERY iteration (ba.cpp:1009-1028), which otherwise costs four launches per iteration.
+static int iterate_eval_impl(gbp_ctx* c, int n) {
+  if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "gbp_iterate_eval: upload first");
+  if (n <= 0) return eval_begin_impl(c);
+  const bool fused = c->persist_ok && !c->comm && c->world == 1 && !c->profile_stages && c->eval_pending < 2 &&
+                     eval_blocks(c->n_tiles) == (c->n_tiles + 3) / 4;
+  if (!fused) {
+    if (int rc = iterate_impl(c, n)) return rc;
+    return eval_begin_impl(c);
+  }
+  if (!c->eval_host) {
+    HIPCHK(c, hipHostMalloc(&c->eval_host, sizeof(DeviceEval) * 1025 * 2, hipHostMallocMapped));
+    HIPCHK(c, hipHostGetDevicePointer(&c->eval_host_dev, c->eval_host, 0));
+    HIPCHK(c, hipEventCreateWithFlags(&c->eval_ev[0], hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->eval_ev[1], hipEventDisableTiming));
+  }
+  const int area = c->eval_parity & 1;
+  DeviceEval* slots = static_cast<DeviceEval*>(c->eval_host_dev) + 1025 * area;
+  PersistEval ev{};
+  ev.on = 1;
+  ev.cam_mu = P<float>(c->cam_mu); ev.lmk_mu = P<float>(c->lmk_mu);
+  ev.num_undamped = c->prm.num_undamped_iters;
+  ev.partials = slots + 1;
+  ev.health = P<unsigned long long>(c->health) + 2 * area;
+  ev.health_next = P<unsigned long long>(c->health) + 2 * (area ^ 1);
+  ev.health_out = reinterpret_cast<unsigned long long*>(slots);
+  gbp_ctx::Span sp{};
+  if (int rc = span_begin(c, sp)) return rc;
+  if (int rc = launch_persist_burst(c, sweep_args(c), n, &ev)) return rc;
+  if (int rc = span_end(c, sp)) return rc;
+  c->timed_iters += (uint64_t)n;
+  c->beliefs_valid = true;
+  HIPCHK(c, hipEventRecord(c->eval_ev[area], c->stream));
+  c->eval_parity ^= 1;
+  c->eval_pending += 1;
+  return GBP_OK;
 }
 
 int gbp_timing(gbp_ctx* c, gbp_timing_out* t, int reset) {
@@ -1479,6 +1531,7 @@ int gbp_new_keyframe(gbp_ctx* c, const gbp_kf_update* u) { return guarded(c, "gb
 int gbp_eval(gbp_ctx* c, gbp_eval_out* o) { return guarded(c, "gbp_eval", [&] { return eval_impl(c, o); }); }
 int gbp_eval_begin(gbp_ctx* c) { return guarded(c, "gbp_eval_begin", [&] { return eval_begin_impl(c); }); }
 int gbp_eval_end(gbp_ctx* c, gbp_eval_out* o) { return guarded(c, "gbp_eval_end", [&] { return eval_end_impl(c, o); }); }
+int gbp_iterate_eval(gbp_ctx* c, int n) { return guarded(c, "gbp_iterate_eval", [&] { return iterate_eval_impl(c, n); }); }
 #ifdef GBP_BUILD_TEST_HOOKS
 int gbp_debug_get(gbp_ctx* c, int what, float* a, float* b) { return guarded(c, "gbp_debug_get", [&] { return debug_get_impl(c, what, a, b); }); }
 int gbp_debug_set_factor_potentials(gbp_ctx* c, const float* eta9E, const float* lam81E) {

@@ -105,15 +105,29 @@ struct BeliefArgs {
 // (the launch-bound configs: fr1xyz = 51 workgroups).  Wave w sweeps tile w (per-factor state stays in registers across
 // iterations), a device-wide barrier, wave w then owns camera w or a group of 16 landmarks in the belief update
 // (its index records and priors stay in registers), a second barrier.
+struct DeviceEval;
+// optional metric phases at the end of a k_persist launch (gbp_iterate_eval): what k_means + k_eval compute, same bits
+struct PersistEval {
+  int on;
+  float* cam_mu;                       // [C][6] metric means (util.cpp:103-108), written by the camera waves
+  float* lmk_mu;                       // [L][3]
+  int num_undamped;
+  DeviceEval* partials;                // [tile workgroups] per-workgroup partial sums (host-mapped memory)
+  unsigned long long* health;          // [2] non-finite means / non-PD beliefs of THIS evaluation (zero on entry)
+  unsigned long long* health_next;     // zeroed for the next evaluation
+  unsigned long long* health_out;      // host-mapped copy of health
+};
 struct PersistArgs {
   SweepArgs s;
   BeliefArgs b;
+  PersistEval ev;
+  unsigned epoch_base;     // arrivals the barrier counter has already seen (launches of one ctx keep counting: no memset per launch)
   uint32_t n_tiles;        // sweep tiles = waves with a phase-A role
   uint32_t n_lmk_groups;   // ceil(L / 16): waves [C, C + n_lmk_groups) own 16 landmarks each in phase B
   int n_iters;
   uint32_t spread;         // the grid is `spread` times larger than the work and only every spread-th workgroup works (4: see launch_persist)
   uint32_t n_work_blocks;  // working workgroups (== gridDim.x unless spread)
-  unsigned* sync;          // [kPersistSyncWords] barrier words, zero on entry
+  unsigned* sync;          // [kPersistSyncWords] barrier words: [0] arrival counter (monotonic over launches), [32] abort word
   unsigned* status;        // host-mapped: set to 1 if a barrier gave up waiting (a workgroup was not resident)
   unsigned long long* trace;  // experiments build only (else NULL): [wave][iteration < kPersistTraceIters][8] wall-clock ticks
 };

@@ -1027,6 +1027,134 @@ __global__ __launch_bounds__(256) void k_beliefs(const BeliefArgs b) {
 }
 
 // =================================================================================================
+// Metric: util.cpp:74-144.  Variable means by an fp64 partial-pivot solve of the fp32 belief
+// (stands in for Eigen's general inverse), residuals in fp32, sums in fp64.
+// =================================================================================================
+// Every loop has compile-time bounds and every row swap is a select, so the 6 x 7 fp64 tableau lives in registers
+// (no scratch: this kernel sits on the critical path of the per-iteration metric of small graphs).
+template <int N>
+GBP_DEV void solve_pivot(const float* A, int lda, const float* b, float* x) {
+  double M[N][N + 1];
+  GBP_UNROLL
+  for (int i = 0; i < N; ++i) {
+    GBP_UNROLL
+    for (int j = 0; j < N; ++j) M[i][j] = A[i * lda + j];
+    M[i][N] = b[i];
+  }
+  GBP_UNROLL
+  for (int k = 0; k < N; ++k) {
+    int piv = k;
+    double best = fabs(M[k][k]);
+    GBP_UNROLL
+    for (int i = k + 1; i < N; ++i)
+      if (fabs(M[i][k]) > best) { best = fabs(M[i][k]); piv = i; }
+    GBP_UNROLL
+    for (int i = k + 1; i < N; ++i) {      // swap rows k and piv (at most one i matches)
+      const bool sw = piv == i;
+      GBP_UNROLL
+      for (int j = 0; j <= N; ++j) {
+        const double t = M[k][j];
+        M[k][j] = sw ? M[i][j] : t;
+        M[i][j] = sw ? t : M[i][j];
+      }
+    }
+    GBP_UNROLL
+    for (int i = k + 1; i < N; ++i) {
+      const double f = M[i][k] / M[k][k];
+      GBP_UNROLL
+      for (int j = k; j <= N; ++j) M[i][j] -= f * M[k][j];
+    }
+  }
+  GBP_UNROLL
+  for (int i = N - 1; i >= 0; --i) {
+    double s = M[i][N];
+    GBP_UNROLL
+    for (int j = i + 1; j < N; ++j) s -= M[i][j] * (double)x[j];
+    x[i] = (float)(s / M[i][i]);
+  }
+}
+
+// health check (SURVEY App. C-2): a belief Lambda is usable by inv6x6 / inv3x3 only while the un-pivoted
+// LDL^T pivots of its lower triangle (matlib.cpp:193-206) stay positive; a non-PD landmark belief is the
+// early-warning sign of the blow-ups seen on fr1xyz.
+template <int N>
+GBP_DEV bool ldl_pivots_positive(const float* A, int lda) {
+  double L[N][N], D[N];
+  bool ok = true;
+  GBP_UNROLL
+  for (int j = 0; j < N; ++j) {
+    double d = A[j * lda + j];
+    GBP_UNROLL
+    for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k] * D[k];
+    D[j] = d;
+    if (!(d > 0.0)) ok = false;
+    GBP_UNROLL
+    for (int i = j + 1; i < N; ++i) {
+      double v = A[i * lda + j];
+      GBP_UNROLL
+      for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k] * D[k];
+      L[i][j] = v / d;
+    }
+  }
+  return ok;
+}
+
+// One factor's share of the metric (util.cpp:95-129): reprojection residual of the belief means.  Shared by k_eval and
+// by the metric phase of k_persist, so that both evaluate it with the same operations in the same order.
+GBP_DEV void eval_factor(const float (&cm)[6], const float (&lmu)[3], float z0, float z1, const float* Kd, double& s_norm, double& s_half) {
+  // eigenso3exp, util.cpp:20-32 (single expression)
+  const float th = sqrtf(cm[3] * cm[3] + cm[4] * cm[4] + cm[5] * cm[5]);
+  float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  if (!(th < 1e-6)) {
+    const float W[9] = {0.f, -cm[5], cm[4], cm[5], 0.f, -cm[3], -cm[4], cm[3], 0.f};
+    const float sa = sinf(th) / th, sb = (1 - cosf(th)) / (th * th);
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) {
+        float ww = 0.f;
+        for (int k = 0; k < 3; ++k) ww += W[r * 3 + k] * W[k * 3 + c];
+        R[r * 3 + c] = R[r * 3 + c] + (sa * W[r * 3 + c] + sb * ww);
+      }
+  }
+  float pcf[3], pr[2];
+  for (int i = 0; i < 3; ++i) pcf[i] = (R[i * 3] * lmu[0] + R[i * 3 + 1] * lmu[1]) + R[i * 3 + 2] * lmu[2];
+  for (int i = 0; i < 3; ++i) pcf[i] += cm[i];
+  for (int i = 0; i < 2; ++i) pr[i] = ((Kd[i * 3] * pcf[0] + Kd[i * 3 + 1] * pcf[1]) + Kd[i * 3 + 2] * pcf[2]) / pcf[2];
+  const float r0 = z0 - pr[0], r1 = z1 - pr[1];
+  s_norm += (double)sqrtf(r0 * r0 + r1 * r1);
+  s_half += (double)(float)(0.5 * (double)(r0 * r0 + r1 * r1));
+}
+// block reduction of the metric partials in a fixed order (deterministic): lane tree via shuffles, then thread 0 adds the 4
+// wave sums; all 256 threads of the workgroup call it
+GBP_DEV void eval_block_reduce(double s_norm, double s_half, unsigned long long n_act, unsigned long long n_rel, unsigned long long n_rob,
+                               DeviceEval* out) {
+  __shared__ double sh_d[2][4];
+  __shared__ unsigned long long sh_u[3][4];
+  for (int off = 32; off > 0; off >>= 1) {
+    s_norm += __shfl_down(s_norm, off);
+    s_half += __shfl_down(s_half, off);
+    n_act += __shfl_down(n_act, off);
+    n_rel += __shfl_down(n_rel, off);
+    n_rob += __shfl_down(n_rob, off);
+  }
+  const uint32_t w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    sh_d[0][w] = s_norm; sh_d[1][w] = s_half;
+    sh_u[0][w] = n_act; sh_u[1][w] = n_rel; sh_u[2][w] = n_rob;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    DeviceEval o;
+    o.sum_norm = ((sh_d[0][0] + sh_d[0][1]) + sh_d[0][2]) + sh_d[0][3];
+    o.sum_half_sq = ((sh_d[1][0] + sh_d[1][1]) + sh_d[1][2]) + sh_d[1][3];
+    o.n_active = sh_u[0][0] + sh_u[0][1] + sh_u[0][2] + sh_u[0][3];
+    o.n_relin = sh_u[1][0] + sh_u[1][1] + sh_u[1][2] + sh_u[1][3];
+    o.n_robust = sh_u[2][0] + sh_u[2][1] + sh_u[2][2] + sh_u[2][3];
+    o.pad = 0;
+    *out = o;
+  }
+}
+
+// =================================================================================================
 // k_persist: n iterations of {k_sweep; k_beliefs} in ONE launch, for graphs whose workgroups are all resident at once.
 //
 // A graph of a few thousand factors (BASELINE configs 1-3: fr1xyz = 204 wavefronts on 1 024 SIMDs) is bound by what
@@ -1090,13 +1218,13 @@ GBP_DEV float4 lmsg_piece_xw(const XwBuf& lmsg, uint32_t pos, uint32_t q) {
   return m;
 }
 
-GBP_DEV void grid_sync(unsigned* sync, unsigned epoch, unsigned nblocks, unsigned* status) {
+GBP_DEV void grid_sync(unsigned* sync, unsigned target /* arrivals to wait for */, unsigned* status) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's write-through stores have been acknowledged
   __syncthreads();
   if (threadIdx.x == 0) {
     __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned spin = 0;
-    while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch * nblocks) {
+    while ((int)(__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {   // wrap-safe
       // bounded wait (~1 s), and once ONE workgroup has given up every other one leaves its barriers at once (sync[32] is
       // the abort word): a launch that can never complete ends in seconds with *status raised, it does not hang the GPU
       if ((++spin & 1023u) == 0u && (spin > (1u << 23) || __hip_atomic_load(sync + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
@@ -1133,6 +1261,7 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
   __shared__ float sh[4][48];
   float4* stage = lm_stage[wib];
   const XwBuf X_lmsg(a.lmsg), X_rowp(a.rowp), X_camb(a.camb), X_lmkb(a.lmkb), X_cmu(a.cam_mu), X_lmu(a.lmk_mu);
+  const XwBuf X_emc(A.ev.cam_mu), X_eml(A.ev.lmk_mu);     // metric means (only with A.ev.on)
 
   // ---- phase-A role: sweep tile w.  State that only this lane ever touches lives in registers for the whole launch.
   const bool has_tile = w < A.n_tiles;
@@ -1292,7 +1421,7 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
       }
     }
     GBP_TRACE(1);
-    grid_sync(A.sync, ++epoch, nblk, A.status);
+    grid_sync(A.sync, A.epoch_base + (++epoch) * nblk, A.status);
     GBP_TRACE(2);
 
     // ================= phase B: the belief update (arithmetic of k_beliefs, roll = 1) =================
@@ -1342,6 +1471,15 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
         cam_cur0 = make_float4(x0c[0], x0c[1], x0c[2], x0c[3]);
         cam_cur1 = make_float4(x0c[4], x0c[5], 0.f, 0.f);
         X_cmu.st4(mu4, cam_cur0); X_cmu.st4(mu4 + 1u, cam_cur1);
+        if (A.ev.on && it + 1 == A.n_iters) {   // metric means of this camera (what k_means computes), from the belief in LDS
+          float x[6];
+          solve_pivot<6>(sh[wib] + 8, 6, sh[wib], x);
+          bool finite = true;
+          GBP_UNROLL
+          for (int i = 0; i < 6; ++i) { X_emc.st1(w * 6u + (uint32_t)i, x[i]); finite &= (x[i] - x[i] == 0.f); }
+          if (!finite) atomicAdd(&A.ev.health[0], 1ull);
+          if (!ldl_pivots_positive<6>(sh[wib] + 8, 6)) atomicAdd(&A.ev.health[1], 1ull);
+        }
         sh[wib][6] = S;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1407,6 +1545,15 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
         u[2] = (used.z - x0l[2]) * (used.z - x0l[2]);
         lmk_cur = make_float4(x0l[0], x0l[1], x0l[2], 0.f);
         X_lmu.st4(mu4, lmk_cur);
+        if (A.ev.on && it + 1 == A.n_iters) {   // metric mean of this landmark (k_means), from the belief record in registers
+          float x[3];
+          solve_pivot<3>(rec + 4, 3, rec, x);
+          bool finite = true;
+          GBP_UNROLL
+          for (int i = 0; i < 3; ++i) { X_eml.st1(l * 3u + (uint32_t)i, x[i]); finite &= (x[i] - x[i] == 0.f); }
+          if (!finite) atomicAdd(&A.ev.health[0], 1ull);
+          if (!ldl_pivots_positive<3>(rec + 4, 3)) atomicAdd(&A.ev.health[1], 1ull);
+        }
       }
       const float u0 = __shfl(u[0], 0, 4), u1 = __shfl(u[1], 0, 4), u2 = __shfl(u[2], 0, 4);
       if (q4 == 0) acc.w = u0;                       // record slot 3
@@ -1414,10 +1561,43 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
       if (lmk_live) X_lmkb.st4(l * 4u + q4, acc);
     }
     GBP_TRACE(3);
-    if (it + 1 < A.n_iters) grid_sync(A.sync, ++epoch, nblk, A.status);
+    if (it + 1 < A.n_iters) grid_sync(A.sync, A.epoch_base + (++epoch) * nblk, A.status);
     GBP_TRACE(4);
   }
 #undef GBP_TRACE
+
+  // ---- optional metric (gbp_iterate_eval): what k_means + k_eval compute after the last iteration, same bits.  The means were
+  // written by the belief owners in the last phase B; one more hand-off, then every tile wave adds its factors' residuals and
+  // the workgroup reduces them in k_eval's order (a workgroup holds the same 256 positions as a block of k_eval) ----
+  if (A.ev.on) {
+    if (bid == 0 && threadIdx.x == 0) { A.ev.health_next[0] = 0ull; A.ev.health_next[1] = 0ull; }
+    grid_sync(A.sync, A.epoch_base + (++epoch) * nblk, A.status);
+    double s_norm = 0, s_half = 0;
+    unsigned long long n_act = 0, n_rel = 0, n_rob = 0;
+    if (has_tile) {
+      const int packed = __float_as_int(lm[13]);
+      const uint32_t flags = (uint32_t)packed & 7u;
+      if (!(flags & kFlagPad)) {
+        if (flags & kFlagRobust) ++n_rob;
+        if ((packed >> 3) == -A.ev.num_undamped) ++n_rel;
+        if (flags & kFlagActive) {
+          float cmv[6], lmu[3];
+          GBP_UNROLL
+          for (int i = 0; i < 6; ++i) cmv[i] = X_emc.ld1(cam_i * 6u + (uint32_t)i);
+          GBP_UNROLL
+          for (int i = 0; i < 3; ++i) lmu[i] = X_eml.ld1(lmk_i * 3u + (uint32_t)i);
+          eval_factor(cmv, lmu, fac[54], fac[55], a.K, s_norm, s_half);
+          ++n_act;
+        }
+      }
+    }
+    const bool tile_block = bid * 4u < A.n_tiles;            // uniform per workgroup
+    if (tile_block) eval_block_reduce(s_norm, s_half, n_act, n_rel, n_rob, A.ev.partials + bid);
+    if (bid == 0 && threadIdx.x == 0) {
+      A.ev.health_out[0] = __hip_atomic_load(&A.ev.health[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      A.ev.health_out[1] = __hip_atomic_load(&A.ev.health[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 
   // ---- what stayed in registers goes back to its arrays ----
   if (has_tile) {
@@ -1476,79 +1656,6 @@ __global__ __launch_bounds__(256) void k_weaken_flags(uint32_t* flag, uint32_t n
   if (f >= 1 && f <= 5) flag[v] = f - 1;
 }
 
-// =================================================================================================
-// Metric: util.cpp:74-144.  Variable means by an fp64 partial-pivot solve of the fp32 belief
-// (stands in for Eigen's general inverse), residuals in fp32, sums in fp64.
-// =================================================================================================
-// Every loop has compile-time bounds and every row swap is a select, so the 6 x 7 fp64 tableau lives in registers
-// (no scratch: this kernel sits on the critical path of the per-iteration metric of small graphs).
-template <int N>
-GBP_DEV void solve_pivot(const float* A, int lda, const float* b, float* x) {
-  double M[N][N + 1];
-  GBP_UNROLL
-  for (int i = 0; i < N; ++i) {
-    GBP_UNROLL
-    for (int j = 0; j < N; ++j) M[i][j] = A[i * lda + j];
-    M[i][N] = b[i];
-  }
-  GBP_UNROLL
-  for (int k = 0; k < N; ++k) {
-    int piv = k;
-    double best = fabs(M[k][k]);
-    GBP_UNROLL
-    for (int i = k + 1; i < N; ++i)
-      if (fabs(M[i][k]) > best) { best = fabs(M[i][k]); piv = i; }
-    GBP_UNROLL
-    for (int i = k + 1; i < N; ++i) {      // swap rows k and piv (at most one i matches)
-      const bool sw = piv == i;
-      GBP_UNROLL
-      for (int j = 0; j <= N; ++j) {
-        const double t = M[k][j];
-        M[k][j] = sw ? M[i][j] : t;
-        M[i][j] = sw ? t : M[i][j];
-      }
-    }
-    GBP_UNROLL
-    for (int i = k + 1; i < N; ++i) {
-      const double f = M[i][k] / M[k][k];
-      GBP_UNROLL
-      for (int j = k; j <= N; ++j) M[i][j] -= f * M[k][j];
-    }
-  }
-  GBP_UNROLL
-  for (int i = N - 1; i >= 0; --i) {
-    double s = M[i][N];
-    GBP_UNROLL
-    for (int j = i + 1; j < N; ++j) s -= M[i][j] * (double)x[j];
-    x[i] = (float)(s / M[i][i]);
-  }
-}
-
-// health check (SURVEY App. C-2): a belief Lambda is usable by inv6x6 / inv3x3 only while the un-pivoted
-// LDL^T pivots of its lower triangle (matlib.cpp:193-206) stay positive; a non-PD landmark belief is the
-// early-warning sign of the blow-ups seen on fr1xyz.
-template <int N>
-GBP_DEV bool ldl_pivots_positive(const float* A, int lda) {
-  double L[N][N], D[N];
-  bool ok = true;
-  GBP_UNROLL
-  for (int j = 0; j < N; ++j) {
-    double d = A[j * lda + j];
-    GBP_UNROLL
-    for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k] * D[k];
-    D[j] = d;
-    if (!(d > 0.0)) ok = false;
-    GBP_UNROLL
-    for (int i = j + 1; i < N; ++i) {
-      double v = A[i * lda + j];
-      GBP_UNROLL
-      for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k] * D[k];
-      L[i][j] = v / d;
-    }
-  }
-  return ok;
-}
-
 __global__ __launch_bounds__(256) void k_means(const float* __restrict__ camb, const float* __restrict__ lmkb,
                                                float* __restrict__ cam_mu, float* __restrict__ lmk_mu, uint32_t n_cams,
                                                uint32_t n_lmks, unsigned long long* health, unsigned long long* health_next,
@@ -1605,54 +1712,10 @@ __global__ __launch_bounds__(256) void k_eval(const uint32_t* __restrict__ row_c
     float cm[6], lmu[3];
     for (int i = 0; i < 6; ++i) cm[i] = cam_mu[(size_t)cam_i * 6 + i];
     for (int i = 0; i < 3; ++i) lmu[i] = lmk_mu[(size_t)lmk_i * 3 + i];
-    // eigenso3exp, util.cpp:20-32 (single expression)
-    const float th = sqrtf(cm[3] * cm[3] + cm[4] * cm[4] + cm[5] * cm[5]);
-    float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    if (!(th < 1e-6)) {
-      const float W[9] = {0.f, -cm[5], cm[4], cm[5], 0.f, -cm[3], -cm[4], cm[3], 0.f};
-      const float sa = sinf(th) / th, sb = (1 - cosf(th)) / (th * th);
-      for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) {
-          float ww = 0.f;
-          for (int k = 0; k < 3; ++k) ww += W[r * 3 + k] * W[k * 3 + c];
-          R[r * 3 + c] = R[r * 3 + c] + (sa * W[r * 3 + c] + sb * ww);
-        }
-    }
-    float pcf[3], pr[2];
-    for (int i = 0; i < 3; ++i) pcf[i] = (R[i * 3] * lmu[0] + R[i * 3 + 1] * lmu[1]) + R[i * 3 + 2] * lmu[2];
-    for (int i = 0; i < 3; ++i) pcf[i] += cm[i];
-    for (int i = 0; i < 2; ++i) pr[i] = ((Kd[i * 3] * pcf[0] + Kd[i * 3 + 1] * pcf[1]) + Kd[i * 3 + 2] * pcf[2]) / pcf[2];
-    const float r0 = zg.z - pr[0], r1 = zg.w - pr[1];
-    s_norm += (double)sqrtf(r0 * r0 + r1 * r1);
-    s_half += (double)(float)(0.5 * (double)(r0 * r0 + r1 * r1));
+    eval_factor(cm, lmu, zg.z, zg.w, Kd, s_norm, s_half);
     ++n_act;
   }
-  // block reduction in a fixed order (deterministic): lane tree via shuffles, then wave 0 adds 4 wave sums
-  __shared__ double sh_d[2][4];
-  __shared__ unsigned long long sh_u[3][4];
-  for (int off = 32; off > 0; off >>= 1) {
-    s_norm += __shfl_down(s_norm, off);
-    s_half += __shfl_down(s_half, off);
-    n_act += __shfl_down(n_act, off);
-    n_rel += __shfl_down(n_rel, off);
-    n_rob += __shfl_down(n_rob, off);
-  }
-  const uint32_t w = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) {
-    sh_d[0][w] = s_norm; sh_d[1][w] = s_half;
-    sh_u[0][w] = n_act; sh_u[1][w] = n_rel; sh_u[2][w] = n_rob;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    DeviceEval o;
-    o.sum_norm = ((sh_d[0][0] + sh_d[0][1]) + sh_d[0][2]) + sh_d[0][3];
-    o.sum_half_sq = ((sh_d[1][0] + sh_d[1][1]) + sh_d[1][2]) + sh_d[1][3];
-    o.n_active = sh_u[0][0] + sh_u[0][1] + sh_u[0][2] + sh_u[0][3];
-    o.n_relin = sh_u[1][0] + sh_u[1][1] + sh_u[1][2] + sh_u[1][3];
-    o.n_robust = sh_u[2][0] + sh_u[2][1] + sh_u[2][2] + sh_u[2][3];
-    o.pad = 0;
-    partials[blockIdx.x] = o;
-  }
+  eval_block_reduce(s_norm, s_half, n_act, n_rel, n_rob, partials + blockIdx.x);
 }
 
 #ifdef GBP_BUILD_TEST_HOOKS
@@ -1970,7 +2033,7 @@ __global__ __launch_bounds__(256) void k_persist_probe(unsigned* sync, unsigned*
   if ((int)spread > 1 && blockIdx.x % spread) return;
   const uint32_t nblk = (int)spread > 1 ? gridDim.x / spread : gridDim.x;
   (void)n_work_blocks;
-  for (unsigned e = 1; e <= 3; ++e) grid_sync(sync, e, nblk, status);
+  for (unsigned e = 1; e <= 3; ++e) grid_sync(sync, e * nblk, status);
 }
 
 static int persist_spread(uint32_t nb) { return nb <= 64 ? 4 : nb <= 128 ? 2 : 1; }

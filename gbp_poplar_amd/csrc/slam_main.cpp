@@ -67,15 +67,23 @@ static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
       pipe.line("Weakening priors \n");
       CLI_CHECK(ctx, gbp_weaken_priors(ctx));
     }
-    CLI_CHECK(ctx, gbp_iterate(ctx, 1));
-    if ((i + 1) % (unsigned)o.eval_every == 0 || i + 1 == niters) {
+    // up to the next host event (keyframe, prior weakening, metric read-back) in one call, like ba_main.cpp
+    unsigned burst = 1;
+    while (i + burst < niters && (i + burst + 1) % (unsigned)o.iters_between_kfs != 0 && (i + burst) % (unsigned)o.eval_every != 0 &&
+           !(((iter + burst + 1) % 2 == 0) && (iter + burst < o.steps * 2)))
+      ++burst;
+    const bool eval_now = (i + burst) % (unsigned)o.eval_every == 0 || i + burst == niters;
+    if (!eval_now) CLI_CHECK(ctx, gbp_iterate(ctx, (int)burst));
+    i += burst - 1;
+    iter += burst - 1;
+    if (eval_now) {
       const unsigned total = (unsigned)o.iters_between_kfs * data_counter + iter, since = iter;
       CLI_CHECK(ctx, pipe.submit([total, since](const gbp_eval_out& e) {
         std::cout << "Iters " << total;
         std::cout << " (since last kf " << since << ") // Reprojection error " << (float)(e.sum_norm / (double)e.n_active);
         std::cout << " // Cost " << (float)e.sum_half_sq << " // n relins: " << e.n_relin;
         std::cout << " // n robust edges " << e.n_robust << "\n";
-      }));
+      }, (int)burst));
       if (o.verbose) {
         CLI_CHECK(ctx, gbp_read(ctx, &rb.out));
         cli::print_verbose(rb);

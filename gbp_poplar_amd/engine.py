@@ -103,6 +103,10 @@ class GbpEngine:
     def eval_begin(self):
         self._chk(self.lib.gbp_eval_begin(self.h), "gbp_eval_begin")
 
+    def iterate_eval(self, n=1):
+        """iterate(n) + eval_begin() in one call (fused into one launch on graphs that run in the persistent kernel)."""
+        self._chk(self.lib.gbp_iterate_eval(self.h, int(n)), "gbp_iterate_eval")
+
     def eval_end(self):
         o = cabi.GbpEvalOut()
         self._chk(self.lib.gbp_eval_end(self.h, C.byref(o)), "gbp_eval_end")

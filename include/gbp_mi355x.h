@@ -191,6 +191,10 @@ int gbp_eval(gbp_ctx* ctx, gbp_eval_out* out);                 /* util.cpp:74-14
  * may be in flight, so the loop of ba.cpp:1001-1028 can queue iteration i+1 before it prints the metric of iteration i. */
 int gbp_eval_begin(gbp_ctx* ctx);
 int gbp_eval_end(gbp_ctx* ctx, gbp_eval_out* out);
+/* gbp_iterate(n) + gbp_eval_begin() in ONE call (collect with gbp_eval_end): the loop of ba.cpp:1001-1028 prints the metric
+ * after every iteration; on a graph that runs in the persistent kernel the metric then rides in the same launch (identical
+ * results), elsewhere it is exactly the two calls. */
+int gbp_iterate_eval(gbp_ctx* ctx, int n_iters);
 int gbp_sync(gbp_ctx* ctx);                                    /* wait for queued device work     */
 int gbp_timing(gbp_ctx* ctx, gbp_timing_out* out, int reset);  /* ba.cpp:980,1056-1058            */
 

@@ -435,6 +435,57 @@ def test_persistent_kernel_full_run_vs_oracle(oracle_mod):
     assert [t[0] for t in tg] == [t[0] for t in to] and [t[3:] for t in tg] == [t[3:] for t in to]
 
 
+def test_iterate_eval_fused_metric_equals_separate_calls(oracle_mod):
+    """gbp_iterate_eval(n) — the iterations AND the metric in one k_persist launch on small graphs (two more phases: what
+    k_means and k_eval compute) — against gbp_iterate(n) followed by gbp_eval(): metric sums, counters, health counters and
+    every belief identical, single iterations (the reference's default loop) and bursts, two evaluations in flight."""
+    from gbp_poplar_amd import _cabi, driver, hostlib
+    from gbp_poplar_amd.engine import GbpEngine
+    for name in ("fr2robot2", "fr1xyz"):
+        bal = _bal(name)
+        K, state, _ = driver.build_inputs(bal, driver.Options(), hostlib)
+        a = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K)
+        b = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K)
+        c = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K, params=_cabi.GbpParams.defaults(persistent=-1))
+        assert a.graph_state() == 2 and c.graph_state() != 2
+        for e in (a, b, c):
+            e.upload(state)
+            e.linearise()
+        it = 0
+        for n in [1] * 12 + [2, 1, 7, 1, 1, 30, 1]:
+            for e in (a, b, c):
+                i = it
+                left = n
+                while left > 0:          # ba.cpp:1003-1006: prior weakening before iterations 1,3,5,7,9 — as separate calls
+                    if (i + 1) % 2 == 0 and i < 10:
+                        e.weaken_priors()
+                    k = 1
+                    while k < left and not ((i + k + 1) % 2 == 0 and i + k < 10):
+                        k += 1
+                    last = left == k
+                    if e is a and last:
+                        e.iterate_eval(k)
+                    else:
+                        e.iterate(k)
+                    i += k
+                    left -= k
+            it += n
+            ea, eb, ec = a.eval_end(), b.eval(), c.eval()
+            assert ea == eb == ec, (name, it, ea, eb, ec)
+            ra, rb = a.read(), b.read()
+            for k in ra:
+                assert np.array_equal(ra[k], rb[k], equal_nan=True), (name, it, k)
+        # two evaluations in flight, collected in order
+        a.iterate_eval(1)
+        a.iterate_eval(3)
+        b.iterate(1)
+        e1 = b.eval()
+        b.iterate(3)
+        e2 = b.eval()
+        assert a.eval_end() == e1 and a.eval_end() == e2
+        assert a.timing()["iterations"] == b.timing()["iterations"]
+
+
 def test_persistent_kernel_is_chosen_by_size():
     """Automatic selection (gbp_params.persistent = 0): the shipped sequences run in k_persist, S1-sized graphs do not;
     a sharded ctx and per_factor_mu = 1 never do."""
