@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <stdexcept>
 #include <string>
@@ -28,6 +29,10 @@ using namespace gbp;
 
 namespace {
 thread_local std::string g_create_error;
+// serialisation of k_persist launches across the ctxs of a process (launch_persist_burst)
+std::mutex g_persist_mu;
+hipStream_t g_persist_last_stream[16] = {};
+hipEvent_t g_persist_event[16] = {};
 
 struct DevBuf {
   void* p = nullptr;
@@ -321,6 +326,11 @@ const char* gbp_last_error(const gbp_ctx* ctx) { return ctx ? ctx->err.c_str() :
 void gbp_destroy(gbp_ctx* c) {
   if (!c) return;
   drop_graph(c);
+  if (c->persist_ok) {   // a later k_persist launch of another ctx must not wait on a stream that no longer exists
+    (void)hipStreamSynchronize(c->stream);
+    std::lock_guard<std::mutex> lock(g_persist_mu);
+    for (hipStream_t& st : g_persist_last_stream) if (st == c->stream || st == c->own_stream) st = nullptr;
+  }
   if (c->comm) { (void)hipStreamSynchronize(c->stream); if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream); delete c->comm; c->comm = nullptr; }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -902,8 +912,25 @@ static int launch_persist_burst(gbp_ctx* c, const SweepArgs& a, int n, const Per
   A.trace = static_cast<unsigned long long*>(c->ptrace.p);      // NULL outside the experiments build
   A.epoch_base = c->persist_epoch_base;
   if (ev) A.ev = *ev;
-  launch_persist(A, c->stream);
-  HIPCHK(c, hipGetLastError());
+  {
+    // Two k_persist launches must never compete for CUs (each spins at its barriers until ALL its workgroups are resident):
+    // inside a process a launch on another stream than the previous one waits for that stream first (launches on the same
+    // stream are ordered anyway and pay nothing).  (Another PROCESS on the same GPU can still starve a launch; the bounded
+    // barrier wait then ends it with an error instead of a hang.)
+    std::lock_guard<std::mutex> lock(g_persist_mu);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    hipStream_t& prev = g_persist_last_stream[dev & 15];
+    if (prev && prev != c->stream) {
+      hipEvent_t& e = g_persist_event[dev & 15];
+      if (!e) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      HIPCHK(c, hipEventRecord(e, prev));                 // everything queued on the previous stream so far, its k_persist included
+      HIPCHK(c, hipStreamWaitEvent(c->stream, e, 0));
+    }
+    launch_persist(A, c->stream);
+    HIPCHK(c, hipGetLastError());
+    prev = c->stream;
+  }
   const unsigned nb = persist_blocks(c->n_tiles, c->C, c->L_loc);
   c->persist_epoch_base += nb * (unsigned)(2 * n - 1 + (ev ? 1 : 0));
   c->persist_launches += 1;
