@@ -977,7 +977,7 @@ static int iterate_impl(gbp_ctx* c, int n) {
     }
   } else if (c->persist_ok && n >= 2) {   // a single iteration is as fast from two launches (measured)
     // small graph: the whole burst in one launch (k_persist)
-    if (int rc = launch_persist_burst(c, a, n, nullptr)) return rc;
+    if (int rc = launch_persist_burst(c, a, n, nullptr)) { c->span_pool.push_back(sp); return rc; }
   } else {
     int left = n;
     bool use_graph = (c->stream == c->own_stream) && c->prm.graph_unroll > 0 && n >= c->prm.graph_unroll && !c->graph_failed;
@@ -1209,7 +1209,7 @@ static int iterate_eval_impl(gbp_ctx* c, int n) {
   ev.health_out = reinterpret_cast<unsigned long long*>(slots);
   gbp_ctx::Span sp{};
   if (int rc = span_begin(c, sp)) return rc;
-  if (int rc = launch_persist_burst(c, sweep_args(c), n, &ev)) return rc;
+  if (int rc = launch_persist_burst(c, sweep_args(c), n, &ev)) { c->span_pool.push_back(sp); return rc; }
   if (int rc = span_end(c, sp)) return rc;
   c->timed_iters += (uint64_t)n;
   c->beliefs_valid = true;
