@@ -1488,21 +1488,24 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
       if (cam_live) X_camb.st1(w * (uint32_t)kCamRec + cj, sh[wib][cj]);
     } else if (lmk_wave) {
       float4 acc = lmk_prior4;
-      {
-        float4 m[15];
+      {  // both batches of loads are issued before the first add (one memory round trip for up to 30 slots: the
+         // wave has 512 registers per lane to itself); the adds stay in slot order
+        float4 m[15], m2[15];
+        const bool second = __any(deg > 15u);
         GBP_UNROLL
         for (int k = 0; k < 15; ++k) m[k] = lmsg_piece_xw(X_lmsg, pos[k], q4);   // unconditional: unused slots hold position 0
+        if (second) {
+          GBP_UNROLL
+          for (int k = 0; k < 15; ++k) m2[k] = lmsg_piece_xw(X_lmsg, pos2[k], q4);
+        }
         GBP_UNROLL
         for (int k = 0; k < 15; ++k)     // adds in slot order
           if ((uint32_t)k < deg) { acc.x = acc.x + m[k].x; acc.y = acc.y + m[k].y; acc.z = acc.z + m[k].z; acc.w = acc.w + m[k].w; }
-      }
-      if (__any(deg > 15u)) {
-        float4 m[15];
-        GBP_UNROLL
-        for (int k = 0; k < 15; ++k) m[k] = lmsg_piece_xw(X_lmsg, pos2[k], q4);
-        GBP_UNROLL
-        for (int k = 0; k < 15; ++k)
-          if (15u + (uint32_t)k < deg) { acc.x = acc.x + m[k].x; acc.y = acc.y + m[k].y; acc.z = acc.z + m[k].z; acc.w = acc.w + m[k].w; }
+        if (second) {
+          GBP_UNROLL
+          for (int k = 0; k < 15; ++k)
+            if (15u + (uint32_t)k < deg) { acc.x = acc.x + m2[k].x; acc.y = acc.y + m2[k].y; acc.z = acc.z + m2[k].z; acc.w = acc.w + m2[k].w; }
+        }
       }
       if (deg > 30u) {
         for (uint32_t s = lp0 + 30u; s < lp1; s += 8) {

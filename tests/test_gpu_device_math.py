@@ -101,9 +101,10 @@ def test_subwave_mapping_of_inv6x6_is_bit_identical():
 
 def test_shared_reciprocal_division_is_the_ieee_division():
     """div_shared (one fp64 reciprocal per divisor, 3 instructions per quotient) against numpy's IEEE fp32 division, bit for
-    bit: 2 M random pairs over the whole exponent range, quotients engineered to sit next to fp32 rounding midpoints,
-    divisors with all-ones / all-zeros significands, powers of two, zeros, infinities, NaNs and the subnormal range (where
-    the fast path must hand over to the slow one)."""
+    bit: random pairs over the whole exponent range, a dense sweep of exponents in [-60, 60] with extreme significands and
+    the edges of that range, quotients engineered to sit next to fp32 rounding midpoints, divisors with
+    all-ones / all-zeros significands, powers of two, signed zeros, infinities, NaNs and the subnormal range (where the fast
+    path must hand over to the slow one)."""
     rng = np.random.default_rng(12)
     cases = []
     n = 200000
@@ -118,6 +119,28 @@ def test_shared_reciprocal_division_is_the_ieee_division():
     half = np.spacing(q) * np.float32(0.5)
     x = ((q.astype(np.float64) + half.astype(np.float64) * rng.choice([-1.0, 1.0], (n, 9))) * m[:, None].astype(np.float64)).astype(np.float32)
     cases.append((x, m))
+    # (e) moderate exponents, uniform in [-60, 60], random and extreme significands; the edges of that range
+    def spread(shape):
+        sig = rng.integers(0, 2 ** 23, shape, dtype=np.uint64)
+        sig = np.where(rng.random(shape) < 0.05, rng.choice(np.array([0, 1, 2 ** 23 - 1, 2 ** 23 - 2, 2 ** 22], np.uint64), shape), sig)
+        bits = (rng.integers(0, 2, shape, dtype=np.uint64) << 31) | (rng.integers(127 - 60, 127 + 60, shape, dtype=np.uint64) << 23) | sig
+        return bits.astype(np.uint32).view(np.float32)
+    for _ in range(3):
+        cases.append((spread((n, 9)), spread(n)))
+    lo, hi = np.float32(2.0 ** -60), np.float32(2.0 ** 60)
+    edge = np.array([lo, np.nextafter(lo, np.float32(0)), np.nextafter(lo, np.float32(1)), hi, np.nextafter(hi, np.float32(0)),
+                     np.nextafter(hi, np.float32(np.inf)), -lo, -hi, 0.0, -0.0, 1.5, -3.25, 7.0], np.float32)
+    ex = np.resize(np.concatenate([edge, -edge]), 27).reshape(3, 9)
+    for mm in edge:
+        if mm != 0:
+            cases.append((ex, np.full(3, mm, np.float32)))
+    # (f) near-midpoint quotients again, now with divisors whose significand is all ones / nearly so, and negative ones
+    for top in (np.float32(2.0) - np.spacing(np.float32(1.0)), np.float32(2.0) - 2 * np.spacing(np.float32(1.0)), np.float32(-1.0) - np.spacing(np.float32(1.0))):
+        mq = np.full(n, top, np.float32) * np.float32(2.0) ** rng.integers(-20, 20, n).astype(np.float32)
+        q = (rng.random((n, 9)).astype(np.float32) + np.float32(1.0))
+        half = np.spacing(q) * np.float32(0.5)
+        x = ((q.astype(np.float64) + half.astype(np.float64) * rng.choice([-1.0, 1.0], (n, 9))) * mq[:, None].astype(np.float64)).astype(np.float32)
+        cases.append((x, mq))
     # (d) special divisors: significand all ones / all zeros, powers of two, tiny, huge
     special = np.array([1.0, 2.0, 0.5, np.float32(2.0) - np.spacing(np.float32(1.0)), np.float32(1.0) + np.spacing(np.float32(1.0)), 3.0,
                         1e-30, 1e30, 1e-38, 3e38, 1e-45, 0.0, -0.0, np.inf, -np.inf, np.nan, -7.0, 4.0], np.float32)
