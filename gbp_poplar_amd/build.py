@@ -62,6 +62,8 @@ def build(force=False, verbose=False, test_hooks=True):
     _build_lib(LIB, [], force, verbose)
     if test_hooks:
         _build_lib(TEST_LIB, ["-DGBP_BUILD_TEST_HOOKS"], force, verbose)
+    if os.path.exists(EXP_LIB):          # keep an existing measurement build in step with the sources (never created here)
+        build_experiments(force, verbose)
     os.makedirs(BIN, exist_ok=True)
     for name, src in CLI_SRCS.items():
         path = os.path.join(CSRC, src)

@@ -36,10 +36,30 @@ static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
   pipe.ctx = ctx;
   pipe.on = !rk.region && !o.verbose;
   unsigned iter = 0;
+  const auto print_iter = [](unsigned it_now, const gbp_eval_out& e) {       // ba.cpp:1020-1024
+    std::cout << "Iter " << it_now << " // Reprojection error " << (float)(e.sum_norm / (double)e.n_active);
+    std::cout << " // Cost " << (float)e.sum_half_sq << " // n relins: " << e.n_relin;
+    std::cout << " // n robust edges " << e.n_robust << "\n";
+    if (e.n_nonfinite) std::cout << "warning: " << e.n_nonfinite << " beliefs are non-finite\n";
+  };
+  std::vector<gbp_eval_out> series;
   for (int i = 0; i < o.n_iters; ++i) {
     if (((iter + 1) % 2 == 0) && (iter < o.steps * 2)) {       // ba.cpp:1003-1006
       pipe.line("Weakening priors \n");
       CLI_CHECK(ctx, gbp_weaken_priors(ctx));
+    }
+    if (pipe.on && o.eval_every == 1) {
+      // the reference's default: the metric after EVERY iteration.  All iterations up to the next prior weakening go down in
+      // one call (gbp_iterate_eval_each: one launch on a graph that runs in the persistent kernel), at most 128 at a time so
+      // that the lines keep coming on a large graph
+      int burst = 1;
+      while (burst < 128 && i + burst < o.n_iters && !(((iter + burst + 1) % 2 == 0) && (iter + burst < o.steps * 2))) ++burst;
+      series.resize((size_t)burst);
+      CLI_CHECK(ctx, gbp_iterate_eval_each(ctx, burst, series.data()));
+      for (int k = 0; k < burst; ++k) print_iter(iter + (unsigned)k, series[(size_t)k]);
+      i += burst - 1;
+      iter += (unsigned)burst;
+      continue;
     }
     // run up to the next host event (prior weakening or read-back) in one call: gbp_iterate(k) replays
     // the captured hipGraph, so with --eval_every > 1 the loop never leaves the device in between
@@ -53,12 +73,7 @@ static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
     iter += burst - 1;
     if (eval_now) {
       const unsigned it_now = iter;
-      CLI_CHECK(ctx, pipe.submit([it_now](const gbp_eval_out& e) {
-        std::cout << "Iter " << it_now << " // Reprojection error " << (float)(e.sum_norm / (double)e.n_active);
-        std::cout << " // Cost " << (float)e.sum_half_sq << " // n relins: " << e.n_relin;
-        std::cout << " // n robust edges " << e.n_robust << "\n";
-        if (e.n_nonfinite) std::cout << "warning: " << e.n_nonfinite << " beliefs are non-finite\n";
-      }, burst));                      // the burst and its metric in one call
+      CLI_CHECK(ctx, pipe.submit([it_now, print_iter](const gbp_eval_out& e) { print_iter(it_now, e); }, burst));   // the burst and its metric in one call
       if (o.verbose) {
         CLI_CHECK(ctx, gbp_read(ctx, &rb.out));
         cli::print_verbose(rb);

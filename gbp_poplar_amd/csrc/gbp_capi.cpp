@@ -89,6 +89,8 @@ struct gbp_ctx {
   std::vector<Span> span_pool;         // reusable event pairs
   void* eval_host = nullptr;           // pinned + device-mapped: k_eval writes the metric partials + health counters here
   void* eval_host_dev = nullptr;
+  void* series_host = nullptr;         // gbp_iterate_eval_each: [kSeriesMax metrics][1 + workgroups] slots, same kind of memory
+  void* series_dev = nullptr;
   int eval_parity = 0, eval_pending = 0;
   hipEvent_t eval_ev[2] = {nullptr, nullptr};
   bool profile_stages = false;
@@ -341,6 +343,7 @@ void gbp_destroy(gbp_ctx* c) {
   for (auto& v : {&c->spans, &c->span_pool})
     for (auto& sp : *v) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
   if (c->eval_host) (void)hipHostFree(c->eval_host);
+  if (c->series_host) (void)hipHostFree(c->series_host);
   if (c->pstatus_host) (void)hipHostFree(c->pstatus_host);
   for (hipEvent_t e : c->eval_ev) if (e) (void)hipEventDestroy(e);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -1203,10 +1206,9 @@ static int iterate_eval_impl(gbp_ctx* c, int n) {
   ev.on = 1;
   ev.cam_mu = P<float>(c->cam_mu); ev.lmk_mu = P<float>(c->lmk_mu);
   ev.num_undamped = c->prm.num_undamped_iters;
-  ev.partials = slots + 1;
+  ev.slots = slots;                    // [0] = health copy, [1 + workgroup] = partial sums (the layout gbp_eval_end reads)
   ev.health = P<unsigned long long>(c->health) + 2 * area;
   ev.health_next = P<unsigned long long>(c->health) + 2 * (area ^ 1);
-  ev.health_out = reinterpret_cast<unsigned long long*>(slots);
   gbp_ctx::Span sp{};
   if (int rc = span_begin(c, sp)) return rc;
   if (int rc = launch_persist_burst(c, sweep_args(c), n, &ev)) { c->span_pool.push_back(sp); return rc; }
@@ -1216,6 +1218,69 @@ static int iterate_eval_impl(gbp_ctx* c, int n) {
   HIPCHK(c, hipEventRecord(c->eval_ev[area], c->stream));
   c->eval_parity ^= 1;
   c->eval_pending += 1;
+  return GBP_OK;
+}
+
+// n iterations with the metric after EVERY one of them (the reference's default loop, ba.cpp:1009-1028 / slam.cpp), blocking:
+// out[k] = what gbp_iterate(1) + gbp_eval_global() would have returned for the k-th of them.  On a graph that runs in
+// k_persist a burst is ONE launch: the metric of iteration k rides in the sweep phase of iteration k + 1 (both only read the
+// beliefs), its partial sums go to host-mapped memory.  Everywhere else it is the loop it replaces, two metrics in flight.
+static int sum_eval(gbp_ctx* c, const DeviceEval* part, uint32_t nb, gbp_eval_out* o) {
+  std::memset(o, 0, sizeof(*o));
+  for (uint32_t b = 1; b <= nb; ++b) {
+    o->sum_norm += part[b].sum_norm; o->sum_half_sq += part[b].sum_half_sq;
+    o->n_active += part[b].n_active; o->n_relin += part[b].n_relin; o->n_robust += part[b].n_robust;
+  }
+  unsigned long long h[2];
+  std::memcpy(h, part, 16);
+  o->n_nonfinite = h[0];
+  o->n_nonpd = h[1];
+  return GBP_OK;
+}
+
+static int iterate_eval_each_impl(gbp_ctx* c, int n, gbp_eval_out* out) {
+  if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "gbp_iterate_eval_each: upload first");
+  if (n < 0 || (n > 0 && !out)) return fail(c, GBP_ERR_INVALID, "gbp_iterate_eval_each: n >= 0 and an array of n results");
+  if (c->eval_pending) return fail(c, GBP_ERR_STATE, "gbp_iterate_eval_each: finish the evaluations in flight (gbp_eval_end) first");
+  const uint32_t nb = eval_blocks(c->n_tiles);
+  const bool fused = c->persist_ok && !c->comm && c->world == 1 && !c->profile_stages && nb == (c->n_tiles + 3) / 4;
+  if (!fused) {
+    int done = 0;
+    for (int k = 0; k < n; ++k) {
+      if (int rc = iterate_impl(c, 1)) return rc;
+      if (int rc = eval_begin_impl(c)) return rc;
+      if (c->eval_pending == 2) { if (int rc = eval_end_impl(c, out + done)) return rc; ++done; }
+    }
+    while (done < n) { if (int rc = eval_end_impl(c, out + done)) return rc; ++done; }
+    return GBP_OK;
+  }
+  const uint32_t stride = nb + 1;
+  if (!c->series_host) {
+    HIPCHK(c, hipHostMalloc(&c->series_host, sizeof(DeviceEval) * (size_t)stride * kSeriesMax, hipHostMallocMapped));
+    HIPCHK(c, hipHostGetDevicePointer(&c->series_dev, c->series_host, 0));
+  }
+  const int area = c->eval_parity & 1;   // both health areas are zero between evaluations; this launch leaves them so
+  for (int done = 0; done < n;) {
+    const int m = std::min(n - done, (int)kSeriesMax);
+    PersistEval ev{};
+    ev.on = 1; ev.each = 1; ev.stride = stride;
+    ev.cam_mu = P<float>(c->cam_mu); ev.lmk_mu = P<float>(c->lmk_mu);
+    ev.num_undamped = c->prm.num_undamped_iters;
+    ev.slots = static_cast<DeviceEval*>(c->series_dev);
+    ev.health = P<unsigned long long>(c->health) + 2 * area;
+    ev.health_next = P<unsigned long long>(c->health) + 2 * (area ^ 1);
+    gbp_ctx::Span sp{};
+    if (int rc = span_begin(c, sp)) return rc;
+    if (int rc = launch_persist_burst(c, sweep_args(c), m, &ev)) { c->span_pool.push_back(sp); return rc; }
+    if (int rc = span_end(c, sp)) return rc;
+    c->timed_iters += (uint64_t)m;
+    c->beliefs_valid = true;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->pstatus_host && *static_cast<volatile unsigned*>(c->pstatus_host) != 0u)
+      return fail(c, GBP_ERR_HIP, "k_persist: a device-wide barrier timed out (workgroups not co-resident); results are invalid");
+    for (int k = 0; k < m; ++k) sum_eval(c, static_cast<const DeviceEval*>(c->series_host) + (size_t)k * stride, nb, out + done + k);
+    done += m;
+  }
   return GBP_OK;
 }
 
@@ -1559,6 +1624,9 @@ int gbp_eval(gbp_ctx* c, gbp_eval_out* o) { return guarded(c, "gbp_eval", [&] { 
 int gbp_eval_begin(gbp_ctx* c) { return guarded(c, "gbp_eval_begin", [&] { return eval_begin_impl(c); }); }
 int gbp_eval_end(gbp_ctx* c, gbp_eval_out* o) { return guarded(c, "gbp_eval_end", [&] { return eval_end_impl(c, o); }); }
 int gbp_iterate_eval(gbp_ctx* c, int n) { return guarded(c, "gbp_iterate_eval", [&] { return iterate_eval_impl(c, n); }); }
+int gbp_iterate_eval_each(gbp_ctx* c, int n, gbp_eval_out* out) {
+  return guarded(c, "gbp_iterate_eval_each", [&] { return iterate_eval_each_impl(c, n, out); });
+}
 #ifdef GBP_BUILD_TEST_HOOKS
 int gbp_debug_get(gbp_ctx* c, int what, float* a, float* b) { return guarded(c, "gbp_debug_get", [&] { return debug_get_impl(c, what, a, b); }); }
 int gbp_debug_set_factor_potentials(gbp_ctx* c, const float* eta9E, const float* lam81E) {

@@ -109,13 +109,14 @@ struct DeviceEval;
 // optional metric phases at the end of a k_persist launch (gbp_iterate_eval): what k_means + k_eval compute, same bits
 struct PersistEval {
   int on;
+  int each;                            // 0: one metric, after the last iteration;  1: after EVERY iteration (gbp_iterate_eval_each)
+  uint32_t stride;                     // DeviceEval slots per metric: [0] = health copy, [1 + workgroup] = partial sums
   float* cam_mu;                       // [C][6] metric means (util.cpp:103-108), written by the camera waves
   float* lmk_mu;                       // [L][3]
   int num_undamped;
-  DeviceEval* partials;                // [tile workgroups] per-workgroup partial sums (host-mapped memory)
+  DeviceEval* slots;                   // [metrics][stride], host-mapped memory; metric k of the launch -> slots + k * stride
   unsigned long long* health;          // [2] non-finite means / non-PD beliefs of THIS evaluation (zero on entry)
   unsigned long long* health_next;     // zeroed for the next evaluation
-  unsigned long long* health_out;      // host-mapped copy of health
 };
 struct PersistArgs {
   SweepArgs s;
@@ -132,6 +133,7 @@ struct PersistArgs {
   unsigned long long* trace;  // experiments build only (else NULL): [wave][iteration < kPersistTraceIters][8] wall-clock ticks
 };
 constexpr int kPersistTraceIters = 16;
+constexpr int kSeriesMax = 128;         // metrics per launch of gbp_iterate_eval_each (longer bursts are split)
 constexpr int kPersistSyncWords = 16 * 32;
 
 struct DeviceEval {  // per-block partials, summed on the host in block order

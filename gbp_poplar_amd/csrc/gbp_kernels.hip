@@ -1341,9 +1341,54 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
   GBP_UNROLL
   for (int k = 0; k < 15; ++k) pos2[k] = (lmk_live && 15u + (uint32_t)k < deg) ? b.lmk_fpos[lp0 + 15u + (uint32_t)k] : 0u;
 
+  // ---- the metric (gbp_iterate_eval / gbp_iterate_eval_each): what k_means + k_eval compute, same bits.  The belief owners
+  // write the metric means in phase B; after the next device-wide hand-off every tile wave adds its factors' residuals and the
+  // workgroup reduces them in k_eval's order (a workgroup holds the same 256 positions as a block of k_eval).  `packed` is the
+  // factor's state word as the sweep of the evaluated iteration left it.
+  const bool tile_block = bid * 4u < A.n_tiles;              // uniform per workgroup
+  auto metric = [&](uint32_t k, int packed, const float (&cmv)[6], const float (&lmu)[3]) {
+    double s_norm = 0, s_half = 0;
+    unsigned long long n_act = 0, n_rel = 0, n_rob = 0;
+    if (has_tile) {
+      const uint32_t flags = (uint32_t)packed & 7u;
+      if (!(flags & kFlagPad)) {
+        if (flags & kFlagRobust) ++n_rob;
+        if ((packed >> 3) == -A.ev.num_undamped) ++n_rel;
+        if (flags & kFlagActive) {
+          eval_factor(cmv, lmu, fac[54], fac[55], a.K, s_norm, s_half);
+          ++n_act;
+        }
+      }
+    }
+    DeviceEval* slots = A.ev.slots + (size_t)k * A.ev.stride;
+    if (tile_block) eval_block_reduce(s_norm, s_half, n_act, n_rel, n_rob, slots + 1 + bid);
+    if (bid == 0 && threadIdx.x == 0) {
+      unsigned long long* out = reinterpret_cast<unsigned long long*>(slots);
+      out[0] = __hip_atomic_load(&A.ev.health[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      out[1] = __hip_atomic_load(&A.ev.health[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (A.ev.each) {   // the next phase B counts from zero (it starts behind the next hand-off)
+        __hip_atomic_store(&A.ev.health[0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&A.ev.health[1], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  };
+  auto metric_means = [&](float (&cmv)[6], float (&lmu)[3]) {
+    GBP_UNROLL
+    for (int i = 0; i < 6; ++i) cmv[i] = X_emc.ld1(cam_i * 6u + (uint32_t)i);
+    GBP_UNROLL
+    for (int i = 0; i < 3; ++i) lmu[i] = X_eml.ld1(lmk_i * 3u + (uint32_t)i);
+  };
+
   unsigned epoch = 0;
   for (int it = 0; it < A.n_iters; ++it) {
     GBP_TRACE(0);
+    const bool ev_means = A.ev.on && (A.ev.each || it + 1 == A.n_iters);     // this iteration's beliefs are evaluated
+    // the metric of iteration it - 1 rides in this phase A (both only READ what phase B left): its loads go out with the
+    // sweep's, its arithmetic runs behind the sweep's stores
+    const bool ev_prev = A.ev.on && A.ev.each && it > 0;
+    float ev_cm[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ev_lm[3] = {0.f, 0.f, 0.f};
+    int ev_packed = 0;
+    if (ev_prev && has_tile) { metric_means(ev_cm, ev_lm); ev_packed = __float_as_int(lm[13]); }
     // ================= phase A: the sweep of this wave's tile =================
     if (has_tile) {
       float cb[44], lb[16], mu[12];
@@ -1420,6 +1465,7 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
         }
       }
     }
+    if (ev_prev) metric((uint32_t)it - 1u, ev_packed, ev_cm, ev_lm);
     GBP_TRACE(1);
     grid_sync(A.sync, A.epoch_base + (++epoch) * nblk, A.status);
     GBP_TRACE(2);
@@ -1471,7 +1517,7 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
         cam_cur0 = make_float4(x0c[0], x0c[1], x0c[2], x0c[3]);
         cam_cur1 = make_float4(x0c[4], x0c[5], 0.f, 0.f);
         X_cmu.st4(mu4, cam_cur0); X_cmu.st4(mu4 + 1u, cam_cur1);
-        if (A.ev.on && it + 1 == A.n_iters) {   // metric means of this camera (what k_means computes), from the belief in LDS
+        if (ev_means) {   // metric means of this camera (what k_means computes), from the belief in LDS
           float x[6];
           solve_pivot<6>(sh[wib] + 8, 6, sh[wib], x);
           bool finite = true;
@@ -1548,7 +1594,7 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
         u[2] = (used.z - x0l[2]) * (used.z - x0l[2]);
         lmk_cur = make_float4(x0l[0], x0l[1], x0l[2], 0.f);
         X_lmu.st4(mu4, lmk_cur);
-        if (A.ev.on && it + 1 == A.n_iters) {   // metric mean of this landmark (k_means), from the belief record in registers
+        if (ev_means) {   // metric mean of this landmark (k_means), from the belief record in registers
           float x[3];
           solve_pivot<3>(rec + 4, 3, rec, x);
           bool finite = true;
@@ -1569,37 +1615,13 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
   }
 #undef GBP_TRACE
 
-  // ---- optional metric (gbp_iterate_eval): what k_means + k_eval compute after the last iteration, same bits.  The means were
-  // written by the belief owners in the last phase B; one more hand-off, then every tile wave adds its factors' residuals and
-  // the workgroup reduces them in k_eval's order (a workgroup holds the same 256 positions as a block of k_eval) ----
+  // ---- the metric of the last iteration: one more hand-off, then as above ----
   if (A.ev.on) {
     if (bid == 0 && threadIdx.x == 0) { A.ev.health_next[0] = 0ull; A.ev.health_next[1] = 0ull; }
     grid_sync(A.sync, A.epoch_base + (++epoch) * nblk, A.status);
-    double s_norm = 0, s_half = 0;
-    unsigned long long n_act = 0, n_rel = 0, n_rob = 0;
-    if (has_tile) {
-      const int packed = __float_as_int(lm[13]);
-      const uint32_t flags = (uint32_t)packed & 7u;
-      if (!(flags & kFlagPad)) {
-        if (flags & kFlagRobust) ++n_rob;
-        if ((packed >> 3) == -A.ev.num_undamped) ++n_rel;
-        if (flags & kFlagActive) {
-          float cmv[6], lmu[3];
-          GBP_UNROLL
-          for (int i = 0; i < 6; ++i) cmv[i] = X_emc.ld1(cam_i * 6u + (uint32_t)i);
-          GBP_UNROLL
-          for (int i = 0; i < 3; ++i) lmu[i] = X_eml.ld1(lmk_i * 3u + (uint32_t)i);
-          eval_factor(cmv, lmu, fac[54], fac[55], a.K, s_norm, s_half);
-          ++n_act;
-        }
-      }
-    }
-    const bool tile_block = bid * 4u < A.n_tiles;            // uniform per workgroup
-    if (tile_block) eval_block_reduce(s_norm, s_half, n_act, n_rel, n_rob, A.ev.partials + bid);
-    if (bid == 0 && threadIdx.x == 0) {
-      A.ev.health_out[0] = __hip_atomic_load(&A.ev.health[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      A.ev.health_out[1] = __hip_atomic_load(&A.ev.health[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    float cmv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, lmu[3] = {0.f, 0.f, 0.f};
+    if (has_tile) metric_means(cmv, lmu);
+    metric(A.ev.each ? (uint32_t)A.n_iters - 1u : 0u, __float_as_int(lm[13]), cmv, lmu);
   }
 
   // ---- what stayed in registers goes back to its arrays ----

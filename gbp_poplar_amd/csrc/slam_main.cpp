@@ -41,6 +41,13 @@ static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
   cli::MetricPipe pipe;
   pipe.ctx = ctx;
   pipe.on = !rk.region && !o.verbose;
+  const auto print_iter = [](unsigned total, unsigned since, const gbp_eval_out& e) {
+    std::cout << "Iters " << total;
+    std::cout << " (since last kf " << since << ") // Reprojection error " << (float)(e.sum_norm / (double)e.n_active);
+    std::cout << " // Cost " << (float)e.sum_half_sq << " // n relins: " << e.n_relin;
+    std::cout << " // n robust edges " << e.n_robust << "\n";
+  };
+  std::vector<gbp_eval_out> series;
   for (unsigned i = 0; i < niters; ++i) {
     if ((i + 1) % (unsigned)o.iters_between_kfs == 0) {         // slam.cpp:1020-1046
       CLI_CHECK(ctx, pipe.flush());                             // the keyframe logic reads beliefs back: no metric in flight
@@ -67,6 +74,20 @@ static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
       pipe.line("Weakening priors \n");
       CLI_CHECK(ctx, gbp_weaken_priors(ctx));
     }
+    if (pipe.on && o.eval_every == 1) {
+      // the reference's default, the metric after EVERY iteration: everything up to the next keyframe / prior weakening in
+      // one call (gbp_iterate_eval_each, see ba_main.cpp)
+      unsigned nb = 1;
+      while (nb < 128 && i + nb < niters && (i + nb + 1) % (unsigned)o.iters_between_kfs != 0 &&
+             !(((iter + nb + 1) % 2 == 0) && (iter + nb < o.steps * 2)))
+        ++nb;
+      series.resize(nb);
+      CLI_CHECK(ctx, gbp_iterate_eval_each(ctx, (int)nb, series.data()));
+      for (unsigned k = 0; k < nb; ++k) print_iter((unsigned)o.iters_between_kfs * data_counter + iter + k, iter + k, series[k]);
+      i += nb - 1;
+      iter += nb;
+      continue;
+    }
     // up to the next host event (keyframe, prior weakening, metric read-back) in one call, like ba_main.cpp
     unsigned burst = 1;
     while (i + burst < niters && (i + burst + 1) % (unsigned)o.iters_between_kfs != 0 && (i + burst) % (unsigned)o.eval_every != 0 &&
@@ -78,12 +99,7 @@ static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
     iter += burst - 1;
     if (eval_now) {
       const unsigned total = (unsigned)o.iters_between_kfs * data_counter + iter, since = iter;
-      CLI_CHECK(ctx, pipe.submit([total, since](const gbp_eval_out& e) {
-        std::cout << "Iters " << total;
-        std::cout << " (since last kf " << since << ") // Reprojection error " << (float)(e.sum_norm / (double)e.n_active);
-        std::cout << " // Cost " << (float)e.sum_half_sq << " // n relins: " << e.n_relin;
-        std::cout << " // n robust edges " << e.n_robust << "\n";
-      }, (int)burst));
+      CLI_CHECK(ctx, pipe.submit([total, since, print_iter](const gbp_eval_out& e) { print_iter(total, since, e); }, (int)burst));
       if (o.verbose) {
         CLI_CHECK(ctx, gbp_read(ctx, &rb.out));
         cli::print_verbose(rb);

@@ -102,6 +102,19 @@ def run_ba(engine, state, opts, n_iters=None, eval_every=1, log=None):
             engine.weaken_priors()
         # up to the next host event (prior weakening, metric read-back, end) in ONE call, like csrc/ba_main.cpp: the
         # engine then runs the burst without leaving the device (hipGraph replay, or k_persist on small graphs)
+        if eval_every == 1 and hasattr(engine, "iterate_eval_each"):
+            # the reference's default, the metric after EVERY iteration: everything up to the next prior weakening in one call
+            burst = 1
+            while it + burst < n_iters and not (((it + burst + 1) % 2 == 0) and (it + burst < opts.steps * 2)):
+                burst += 1
+            for k, ev in enumerate(engine.iterate_eval_each(burst)):
+                m = metric(ev)
+                traj.append((it + k, m[0], m[1], int(ev["n_relin"]), int(ev["n_robust"])))
+                if log:
+                    log("Iter %d // Reprojection error %.6f // Cost %.6f // n relins: %d // n robust edges %d"
+                        % (it + k, m[0], m[1], ev["n_relin"], ev["n_robust"]))
+            it += burst
+            continue
         burst = 1
         while (it + burst < n_iters and not (eval_every and (it + burst) % eval_every == 0)
                and not (((it + burst + 1) % 2 == 0) and (it + burst < opts.steps * 2))):
@@ -158,6 +171,20 @@ def run_slam(engine, host, bal, state, extra, opts, iters_between_kfs=None, max_
                 log("Adding keyframe %d, %d new landmarks" % (data_counter + 1, n_new))
         if ((it + 1) % 2 == 0) and (it < opts.steps * 2):
             engine.weaken_priors()
+        if eval_every == 1 and hasattr(engine, "iterate_eval_each"):
+            burst = 1                   # the metric after EVERY iteration, up to the next keyframe / prior weakening in one call
+            while (i + burst < niters and (i + burst + 1) % ibk != 0
+                   and not (((it + burst + 1) % 2 == 0) and (it + burst < opts.steps * 2))):
+                burst += 1
+            for k, ev in enumerate(engine.iterate_eval_each(burst)):
+                m = metric(ev)
+                traj.append((i + k, m[0], m[1], int(ev["n_relin"]), int(ev["n_robust"])))
+                if log:
+                    log("Iters %d (since last kf %d) // Reprojection error %.6f // Cost %.6f // n relins: %d // n robust edges %d"
+                        % (ibk * data_counter + it + k, it + k, m[0], m[1], ev["n_relin"], ev["n_robust"]))
+            i += burst
+            it += burst
+            continue
         burst = 1                       # up to the next keyframe / prior weakening / read-back in one call
         while (i + burst < niters and (i + burst + 1) % ibk != 0 and not (eval_every and (i + burst) % eval_every == 0)
                and not (((it + burst + 1) % 2 == 0) and (it + burst < opts.steps * 2))):

@@ -107,6 +107,14 @@ class GbpEngine:
         """iterate(n) + eval_begin() in one call (fused into one launch on graphs that run in the persistent kernel)."""
         self._chk(self.lib.gbp_iterate_eval(self.h, int(n)), "gbp_iterate_eval")
 
+    def iterate_eval_each(self, n):
+        """n iterations with the metric after every one (blocking); one launch per burst on graphs that run in the
+        persistent kernel.  Returns a list of n dicts like eval()."""
+        n = int(n)
+        arr = (cabi.GbpEvalOut * max(n, 1))()
+        self._chk(self.lib.gbp_iterate_eval_each(self.h, n, arr), "gbp_iterate_eval_each")
+        return [{k: getattr(arr[i], k) for k, _ in arr[i]._fields_} for i in range(n)]
+
     def eval_end(self):
         o = cabi.GbpEvalOut()
         self._chk(self.lib.gbp_eval_end(self.h, C.byref(o)), "gbp_eval_end")

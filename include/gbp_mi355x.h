@@ -24,7 +24,7 @@ extern "C" {
 
 /* 2: gbp_timing_out gained exchange_ms, gbp_status gained GBP_ERR_COMM, the gbp_debug_* test hooks moved to
  *    gbp_mi355x_debug.h / libgbp_mi355x_test.so.  Callers compare gbp_abi_version() with the header they were built against. */
-#define GBP_ABI_VERSION 2
+#define GBP_ABI_VERSION 3
 
 typedef enum {
   GBP_OK = 0,
@@ -195,6 +195,11 @@ int gbp_eval_end(gbp_ctx* ctx, gbp_eval_out* out);
  * after every iteration; on a graph that runs in the persistent kernel the metric then rides in the same launch (identical
  * results), elsewhere it is exactly the two calls. */
 int gbp_iterate_eval(gbp_ctx* ctx, int n_iters);
+/* n iterations with the metric after EVERY one (what the loops of ba.cpp:1001-1028 and slam.cpp print), blocking: out[k] is
+ * what gbp_iterate(ctx, 1) followed by gbp_eval would have returned for the k-th of them.  A burst between two host events
+ * (prior weakening, a new keyframe) is ONE launch on a graph that runs in the persistent kernel — the metric of iteration k
+ * is computed inside the sweep phase of iteration k + 1 — and the plain loop elsewhere.  No evaluation may be in flight. */
+int gbp_iterate_eval_each(gbp_ctx* ctx, int n_iters, gbp_eval_out* out /* [n_iters] */);
 int gbp_sync(gbp_ctx* ctx);                                    /* wait for queued device work     */
 int gbp_timing(gbp_ctx* ctx, gbp_timing_out* out, int reset);  /* ba.cpp:980,1056-1058            */
 

@@ -360,6 +360,22 @@ def _full_snapshot(eng):
     return d
 
 
+def _ragged_bal():
+    """Few factors, many landmarks (more belief waves than sweep tiles), a hub landmark of degree > 30, cameras with one row;
+    with the parameters that make it relinearise early."""
+    rng = np.random.default_rng(11)
+    C, L, E = 9, 700, 1500
+    cam_id = np.sort(rng.integers(0, C, E)).astype(np.uint32)
+    lmk_id = rng.integers(0, L, E).astype(np.uint32)
+    lmk_id[rng.random(E) < 0.03] = 5             # hub landmark: slots beyond the index record
+    cam_id[:C] = np.arange(C)
+    return _tiny_problem(list(cam_id), list(lmk_id), C, L, seed=3), dict(dmu_threshold=0.05, min_linear_iters=3, num_undamped_iters=2)
+
+
+def _ragged_active(bal):
+    return (np.random.default_rng(5).random(bal["n_edges"]) < 0.9).astype(np.uint32)
+
+
 @pytest.mark.parametrize("name", ["fr2robot2", "fr1xyz", "ragged"])
 def test_persistent_kernel_equals_two_kernel_path(name, oracle_mod):
     """gbp_iterate(n) through k_persist (sweep + device-wide barrier + beliefs + barrier, n times in ONE launch, per-factor
@@ -372,20 +388,13 @@ def test_persistent_kernel_equals_two_kernel_path(name, oracle_mod):
     opts = driver.Options()
     kw = {}
     if name == "ragged":
-        rng = np.random.default_rng(11)
-        C, L, E = 9, 700, 1500                       # few factors, many landmarks: more belief waves than sweep tiles
-        cam_id = np.sort(rng.integers(0, C, E)).astype(np.uint32)
-        lmk_id = rng.integers(0, L, E).astype(np.uint32)
-        lmk_id[rng.random(E) < 0.03] = 5             # hub landmark: degree > 15 (slots beyond the index record)
-        cam_id[:C] = np.arange(C)
-        bal = _tiny_problem(list(cam_id), list(lmk_id), C, L, seed=3)
+        bal, kw = _ragged_bal()
         opts.undamped_start = 2
-        kw = dict(dmu_threshold=0.05, min_linear_iters=3, num_undamped_iters=2)
     else:
         bal = _bal(name)
     K, state, _ = driver.build_inputs(bal, opts, hostlib)
     if name == "ragged":
-        state["active_flag"] = (np.random.default_rng(5).random(bal["n_edges"]) < 0.9).astype(np.uint32)
+        state["active_flag"] = _ragged_active(bal)
     engs = [GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K, hooks=True,
                       params=_cabi.GbpParams.defaults(persistent=mode, **kw)) for mode in (1, -1)]
     assert engs[0].graph_state() == 2 and engs[1].graph_state() != 2
@@ -484,6 +493,61 @@ def test_iterate_eval_fused_metric_equals_separate_calls(oracle_mod):
         e2 = b.eval()
         assert a.eval_end() == e1 and a.eval_end() == e2
         assert a.timing()["iterations"] == b.timing()["iterations"]
+
+
+def test_iterate_eval_each_equals_one_iteration_and_one_metric_at_a_time(oracle_mod):
+    """gbp_iterate_eval_each(n): n iterations with the metric after every one — ONE k_persist launch per burst on small graphs,
+    the metric of iteration k computed inside the sweep phase of iteration k + 1 — against n times {gbp_iterate(1); gbp_eval()}:
+    every metric (sums, counters, health counters) and every belief identical.  Bursts of 1, a few, 129 and 300 (a launch carries
+    at most 128 metrics), prior weakening between bursts, then gbp_iterate_eval and plain gbp_eval still work; c is the same
+    entry point on the two-kernel path."""
+    from gbp_poplar_amd import _cabi, driver, hostlib
+    from gbp_poplar_amd.engine import GbpEngine
+    for name in ("fr2robot2", "fr1xyz", "ragged"):
+        opts, kw = driver.Options(), {}
+        if name == "ragged":
+            bal, kw = _ragged_bal()
+            opts.undamped_start = 2
+        else:
+            bal = _bal(name)
+        K, state, _ = driver.build_inputs(bal, opts, hostlib)
+        if name == "ragged":
+            state["active_flag"] = _ragged_active(bal)
+        a = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K, params=_cabi.GbpParams.defaults(persistent=1, **kw))
+        b = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K, params=_cabi.GbpParams.defaults(persistent=-1, **kw))
+        c = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K, params=_cabi.GbpParams.defaults(persistent=-1, **kw))
+        assert a.graph_state() == 2 and c.graph_state() != 2
+        for e in (a, b, c):
+            e.upload(state)
+            e.linearise()
+        it = 0
+        for n in (1, 1, 2, 2, 2, 2, 5, 1, 129, 0, 300 if name == "fr1xyz" else 40):
+            if it in (1, 3, 5, 7, 9):
+                for e in (a, b, c):
+                    e.weaken_priors()
+            ea = a.iterate_eval_each(n)
+            ec = c.iterate_eval_each(n)
+            eb = []
+            for _ in range(n):
+                b.iterate(1)
+                eb.append(b.eval())
+            assert len(ea) == n and ea == eb, (name, it, n, [i for i in range(n) if ea[i] != eb[i]][:5])
+            assert ec == eb, (name, it, n)
+            it += n
+            ra, rb = a.read(), b.read()
+            for k in ra:
+                assert np.array_equal(ra[k], rb[k], equal_nan=True), (name, it, k)
+        a.iterate_eval(3)
+        b.iterate(3)
+        assert a.eval_end() == b.eval()
+        a.iterate(2)
+        b.iterate(2)
+        assert a.eval() == b.eval()
+        assert a.timing()["iterations"] == b.timing()["iterations"]
+        a.eval_begin()
+        with pytest.raises(RuntimeError):
+            a.iterate_eval_each(1)       # an evaluation is in flight
+        a.eval_end()
 
 
 def test_persistent_kernel_is_chosen_by_size():
