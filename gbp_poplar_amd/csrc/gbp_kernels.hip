@@ -1296,22 +1296,25 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
   const uint32_t cb_rec4 = cam_i * (uint32_t)kCamRec4, lb_rec4 = lmk_i * (uint32_t)kLmkRec4;   // loop-invariant: phase A is ONE round of loads
   const uint32_t cmu_rec4 = cam_i * 4u, lmu_rec4 = lmk_i * 2u;
 
-  // ---- phase-B role: camera w (lanes 0..43 = the record), or landmarks 16 (w - C) .. + 15 (4 lanes each)
-  const bool cam_wave = w < b.n_cams;
-  const bool lmk_wave = !cam_wave && (w - b.n_cams) < A.n_lmk_groups;
+  // ---- phase-B role: camera v (lanes 0..43 = the record), or landmarks 16 (v - C) .. + 15 (4 lanes each).  Roles are
+  // numbered ACROSS the workgroups (v = wave-in-workgroup * workgroups + workgroup): the camera waves, whose lane 0 runs long
+  // serial fp64 chains when the metric rides along, land one per CU instead of four
+  const uint32_t v = wib * nblk + bid;
+  const bool cam_wave = v < b.n_cams;
+  const bool lmk_wave = !cam_wave && (v - b.n_cams) < A.n_lmk_groups;
   const uint32_t cj = lane;                                   // camera role: element of the 44-float record
   const bool cam_live = cam_wave && cj < (uint32_t)kCamRec;
   uint32_t r0 = 0, r1 = 0;
   float cam_prior_j = 0.f;
   float4 cam_cur0 = make_float4(0.f, 0.f, 0.f, 0.f), cam_cur1 = cam_cur0;   // mean of the belief the next sweep consumes
   if (cam_wave) {
-    r0 = b.cam_row_ptr[w]; r1 = b.cam_row_ptr[w + 1];
-    if (cam_live) cam_prior_j = b.cam_prior[(size_t)w * kCamRec + cj];
+    r0 = b.cam_row_ptr[v]; r1 = b.cam_row_ptr[v + 1];
+    if (cam_live) cam_prior_j = b.cam_prior[(size_t)v * kCamRec + cj];
     // (sc1 like EVERY access of this launch to an array that crosses waves: a plain load could leave a copy in this XCD's L2
     // that goes stale when another XCD rewrites the neighbouring half of the 128-B line)
-    cam_cur0 = X_cmu.ld4(w * 4u); cam_cur1 = X_cmu.ld4(w * 4u + 1u);
+    cam_cur0 = X_cmu.ld4(v * 4u); cam_cur1 = X_cmu.ld4(v * 4u + 1u);
   }
-  const uint32_t l = lmk_wave ? (w - b.n_cams) * 16 + (lane >> 2) : 0u, q4 = lane & 3;
+  const uint32_t l = lmk_wave ? (v - b.n_cams) * 16 + (lane >> 2) : 0u, q4 = lane & 3;
   const bool lmk_live = lmk_wave && l < b.n_lmks;
   uint4 ix = make_uint4(0u, 0u, 0u, 0u);
   float4 lmk_prior4 = make_float4(0.f, 0.f, 0.f, 0.f), lmk_cur = lmk_prior4;
@@ -1497,7 +1500,7 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
         }
       }
       if (cam_live) {
-        b.cam_local[(size_t)w * kCamRec + cj] = acc;
+        b.cam_local[(size_t)v * kCamRec + cj] = acc;
         sh[wib][cj] = cam_prior_j + acc;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1507,8 +1510,18 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
         float cb[44], x0c[6];
         GBP_UNROLL
         for (int i = 0; i < 44; ++i) cb[i] = sh[wib][i];
-        cam_mean(cb, x0c);
-        const uint32_t mu4 = w * 4u;            // [0,1] = means of the current belief, [2,3] = means the last sweep used
+        // three independent dependent-chains on ONE lane (hoisted mean; with the metric, the fp64 pivoted solve and the fp64
+        // LDL pivots): computed together, before any store or branch, so that the scheduler can interleave them
+        float xm[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        bool pd = true;
+        if (ev_means) {   // metric means of this camera (what k_means computes), from the belief in LDS
+          solve_pivot<6>(sh[wib] + 8, 6, sh[wib], xm);
+          pd = ldl_pivots_positive<6>(sh[wib] + 8, 6);
+          cam_mean(cb, x0c);
+        } else {
+          cam_mean(cb, x0c);
+        }
+        const uint32_t mu4 = v * 4u;            // [0,1] = means of the current belief, [2,3] = means the last sweep used
         X_cmu.st4(mu4 + 2u, cam_cur0); X_cmu.st4(mu4 + 3u, cam_cur1);
         const float used[6] = {cam_cur0.x, cam_cur0.y, cam_cur0.z, cam_cur0.w, cam_cur1.x, cam_cur1.y};
         float S = 0.f;
@@ -1517,21 +1530,19 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
         cam_cur0 = make_float4(x0c[0], x0c[1], x0c[2], x0c[3]);
         cam_cur1 = make_float4(x0c[4], x0c[5], 0.f, 0.f);
         X_cmu.st4(mu4, cam_cur0); X_cmu.st4(mu4 + 1u, cam_cur1);
-        if (ev_means) {   // metric means of this camera (what k_means computes), from the belief in LDS
-          float x[6];
-          solve_pivot<6>(sh[wib] + 8, 6, sh[wib], x);
+        if (ev_means) {
           bool finite = true;
           GBP_UNROLL
-          for (int i = 0; i < 6; ++i) { X_emc.st1(w * 6u + (uint32_t)i, x[i]); finite &= (x[i] - x[i] == 0.f); }
+          for (int i = 0; i < 6; ++i) { X_emc.st1(v * 6u + (uint32_t)i, xm[i]); finite &= (xm[i] - xm[i] == 0.f); }
           if (!finite) atomicAdd(&A.ev.health[0], 1ull);
-          if (!ldl_pivots_positive<6>(sh[wib] + 8, 6)) atomicAdd(&A.ev.health[1], 1ull);
+          if (!pd) atomicAdd(&A.ev.health[1], 1ull);
         }
         sh[wib][6] = S;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (cam_live) X_camb.st1(w * (uint32_t)kCamRec + cj, sh[wib][cj]);
+      if (cam_live) X_camb.st1(v * (uint32_t)kCamRec + cj, sh[wib][cj]);
     } else if (lmk_wave) {
       float4 acc = lmk_prior4;
       {  // both batches of loads are issued before the first add (one memory round trip for up to 30 slots: the

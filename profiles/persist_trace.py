@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Where does an iteration of k_persist spend its time?  Wall-clock stamps (100 MHz) written by lane 0 of every wave
 around the two phases and the two barriers (experiments build), averaged over iterations 2..15 of a burst in the
-steady state of the ./ba flow.   python profiles/persist_trace.py [fr1xyz]"""
+steady state of the ./ba flow.   python profiles/persist_trace.py [fr1xyz] [each]
+(`each`: the traced burst is gbp_iterate_eval_each — the metric after every iteration rides in the launch)"""
 import ctypes as C
 import os
 import sys
@@ -33,7 +34,10 @@ lib.gbp_debug_ticks.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 lib.gbp_debug_ticks(eng.h, None, 0)
 redo = (C.c_ulonglong * 4)()
 lib.gbp_debug_div_redo(redo, 1)
-eng.iterate(32)
+if "each" in sys.argv[2:]:
+    eng.iterate_eval_each(32)
+else:
+    eng.iterate(32)
 eng.sync()
 lib.gbp_debug_div_redo(redo, 0)
 print("div_shared slow path in 32 iterations: %d x (54 values), %d x (9 values), %d x (other)" % (redo[0], redo[1], redo[2]))
@@ -53,7 +57,8 @@ it_time = (t[:, 3:, 0] - t[:, 2:-1, 0])
 print("### %s: %d waves; iteration (start to start) %.2f us" % (name, waves, it_time.mean()))
 print("| waves | sweep phase us | wait at barrier 1 us | belief phase us | wait at barrier 2 us |")
 print("|---|---|---|---|---|")
-groups = (("camera waves (0..%d)" % (Cn - 1), slice(0, Cn)), ("landmark waves", slice(Cn, Cn + (L + 15) // 16)), ("all", slice(0, waves)))
+role = (np.arange(waves) % 4) * (waves // 4) + np.arange(waves) // 4        # belief-phase role of wave w (k_persist: v = wib * workgroups + workgroup)
+groups = (("camera waves (%d)" % Cn, role < Cn), ("landmark waves", (role >= Cn) & (role < Cn + (L + 15) // 16)), ("all", slice(0, waves)))
 for label, sl in groups:
     m = d[sl].mean(axis=(0, 1))
     print("| %s | %.2f | %.2f | %.2f | %.2f |" % (label, m[0], m[1], m[2], m[3]))
