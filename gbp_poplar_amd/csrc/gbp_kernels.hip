@@ -374,8 +374,7 @@ GBP_DEV void factor_update(float (&fac)[56], const float (&cm)[28], float (&mu)[
 #endif
 constexpr int kWpb = GBP_SWEEP_WPB;
 template <bool HOIST, int ABL>
-GBP_DEV void sweep_tile(const SweepArgs& a) {
-  const uint32_t wslot = (blockIdx.x + a.block0 * (4 / kWpb)) * kWpb + (threadIdx.x >> 6);
+GBP_DEV void sweep_tile(const SweepArgs& a, const uint32_t wslot) {
   const uint32_t tile = a.tile_perm ? (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tile_perm[wslot]) : wslot;
   const uint32_t lane = threadIdx.x & 63, p = tile * 64 + lane;
 
@@ -501,12 +500,22 @@ GBP_DEV void sweep_tile(const SweepArgs& a) {
 }
 
 template <bool HOIST, int ABL = 0>
-__global__ __launch_bounds__(64 * kWpb) void k_sweep(const SweepArgs a) { sweep_tile<HOIST, ABL>(a); }
+__global__ __launch_bounds__(64 * kWpb) void k_sweep(const SweepArgs a) {
+  sweep_tile<HOIST, ABL>(a, (blockIdx.x + a.block0 * (4 / kWpb)) * kWpb + (threadIdx.x >> 6));
+}
 
 #ifdef GBP_BUILD_EXPERIMENTS
 // Mapping experiment (profiles/time_mapping.py): the SAME sweep forced to three wavefronts per SIMD
 // (<= 168 VGPRs): what a third wave buys against what the spills cost.
-__global__ __launch_bounds__(64 * kWpb) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_sweep_w3(const SweepArgs a) { sweep_tile<true, 0>(a); }
+__global__ __launch_bounds__(64 * kWpb) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_sweep_w3(const SweepArgs a) {
+  sweep_tile<true, 0>(a, (blockIdx.x + a.block0 * (4 / kWpb)) * kWpb + (threadIdx.x >> 6));
+}
+// Mapping experiment (gbp_params.reserved[0] = 2): the same sweep as RESIDENT waves that loop over the tiles (grid = what
+// fits the chip at two waves per SIMD) instead of one wave per tile: a wave's stores overlap the next tile's loads, no
+// wave slot idles between a retiring wave and its successor.
+__global__ __launch_bounds__(256) void k_sweep_loop(const SweepArgs a, const uint32_t n_slots) {
+  for (uint32_t ws = blockIdx.x * 4 + (threadIdx.x >> 6); ws < n_slots; ws += gridDim.x * 4) sweep_tile<true, 0>(a, ws);
+}
 #endif
 
 #ifdef GBP_BUILD_EXPERIMENTS
@@ -1888,6 +1897,11 @@ void launch_sweep_blocks(SweepArgs a, uint32_t block0, uint32_t block1, bool hoi
 #ifdef GBP_BUILD_EXPERIMENTS
   if (a.variant == 1 && hoist) {   // gbp_params.reserved[0] = 1: the sub-wave mapping (mapping experiments, parity test)
     hipLaunchKernelGGL(k_sweep_coop16, dim3((block1 - block0) * 16), dim3(256), 0, s, a);   // needs block0 == 0 (whole sweeps only)
+    return;
+  }
+  if (a.variant >= 2 && hoist && block0 == 0) {   // reserved[0] = 2 + k: resident looping waves, grid = (k ? k : 512) workgroups
+    const uint32_t nb = a.variant > 2 ? (uint32_t)a.variant : 512u;
+    hipLaunchKernelGGL(k_sweep_loop, dim3(nb < block1 ? nb : block1), dim3(256), 0, s, a, block1 * 4);
     return;
   }
 #endif
