@@ -23,7 +23,9 @@ extern "C" {
 #endif
 
 /* 2: gbp_timing_out gained exchange_ms, gbp_status gained GBP_ERR_COMM, the gbp_debug_* test hooks moved to
- *    gbp_mi355x_debug.h / libgbp_mi355x_test.so.  Callers compare gbp_abi_version() with the header they were built against. */
+ *    gbp_mi355x_debug.h / libgbp_mi355x_test.so; gbp_params.persistent, gbp_iterate_eval.
+ * 3: gbp_iterate_eval_each.
+ * Callers compare gbp_abi_version() with the header they were built against. */
 #define GBP_ABI_VERSION 3
 
 typedef enum {
