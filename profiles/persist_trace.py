@@ -79,6 +79,17 @@ bp = d[:, :, 2]
 for label, sl in groups[:2]:
     x = bp[sl]
     print("| belief phase, %s | %.2f | %.2f | %.2f | %.2f | %.2f |" % (label, x.min(), np.median(x), x.mean(), np.percentile(x, 90), x.max()))
+# belief phase of the landmark waves against the largest degree among their 16 landmarks (index record: 15 slots; 16..30: second batch)
+deg = np.bincount(bal["lmk_id"], minlength=L)
+lw = np.nonzero((role >= Cn) & (role < Cn + (L + 15) // 16))[0]
+gmax = np.array([deg[(role[w] - Cn) * 16:(role[w] - Cn) * 16 + 16].max() for w in lw])
+gsum = np.array([deg[(role[w] - Cn) * 16:(role[w] - Cn) * 16 + 16].sum() for w in lw])
+for lo, hi in ((0, 8), (9, 15), (16, 22), (23, 30), (31, 10 ** 6)):
+    sel = (gmax >= lo) & (gmax <= hi)
+    if sel.any():
+        x = bp[lw[sel]]
+        print("| landmark waves, largest degree %d..%d (%d waves, %.0f factors per wave) | %.2f | %.2f | %.2f | %.2f | %.2f |"
+              % (lo, min(hi, gmax.max()), sel.sum(), gsum[sel].mean(), x.min(), np.median(x), x.mean(), np.percentile(x, 90), x.max()))
 tk = np.zeros((waves, 16), np.uint64)
 lib.gbp_debug_ticks(eng.h, tk.ctypes.data_as(C.c_void_p), waves)
 tk = tk.astype(np.float64) / 100.0
