@@ -19,6 +19,16 @@ Workloads
 exactly BASELINE.json's metric, and it aggregates over ranks like tokens/s does (raw iterations/s of the larger
 graph is in config.iters_per_sec).
 
+configs (N = 1, default workload): the other half of BASELINE.json's metric — "fr1xyz and 1M-factor synthetic" — and config 3
+(the incremental SLAM path on fr2robot2).  `bin/ba --bal_file fr1xyz.txt` and `bin/slam --bal_file fr2robot2.txt` (the C++
+executables on top of the C-ABI, default flags = the reference's loop, ba.cpp:1001-1053 / slam.cpp:1018-1103: the metric printed
+after every iteration) run as fresh child processes BEFORE this process touches the GPU, each a second time with --eval_every 100
+(the iterations alone); reported per config: iterations/s of the loop (wall) and of the device, us per iteration, which path the
+library chose (gbp_graph_state: 2 = the persistent kernel), the final mean reprojection error and RMSE = sqrt(2 cost / N) with the
+converged-band check (fr1xyz: 1.42-1.47 px) or the 1e-3 check against tests/golden/trajectories.npz (fr2robot2, mean
+of the last 50 iterations), and a cpu_baseline: the oracle driving the same loop on the same file (threads stated, a stated
+prefix of the iterations; device conventions, so its metric at the last prefix iteration must equal the GPU's printed one).
+
 The warm-up runs the reference's start of a BA run (LINEARISE, prior weakening on iterations 1,3,5,7,9) so the timed
 iterations are steady-state sweeps of a converging problem.
 
@@ -89,6 +99,8 @@ def parse(argv=None):
                     help="camera ranges of the pipelined all-gather (default: 1)")
     ap.add_argument("--tile-order", type=int, default=0, help="gbp_params.tile_order: 0 = default, 1 = sequential, 2 = sweep tiles XCD-aware too")
     ap.add_argument("--master-port", type=int, default=0, help="self-launch: rendezvous port (0 = pick a free one)")
+    ap.add_argument("--small-configs", choices=["auto", "on", "off"], default="auto",
+                    help="the fr1xyz (./ba) and fr2robot2 (./slam) halves of the metric through the C++ CLIs (auto: with the default N = 1 workload)")
     # internal modes
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)       # the process rocprofv3 profiles
     ap.add_argument("--launch-selftest", action="store_true", help=argparse.SUPPRESS)  # CPU test of the self-launcher (gloo)
@@ -268,6 +280,140 @@ def pmc_child(a):
     return 0
 
 
+# ---- BASELINE configs 1-3: fr1xyz through ./ba, fr2robot2 through ./slam (C++ CLIs on the C-ABI) ------------------------
+
+SEQ_DIR = os.path.join(ROOT, "data", "sequences")
+BIN_DIR = os.path.join(ROOT, "gbp_poplar_amd", "bin")
+SMALL_CONFIGS = {
+    # name: (tool, sequence, golden key or None, converged band of the final mean reprojection error or None, CPU prefix)
+    "fr1xyz": ("ba", "fr1xyz", None, (1.42, 1.47), 300),
+    "slam_fr2robot2": ("slam", "fr2robot2", "slam_fr2robot2", None, 2100),
+}
+_ITER_RE = None
+
+
+def parse_iter_lines(stdout):
+    """[(iteration, mean reproj, cost, n_relins, n_robust)] from the `Iter ...` / `Iters ...` lines (ba.cpp:1026-1028, slam.cpp:1073-1076)."""
+    import re
+    global _ITER_RE
+    if _ITER_RE is None:
+        _ITER_RE = re.compile(r"^Iters? (\d+)(?: \(since last kf \d+\))? // Reprojection error (\S+) // Cost (\S+) // n relins: (\d+) // n robust edges (\d+)")
+    rows = []
+    for line in stdout.splitlines():
+        m = _ITER_RE.match(line)
+        if m:
+            rows.append((int(m.group(1)), float(m.group(2)), float(m.group(3)), int(m.group(4)), int(m.group(5))))
+    return rows
+
+
+def run_cli(tool, seq, extra=(), timeout=600):
+    """One run of bin/<tool> on a shipped sequence as a fresh process; returns (its --profile report, parsed metric lines)."""
+    exe = os.path.join(BIN_DIR, tool)
+    if not os.path.exists(exe):
+        raise RuntimeError("%s is missing: python -m gbp_poplar_amd.build" % exe)
+    tmp = tempfile.mkdtemp(prefix="gbp_cli_", dir="/tmp")
+    env = dict(os.environ, GC_PROFILE_LOG_DIR=tmp)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        t0 = time.perf_counter()
+        p = subprocess.run([exe, "--bal_file", os.path.join(SEQ_DIR, seq + ".txt"), "--profile", "1", *extra], env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+        wall = time.perf_counter() - t0
+        if p.returncode != 0:
+            raise RuntimeError("%s %s exited with %d: %s" % (tool, seq, p.returncode, p.stderr[-400:]))
+        rep = json.load(open(os.path.join(tmp, "gbp_profile.json")))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    rep["process_wall_s"] = wall
+    return rep, parse_iter_lines(p.stdout)
+
+
+def small_config_gpu(name):
+    """The GPU half of one small config: default flags (metric every iteration) + --eval_every 100 (iterations alone)."""
+    tool, seq, gold_key, band, _ = SMALL_CONFIGS[name]
+    rep, rows = run_cli(tool, seq)
+    rep100, _ = run_cli(tool, seq, ("--eval_every", "100"))
+    n = int(rep["iterations"])
+    out = {
+        "tool": "bin/%s --bal_file data/sequences/%s.txt (default flags: the metric after every iteration, %s)"
+                % (tool, seq, "ba.cpp:1001-1053" if tool == "ba" else "slam.cpp:1018-1103"),
+        "iterations": n,
+        "iters_per_sec": round(n / rep["loop_s"], 1),
+        "iters_per_sec_is": "iterations / wall time of the iteration loop (metric printed after every iteration, like the reference's loop)",
+        "loop_wall_ms": round(rep["loop_s"] * 1e3, 2), "process_wall_s": round(rep["process_wall_s"], 3), "setup_s": round(rep["setup_s"], 4),
+        "device_ms": round(rep["device_ms"], 2), "iters_per_sec_device": round(rep["iters_per_s_device"], 1),
+        "us_per_iter_device": round(1e3 * rep["device_ms"] / max(rep["device_iterations"], 1), 2),
+        "eval_every_100": {"iters_per_sec": round(n / rep100["loop_s"], 1), "loop_wall_ms": round(rep100["loop_s"] * 1e3, 2),
+                           "device_ms": round(rep100["device_ms"], 2), "iters_per_sec_device": round(rep100["iters_per_s_device"], 1),
+                           "us_per_iter_device": round(1e3 * rep100["device_ms"] / max(rep100["device_iterations"], 1), 2),
+                           "final_mean_reproj_px": rep100.get("final_mean_reproj_px"), "graph_state": rep100["graph_state"]},
+        "graph_state": rep["graph_state"],
+        "path": {2: "k_persist (bursts inside one launch)", 1: "hipGraph replay", 0: "direct launches", -1: "direct launches (capture failed)"}.get(rep["graph_state"]),
+        "final_mean_reproj_px": rep.get("final_mean_reproj_px"), "final_cost": rep.get("final_cost"), "rmse_px": rep.get("final_rmse_px"),
+        "n_active": rep.get("n_active"), "n_relin_final": rep.get("n_relin"), "n_robust_final": rep.get("n_robust"),
+        "nonfinite_beliefs": rep.get("n_nonfinite"),
+        "same_final_metric_with_eval_every_100": rep.get("final_mean_reproj_px") == rep100.get("final_mean_reproj_px"),
+    }
+    if band:
+        out["converged_band_px"] = list(band)
+        out["in_converged_band"] = bool(band[0] <= rep["final_mean_reproj_px"] <= band[1])
+    if gold_key:
+        import numpy as np
+        g = np.load(os.path.join(ROOT, "tests", "golden", "trajectories.npz"))[gold_key]   # rows: it, mean, cost, rmse, relins, robust, n_active
+        tail = g[-50:]
+        mine = [r for r in rows if r[0] >= 0][-50:]
+        n_act = float(rep.get("n_active") or tail[-1, 6])
+        my_mean = sum(r[1] for r in mine) / len(mine)
+        my_rmse = sum((2.0 * r[2] / n_act) ** 0.5 for r in mine) / len(mine)
+        out["golden"] = {"file": "tests/golden/trajectories.npz:" + gold_key, "what": "mean over the last 50 iterations (reference-math build, libm trig, slot-order sums)",
+                         "mean_reproj_px": round(float(tail[:, 1].mean()), 6), "rmse_px": round(float(tail[:, 3].mean()), 6),
+                         "gpu_mean_reproj_px": round(my_mean, 6), "gpu_rmse_px": round(my_rmse, 6),
+                         "rel_diff_mean": abs(my_mean - float(tail[:, 1].mean())) / float(tail[:, 1].mean()),
+                         "rel_diff_rmse": abs(my_rmse - float(tail[:, 3].mean())) / float(tail[:, 3].mean())}
+        out["golden"]["within_1e-3"] = bool(max(out["golden"]["rel_diff_mean"], out["golden"]["rel_diff_rmse"]) <= 1e-3)
+    return out, rows
+
+
+def small_config_cpu(name, gpu_rows):
+    """The oracle (oracle/, OpenMP) driving the same loop on the same file for a stated prefix of the iterations, in the
+    device's conventions (row-tree camera sums, correctly rounded sin / cos): its metric at the last prefix iteration must
+    be the one the GPU printed for that iteration."""
+    from gbp_poplar_amd import driver, hostlib
+    from oracle import oracle as orc
+    tool, seq, _, _, prefix = SMALL_CONFIGS[name]
+    cores = host_cores()
+    orc.set_threads(cores)
+    bal = hostlib.bal_read(os.path.join(SEQ_DIR, seq + ".txt"))
+    opts = driver.Options()
+    slam = tool == "slam"
+    K, state, extra = driver.build_inputs(bal, opts, hostlib, slam=slam)
+    o = orc.Oracle(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K)
+    o.set_sum_order(1)
+    orc.set_trig_mode(1)
+    try:
+        t0 = time.perf_counter()
+        if slam:
+            traj = driver.run_slam(o, hostlib, bal, state, extra, opts, max_iters=prefix)
+        else:
+            traj = driver.run_ba(o, state, opts, n_iters=prefix)
+        dt = time.perf_counter() - t0
+    finally:
+        orc.set_trig_mode(0)
+        o.close()
+    n = len(traj) - 1
+    last = traj[-1]
+    gpu_same = [r for r in gpu_rows if r[0] >= 0][n - 1] if len(gpu_rows) >= n else None
+    out = {"value": round(n / dt, 1), "unit": "iters/s", "cores": cores, "kind": "port",
+           "sample": "first %d of the run's iterations, same file, same loop (upload + LINEARISE + metric after every iteration included; "
+                     "oracle/, gcc -O2 -fopenmp, %d threads)" % (n, cores),
+           "iterations": n, "seconds": round(dt, 3), "mean_reproj_px_at_last_prefix_iteration": last[1]}
+    if gpu_same is not None:
+        out["gpu_mean_reproj_px_same_iteration"] = gpu_same[1]
+        out["same_iteration_metric_matches"] = bool(abs(gpu_same[1] - last[1]) <= 1e-5 * abs(last[1]))   # stdout carries six digits
+    return out
+
+
 # ---- the measured run ---------------------------------------------------------------------------------------
 
 def warm_start(eng, opts, warmup):
@@ -390,6 +536,16 @@ def main(argv=None):
                 traffic_err = (traffic_err or "") + " | profiles/traffic_S1.json is stale (stamp mismatch)"
         except Exception as exc:  # noqa: BLE001
             traffic_err = (traffic_err or "") + " | " + repr(exc)
+
+    # ---- the small configs through the C++ CLIs: fresh child processes, BEFORE this process touches the GPU ----
+    small, small_rows = {}, {}
+    want_small = a.small_configs == "on" or (a.small_configs == "auto" and s1_like and (a.cams, a.lmks, a.obs) == (1000, 100000, 10))
+    if rank == 0 and want_small:
+        for name in SMALL_CONFIGS:
+            try:
+                small[name], small_rows[name] = small_config_gpu(name)
+            except Exception as exc:  # noqa: BLE001 — the S1 line must still be produced; the failure is in the line
+                small[name] = {"error": repr(exc)}
 
     import torch
     if not torch.cuda.is_available():
@@ -563,6 +719,14 @@ def main(argv=None):
         g = gpu_accuracy_run(bal, K, state, opts, cpu["iterations"])
         cpu["gpu_rmse_px_same_iterations"] = g["rmse_px"]
         cpu["rmse_rel_diff"] = abs(g["rmse_px"] - cpu["rmse_px"]) / cpu["rmse_px"]
+    if rank == 0 and a.cpu_seconds > 0:
+        for name in small:
+            if "error" not in small[name]:
+                try:
+                    small[name]["cpu_baseline"] = small_config_cpu(name, small_rows[name])
+                    small[name]["speedup_vs_cpu_baseline"] = round(small[name]["iters_per_sec"] / small[name]["cpu_baseline"]["value"], 1)
+                except Exception as exc:  # noqa: BLE001
+                    small[name]["cpu_baseline"] = {"error": repr(exc)}
 
     if rank == 0:
         ips = a.steps / dt
@@ -586,6 +750,8 @@ def main(argv=None):
             out["roofline"] = roof
         if cpu:
             out["cpu_baseline"] = cpu
+        if small:
+            out["configs"] = small
     if dist is not None:
         # tear the library's communicator down while every rank is still alive and in step (ncclCommDestroy from a
         # destructor at interpreter exit could wait for a peer that is already gone), then torch's group

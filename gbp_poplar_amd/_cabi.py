@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-GBP_ABI_VERSION = 3          # include/gbp_mi355x.h
+GBP_ABI_VERSION = 4          # include/gbp_mi355x.h
 
 c_f32p = C.POINTER(C.c_float)
 c_f64p = C.POINTER(C.c_double)
@@ -24,7 +24,8 @@ class GbpParams(C.Structure):
     _fields_ = [("maxeta_damping", C.c_float), ("num_undamped_iters", C.c_int32),
                 ("dmu_threshold", C.c_float), ("min_linear_iters", C.c_int32),
                 ("nstds", C.c_float), ("relin_mode", C.c_int32), ("graph_unroll", C.c_int32),
-                ("per_factor_mu", C.c_int32), ("tile_order", C.c_int32), ("persistent", C.c_int32), ("reserved", C.c_int32 * 2)]
+                ("per_factor_mu", C.c_int32), ("tile_order", C.c_int32), ("persistent", C.c_int32), ("reserved", C.c_int32 * 1),
+                ("persist_coop", C.c_int32)]
 
     @classmethod
     def defaults(cls, **kw):

@@ -128,6 +128,11 @@ def load(hooks=False):
         except ImportError:
             pass
     lib = C.CDLL(path)
+    lib.gbp_abi_version.restype = C.c_int        # first: a stale .so gets the rebuild message, not an AttributeError for a new symbol
+    lib.gbp_abi_version.argtypes = []
+    if lib.gbp_abi_version() != cabi.GBP_ABI_VERSION:
+        raise RuntimeError("%s has ABI version %d, these bindings were written for %d — rebuild (python -m gbp_poplar_amd.build)"
+                           % (path, lib.gbp_abi_version(), cabi.GBP_ABI_VERSION))
     sigs = dict(_SIGS)
     if hooks:
         sigs.update(_DEBUG_SIGS)
@@ -135,9 +140,6 @@ def load(hooks=False):
         fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.gbp_abi_version() != cabi.GBP_ABI_VERSION:
-        raise RuntimeError("%s has ABI version %d, these bindings were written for %d — rebuild (python -m gbp_poplar_amd.build)"
-                           % (path, lib.gbp_abi_version(), cabi.GBP_ABI_VERSION))
     if hooks == "exp":
         _exp_lib = lib
     elif hooks:

@@ -36,7 +36,9 @@ static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
   pipe.ctx = ctx;
   pipe.on = !rk.region && !o.verbose;
   unsigned iter = 0;
-  const auto print_iter = [](unsigned it_now, const gbp_eval_out& e) {       // ba.cpp:1020-1024
+  cli::RunReport rep;
+  const auto print_iter = [&rep](unsigned it_now, const gbp_eval_out& e) {   // ba.cpp:1020-1024
+    rep.last = e; rep.have_metric = true;
     std::cout << "Iter " << it_now << " // Reprojection error " << (float)(e.sum_norm / (double)e.n_active);
     std::cout << " // Cost " << (float)e.sum_half_sq << " // n relins: " << e.n_relin;
     std::cout << " // n robust edges " << e.n_robust << "\n";
@@ -73,7 +75,7 @@ static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
     iter += burst - 1;
     if (eval_now) {
       const unsigned it_now = iter;
-      CLI_CHECK(ctx, pipe.submit([it_now, print_iter](const gbp_eval_out& e) { print_iter(it_now, e); }, burst));   // the burst and its metric in one call
+      CLI_CHECK(ctx, pipe.submit([it_now, &print_iter](const gbp_eval_out& e) { print_iter(it_now, e); }, burst));   // the burst and its metric in one call
       if (o.verbose) {
         CLI_CHECK(ctx, gbp_read(ctx, &rb.out));
         cli::print_verbose(rb);
@@ -90,7 +92,10 @@ static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
   std::cout << "Total time: " << wall << " s (set-up " << std::chrono::duration<double>(t_loop - t0).count() << " s, iteration loop "
             << std::chrono::duration<double>(t_end - t_loop).count() << " s); device time in GBP iterations: " << tm.total_ms << " ms over " << tm.iterations
             << " iterations (" << (tm.total_ms > 0 ? 1e3 * (double)tm.iterations / tm.total_ms : 0.0) << " iters/s)\n";
-  if (o.profile) cli::write_profile(ctx, "ba", wall, o.n_iters);
+  rep.wall_s = wall; rep.setup_s = std::chrono::duration<double>(t_loop - t0).count();
+  rep.loop_s = std::chrono::duration<double>(t_end - t_loop).count(); rep.iters = o.n_iters;
+  if (o.profile) cli::write_profile(ctx, "ba", rep);
+  cli::print_warning(ctx);
   const int wrc = cli::write_solution(o, P, ctx, rk.region != nullptr);
   gbp_destroy(ctx);
   return wrc;

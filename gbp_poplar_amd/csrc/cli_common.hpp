@@ -415,16 +415,42 @@ struct MetricPipe {
     }                                                                                     \
   } while (0)
 
-inline void write_profile(gbp_ctx* ctx, const char* tool, double wall_s, long iters) {  // ba.cpp:1060-1082
+// a call that returned GBP_OK can leave a `warning: ...` in gbp_last_error (a recovered time-out of the persistent kernel)
+inline void print_warning(gbp_ctx* ctx) {
+  const char* w = gbp_last_error(ctx);
+  if (w && std::strncmp(w, "warning:", 8) == 0) std::cerr << w << "\n";
+}
+
+// --profile (ba.cpp:410-413,1060-1082 dump Poplar's execution / graph profile): here a one-line JSON report with the times of
+// the run, which iteration path the library chose and the LAST printed metric at full precision (stdout carries six digits).
+// bench.py reads it for the fr1xyz / fr2robot2 halves of BASELINE.json's metric.
+struct RunReport {
+  double wall_s = 0, setup_s = 0, loop_s = 0;
+  long iters = 0;
+  bool have_metric = false;
+  gbp_eval_out last{};
+};
+
+inline void write_profile(gbp_ctx* ctx, const char* tool, const RunReport& r) {
   const char* dir = std::getenv("GC_PROFILE_LOG_DIR");
   const std::string path = std::string(dir ? dir : ".") + "/gbp_profile.json";
   gbp_timing_out t{};
   gbp_timing(ctx, &t, 0);
   if (FILE* f = std::fopen(path.c_str(), "w")) {
-    std::fprintf(f, "{\"tool\": \"%s\", \"iterations\": %ld, \"wall_s\": %.6f, \"device_ms\": %.3f, \"iters_per_s_device\": %.3f, "
-                    "\"algorithmic_bytes_per_iter\": %llu, \"device_bytes_allocated\": %llu}\n",
-                 tool, iters, wall_s, t.total_ms, t.total_ms > 0 ? 1e3 * (double)t.iterations / t.total_ms : 0.0,
+    std::fprintf(f, "{\"tool\": \"%s\", \"iterations\": %ld, \"wall_s\": %.6f, \"setup_s\": %.6f, \"loop_s\": %.6f, \"device_ms\": %.3f, "
+                    "\"device_iterations\": %llu, \"iters_per_s_device\": %.3f, \"graph_state\": %d, "
+                    "\"algorithmic_bytes_per_iter\": %llu, \"device_bytes_allocated\": %llu",
+                 tool, r.iters, r.wall_s, r.setup_s, r.loop_s, t.total_ms, (unsigned long long)t.iterations,
+                 t.total_ms > 0 ? 1e3 * (double)t.iterations / t.total_ms : 0.0, gbp_graph_state(ctx),
                  (unsigned long long)t.algorithmic_bytes_per_iter, (unsigned long long)t.device_bytes_allocated);
+    if (r.have_metric && r.last.n_active) {
+      const double n = (double)r.last.n_active;
+      std::fprintf(f, ", \"final_mean_reproj_px\": %.9g, \"final_cost\": %.9g, \"final_rmse_px\": %.9g, \"n_active\": %llu, "
+                      "\"n_relin\": %llu, \"n_robust\": %llu, \"n_nonfinite\": %llu",
+                   r.last.sum_norm / n, r.last.sum_half_sq, std::sqrt(2.0 * r.last.sum_half_sq / n), (unsigned long long)r.last.n_active,
+                   (unsigned long long)r.last.n_relin, (unsigned long long)r.last.n_robust, (unsigned long long)r.last.n_nonfinite);
+    }
+    std::fprintf(f, "}\n");
     std::fclose(f);
     std::cout << "Profile written to " << path << "\n";
   }

@@ -29,10 +29,15 @@ using namespace gbp;
 
 namespace {
 thread_local std::string g_create_error;
-// serialisation of k_persist launches across the ctxs of a process (launch_persist_burst)
+// Serialisation of k_persist launches across the ctxs / streams of a process (launch_persist_burst): a library-owned event
+// per device is recorded behind every launch, the next launch from another ctx or stream waits for it.  No stream handle of
+// another ctx is ever touched (it may have been destroyed by its owner); the two "last" words are compared, never used.
 std::mutex g_persist_mu;
-hipStream_t g_persist_last_stream[16] = {};
 hipEvent_t g_persist_event[16] = {};
+const void* g_persist_last_ctx[16] = {};
+const void* g_persist_last_stream[16] = {};
+constexpr int kPersistChunk = 4096;      // iterations per k_persist launch (a launch cannot be pre-empted: ~60 ms at 15 us each)
+constexpr size_t kPersistLogMax = 8;     // launches in flight without a validated completion
 
 struct DevBuf {
   void* p = nullptr;
@@ -55,7 +60,7 @@ struct gbp_ctx {
   // device memory
   std::vector<DevBuf*> all;
   DevBuf row_cam, lmk_idx, fac, cmsg, mu, lmsg, camb, camp, lmkb, lmkp, rowp, local, d_cam_row_ptr, d_lmk_ptr, cwf, lwf,
-      cscale, lscale, cam_mu, lmk_mu, dK, evalp, hmu_c, hmu_l, d_lmk_fpos, d_lmk_ix, health, tile_perm;
+      cscale, lscale, cam_mu, lmk_mu, dK, evalp, hmu_c, hmu_l, clin, d_lmk_fpos, d_lmk_ix, health, tile_perm;
   DevBuf st_a, st_b;                   // [Ep] scratch of the per-factor state get / set kernels
   std::vector<uint8_t> active_host;    // [Ep] host shadow of the active flags (hoist guard of gbp_new_keyframe)
   bool use_tile_perm = false;
@@ -95,7 +100,20 @@ struct gbp_ctx {
   hipEvent_t eval_ev[2] = {nullptr, nullptr};
   bool profile_stages = false;
   // k_persist (small graphs): n iterations in one launch
-  bool persist_ok = false;             // the graph is eligible and co-resident on this GPU
+  bool persist_ok = false;             // bursts run inside k_persist (eligible, co-resident, no time-out since the last upload)
+  bool persist_eligible = false;       // what persist_ok returns to at the next gbp_upload after a recovered time-out
+  bool persist_coop = false;           // launched with hipLaunchCooperativeKernel (co-residency guaranteed by the runtime / driver)
+  // A launch whose barrier timed out (workgroups not co-resident: e.g. another process holds CUs) is UNDONE and replayed on the
+  // two-kernel path: every launch is preceded by a snapshot of the arrays it mutates (one copy kernel, skipped once the abort
+  // word is set), later launches of the ctx return at once, and the host — at the next point where it synchronises anyway —
+  // restores the snapshot and replays the logged launches from the first failed one on.
+  struct Burst { unsigned seq; int n; int mode; int area; };   // mode 0 = gbp_iterate, 1 = gbp_iterate_eval (metric in eval area `area`), 2 = eval_each (blocking)
+  std::vector<Burst> persist_log;      // launched, completion not yet validated
+  unsigned persist_seq = 0;
+  DevBuf psnap;                        // snapshot arena
+  CopySegs snap_save{}, snap_restore{};
+  std::string warn;                    // text of the last recovered incident (also left in `err`, the call returns GBP_OK)
+  uint64_t persist_recoveries = 0;
   DevBuf psync;                        // barrier words
   DevBuf ptrace;                       // experiments build: per-phase time stamps of k_persist (gbp_debug_persist_trace)
   void* pstatus_host = nullptr;        // pinned + device-mapped: raised by the kernel if a barrier gave up
@@ -139,7 +157,7 @@ SweepArgs sweep_args(gbp_ctx* c) {
   a.row_cam = P<uint32_t>(c->row_cam); a.lmk_idx = P<uint32_t>(c->lmk_idx); a.fac = P<float4>(c->fac); a.cmsg = P<float4>(c->cmsg);
   a.mu = P<float4>(c->mu); a.lmsg = P<float4>(c->lmsg); a.camb = P<float4>(c->camb); a.lmkb = P<float4>(c->lmkb);
   a.rowp = P<float4>(c->rowp);
-  a.cam_mu = P<float4>(c->hmu_c); a.lmk_mu = P<float4>(c->hmu_l);
+  a.cam_mu = P<float4>(c->hmu_c); a.lmk_mu = P<float4>(c->hmu_l); a.cam_lin = P<float4>(c->clin);
   std::memcpy(a.K, c->K, sizeof(a.K));
   a.hp.maxeta_damping = c->prm.maxeta_damping; a.hp.num_undamped_iters = c->prm.num_undamped_iters;
   a.hp.dmu_threshold = c->prm.dmu_threshold; a.hp.min_linear_iters = c->prm.min_linear_iters;
@@ -160,7 +178,7 @@ BeliefArgs belief_args(gbp_ctx* c) {
   BeliefArgs b{};
   b.rowp = P<float>(c->rowp); b.cam_row_ptr = P<uint32_t>(c->d_cam_row_ptr); b.cam_prior = P<float>(c->camp);
   b.cam_local = P<float>(c->local); b.gathered = nullptr; b.world = c->world;
-  b.camb = P<float>(c->camb); b.cam_mu = P<float4>(c->hmu_c); b.n_cams = c->C;
+  b.camb = P<float>(c->camb); b.cam_mu = P<float4>(c->hmu_c); b.cam_lin = P<float4>(c->clin); b.n_cams = c->C;
   b.lmk_prior = P<float4>(c->lmkp); b.lmsg = P<float4>(c->lmsg); b.lmk_ptr = P<uint32_t>(c->d_lmk_ptr);
   b.lmk_fpos = P<uint32_t>(c->d_lmk_fpos); b.lmk_ix = P<uint32_t>(c->d_lmk_ix);
   b.lmkb = P<float4>(c->lmkb); b.lmk_mu = P<float4>(c->hmu_l); b.n_lmks = c->L_loc;
@@ -328,10 +346,10 @@ const char* gbp_last_error(const gbp_ctx* ctx) { return ctx ? ctx->err.c_str() :
 void gbp_destroy(gbp_ctx* c) {
   if (!c) return;
   drop_graph(c);
-  if (c->persist_ok) {   // a later k_persist launch of another ctx must not wait on a stream that no longer exists
+  if (c->persist_eligible) {   // its launches have ended before its memory goes away; the "last launcher" words are only ever compared
     (void)hipStreamSynchronize(c->stream);
     std::lock_guard<std::mutex> lock(g_persist_mu);
-    for (hipStream_t& st : g_persist_last_stream) if (st == c->stream || st == c->own_stream) st = nullptr;
+    for (const void*& p : g_persist_last_ctx) if (p == c) p = &g_persist_mu;      // "someone else": the next launcher waits for the device's event
   }
   if (c->comm) { (void)hipStreamSynchronize(c->stream); if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream); delete c->comm; c->comm = nullptr; }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -365,7 +383,7 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
   c->C = pr->n_cams; c->L = pr->n_lmks; c->E = pr->n_edges;
   std::memcpy(c->K, pr->K, sizeof(c->K));
   if (prm) c->prm = *prm; else gbp_default_params(&c->prm);
-  if (const char* gu = std::getenv("GBP_GRAPH_UNROLL")) c->prm.graph_unroll = std::atoi(gu);   // measurements: callers that pass no params (the CLIs)
+  if (const char* gu = prm ? nullptr : std::getenv("GBP_GRAPH_UNROLL")) c->prm.graph_unroll = std::atoi(gu);   // measurements through callers that pass NO params (the CLIs); explicit params always win
   c->sharded_graph = c->prm.graph_unroll > 0;                // a sharded iteration is captured only on explicit request
   if (c->prm.graph_unroll == 0) c->prm.graph_unroll = 10;   // < 0: never capture, always direct launches
   c->hoist = c->prm.per_factor_mu == 0;
@@ -434,7 +452,7 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
   A(c->cwf, (size_t)C * 4); A(c->lwf, (size_t)c->L_loc * 4); A(c->cscale, (size_t)C * 4); A(c->lscale, (size_t)c->L_loc * 4);
   A(c->cam_mu, (size_t)C * 6 * 4); A(c->lmk_mu, (size_t)c->L_loc * 3 * 4); A(c->dK, 16 * 4);
   A(c->evalp, sizeof(DeviceEval) * 16); A(c->health, 32);
-  A(c->hmu_c, (size_t)C * 4 * 16); A(c->hmu_l, (size_t)c->L_loc * 2 * 16);
+  A(c->hmu_c, (size_t)C * 4 * 16); A(c->hmu_l, (size_t)c->L_loc * 2 * 16); A(c->clin, (size_t)C * 5 * 16);
   A(c->st_a, Ep * 4); A(c->st_b, Ep * 4);
   if (rc != GBP_OK) { g_create_error = c->err; return rc; }
   auto CK = [&](hipError_t e, const char* what) {
@@ -500,8 +518,10 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
   if (rc != GBP_OK) return rc;
   // ---- persistent iteration kernel: only where every workgroup of the graph is resident at once ----
   {
-    const char* pe = std::getenv("GBP_PERSIST");                     // measurements: -1 / 0 / 1 like gbp_params.persistent
+    const char* pe = prm ? nullptr : std::getenv("GBP_PERSIST");     // measurements through the CLIs (they pass no params): -1 / 0 / 1 like gbp_params.persistent
     const int mode = pe ? std::atoi(pe) : c->prm.persistent;
+    const char* pc = prm ? nullptr : std::getenv("GBP_PERSIST_COOP");
+    const int coop_mode = pc ? std::atoi(pc) : c->prm.persist_coop;  // 0 = cooperative launch where the device offers it, 1 = insist, -1 = plain launch + probe
     const uint32_t nb = persist_blocks(c->n_tiles, c->C, c->L_loc);
     // measured (profiles/r03_small_graphs.md): the shipped sequences (19 - 61 workgroups, relinearising in every sweep) run
     // 1.55 - 1.82x faster in k_persist; converging synthetic graphs 1.21x at 63 workgroups, break even at 125
@@ -519,12 +539,56 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
         } else {
           g_create_error = c->err;
         }
-        // the occupancy query says the workgroups fit; the probe checks that THIS device's dispatcher really keeps them
-        // resident together under the placement k_persist uses (three barriers, no work): a failure costs ~1 s once and
-        // leaves the ctx on the two-kernel path
-        c->persist_ok = rc == GBP_OK && persist_probe(c->n_tiles, c->C, c->L_loc, P<unsigned>(c->psync), static_cast<unsigned*>(c->pstatus_dev),
-                                                      static_cast<volatile unsigned*>(c->pstatus_host), c->stream);
-        if (c->persist_ok) CK(hipMemset(c->psync.p, 0, kPersistSyncWords * sizeof(unsigned)), "hipMemset");   // counter back to 0 after the probe
+        if (rc == GBP_OK) {
+          // Co-residency.  Cooperative launch (default where the device reports it): the runtime refuses a grid that cannot be
+          // resident at once and the driver never runs two cooperative grids side by side, whichever process they belong to.
+          // Plain launch: the occupancy query says the workgroups fit; a probe (the placement + three barriers, no work) checks
+          // that THIS device's dispatcher keeps them resident together — under the process-wide lock and behind the device's
+          // last k_persist launch, so that it does not compete with one.  Either probe failing leaves the ctx on the two-kernel
+          // path and says so in gbp_last_error.
+          int dev = 0, coop_attr = 0;
+          (void)hipGetDevice(&dev);
+          (void)hipDeviceGetAttribute(&coop_attr, hipDeviceAttributeCooperativeLaunch, dev);
+          std::lock_guard<std::mutex> lock(g_persist_mu);
+          if (g_persist_event[dev & 15] && g_persist_last_ctx[dev & 15]) (void)hipStreamWaitEvent(c->stream, g_persist_event[dev & 15], 0);
+          bool ok = false;
+          if (coop_mode >= 0 && coop_attr) {
+            ok = persist_probe(c->n_tiles, c->C, c->L_loc, P<unsigned>(c->psync), static_cast<unsigned*>(c->pstatus_dev),
+                               static_cast<volatile unsigned*>(c->pstatus_host), true, c->stream);
+            c->persist_coop = ok;
+            if (!ok) c->err = "k_persist: the cooperative launch was refused or its barriers timed out";
+          }
+          if (!ok && coop_mode <= 0) {
+            ok = persist_probe(c->n_tiles, c->C, c->L_loc, P<unsigned>(c->psync), static_cast<unsigned*>(c->pstatus_dev),
+                               static_cast<volatile unsigned*>(c->pstatus_host), false, c->stream);
+            if (!ok) c->err = "k_persist: the workgroups of this graph are not co-resident under the spread placement on this device (probe timed out)";
+          }
+          if (!ok) c->err += "; iterations run on the two-kernel path";
+          c->persist_ok = c->persist_eligible = ok;
+          if (ok) CK(hipMemset(c->psync.p, 0, kPersistSyncWords * sizeof(unsigned)), "hipMemset");   // counter back to 0 after the probe
+          else (void)hipGetLastError();
+        }
+        if (rc == GBP_OK && c->persist_ok) {
+          // snapshot arena: one slot for every array a k_persist launch mutates
+          DevBuf* segs[] = {&c->lmsg, &c->cmsg, &c->fac, &c->rowp, &c->camb, &c->lmkb, &c->hmu_c, &c->hmu_l, &c->clin, &c->local};
+          size_t total = 0;
+          for (DevBuf* b : segs) total += b->bytes;
+          rc = dev_alloc(c, c->psnap, total);
+          if (rc == GBP_OK) {
+            size_t off = 0;
+            int i = 0;
+            for (DevBuf* b : segs) {
+              void* slot = static_cast<char*>(c->psnap.p) + off;
+              c->snap_save.src[i] = b->p; c->snap_save.dst[i] = slot; c->snap_save.n4[i] = b->bytes / 16;
+              c->snap_restore.src[i] = slot; c->snap_restore.dst[i] = b->p; c->snap_restore.n4[i] = b->bytes / 16;
+              off += b->bytes;
+              ++i;
+            }
+            c->snap_save.n = c->snap_restore.n = i;
+          } else {
+            g_create_error = c->err;
+          }
+        }
       }
     }
     if (rc != GBP_OK) return rc;
@@ -534,8 +598,19 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
   return GBP_OK;
 }
 
+// ---- k_persist launches in flight: validation and recovery (defined with launch_persist_burst below) ----
+static int persist_check(gbp_ctx* c, unsigned upto);
+// Every entry point that enqueues other device work, or changes what the launches in flight depend on, first makes sure
+// they completed without a barrier time-out (and repairs the state if one did): free when nothing is in flight.
+static int settle(gbp_ctx* c) {
+  if (c->persist_log.empty()) return GBP_OK;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return persist_check(c, 0);
+}
+
 int gbp_set_stream(gbp_ctx* c, void* s) {
   if (!c) return GBP_ERR_INVALID;
+  if (int rc = settle(c)) return rc;
   drop_graph(c);
   c->stream = s ? static_cast<hipStream_t>(s) : c->own_stream;
   return GBP_OK;
@@ -550,9 +625,7 @@ int gbp_set_exchange_buffers(gbp_ctx* c, void* send_dev, void* recv_dev) {
 int gbp_sync(gbp_ctx* c) {
   if (!c) return GBP_ERR_INVALID;
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (c->pstatus_host && *static_cast<volatile unsigned*>(c->pstatus_host) != 0u)
-    return fail(c, GBP_ERR_HIP, "k_persist: a device-wide barrier timed out (workgroups not co-resident); results are invalid");
-  return GBP_OK;
+  return persist_check(c, 0);
 }
 
 // WRITE_PROG (ba.cpp:868-886).  Also zeroes every tensor the reference leaves uninitialised
@@ -572,6 +645,15 @@ static int upload_impl(gbp_ctx* c, const gbp_state_in* in) {
           return fail(c, GBP_ERR_INVALID, "gbp_upload: non-zero oldmu needs gbp_params.per_factor_mu = 1 (the reference uploads zeros, ba.cpp:582-583)");
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->pstatus_host) {
+    // a fresh start for the persistent kernel too: whatever its launches in flight did is overwritten below; a ctx that left
+    // the persistent path after a recovered time-out gets it back
+    c->persist_log.clear();
+    HIPCHK(c, hipMemset(c->psync.p, 0, kPersistSyncWords * sizeof(unsigned)));
+    *static_cast<volatile unsigned*>(c->pstatus_host) = 0u;
+    c->persist_epoch_base = 0;
+    c->persist_ok = c->persist_eligible;
+  }
   const size_t Ep = c->Ep;
   std::vector<float> rec0(Ep * 16, 0.f), fac(Ep * kFacG * 4, 0.f), mu(c->hoist ? 0 : Ep * kMuG * 4, 0.f);
   c->active_host.assign(Ep, 0);
@@ -601,6 +683,7 @@ static int upload_impl(gbp_ctx* c, const gbp_state_in* in) {
   HIPCHK(c, hipMemset(c->lmkb.p, 0, c->lmkb.bytes));
   HIPCHK(c, hipMemset(c->hmu_c.p, 0, c->hmu_c.bytes));
   HIPCHK(c, hipMemset(c->hmu_l.p, 0, c->hmu_l.bytes));
+  HIPCHK(c, hipMemset(c->clin.p, 0, c->clin.bytes));
   std::vector<float> rec;
   pack_cam(in->cam_priors_eta, in->cam_priors_lambda, c->C, rec);
   HIPCHK(c, hipMemcpy(c->camp.p, rec.data(), rec.size() * 4, hipMemcpyHostToDevice));
@@ -622,6 +705,7 @@ static int upload_impl(gbp_ctx* c, const gbp_state_in* in) {
 
 int gbp_refresh_begin(gbp_ctx* c) {
   if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "upload first");
+  if (int rc = settle(c)) return rc;
   float4* dst = exch(c) ? static_cast<float4*>(c->send_dev) : P<float4>(c->local);
   if (!dst) return fail(c, GBP_ERR_STATE, "exchange buffers not set");
   enqueue_cam_partials(c, reinterpret_cast<float*>(dst));
@@ -631,6 +715,7 @@ int gbp_refresh_begin(gbp_ctx* c) {
 
 int gbp_refresh_end(gbp_ctx* c) {
   if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "upload first");
+  if (int rc = settle(c)) return rc;
   const int rc = refresh_beliefs_from_partials(c, false);
   if (rc == GBP_OK) c->beliefs_valid = true;
   return rc;
@@ -638,6 +723,7 @@ int gbp_refresh_end(gbp_ctx* c) {
 
 int gbp_linearise_factors(gbp_ctx* c) {
   if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "upload first");
+  if (int rc = settle(c)) return rc;
   launch_linearise(sweep_args(c), c->n_tiles, c->stream);
   HIPCHK(c, hipGetLastError());
   return GBP_OK;
@@ -788,6 +874,7 @@ static int linearise_impl(gbp_ctx* c) {
 
 static int iterate_begin_impl(gbp_ctx* c) {
   if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "upload first");
+  if (int rc = settle(c)) return rc;
   float4* dst = exch(c) ? static_cast<float4*>(c->send_dev) : P<float4>(c->local);
   if (!dst) return fail(c, GBP_ERR_STATE, "exchange buffers not set");
   if (c->profile_stages) {  // bracket the sweep launch; the pair is read (and timed_iters counted) by gbp_timing
@@ -826,6 +913,7 @@ static int set_exchange_chunks_impl(gbp_ctx* c, int n) {
 int gbp_iterate_begin_chunk(gbp_ctx* c, int chunk) {
   if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "upload first");
   if (chunk < 0 || chunk >= c->exch_chunks) return fail(c, GBP_ERR_INVALID, "gbp_iterate_begin_chunk: bad chunk");
+  if (int rc = settle(c)) return rc;
   float* dst = exch(c) ? static_cast<float*>(c->send_dev) : P<float>(c->local);
   if (!dst) return fail(c, GBP_ERR_STATE, "exchange buffers not set");
   const uint32_t n_blocks = c->n_tiles / 4;
@@ -850,6 +938,7 @@ int gbp_iterate_begin_chunk(gbp_ctx* c, int chunk) {
 // all-gather of the camera partials is in flight (between gbp_iterate_begin and gbp_iterate_end).
 int gbp_iterate_local(gbp_ctx* c) {
   if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "upload first");
+  if (int rc = settle(c)) return rc;
   BeliefArgs b = belief_args(c);
   b.roll = 1;
   launch_beliefs(b, false, true, c->stream);
@@ -860,6 +949,7 @@ int gbp_iterate_local(gbp_ctx* c) {
 
 int gbp_iterate_end(gbp_ctx* c) {
   if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "upload first");
+  if (int rc = settle(c)) return rc;
   const int rc = refresh_beliefs_from_partials(c, true, !c->lmk_half_done);
   c->lmk_half_done = false;
   if (rc == GBP_OK) c->beliefs_valid = true;
@@ -892,6 +982,7 @@ static bool ensure_graph(gbp_ctx* c, const SweepArgs& a) {
 // graph capture + instantiation + upload of the executable graph.  Executes no iteration.
 int gbp_prepare(gbp_ctx* c) {
   if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "gbp_prepare: upload first");
+  if (int rc = settle(c)) return rc;
   if (c->comm || c->world > 1) return GBP_OK;               // sharded iterations run from direct launches by default
   if (c->persist_ok) return GBP_OK;                         // multi-iteration bursts run inside k_persist: nothing to capture
   if (ensure_graph(c, sweep_args(c))) (void)hipGraphUpload(c->graph_exec, c->stream);
@@ -899,11 +990,92 @@ int gbp_prepare(gbp_ctx* c) {
   return GBP_OK;
 }
 
+// GBP_PROG x n on the two-kernel path: replay of a captured hipGraph of `graph_unroll` iterations, remainder launched directly.
+static int iterate_plain(gbp_ctx* c, const SweepArgs& a, int n) {
+  int left = n;
+  bool use_graph = (c->stream == c->own_stream) && c->prm.graph_unroll > 0 && n >= c->prm.graph_unroll && !c->graph_failed;
+  if (use_graph && !c->graph_exec) use_graph = ensure_graph(c, a);
+  if (use_graph) {
+    while (left >= c->graph_iters) {
+      HIPCHK(c, hipGraphLaunch(c->graph_exec, c->stream));
+      left -= c->graph_iters;
+    }
+  }
+  for (; left > 0; --left) enqueue_iteration(c, a);
+  HIPCHK(c, hipGetLastError());
+  return GBP_OK;
+}
+
+static int eval_enqueue(gbp_ctx* c, int area);
+
+// A k_persist launch gave up at a barrier (*pstatus_host = its number): undo it and everything queued behind it, replay
+// on the two-kernel path.  The snapshot kernel of every later launch saw the abort word and left the arena alone, so the
+// arena holds the state the first failed launch started from.
+static int persist_recover(gbp_ctx* c) {
+  HIPCHK(c, hipStreamSynchronize(c->stream));        // the failed launch and the no-op launches behind it have ended
+  const unsigned first = *static_cast<volatile unsigned*>(c->pstatus_host);
+  std::vector<gbp_ctx::Burst> redo;
+  for (const gbp_ctx::Burst& b : c->persist_log)
+    if (b.seq >= first) redo.push_back(b);
+  c->persist_log.clear();
+  launch_copy_segments(c->snap_restore, nullptr, c->stream);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemsetAsync(c->psync.p, 0, kPersistSyncWords * sizeof(unsigned), c->stream));
+  HIPCHK(c, hipMemsetAsync(c->health.p, 0, 32, c->stream));       // both areas are zero between evaluations
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *static_cast<volatile unsigned*>(c->pstatus_host) = 0u;
+  c->persist_epoch_base = 0;
+  c->persist_ok = false;                              // until the next gbp_upload
+  c->persist_recoveries += 1;
+  const SweepArgs a = sweep_args(c);
+  long iters = 0;
+  for (const gbp_ctx::Burst& b : redo) {
+    if (b.mode == 2) continue;                        // gbp_iterate_eval_each is blocking: it replays its own burst
+    if (int rc = iterate_plain(c, a, b.n)) return rc;
+    iters += b.n;
+    if (b.mode == 1)
+      if (int rc = eval_enqueue(c, b.area)) return rc;
+  }
+  c->warn = "warning: a device-wide barrier of the persistent kernel timed out in launch " + std::to_string(first) +
+            " of this ctx (its workgroups were not co-resident: is another process using the GPU?); the state was restored and " +
+            std::to_string(iters) + " iterations were replayed on the two-kernel path (identical results); the ctx stays on that path until the next gbp_upload";
+  c->err = c->warn;
+  return GBP_OK;
+}
+
+// The stream has been synchronised, or an event recorded behind launch `upto` has completed (0 = everything queued has).
+static int persist_check(gbp_ctx* c, unsigned upto) {
+  if (!c->pstatus_host || c->persist_log.empty()) return GBP_OK;
+  if (*static_cast<volatile unsigned*>(c->pstatus_host) != 0u) return persist_recover(c);
+  if (upto == 0) c->persist_log.clear();
+  else
+    while (!c->persist_log.empty() && c->persist_log.front().seq <= upto) c->persist_log.erase(c->persist_log.begin());
+  return GBP_OK;
+}
+
+static bool stream_is_capturing(gbp_ctx* c) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(c->stream, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return st != hipStreamCaptureStatusNone;
+}
+
+// May the next burst of this ctx run inside k_persist?  Makes room in the log of unvalidated launches first (which may
+// find a time-out, recover, and take the ctx off the persistent path).  Not while the stream is being captured: the
+// barrier targets are launch arguments computed by the host, a replayed graph would wait for arrivals long past.
+static int persist_ready(gbp_ctx* c, bool* yes) {
+  *yes = false;
+  if (!c->persist_ok || c->comm || c->world != 1 || c->profile_stages) return GBP_OK;
+  if (c->persist_log.size() >= kPersistLogMax)
+    if (int rc = settle(c)) return rc;
+  *yes = c->persist_ok && !stream_is_capturing(c);
+  return GBP_OK;
+}
+
+constexpr int kNotLaunched = 1;    // launch_persist_burst: nothing ran, the ctx has left the persistent path
+
 // n iterations inside ONE k_persist launch (+ the metric phases when `ev` is given).  The barrier counter keeps counting
 // across the launches of a ctx (no memset per launch): the host tracks how many arrivals it has seen.
-static int launch_persist_burst(gbp_ctx* c, const SweepArgs& a, int n, const PersistEval* ev) {
-  if (*static_cast<volatile unsigned*>(c->pstatus_host) != 0u)
-    return fail(c, GBP_ERR_HIP, "k_persist: a device-wide barrier timed out in an earlier launch (workgroups not co-resident)");
+static int launch_persist_burst(gbp_ctx* c, const SweepArgs& a, int n, const PersistEval* ev, int mode, int area) {
   PersistArgs A{};
   A.s = a;
   A.b = belief_args(c);
@@ -914,40 +1086,59 @@ static int launch_persist_burst(gbp_ctx* c, const SweepArgs& a, int n, const Per
   A.status = static_cast<unsigned*>(c->pstatus_dev);
   A.trace = static_cast<unsigned long long*>(c->ptrace.p);      // NULL outside the experiments build
   A.epoch_base = c->persist_epoch_base;
+  A.seq = c->persist_seq + 1;
   if (ev) A.ev = *ev;
   {
-    // Two k_persist launches must never compete for CUs (each spins at its barriers until ALL its workgroups are resident):
-    // inside a process a launch on another stream than the previous one waits for that stream first (launches on the same
-    // stream are ordered anyway and pay nothing).  (Another PROCESS on the same GPU can still starve a launch; the bounded
-    // barrier wait then ends it with an error instead of a hang.)
+    // Two k_persist launches must never compete for CUs (each spins at its barriers until ALL its workgroups are resident).
+    // Across processes that is the cooperative launch's guarantee; inside a process a launch from another ctx or stream than
+    // the previous one waits for the event recorded behind that one (launches on one stream are ordered anyway).
     std::lock_guard<std::mutex> lock(g_persist_mu);
     int dev = 0;
     (void)hipGetDevice(&dev);
-    hipStream_t& prev = g_persist_last_stream[dev & 15];
-    if (prev && prev != c->stream) {
-      hipEvent_t& e = g_persist_event[dev & 15];
-      if (!e) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-      HIPCHK(c, hipEventRecord(e, prev));                 // everything queued on the previous stream so far, its k_persist included
+    hipEvent_t& e = g_persist_event[dev & 15];
+    if (!e) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (g_persist_last_ctx[dev & 15] && (g_persist_last_ctx[dev & 15] != c || g_persist_last_stream[dev & 15] != c->stream))
       HIPCHK(c, hipStreamWaitEvent(c->stream, e, 0));
-    }
-    launch_persist(A, c->stream);
+    launch_copy_segments(c->snap_save, P<unsigned>(c->psync) + 32, c->stream);       // skipped on the device once the abort word is set
     HIPCHK(c, hipGetLastError());
-    prev = c->stream;
+    const hipError_t le = launch_persist(A, c->persist_coop, c->stream);
+    if (le != hipSuccess) {
+      (void)hipGetLastError();
+      if (!c->persist_coop) return fail(c, GBP_ERR_HIP, std::string("k_persist launch: ") + hipGetErrorString(le));
+      // the runtime refused the cooperative grid: nothing ran, nothing is lost — this ctx continues on the two-kernel path
+      c->persist_ok = c->persist_eligible = false;
+      c->warn = std::string("warning: the cooperative launch of the persistent kernel was refused (") + hipGetErrorString(le) +
+                "); iterations run on the two-kernel path";
+      c->err = c->warn;
+      return kNotLaunched;
+    }
+    HIPCHK(c, hipEventRecord(e, c->stream));
+    g_persist_last_ctx[dev & 15] = c;
+    g_persist_last_stream[dev & 15] = c->stream;
   }
   const unsigned nb = persist_blocks(c->n_tiles, c->C, c->L_loc);
-  c->persist_epoch_base += nb * (unsigned)(2 * n - 1 + (ev ? 1 : 0));
+  c->persist_epoch_base += nb * (unsigned)(2 * n - 1 + (ev ? 1 : 0));      // n <= kPersistChunk; the counter wraps, grid_sync compares wrap-safe
+  c->persist_seq += 1;
+  c->persist_log.push_back(gbp_ctx::Burst{c->persist_seq, n, mode, area});
   c->persist_launches += 1;
   return GBP_OK;
 }
 
-// GBP_PROG x n (ba.cpp:895-905) on one GPU: replay of a captured hipGraph of `graph_unroll`
-// iterations, remainder launched directly.
+// GBP_PROG x n (ba.cpp:895-905) on one GPU: inside the persistent kernel (small graphs), else hipGraph replay / direct launches.
 static int iterate_impl(gbp_ctx* c, int n) {
   if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "gbp_iterate: upload first");
   if (n <= 0) return GBP_OK;
-  if (c->comm) return iterate_sharded(c, n);
+  if (c->comm) {
+    if (int rc = settle(c)) return rc;
+    return iterate_sharded(c, n);
+  }
   if (c->world > 1)
     return fail(c, GBP_ERR_STATE, "sharded ctx without a communicator: gbp_comm_init first, or use gbp_iterate_begin / exchange / gbp_iterate_end");
+  bool persist = false;
+  if (n >= 2)                          // a single iteration is as fast from two launches (measured)
+    if (int rc = persist_ready(c, &persist)) return rc;
+  if (!persist)
+    if (int rc = settle(c)) return rc;
   const SweepArgs a = sweep_args(c);
   gbp_ctx::Span sp{};
   if (int rc = span_begin(c, sp)) return rc;
@@ -978,20 +1169,27 @@ static int iterate_impl(gbp_ctx* c, int n) {
       HIPCHK(c, hipEventElapsedTime(&b_ms, ev[2 * i + 1], ev[2 * i + 2]));
       c->sweep_ms += a_ms; c->belief_ms += b_ms;
     }
-  } else if (c->persist_ok && n >= 2) {   // a single iteration is as fast from two launches (measured)
-    // small graph: the whole burst in one launch (k_persist)
-    if (int rc = launch_persist_burst(c, a, n, nullptr)) { c->span_pool.push_back(sp); return rc; }
-  } else {
-    int left = n;
-    bool use_graph = (c->stream == c->own_stream) && c->prm.graph_unroll > 0 && n >= c->prm.graph_unroll && !c->graph_failed;
-    if (use_graph && !c->graph_exec) use_graph = ensure_graph(c, a);
-    if (use_graph) {
-      while (left >= c->graph_iters) {
-        HIPCHK(c, hipGraphLaunch(c->graph_exec, c->stream));
-        left -= c->graph_iters;
+  } else if (persist) {
+    // small graph: the whole burst in one launch (k_persist); very long bursts in pieces, a launch cannot be pre-empted
+    for (int left = n; left > 0;) {
+      const int m = std::min(left, kPersistChunk);
+      int rc = launch_persist_burst(c, a, m, nullptr, 0, 0);
+      if (rc == GBP_OK) {
+        left -= m;
+        if (left > 0) {
+          rc = persist_ready(c, &persist);
+          if (rc == GBP_OK && !persist) rc = kNotLaunched;
+        }
       }
+      if (rc == kNotLaunched) {        // the ctx left the persistent path: the rest on the two-kernel path
+        rc = settle(c);
+        if (rc == GBP_OK) rc = iterate_plain(c, a, left);
+        left = 0;
+      }
+      if (rc != GBP_OK) { c->span_pool.push_back(sp); return rc; }
     }
-    for (; left > 0; --left) enqueue_iteration(c, a);
+  } else {
+    if (int rc = iterate_plain(c, a, n)) { c->span_pool.push_back(sp); return rc; }
   }
   HIPCHK(c, hipGetLastError());
   if (int rc = span_end(c, sp)) return rc;
@@ -1003,6 +1201,7 @@ static int iterate_impl(gbp_ctx* c, int n) {
 // WEAKEN_PRIORS (ba.cpp:863-865): WeakenPriorVertex on every variable, then prog_ub.
 int gbp_weaken_priors(gbp_ctx* c) {
   if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "gbp_weaken_priors: upload first");
+  if (int rc = settle(c)) return rc;
   launch_weaken(P<float4>(c->camp), P<float>(c->cscale), P<uint32_t>(c->cwf), c->C, kCamRec4, c->stream);
   if (c->L_loc) launch_weaken(P<float4>(c->lmkp), P<float>(c->lscale), P<uint32_t>(c->lwf), c->L_loc, kLmkRec4, c->stream);
   HIPCHK(c, hipGetLastError());
@@ -1052,7 +1251,7 @@ static int read_impl(gbp_ctx* c, gbp_state_out* o) {
 // READ_PRIORS (slam.cpp:913-917)
 static int read_priors_impl(gbp_ctx* c, gbp_priors_out* o) {
   if (!c || !o) return GBP_ERR_INVALID;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (int rc = gbp_sync(c)) return rc;
   std::vector<float> rec((size_t)c->C * kCamRec);
   HIPCHK(c, hipMemcpy(rec.data(), c->camp.p, rec.size() * 4, hipMemcpyDeviceToHost));
   for (uint32_t k = 0; k < c->C; ++k) {
@@ -1073,7 +1272,7 @@ static int read_priors_impl(gbp_ctx* c, gbp_priors_out* o) {
 // NEW_KEYFRAME (slam.cpp:919-928): re-upload damping_count, priors, flags; then prog_ub.
 static int new_keyframe_impl(gbp_ctx* c, const gbp_kf_update* u) {
   if (!c || !u || !c->uploaded) return fail(c, GBP_ERR_STATE, "gbp_new_keyframe: upload first");
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (int rc = gbp_sync(c)) return rc;
   if (u->damping_count || u->active_flag) {
     // edit the per-factor scalars in place on the device: 8 bytes per factor go over PCIe, not the 64-byte records
     std::vector<int32_t> cnt(c->Ep, 0);
@@ -1127,16 +1326,17 @@ static int new_keyframe_impl(gbp_ctx* c, const gbp_kf_update* u) {
 // no copy launch) and records an event; end waits for that event only and sums the partials in block order.  Two
 // evaluations may be in flight (two result areas).  The health counters are accumulated with atomics in device memory,
 // double-buffered so that no memset launch is needed: k_means zeroes the pair the next evaluation will use.
-static int eval_begin_impl(gbp_ctx* c) {
-  if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "gbp_eval: upload first");
-  if (c->eval_pending >= 2) return fail(c, GBP_ERR_STATE, "gbp_eval_begin: two evaluations already in flight, call gbp_eval_end first");
-  if (!c->eval_host) {
-    HIPCHK(c, hipHostMalloc(&c->eval_host, sizeof(DeviceEval) * 1025 * 2, hipHostMallocMapped));
-    HIPCHK(c, hipHostGetDevicePointer(&c->eval_host_dev, c->eval_host, 0));
-    HIPCHK(c, hipEventCreateWithFlags(&c->eval_ev[0], hipEventDisableTiming));
-    HIPCHK(c, hipEventCreateWithFlags(&c->eval_ev[1], hipEventDisableTiming));
-  }
-  const int area = c->eval_parity & 1;
+static int eval_alloc(gbp_ctx* c) {
+  if (c->eval_host) return GBP_OK;
+  HIPCHK(c, hipHostMalloc(&c->eval_host, sizeof(DeviceEval) * 1025 * 2, hipHostMallocMapped));
+  HIPCHK(c, hipHostGetDevicePointer(&c->eval_host_dev, c->eval_host, 0));
+  HIPCHK(c, hipEventCreateWithFlags(&c->eval_ev[0], hipEventDisableTiming));
+  HIPCHK(c, hipEventCreateWithFlags(&c->eval_ev[1], hipEventDisableTiming));
+  return GBP_OK;
+}
+
+// k_means + k_eval of the current beliefs into result area `area`, its event recorded behind them
+static int eval_enqueue(gbp_ctx* c, int area) {
   DeviceEval* slots = static_cast<DeviceEval*>(c->eval_host_dev) + 1025 * area;
   unsigned long long* h_cur = P<unsigned long long>(c->health) + 2 * area;
   unsigned long long* h_next = P<unsigned long long>(c->health) + 2 * (area ^ 1);
@@ -1146,22 +1346,23 @@ static int eval_begin_impl(gbp_ctx* c) {
               P<float>(c->dK), c->prm.num_undamped_iters, slots + 1, h_cur, reinterpret_cast<unsigned long long*>(slots), c->n_tiles, c->stream);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->eval_ev[area], c->stream));
+  return GBP_OK;
+}
+
+static int eval_begin_impl(gbp_ctx* c) {
+  if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "gbp_eval: upload first");
+  if (c->eval_pending >= 2) return fail(c, GBP_ERR_STATE, "gbp_eval_begin: two evaluations already in flight, call gbp_eval_end first");
+  if (int rc = settle(c)) return rc;
+  if (int rc = eval_alloc(c)) return rc;
+  const int area = c->eval_parity & 1;
+  if (int rc = eval_enqueue(c, area)) return rc;
   c->eval_parity ^= 1;
   c->eval_pending += 1;
   return GBP_OK;
 }
 
-static int eval_end_impl(gbp_ctx* c, gbp_eval_out* o) {
-  if (!c || !o) return GBP_ERR_INVALID;
-  if (c->eval_pending < 1) return fail(c, GBP_ERR_STATE, "gbp_eval_end: no evaluation in flight");
+static int sum_eval(gbp_ctx* c, const DeviceEval* part, uint32_t nb, gbp_eval_out* o) {
   std::memset(o, 0, sizeof(*o));
-  const int area = (c->eval_parity + (c->eval_pending == 2 ? 0 : 1)) & 1;   // the OLDEST pending evaluation
-  HIPCHK(c, hipEventSynchronize(c->eval_ev[area]));
-  c->eval_pending -= 1;
-  if (c->pstatus_host && *static_cast<volatile unsigned*>(c->pstatus_host) != 0u)
-    return fail(c, GBP_ERR_HIP, "k_persist: a device-wide barrier timed out (workgroups not co-resident); results are invalid");
-  const uint32_t nb = eval_blocks(c->n_tiles);
-  const DeviceEval* part = static_cast<const DeviceEval*>(c->eval_host) + 1025 * area;
   for (uint32_t b = 1; b <= nb; ++b) {
     o->sum_norm += part[b].sum_norm; o->sum_half_sq += part[b].sum_half_sq;
     o->n_active += part[b].n_active; o->n_relin += part[b].n_relin; o->n_robust += part[b].n_robust;
@@ -1173,6 +1374,27 @@ static int eval_end_impl(gbp_ctx* c, gbp_eval_out* o) {
   o->n_nonfinite = h[0];
   o->n_nonpd = h[1];
   return GBP_OK;
+}
+
+static int eval_end_impl(gbp_ctx* c, gbp_eval_out* o) {
+  if (!c || !o) return GBP_ERR_INVALID;
+  if (c->eval_pending < 1) return fail(c, GBP_ERR_STATE, "gbp_eval_end: no evaluation in flight");
+  std::memset(o, 0, sizeof(*o));
+  const int area = (c->eval_parity + (c->eval_pending == 2 ? 0 : 1)) & 1;   // the OLDEST pending evaluation
+  HIPCHK(c, hipEventSynchronize(c->eval_ev[area]));
+  if (!c->persist_log.empty()) {
+    // the metric may have come out of a k_persist launch: that launch (the oldest logged one for this area) and everything
+    // before it have completed — validate them; after a time-out the recovery has re-queued the metric behind the replay
+    unsigned upto = 0;
+    for (const gbp_ctx::Burst& b : c->persist_log)
+      if (b.mode == 1 && b.area == area) { upto = b.seq; break; }
+    const bool failed = *static_cast<volatile unsigned*>(c->pstatus_host) != 0u;
+    if (failed || upto)
+      if (int rc = persist_check(c, upto)) return rc;
+    if (failed) HIPCHK(c, hipEventSynchronize(c->eval_ev[area]));
+  }
+  c->eval_pending -= 1;
+  return sum_eval(c, static_cast<const DeviceEval*>(c->eval_host) + 1025 * area, eval_blocks(c->n_tiles), o);
 }
 
 static int eval_impl(gbp_ctx* c, gbp_eval_out* o) {
@@ -1188,99 +1410,96 @@ static int eval_impl(gbp_ctx* c, gbp_eval_out* o) {
 static int iterate_eval_impl(gbp_ctx* c, int n) {
   if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "gbp_iterate_eval: upload first");
   if (n <= 0) return eval_begin_impl(c);
-  const bool fused = c->persist_ok && !c->comm && c->world == 1 && !c->profile_stages && c->eval_pending < 2 &&
-                     eval_blocks(c->n_tiles) == (c->n_tiles + 3) / 4;
-  if (!fused) {
-    if (int rc = iterate_impl(c, n)) return rc;
-    return eval_begin_impl(c);
+  bool fused = false;
+  if (c->eval_pending < 2 && n <= kPersistChunk && eval_blocks(c->n_tiles) == (c->n_tiles + 3) / 4)
+    if (int rc = persist_ready(c, &fused)) return rc;
+  if (fused) {
+    if (int rc = eval_alloc(c)) return rc;
+    const int area = c->eval_parity & 1;
+    DeviceEval* slots = static_cast<DeviceEval*>(c->eval_host_dev) + 1025 * area;
+    PersistEval ev{};
+    ev.on = 1;
+    ev.cam_mu = P<float>(c->cam_mu); ev.lmk_mu = P<float>(c->lmk_mu);
+    ev.num_undamped = c->prm.num_undamped_iters;
+    ev.slots = slots;                    // [0] = health copy, [1 + workgroup] = partial sums (the layout gbp_eval_end reads)
+    ev.health = P<unsigned long long>(c->health) + 2 * area;
+    ev.health_next = P<unsigned long long>(c->health) + 2 * (area ^ 1);
+    gbp_ctx::Span sp{};
+    if (int rc = span_begin(c, sp)) return rc;
+    const int lrc = launch_persist_burst(c, sweep_args(c), n, &ev, 1, area);
+    if (lrc == GBP_OK) {
+      if (int rc = span_end(c, sp)) return rc;
+      c->timed_iters += (uint64_t)n;
+      c->beliefs_valid = true;
+      HIPCHK(c, hipEventRecord(c->eval_ev[area], c->stream));
+      c->eval_parity ^= 1;
+      c->eval_pending += 1;
+      return GBP_OK;
+    }
+    c->span_pool.push_back(sp);
+    if (lrc != kNotLaunched) return lrc;
   }
-  if (!c->eval_host) {
-    HIPCHK(c, hipHostMalloc(&c->eval_host, sizeof(DeviceEval) * 1025 * 2, hipHostMallocMapped));
-    HIPCHK(c, hipHostGetDevicePointer(&c->eval_host_dev, c->eval_host, 0));
-    HIPCHK(c, hipEventCreateWithFlags(&c->eval_ev[0], hipEventDisableTiming));
-    HIPCHK(c, hipEventCreateWithFlags(&c->eval_ev[1], hipEventDisableTiming));
-  }
-  const int area = c->eval_parity & 1;
-  DeviceEval* slots = static_cast<DeviceEval*>(c->eval_host_dev) + 1025 * area;
-  PersistEval ev{};
-  ev.on = 1;
-  ev.cam_mu = P<float>(c->cam_mu); ev.lmk_mu = P<float>(c->lmk_mu);
-  ev.num_undamped = c->prm.num_undamped_iters;
-  ev.slots = slots;                    // [0] = health copy, [1 + workgroup] = partial sums (the layout gbp_eval_end reads)
-  ev.health = P<unsigned long long>(c->health) + 2 * area;
-  ev.health_next = P<unsigned long long>(c->health) + 2 * (area ^ 1);
-  gbp_ctx::Span sp{};
-  if (int rc = span_begin(c, sp)) return rc;
-  if (int rc = launch_persist_burst(c, sweep_args(c), n, &ev)) { c->span_pool.push_back(sp); return rc; }
-  if (int rc = span_end(c, sp)) return rc;
-  c->timed_iters += (uint64_t)n;
-  c->beliefs_valid = true;
-  HIPCHK(c, hipEventRecord(c->eval_ev[area], c->stream));
-  c->eval_parity ^= 1;
-  c->eval_pending += 1;
-  return GBP_OK;
+  if (int rc = iterate_impl(c, n)) return rc;
+  return eval_begin_impl(c);
 }
 
 // n iterations with the metric after EVERY one of them (the reference's default loop, ba.cpp:1009-1028 / slam.cpp), blocking:
 // out[k] = what gbp_iterate(1) + gbp_eval_global() would have returned for the k-th of them.  On a graph that runs in
 // k_persist a burst is ONE launch: the metric of iteration k rides in the sweep phase of iteration k + 1 (both only read the
 // beliefs), its partial sums go to host-mapped memory.  Everywhere else it is the loop it replaces, two metrics in flight.
-static int sum_eval(gbp_ctx* c, const DeviceEval* part, uint32_t nb, gbp_eval_out* o) {
-  std::memset(o, 0, sizeof(*o));
-  for (uint32_t b = 1; b <= nb; ++b) {
-    o->sum_norm += part[b].sum_norm; o->sum_half_sq += part[b].sum_half_sq;
-    o->n_active += part[b].n_active; o->n_relin += part[b].n_relin; o->n_robust += part[b].n_robust;
-  }
-  unsigned long long h[2];
-  std::memcpy(h, part, 16);
-  o->n_nonfinite = h[0];
-  o->n_nonpd = h[1];
-  return GBP_OK;
-}
-
 static int iterate_eval_each_impl(gbp_ctx* c, int n, gbp_eval_out* out) {
   if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "gbp_iterate_eval_each: upload first");
   if (n < 0 || (n > 0 && !out)) return fail(c, GBP_ERR_INVALID, "gbp_iterate_eval_each: n >= 0 and an array of n results");
   if (c->eval_pending) return fail(c, GBP_ERR_STATE, "gbp_iterate_eval_each: finish the evaluations in flight (gbp_eval_end) first");
+  if (int rc = settle(c)) return rc;                  // blocking call: nothing of this ctx stays in flight across it
   const uint32_t nb = eval_blocks(c->n_tiles);
-  const bool fused = c->persist_ok && !c->comm && c->world == 1 && !c->profile_stages && nb == (c->n_tiles + 3) / 4;
-  if (!fused) {
-    int done = 0;
-    for (int k = 0; k < n; ++k) {
-      if (int rc = iterate_impl(c, 1)) return rc;
-      if (int rc = eval_begin_impl(c)) return rc;
-      if (c->eval_pending == 2) { if (int rc = eval_end_impl(c, out + done)) return rc; ++done; }
+  bool fused = false;
+  if (nb == (c->n_tiles + 3) / 4)
+    if (int rc = persist_ready(c, &fused)) return rc;
+  int done = 0;
+  if (fused) {
+    const uint32_t stride = nb + 1;
+    if (!c->series_host) {
+      HIPCHK(c, hipHostMalloc(&c->series_host, sizeof(DeviceEval) * (size_t)stride * kSeriesMax, hipHostMallocMapped));
+      HIPCHK(c, hipHostGetDevicePointer(&c->series_dev, c->series_host, 0));
     }
-    while (done < n) { if (int rc = eval_end_impl(c, out + done)) return rc; ++done; }
-    return GBP_OK;
+    const int area = c->eval_parity & 1;   // both health areas are zero between evaluations; this launch leaves them so
+    while (done < n && fused) {
+      const int m = std::min(n - done, (int)kSeriesMax);
+      PersistEval ev{};
+      ev.on = 1; ev.each = 1; ev.stride = stride;
+      ev.cam_mu = P<float>(c->cam_mu); ev.lmk_mu = P<float>(c->lmk_mu);
+      ev.num_undamped = c->prm.num_undamped_iters;
+      ev.slots = static_cast<DeviceEval*>(c->series_dev);
+      ev.health = P<unsigned long long>(c->health) + 2 * area;
+      ev.health_next = P<unsigned long long>(c->health) + 2 * (area ^ 1);
+      gbp_ctx::Span sp{};
+      if (int rc = span_begin(c, sp)) return rc;
+      const int lrc = launch_persist_burst(c, sweep_args(c), m, &ev, 2, area);
+      if (lrc != GBP_OK) {
+        c->span_pool.push_back(sp);
+        if (lrc != kNotLaunched) return lrc;
+        fused = false;
+        break;
+      }
+      if (int rc = span_end(c, sp)) return rc;
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      const bool failed = *static_cast<volatile unsigned*>(c->pstatus_host) != 0u;
+      if (int rc = persist_check(c, 0)) return rc;      // a time-out: state restored to the start of this burst
+      if (failed) { fused = false; break; }             // ... which the plain loop below now runs
+      c->timed_iters += (uint64_t)m;
+      c->beliefs_valid = true;
+      for (int k = 0; k < m; ++k) sum_eval(c, static_cast<const DeviceEval*>(c->series_host) + (size_t)k * stride, nb, out + done + k);
+      done += m;
+    }
   }
-  const uint32_t stride = nb + 1;
-  if (!c->series_host) {
-    HIPCHK(c, hipHostMalloc(&c->series_host, sizeof(DeviceEval) * (size_t)stride * kSeriesMax, hipHostMallocMapped));
-    HIPCHK(c, hipHostGetDevicePointer(&c->series_dev, c->series_host, 0));
+  int collected = done;
+  for (int k = done; k < n; ++k) {
+    if (int rc = iterate_impl(c, 1)) return rc;
+    if (int rc = eval_begin_impl(c)) return rc;
+    if (c->eval_pending == 2) { if (int rc = eval_end_impl(c, out + collected)) return rc; ++collected; }
   }
-  const int area = c->eval_parity & 1;   // both health areas are zero between evaluations; this launch leaves them so
-  for (int done = 0; done < n;) {
-    const int m = std::min(n - done, (int)kSeriesMax);
-    PersistEval ev{};
-    ev.on = 1; ev.each = 1; ev.stride = stride;
-    ev.cam_mu = P<float>(c->cam_mu); ev.lmk_mu = P<float>(c->lmk_mu);
-    ev.num_undamped = c->prm.num_undamped_iters;
-    ev.slots = static_cast<DeviceEval*>(c->series_dev);
-    ev.health = P<unsigned long long>(c->health) + 2 * area;
-    ev.health_next = P<unsigned long long>(c->health) + 2 * (area ^ 1);
-    gbp_ctx::Span sp{};
-    if (int rc = span_begin(c, sp)) return rc;
-    if (int rc = launch_persist_burst(c, sweep_args(c), m, &ev)) { c->span_pool.push_back(sp); return rc; }
-    if (int rc = span_end(c, sp)) return rc;
-    c->timed_iters += (uint64_t)m;
-    c->beliefs_valid = true;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->pstatus_host && *static_cast<volatile unsigned*>(c->pstatus_host) != 0u)
-      return fail(c, GBP_ERR_HIP, "k_persist: a device-wide barrier timed out (workgroups not co-resident); results are invalid");
-    for (int k = 0; k < m; ++k) sum_eval(c, static_cast<const DeviceEval*>(c->series_host) + (size_t)k * stride, nb, out + done + k);
-    done += m;
-  }
+  while (collected < n) { if (int rc = eval_end_impl(c, out + collected)) return rc; ++collected; }
   return GBP_OK;
 }
 
@@ -1312,7 +1531,7 @@ int gbp_set_profiling(gbp_ctx* c, int per_stage_events) {
 // Entries of factors outside the local shard are left untouched.
 static int debug_get_impl(gbp_ctx* c, int what, float* a, float* b) {
   if (!c || !a || !b) return GBP_ERR_INVALID;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (int rc = gbp_sync(c)) return rc;
   auto tri = [](int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; };
   if (what == 0) {
     std::vector<float> f((size_t)c->Ep * kFacG * 4);
@@ -1381,6 +1600,7 @@ static int debug_get_impl(gbp_ctx* c, int what, float* a, float* b) {
 // The ctx state is garbage afterwards; upload again before using it.
 int gbp_debug_time_sweep(gbp_ctx* c, int ablation, int reps, double* avg_us) {
   if (!c || !avg_us || reps <= 0 || !c->uploaded) return GBP_ERR_INVALID;
+  if (int rc = settle(c)) return rc;
   const SweepArgs a = sweep_args(c);
   bool built = true;
   auto one = [&]() {
@@ -1435,7 +1655,7 @@ int gbp_debug_persist_trace(gbp_ctx* c, unsigned long long* out, int cap_waves) 
 // symmetric blocks and Lambda_cl are taken; Lambda_lc is implied).  Test hook only.
 static int debug_set_factor_potentials_impl(gbp_ctx* c, const float* eta9E, const float* lam81E) {
   if (!c || !eta9E || !lam81E) return GBP_ERR_INVALID;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (int rc = gbp_sync(c)) return rc;
   auto tri = [](int i, int j) { return i * (i + 1) / 2 + j; };
   std::vector<float> f((size_t)c->Ep * kFacG * 4);
   HIPCHK(c, hipMemcpy(f.data(), c->fac.p, f.size() * 4, hipMemcpyDeviceToHost));
@@ -1456,6 +1676,7 @@ static int debug_set_factor_potentials_impl(gbp_ctx* c, const float* eta9E, cons
 
 // ---- communicator: the exchange step owned by the library (RCCL over xGMI from the C++ host) ------------------------
 static int comm_attach(gbp_ctx* c, gbp::Comm* comm) {
+  if (int rc = settle(c)) { delete comm; return rc; }
   c->comm = comm;
   // A second HSA queue makes every dispatch of the main queue slower (measured: +10 us per sharded iteration on the
   // config-5 shard shape, 0.183 vs 0.174 ms with a 1-rank communicator), so overlapping the all-gather with the

@@ -180,12 +180,69 @@ struct Lin {
   float hx[2];
 };
 
-template <bool FAST_TRIG = false>
-GBP_DEV void jac_hfunc(const float (&cam)[6], const float (&lmk)[3], const float (&K)[9], Lin& o) {
+// The part of Jac that depends on the CAMERA's linearisation point only (bafuncs.cpp:31-55, 166-199):
+//   R = so3exp(w)                       (fp64-evaluated sin / cos: the long serial chain of a relinearisation)
+//   N = (R^T - I) [w]x + w w^T          (the camera-only factor of dRy/dw = -R [y]x N / |w|^2)
+//   d = |w|^2
+// Every factor of a camera that relinearises in one sweep evaluates these with identical inputs — ~1 000 times per camera
+// on the 1M-factor graph.  They are computed ONCE per camera where the hoisted mean is produced (k_beliefs camera part,
+// k_persist camera role), with the very operations below, and stored as 20 floats per camera (5 float4: R 0-8, N 9-17,
+// d 18, pad); relinearising lanes load them.  k_linearise and the per-factor-mu mode call cam_lin themselves: same bits.
+struct CamLin {
   float R[9];
-  const float v[3] = {cam[3], cam[4], cam[5]};
-  GBP_TICK(1);
-  so3exp<FAST_TRIG>(v, R);
+  float N[9];
+  float den;
+};
+constexpr int kCamLin4 = 5;   // float4 per camera of the CAM_LIN array
+
+template <bool FAST_TRIG = false>
+GBP_DEV void cam_lin(const float (&v)[3], CamLin& c) {
+  so3exp<FAST_TRIG>(v, c.R);
+  const float vh[9] = {0.f, -v[2], v[1], v[2], 0.f, -v[0], -v[1], v[0], 0.f};
+  float RtI[9];
+  GBP_UNROLL
+  for (int i = 0; i < 3; ++i) {
+    GBP_UNROLL
+    for (int j = 0; j < 3; ++j) {
+      float t = (i == j) ? -1.f : 0.f;
+      t += c.R[j * 3 + i];
+      RtI[i * 3 + j] = t;
+    }
+  }
+  GBP_UNROLL
+  for (int i = 0; i < 3; ++i) {
+    GBP_UNROLL
+    for (int j = 0; j < 3; ++j) {
+      float b = 0.f;
+      GBP_UNROLL
+      for (int k = 0; k < 3; ++k)
+        if (k != j) b += RtI[i * 3 + k] * vh[k * 3 + j];  // hat matrices have a zero diagonal
+      c.N[i * 3 + j] = b + v[i] * v[j];
+    }
+  }
+  float den = 0.f;
+  GBP_UNROLL
+  for (int i = 0; i < 3; ++i) den += v[i] * v[i];
+  c.den = den;
+}
+GBP_DEV void cam_lin_pack(const CamLin& c, float4 (&q)[kCamLin4]) {
+  q[0] = make_float4(c.R[0], c.R[1], c.R[2], c.R[3]);
+  q[1] = make_float4(c.R[4], c.R[5], c.R[6], c.R[7]);
+  q[2] = make_float4(c.R[8], c.N[0], c.N[1], c.N[2]);
+  q[3] = make_float4(c.N[3], c.N[4], c.N[5], c.N[6]);
+  q[4] = make_float4(c.N[7], c.N[8], c.den, 0.f);
+}
+GBP_DEV void cam_lin_unpack(const float4 (&q)[kCamLin4], CamLin& c) {
+  c.R[0] = q[0].x; c.R[1] = q[0].y; c.R[2] = q[0].z; c.R[3] = q[0].w;
+  c.R[4] = q[1].x; c.R[5] = q[1].y; c.R[6] = q[1].z; c.R[7] = q[1].w;
+  c.R[8] = q[2].x; c.N[0] = q[2].y; c.N[1] = q[2].z; c.N[2] = q[2].w;
+  c.N[3] = q[3].x; c.N[4] = q[3].y; c.N[5] = q[3].z; c.N[6] = q[3].w;
+  c.N[7] = q[4].x; c.N[8] = q[4].y; c.den = q[4].z;
+}
+
+// hfunc + Jac of one factor from the camera-only terms `cl` of its camera (cl == cam_lin(cam[3..5]))
+GBP_DEV void jac_hfunc_lin(const float (&cam)[6], const float (&lmk)[3], const float (&K)[9], const CamLin& cl, Lin& o) {
+  const float (&R)[9] = cl.R;
   GBP_TICK(2);
   float yc[3];
   GBP_UNROLL
@@ -223,37 +280,20 @@ GBP_DEV void jac_hfunc(const float (&cam)[6], const float (&lmk)[3], const float
   o.Jkf[0] = jp00; o.Jkf[1] = 0.f;  o.Jkf[2] = jp02;
   o.Jkf[6] = 0.f;  o.Jkf[7] = jp11; o.Jkf[8] = jp12;
 
-  // rotation block: dRy/dw = -R [y]x (w w^T + (R^T - I)[w]x) / |w|^2   (bafuncs.cpp:178-204)
-  const float vh[9] = {0.f, -v[2], v[1], v[2], 0.f, -v[0], -v[1], v[0], 0.f};
+  // rotation block: dRy/dw = -R [y]x (w w^T + (R^T - I)[w]x) / |w|^2   (bafuncs.cpp:178-204); the bracket and |w|^2 are cl.N, cl.den
   const float yh[9] = {0.f, -lmk[2], lmk[1], lmk[2], 0.f, -lmk[0], -lmk[1], lmk[0], 0.f};
-  float RtI[9], Ry[9], num[9], dR[9];
+  float Ry[9], dR[9];
   GBP_UNROLL
   for (int i = 0; i < 3; ++i) {
     GBP_UNROLL
     for (int j = 0; j < 3; ++j) {
-      float t = (i == j) ? -1.f : 0.f;
-      t += R[j * 3 + i];
-      RtI[i * 3 + j] = t;
-    }
-  }
-  GBP_UNROLL
-  for (int i = 0; i < 3; ++i) {
-    GBP_UNROLL
-    for (int j = 0; j < 3; ++j) {
-      float a = 0.f, b = 0.f;
+      float a = 0.f;
       GBP_UNROLL
       for (int k = 0; k < 3; ++k)
-        if (k != j) {  // hat matrices have a zero diagonal
-          a += R[i * 3 + k] * yh[k * 3 + j];
-          b += RtI[i * 3 + k] * vh[k * 3 + j];
-        }
+        if (k != j) a += R[i * 3 + k] * yh[k * 3 + j];  // hat matrices have a zero diagonal
       Ry[i * 3 + j] = a;
-      num[i * 3 + j] = b + v[i] * v[j];
     }
   }
-  float den = 0.f;
-  GBP_UNROLL
-  for (int i = 0; i < 3; ++i) den += v[i] * v[i];
   float ndR[9];
   GBP_UNROLL
   for (int i = 0; i < 3; ++i) {
@@ -261,11 +301,11 @@ GBP_DEV void jac_hfunc(const float (&cam)[6], const float (&lmk)[3], const float
     for (int j = 0; j < 3; ++j) {
       float a = 0.f;
       GBP_UNROLL
-      for (int k = 0; k < 3; ++k) a += Ry[i * 3 + k] * num[k * 3 + j];
+      for (int k = 0; k < 3; ++k) a += Ry[i * 3 + k] * cl.N[k * 3 + j];
       ndR[i * 3 + j] = -a;
     }
   }
-  div_shared(ndR, den, dR);
+  div_shared(ndR, cl.den, dR);
   GBP_UNROLL
   for (int j = 0; j < 3; ++j) {
     float a0 = 0.f, a1 = 0.f;
@@ -276,6 +316,15 @@ GBP_DEV void jac_hfunc(const float (&cam)[6], const float (&lmk)[3], const float
     o.Jkf[3 + j] = a0;
     o.Jkf[9 + j] = a1;
   }
+}
+
+template <bool FAST_TRIG = false>
+GBP_DEV void jac_hfunc(const float (&cam)[6], const float (&lmk)[3], const float (&K)[9], Lin& o) {
+  CamLin cl;
+  const float v[3] = {cam[3], cam[4], cam[5]};
+  GBP_TICK(1);
+  cam_lin<FAST_TRIG>(v, cl);
+  jac_hfunc_lin(cam, lmk, K, cl, o);
 }
 
 }  // namespace gbpdev

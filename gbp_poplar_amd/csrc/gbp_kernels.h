@@ -63,6 +63,7 @@ struct SweepArgs {
   float4* rowp;
   const float4* cam_mu;   // [C][4]: hoisted camera means (current x2 float4, used-by-last-sweep x2)
   const float4* lmk_mu;   // [L][2]
+  const float4* cam_lin;  // [C][5]: camera-only Jacobian terms of the current hoisted mean (R 9, N 9, |w|^2; gbp_device_math.hpp CamLin)
   float K[9];
   Hyper hp;
   uint32_t block0;           // first 256-factor block of this launch (pieces of a sweep: pipelined exchange)
@@ -81,7 +82,7 @@ struct BeliefArgs {
   float* cam_local;          // [C][44] local row sums (kept for prior-only refreshes / the exchange buffer)
   const float* gathered;     // != nullptr: belief = prior + sum_r gathered[r] instead of the row sums
   int world;
-  float* camb; float4* cam_mu; uint32_t n_cams;
+  float* camb; float4* cam_mu; float4* cam_lin; uint32_t n_cams;
   // landmark part
   const float4* lmk_prior; const float4* lmsg; const uint32_t* lmk_ptr; const uint32_t* lmk_fpos;
   const uint32_t* lmk_ix;   // [L][16]: degree, device positions of slots 1..15 (one 64-B index record per landmark)
@@ -129,8 +130,17 @@ struct PersistArgs {
   uint32_t spread;         // the grid is `spread` times larger than the work and only every spread-th workgroup works (4: see launch_persist)
   uint32_t n_work_blocks;  // working workgroups (== gridDim.x unless spread)
   unsigned* sync;          // [kPersistSyncWords] barrier words: [0] arrival counter (monotonic over launches), [32] abort word
-  unsigned* status;        // host-mapped: set to 1 if a barrier gave up waiting (a workgroup was not resident)
+  unsigned* status;        // host-mapped: set to `seq` by the first workgroup that gives up at a barrier (a workgroup was not resident)
+  unsigned seq;            // number of this launch in the ctx (>= 1): tells the host WHICH launch failed first (later ones return at once)
   unsigned long long* trace;  // experiments build only (else NULL): [wave][iteration < kPersistTraceIters][8] wall-clock ticks
+};
+// snapshot / restore of the arrays a k_persist launch mutates (k_copy_segments)
+constexpr int kMaxCopySegs = 12;
+struct CopySegs {
+  int n;
+  const void* src[kMaxCopySegs];
+  void* dst[kMaxCopySegs];
+  size_t n4[kMaxCopySegs];     // float4 elements of each segment
 };
 constexpr int kPersistTraceIters = 16;
 constexpr int kSeriesMax = 128;         // metrics per launch of gbp_iterate_eval_each (longer bursts are split)
@@ -148,10 +158,14 @@ void launch_linearise(const SweepArgs& a, uint32_t n_tiles, hipStream_t s);
 void launch_beliefs(BeliefArgs b, bool do_cam, bool do_lmk, hipStream_t s);
 uint32_t persist_blocks(uint32_t n_tiles, uint32_t n_cams, uint32_t n_lmks);   // workgroups k_persist needs for a graph
 int persist_max_resident_blocks();                                            // how many of them this GPU keeps resident at once
-void launch_persist(PersistArgs a, hipStream_t s);
+// cooperative != 0: hipLaunchCooperativeKernel — the runtime refuses a grid that cannot be co-resident on the device and the
+// driver never runs two cooperative grids (of any process) side by side; 0: plain launch (the creation-time probe vouches for
+// the placement inside this process only).  Returns the launch status.
+hipError_t launch_persist(PersistArgs a, bool cooperative, hipStream_t s);
+void launch_copy_segments(const CopySegs& t, const unsigned* guard /* abort word or NULL */, hipStream_t s);
 // runs the placement + barriers of k_persist for this graph once (blocking); false = the workgroups are not co-resident here
 bool persist_probe(uint32_t n_tiles, uint32_t n_cams, uint32_t n_lmks, unsigned* sync, unsigned* status_dev, volatile unsigned* status_host,
-                   hipStream_t s);
+                   bool cooperative, hipStream_t s);
 void launch_weaken(float4* prior, const float* scaling, uint32_t* flag, uint32_t n, int rec4, hipStream_t s);
 void launch_state_get(const float4* lmsg, float* damping, int* packed, uint32_t n, hipStream_t s);
 void launch_state_set(float4* lmsg, const int* new_count, const uint32_t* ctl, uint32_t n, hipStream_t s);

@@ -100,10 +100,10 @@ GBP_DEV void belief_means(const float (&cb)[44], const float (&lb)[16], float (&
 // J^T J / J^T (J x0 + z - h(x0)) onto the potential, Huber-rescale.  Returns the robust flag.
 template <int ABL = 0>   // ABL: timing experiments only (256 = hardware sin/cos, 512 = reciprocal multiply for the Huber rescale)
 GBP_DEV bool relin_core(float (&fac)[56], const float (&x0c)[6], const float (&x0l)[3], const float (&K)[9],
-                        float var, float nstds) {
+                        float var, float nstds, const CamLin& cl /* == cam_lin(x0c[3..5]) */) {
   Lin L;
   GBP_TICK(0);
-  jac_hfunc<(ABL & 256) != 0>(x0c, x0l, K, L);
+  jac_hfunc_lin(x0c, x0l, K, cl, L);
   GBP_TICK(3);
   GBP_UNROLL
   for (int i = 0; i < 6; ++i) {
@@ -185,7 +185,8 @@ GBP_DEV bool relin_core(float (&fac)[56], const float (&x0c)[6], const float (&x
 
 // One factor's share of a sweep on register state: PrepMessageVertex + the four Compute*Message*Vertex classes
 // (gbp_codelets.cpp:215-710).  Shared by k_sweep (state streamed from HBM every launch) and k_persist (state kept in
-// registers across iterations).  `means(x0c, x0l)` supplies the hoisted linearisation point when a lane relinearises.
+// registers across iterations).  `means(x0c, x0l, cl)` supplies the hoisted linearisation point and the camera-only Jacobian
+// terms of that point when a lane relinearises.
 template <bool HOIST, int ABL, class Means>
 GBP_DEV void factor_update(float (&fac)[56], const float (&cm)[28], float (&mu)[12], const float (&lm)[16], const float (&cb)[44],
                            const float (&lb)[16], const float (&K)[9], const Hyper& hp, float& damping, int& count, uint32_t& flags,
@@ -212,6 +213,7 @@ GBP_DEV void factor_update(float (&fac)[56], const float (&cm)[28], float (&mu)[
     if (0 == count) damping = hp.maxeta_damping;
     count += 1;
     float x0c[6], x0l[3];
+    CamLin cl;
     float d2;
     if (HOIST) {
       d2 = cb[6];
@@ -243,8 +245,13 @@ GBP_DEV void factor_update(float (&fac)[56], const float (&cm)[28], float (&mu)[
         for (int i = 0; i < 6; ++i) x0c[i] = cb[i] + 0.5f;
         GBP_UNROLL
         for (int i = 0; i < 3; ++i) x0l[i] = lb[i] + 0.5f;
-      } else if (HOIST) {  // linearisation point = the hoisted means (rare path: loaded only here)
-        means(x0c, x0l);
+        const float w[3] = {x0c[3], x0c[4], x0c[5]};
+        cam_lin<(ABL & 256) != 0>(w, cl);
+      } else if (HOIST) {  // linearisation point = the hoisted means + the camera's CAM_LIN record (rare path: loaded only here)
+        means(x0c, x0l, cl);
+      } else {
+        const float w[3] = {x0c[3], x0c[4], x0c[5]};
+        cam_lin<(ABL & 256) != 0>(w, cl);
       }
       damping = 0.f;
       count = -hp.num_undamped_iters;
@@ -252,7 +259,7 @@ GBP_DEV void factor_update(float (&fac)[56], const float (&cm)[28], float (&mu)[
         GBP_UNROLL
         for (int i = 0; i < 54; ++i) fac[i] = 0.f;
       }
-      const bool robust = relin_core<ABL>(fac, x0c, x0l, K, var, hp.nstds);
+      const bool robust = relin_core<ABL>(fac, x0c, x0l, K, var, hp.nstds, cl);
       flags = robust ? (flags | kFlagRobust) : (flags & ~kFlagRobust);
     }
 
@@ -441,11 +448,15 @@ GBP_DEV void sweep_tile(const SweepArgs& a, const uint32_t wslot) {
   float oc_eta[6], oc_lam[36], ol[16];
   bool relin;
   factor_update<HOIST, ABL>(fac, cm, mu, lm, cb, lb, K, a.hp, damping, count, flags, var, active, oc_eta, oc_lam, ol, relin,
-                            [&](float (&x0c)[6], float (&x0l)[3]) {   // rare path: the hoisted means are loaded only by relinearising lanes
+                            [&](float (&x0c)[6], float (&x0l)[3], CamLin& cl) {   // rare path: loaded only by relinearising lanes
                               const float4 m0 = a.cam_mu[(size_t)cam_i * 4], m1 = a.cam_mu[(size_t)cam_i * 4 + 1];
                               const float4 l0 = a.lmk_mu[(size_t)lmk_i * 2];
+                              float4 q[kCamLin4];
+                              GBP_UNROLL
+                              for (int g = 0; g < kCamLin4; ++g) q[g] = a.cam_lin[(size_t)cam_i * kCamLin4 + g];
                               x0c[0] = m0.x; x0c[1] = m0.y; x0c[2] = m0.z; x0c[3] = m0.w; x0c[4] = m1.x; x0c[5] = m1.y;
                               x0l[0] = l0.x; x0l[1] = l0.y; x0l[2] = l0.z;
+                              cam_lin_unpack(q, cl);
                             });
 
   // ---- outputs --------------------------------------------------------------------------------
@@ -655,7 +666,10 @@ __global__ __launch_bounds__(256) void k_sweep_coop16(const SweepArgs a) {
           GBP_UNROLL
           for (int i = 0; i < 54; ++i) fr[i] = 0.f;
         }
-        const bool robust = relin_core<0>(fr, x0c, x0l, K, var, a.hp.nstds);
+        CamLin cl;
+        const float wv[3] = {x0c[3], x0c[4], x0c[5]};
+        cam_lin(wv, cl);
+        const bool robust = relin_core<0>(fr, x0c, x0l, K, var, a.hp.nstds, cl);
         GBP_UNROLL
         for (int i = 0; i < 54; ++i) w[kF + i] = fr[i];
         w[kStride - 1] = robust ? 1.f : 0.f;
@@ -822,7 +836,10 @@ __global__ __launch_bounds__(256) void k_linearise(const SweepArgs a) {
   GBP_UNROLL
   for (int i = 0; i < 54; ++i) fac[i] = 0.f;
   belief_means(cb, lb, x0c, x0l);
-  const bool robust = relin_core(fac, x0c, x0l, K, st.z, a.hp.nstds);
+  CamLin cl;
+  const float wv[3] = {x0c[3], x0c[4], x0c[5]};
+  cam_lin(wv, cl);
+  const bool robust = relin_core(fac, x0c, x0l, K, st.z, a.hp.nstds, cl);
   flags = robust ? (flags | kFlagRobust) : (flags & ~kFlagRobust);
   st.y = __int_as_float((packed & ~7) | (int)flags);
   a.lmsg[(size_t)p * 4 + 3] = st;
@@ -925,6 +942,15 @@ __global__ __launch_bounds__(256) void k_beliefs(const BeliefArgs b) {
         mu[0] = make_float4(x0c[0], x0c[1], x0c[2], x0c[3]);
         mu[1] = make_float4(x0c[4], x0c[5], 0.f, 0.f);
         sh[j][6] = S;
+        // camera-only Jacobian terms of this mean (gbp_device_math.hpp: cam_lin), once per camera instead of once per
+        // relinearising factor
+        CamLin cl;
+        const float wv[3] = {x0c[3], x0c[4], x0c[5]};
+        cam_lin(wv, cl);
+        float4 q[kCamLin4];
+        cam_lin_pack(cl, q);
+        GBP_UNROLL
+        for (int g = 0; g < kCamLin4; ++g) b.cam_lin[(size_t)cj * kCamLin4 + g] = q[g];
       }
     }
     __syncthreads();
@@ -1227,19 +1253,26 @@ GBP_DEV float4 lmsg_piece_xw(const XwBuf& lmsg, uint32_t pos, uint32_t q) {
   return m;
 }
 
-GBP_DEV void grid_sync(unsigned* sync, unsigned target /* arrivals to wait for */, unsigned* status) {
+constexpr unsigned long long kBarrierTimeoutTicks = 150000000ull;   // 1.5 s of the 100 MHz wall clock
+GBP_DEV void grid_sync(unsigned* sync, unsigned target /* arrivals to wait for */, unsigned* status, unsigned seq /* what a time-out writes to *status */) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's write-through stores have been acknowledged
   __syncthreads();
   if (threadIdx.x == 0) {
     __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned spin = 0;
+    unsigned long long t0 = 0;
     while ((int)(__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {   // wrap-safe
-      // bounded wait (~1 s), and once ONE workgroup has given up every other one leaves its barriers at once (sync[32] is
-      // the abort word): a launch that can never complete ends in seconds with *status raised, it does not hang the GPU
-      if ((++spin & 1023u) == 0u && (spin > (1u << 23) || __hip_atomic_load(sync + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-        __hip_atomic_store(sync + 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *status = 1u;
-        break;
+      // bounded wait (1.5 s by the wall clock), and once ONE workgroup has given up every other one leaves its barriers at once
+      // (sync[32] is the abort word): a launch that can never complete ends in seconds with *status raised, it does not hang
+      // the GPU.  The abort word stays set: later launches of the ctx return at once (k_persist prologue) until the host has
+      // restored the state the failed launch started from (gbp_capi.cpp: persist_recover).
+      if ((++spin & 255u) == 0u) {
+        const unsigned long long now = wall_clock64();
+        if (t0 == 0) t0 = now;
+        if (now - t0 > kBarrierTimeoutTicks || __hip_atomic_load(sync + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+          if (__hip_atomic_exchange(sync + 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) *status = seq;   // the first to give up names the launch
+          break;
+        }
       }
       __builtin_amdgcn_s_sleep(1);
     }
@@ -1247,11 +1280,26 @@ GBP_DEV void grid_sync(unsigned* sync, unsigned target /* arrivals to wait for *
   __syncthreads();
 }
 
+// Snapshot / restore of the arrays a k_persist launch mutates (one launch for all of them): taken before every launch so that
+// a launch whose barrier timed out can be undone and replayed on the two-kernel path.  `guard` != NULL: do nothing once the
+// abort word is set — the snapshot then still holds the state the FIRST failed launch started from.
+__global__ __launch_bounds__(256) void k_copy_segments(const CopySegs t, const unsigned* guard) {
+  if (guard && __hip_atomic_load(guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+  for (int sgi = 0; sgi < t.n; ++sgi) {
+    const float4* src = static_cast<const float4*>(t.src[sgi]);
+    float4* dst = static_cast<float4*>(t.dst[sgi]);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < t.n4[sgi]; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+  }
+}
+
 template <int ABL = 0>   // ABL: timing experiments only (see k_sweep)
 __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
   const SweepArgs& a = A.s;
   const BeliefArgs& b = A.b;
   const uint32_t wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // an earlier launch of this ctx gave up at a barrier: the state is not what this launch expects — touch nothing (the host
+  // restores the snapshot and replays; every workgroup reads the same word before anyone could write it in THIS launch)
+  if (__hip_atomic_load(A.sync + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
   // placement (profiles/r03_small_graphs.md): the grid is `spread` times larger than the work; filler workgroups leave at once.
   // spread > 0: workgroup b works iff b % spread == 0;  spread < 0 (s = -spread): iff (b / 8) % s == 0 (every XCD keeps working,
   // every s-th dispatch slot inside an XCD)
@@ -1269,7 +1317,7 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
   __shared__ float4 lm_stage[4][64 * 4];
   __shared__ float sh[4][48];
   float4* stage = lm_stage[wib];
-  const XwBuf X_lmsg(a.lmsg), X_rowp(a.rowp), X_camb(a.camb), X_lmkb(a.lmkb), X_cmu(a.cam_mu), X_lmu(a.lmk_mu);
+  const XwBuf X_lmsg(a.lmsg), X_rowp(a.rowp), X_camb(a.camb), X_lmkb(a.lmkb), X_cmu(a.cam_mu), X_lmu(a.lmk_mu), X_clin(a.cam_lin);
   const XwBuf X_emc(A.ev.cam_mu), X_eml(A.ev.lmk_mu);     // metric means (only with A.ev.on)
 
   // ---- phase-A role: sweep tile w.  State that only this lane ever touches lives in registers for the whole launch.
@@ -1303,7 +1351,7 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
   GBP_UNROLL
   for (int i = 0; i < 9; ++i) K[i] = a.K[i];
   const uint32_t cb_rec4 = cam_i * (uint32_t)kCamRec4, lb_rec4 = lmk_i * (uint32_t)kLmkRec4;   // loop-invariant: phase A is ONE round of loads
-  const uint32_t cmu_rec4 = cam_i * 4u, lmu_rec4 = lmk_i * 2u;
+  const uint32_t cmu_rec4 = cam_i * 4u, lmu_rec4 = lmk_i * 2u, clin_rec4 = cam_i * (uint32_t)kCamLin4;
 
   // ---- phase-B role: camera v (lanes 0..43 = the record), or landmarks 16 (v - C) .. + 15 (4 lanes each).  Roles are
   // numbered ACROSS the workgroups (v = wave-in-workgroup * workgroups + workgroup): the camera waves, whose lane 0 runs long
@@ -1407,6 +1455,9 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
       // the linearisation point of a relinearising lane is fetched with the beliefs (one round of loads per phase)
       const float4 l0 = X_lmu.ld4(lmu_rec4);
       const float4 m0 = X_cmu.ld4(cmu_rec4), m1 = X_cmu.ld4(cmu_rec4 + 1u);
+      float4 clq[kCamLin4];
+      GBP_UNROLL
+      for (int g = 0; g < kCamLin4; ++g) clq[g] = X_clin.ld4(clin_rec4 + (uint32_t)g);
       load_rec_xw<kLmkRec4>(X_lmkb, lb_rec4, lb);
       load_rec_xw<kCamRec4>(X_camb, cb_rec4, cb);
 #ifdef GBP_BUILD_EXPERIMENTS
@@ -1421,9 +1472,10 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
       float oc_eta[6], oc_lam[36], ol[16];
       bool relin;
       factor_update<true, ABL>(fac, cm, mu, lm, cb, lb, K, a.hp, damping, count, flags, var, active, oc_eta, oc_lam, ol, relin,
-                             [&](float (&x0c)[6], float (&x0l)[3]) {
+                             [&](float (&x0c)[6], float (&x0l)[3], CamLin& cl) {
                                x0c[0] = m0.x; x0c[1] = m0.y; x0c[2] = m0.z; x0c[3] = m0.w; x0c[4] = m1.x; x0c[5] = m1.y;
                                x0l[0] = l0.x; x0l[1] = l0.y; x0l[2] = l0.z;
+                               cam_lin_unpack(clq, cl);
                              });
       fac_dirty = fac_dirty || (active && relin);
 #ifdef GBP_BUILD_EXPERIMENTS
@@ -1479,7 +1531,7 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
     }
     if (ev_prev) metric((uint32_t)it - 1u, ev_packed, ev_cm, ev_lm);
     GBP_TRACE(1);
-    grid_sync(A.sync, A.epoch_base + (++epoch) * nblk, A.status);
+    grid_sync(A.sync, A.epoch_base + (++epoch) * nblk, A.status, A.seq);
     GBP_TRACE(2);
 
     // ================= phase B: the belief update (arithmetic of k_beliefs, roll = 1) =================
@@ -1539,6 +1591,15 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
         cam_cur0 = make_float4(x0c[0], x0c[1], x0c[2], x0c[3]);
         cam_cur1 = make_float4(x0c[4], x0c[5], 0.f, 0.f);
         X_cmu.st4(mu4, cam_cur0); X_cmu.st4(mu4 + 1u, cam_cur1);
+        {  // camera-only Jacobian terms of the new mean (what k_beliefs stores): the relinearising lanes of the next sweep load them
+          CamLin cl;
+          const float wv[3] = {x0c[3], x0c[4], x0c[5]};
+          cam_lin(wv, cl);
+          float4 q[kCamLin4];
+          cam_lin_pack(cl, q);
+          GBP_UNROLL
+          for (int g = 0; g < kCamLin4; ++g) X_clin.st4(v * (uint32_t)kCamLin4 + (uint32_t)g, q[g]);
+        }
         if (ev_means) {
           bool finite = true;
           GBP_UNROLL
@@ -1630,7 +1691,7 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
       if (lmk_live) X_lmkb.st4(l * 4u + q4, acc);
     }
     GBP_TRACE(3);
-    if (it + 1 < A.n_iters) grid_sync(A.sync, A.epoch_base + (++epoch) * nblk, A.status);
+    if (it + 1 < A.n_iters) grid_sync(A.sync, A.epoch_base + (++epoch) * nblk, A.status, A.seq);
     GBP_TRACE(4);
   }
 #undef GBP_TRACE
@@ -1638,7 +1699,7 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
   // ---- the metric of the last iteration: one more hand-off, then as above ----
   if (A.ev.on) {
     if (bid == 0 && threadIdx.x == 0) { A.ev.health_next[0] = 0ull; A.ev.health_next[1] = 0ull; }
-    grid_sync(A.sync, A.epoch_base + (++epoch) * nblk, A.status);
+    grid_sync(A.sync, A.epoch_base + (++epoch) * nblk, A.status, A.seq);
     float cmv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, lmu[3] = {0.f, 0.f, 0.f};
     if (has_tile) metric_means(cmv, lmu);
     metric(A.ev.each ? (uint32_t)A.n_iters - 1u : 0u, __float_as_int(lm[13]), cmv, lmu);
@@ -2083,19 +2144,29 @@ __global__ __launch_bounds__(256) void k_persist_probe(unsigned* sync, unsigned*
   if ((int)spread > 1 && blockIdx.x % spread) return;
   const uint32_t nblk = (int)spread > 1 ? gridDim.x / spread : gridDim.x;
   (void)n_work_blocks;
-  for (unsigned e = 1; e <= 3; ++e) grid_sync(sync, e * nblk, status);
+  for (unsigned e = 1; e <= 3; ++e) grid_sync(sync, e * nblk, status, 1u);
 }
 
 static int persist_spread(uint32_t nb) { return nb <= 64 ? 4 : nb <= 128 ? 2 : 1; }
 
 bool persist_probe(uint32_t n_tiles, uint32_t n_cams, uint32_t n_lmks, unsigned* sync, unsigned* status_dev, volatile unsigned* status_host,
-                   hipStream_t s) {
+                   bool cooperative, hipStream_t s) {
   const uint32_t nb = persist_blocks(n_tiles, n_cams, n_lmks);
   const int spread = persist_spread(nb);
   if (hipMemsetAsync(sync, 0, kPersistSyncWords * sizeof(unsigned), s) != hipSuccess) return false;
-  // 96 KiB of dynamic LDS per workgroup: at most ONE workgroup per CU (160 KiB), like k_persist's 340 registers per lane
+  // 96 KiB of dynamic LDS per workgroup: at most ONE workgroup per CU (160 KiB), like k_persist's ~450 registers per lane
+  // (profiles/r04_resources.md)
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_persist_probe), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) return false;
-  hipLaunchKernelGGL(k_persist_probe, dim3(nb * (uint32_t)spread), dim3(256), 96 * 1024, s, sync, status_dev, (uint32_t)spread, nb);
+  if (cooperative) {
+    uint32_t sp = (uint32_t)spread, nwb = nb;
+    void* args[] = {&sync, &status_dev, &sp, &nwb};
+    if (hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_persist_probe), dim3(nb * (uint32_t)spread), dim3(256), args, 96 * 1024, s) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+  } else {
+    hipLaunchKernelGGL(k_persist_probe, dim3(nb * (uint32_t)spread), dim3(256), 96 * 1024, s, sync, status_dev, (uint32_t)spread, nb);
+  }
   if (hipStreamSynchronize(s) != hipSuccess) return false;
   const bool ok = *status_host == 0u;
   *status_host = 0u;
@@ -2114,7 +2185,13 @@ int persist_max_resident_blocks() {
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_persist<0>, 256, 0) != hipSuccess) return 0;
   return per_cu * prop.multiProcessorCount;
 }
-void launch_persist(PersistArgs A, hipStream_t s) {
+void launch_copy_segments(const CopySegs& t, const unsigned* guard, hipStream_t s) {
+  size_t most = 0;
+  for (int i = 0; i < t.n; ++i) most = t.n4[i] > most ? t.n4[i] : most;
+  const uint32_t blocks = (uint32_t)(most / 256 > 1024 ? 1024 : (most + 255) / 256);
+  hipLaunchKernelGGL(k_copy_segments, dim3(blocks ? blocks : 1), dim3(256), 0, s, t, guard);
+}
+hipError_t launch_persist(PersistArgs A, bool cooperative, hipStream_t s) {
   A.n_lmk_groups = (A.b.n_lmks + 15) / 16;
   const uint32_t nb = persist_blocks(A.n_tiles, A.b.n_cams, A.b.n_lmks);
   // Placement: the grid is 4x the work and only every 4th workgroup works (the fillers leave at once).  Measured
@@ -2132,14 +2209,19 @@ void launch_persist(PersistArgs A, hipStream_t s) {
   static const int env_abl = std::getenv("GBP_PERSIST_ABL") ? std::atoi(std::getenv("GBP_PERSIST_ABL")) : 0;
   if (env_abl) {
     A.spread = 1;
-    if (env_abl == 256) { hipLaunchKernelGGL(k_persist<256>, dim3(nb), dim3(256), 0, s, A); return; }
-    if (env_abl == 64) { hipLaunchKernelGGL(k_persist<64>, dim3(nb), dim3(256), 0, s, A); return; }
-    if (env_abl == 768) { hipLaunchKernelGGL(k_persist<768>, dim3(nb), dim3(256), 0, s, A); return; }
+    if (env_abl == 256) { hipLaunchKernelGGL(k_persist<256>, dim3(nb), dim3(256), 0, s, A); return hipGetLastError(); }
+    if (env_abl == 64) { hipLaunchKernelGGL(k_persist<64>, dim3(nb), dim3(256), 0, s, A); return hipGetLastError(); }
+    if (env_abl == 768) { hipLaunchKernelGGL(k_persist<768>, dim3(nb), dim3(256), 0, s, A); return hipGetLastError(); }
   }
 #endif
   A.spread = (uint32_t)spread;
   const uint32_t grid = spread > 1 ? nb * (uint32_t)spread : spread < -1 ? ((nb + 7) / 8) * (uint32_t)(-spread) * 8 : nb;
+  if (cooperative) {
+    void* args[] = {&A};
+    return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_persist<0>), dim3(grid), dim3(256), args, 0, s);
+  }
   hipLaunchKernelGGL(k_persist<0>, dim3(grid), dim3(256), 0, s, A);
+  return hipGetLastError();
 }
 void launch_weaken(float4* prior, const float* scaling, uint32_t* flag, uint32_t n, int rec4, hipStream_t s) {
   hipLaunchKernelGGL(k_weaken, dim3(blocks_for((uint64_t)n * rec4)), dim3(256), 0, s, prior, scaling, flag, n, rec4);

@@ -41,7 +41,9 @@ static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
   cli::MetricPipe pipe;
   pipe.ctx = ctx;
   pipe.on = !rk.region && !o.verbose;
-  const auto print_iter = [](unsigned total, unsigned since, const gbp_eval_out& e) {
+  cli::RunReport rep;
+  const auto print_iter = [&rep](unsigned total, unsigned since, const gbp_eval_out& e) {
+    rep.last = e; rep.have_metric = true;
     std::cout << "Iters " << total;
     std::cout << " (since last kf " << since << ") // Reprojection error " << (float)(e.sum_norm / (double)e.n_active);
     std::cout << " // Cost " << (float)e.sum_half_sq << " // n relins: " << e.n_relin;
@@ -99,7 +101,7 @@ static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
     iter += burst - 1;
     if (eval_now) {
       const unsigned total = (unsigned)o.iters_between_kfs * data_counter + iter, since = iter;
-      CLI_CHECK(ctx, pipe.submit([total, since, print_iter](const gbp_eval_out& e) { print_iter(total, since, e); }, (int)burst));
+      CLI_CHECK(ctx, pipe.submit([total, since, &print_iter](const gbp_eval_out& e) { print_iter(total, since, e); }, (int)burst));
       if (o.verbose) {
         CLI_CHECK(ctx, gbp_read(ctx, &rb.out));
         cli::print_verbose(rb);
@@ -116,7 +118,10 @@ static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
   std::cout << "Total time: " << wall << " s (set-up " << std::chrono::duration<double>(t_loop - t0).count() << " s, iteration loop "
             << std::chrono::duration<double>(t_end - t_loop).count() << " s); device time in GBP iterations: " << tm.total_ms << " ms over " << tm.iterations
             << " iterations (" << (tm.total_ms > 0 ? 1e3 * (double)tm.iterations / tm.total_ms : 0.0) << " iters/s)\n";
-  if (o.profile) cli::write_profile(ctx, "slam", wall, niters);
+  rep.wall_s = wall; rep.setup_s = std::chrono::duration<double>(t_loop - t0).count();
+  rep.loop_s = std::chrono::duration<double>(t_end - t_loop).count(); rep.iters = (long)niters;
+  if (o.profile) cli::write_profile(ctx, "slam", rep);
+  cli::print_warning(ctx);
   const int wrc = cli::write_solution(o, P, ctx, rk.region != nullptr);
   gbp_destroy(ctx);
   return wrc;

@@ -48,6 +48,10 @@ class GbpEngine:
         if rc != 0:
             raise GbpError("%s: %s (status %d)" % (what, self.lib.gbp_last_error(self.h).decode(), rc))
 
+    def last_error(self):
+        """Text of the last error — or of the last recovered incident (a call that returned 0 can leave a `warning: ...` here)."""
+        return self.lib.gbp_last_error(self.h).decode()
+
     # ---- program list ----
     def upload(self, state):
         keep = []

@@ -25,8 +25,10 @@ extern "C" {
 /* 2: gbp_timing_out gained exchange_ms, gbp_status gained GBP_ERR_COMM, the gbp_debug_* test hooks moved to
  *    gbp_mi355x_debug.h / libgbp_mi355x_test.so; gbp_params.persistent, gbp_iterate_eval.
  * 3: gbp_iterate_eval_each.
+ * 4: gbp_params.persist_coop (was reserved[1]); a barrier time-out of the persistent kernel is recovered inside the library
+ *    (state restored, burst replayed on the two-kernel path, GBP_OK + a warning in gbp_last_error) instead of GBP_ERR_HIP.
  * Callers compare gbp_abi_version() with the header they were built against. */
-#define GBP_ABI_VERSION 3
+#define GBP_ABI_VERSION 4
 
 typedef enum {
   GBP_OK = 0,
@@ -81,8 +83,20 @@ typedef struct {
                                   (BASELINE configs 1-3) runs the n iterations inside ONE kernel launch (k_persist: per-factor
                                   state in registers, device-wide barriers instead of kernel boundaries; identical results):
                                   0 (default) = automatically up to 96 workgroups (24 576 factor positions; all shipped sequences need <= 61), 1 = whenever the graph is
-                                  co-resident, -1 = never.  Single-GPU ctx with hoisted means only. */
-  int32_t reserved[2];
+                                  co-resident, -1 = never.  Single-GPU ctx with hoisted means only.
+                                  The device-wide barriers inside that kernel need all of its workgroups resident at once; two things
+                                  stand behind that (persist_coop below) and a third behind both: a barrier that waits longer than
+                                  1.5 s gives up, every later launch of the ctx returns at once, and the library — at the next call
+                                  that synchronises anyway — restores the snapshot taken before the failed launch, replays the
+                                  affected bursts on the two-kernel path (identical results), returns GBP_OK and leaves a warning in
+                                  gbp_last_error; the ctx then stays on the two-kernel path until the next gbp_upload. */
+  int32_t reserved[1];
+  int32_t persist_coop;        /* how the persistent kernel is launched: 0 (default) = hipLaunchCooperativeKernel where the device
+                                  offers it (the runtime refuses a grid that cannot be co-resident, the driver never runs two
+                                  cooperative grids side by side — also not those of two PROCESSES), else a plain launch vouched for
+                                  by a creation-time probe of the placement (this process only; its launches are serialised);
+                                  1 = cooperative or not at all, -1 = plain launch + probe.  Not capturable: while the ctx's stream
+                                  is being captured gbp_iterate uses the two-kernel path. */
 } gbp_params;
 
 /* Landmark shard of a multi-GPU run (one process per GPU).  The global problem is passed to

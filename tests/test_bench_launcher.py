@@ -115,3 +115,49 @@ def test_bench_native_communicator_failure_is_fatal():
                        stderr=subprocess.PIPE, text=True, timeout=600)
     assert p.returncode == 4, (p.returncode, p.stderr[-2000:])
     assert "could not be set up" in p.stderr and not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def test_cli_metric_lines_are_parsed():
+    sys.path.insert(0, ROOT)
+    import bench
+    rows = bench.parse_iter_lines("Initial Reprojection error: 20.4 Cost 1e6\n"
+                                  "Iter 0 // Reprojection error 3.84 // Cost 636719 // n relins: 0 // n robust edges 1337\n"
+                                  "Weakening priors \n"
+                                  "Iters 701 (since last kf 1) // Reprojection error 0.7036 // Cost 363.876 // n relins: 5 // n robust edges 27\n")
+    assert rows == [(0, 3.84, 636719.0, 0, 1337), (701, 0.7036, 363.876, 5, 27)]
+    assert set(bench.SMALL_CONFIGS) == {"fr1xyz", "slam_fr2robot2"}
+
+
+def test_small_config_cpu_baseline_runs_the_reference_loop(monkeypatch):
+    """The CPU leg of bench.py's `configs` block: the oracle through driver.run_ba / run_slam on the shipped file (short prefix here)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setitem(bench.SMALL_CONFIGS, "fr1xyz", ("ba", "fr1xyz", None, (1.42, 1.47), 12))
+    monkeypatch.setitem(bench.SMALL_CONFIGS, "slam_fr2robot2", ("slam", "fr2robot2", "slam_fr2robot2", None, 40))
+    for name in ("fr1xyz", "slam_fr2robot2"):
+        c = bench.small_config_cpu(name, [])
+        assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["iterations"] in (12, 40)
+        assert "first %d of the run's iterations" % c["iterations"] in c["sample"]
+
+
+@pytest.mark.gpu
+def test_bench_line_carries_the_fr1xyz_and_slam_configs():
+    """BASELINE.json's metric is "fr1xyz AND the 1M-factor synthetic graph" — the driver-run JSON line
+    carries `configs.fr1xyz` (bin/ba, default flags) and `configs.slam_fr2robot2` (bin/slam, config 3): iterations/s, the
+    path that ran, final mean reprojection error + RMSE with the band / golden check, and a CPU baseline each."""
+    out = _bench_gpu("--small-configs", "on", "--cpu-seconds", "1", "--pmc", "off", "--profile-steps", "0")
+    cfg = out["configs"]
+    fx, sl = cfg["fr1xyz"], cfg["slam_fr2robot2"]
+    for c in (fx, sl):
+        assert "error" not in c, c
+        for k in ("iters_per_sec", "iters_per_sec_device", "us_per_iter_device", "final_mean_reproj_px", "rmse_px", "graph_state",
+                  "cpu_baseline", "eval_every_100", "loop_wall_ms"):
+            assert k in c and c[k] is not None, k
+        assert c["graph_state"] == 2 and c["iters_per_sec"] > 0 and c["nonfinite_beliefs"] == 0
+        cb = c["cpu_baseline"]
+        assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and "sample" in cb
+        assert cb["same_iteration_metric_matches"] is True, cb
+        assert c["same_final_metric_with_eval_every_100"] is True
+    assert fx["iterations"] == 1500 and fx["in_converged_band"] is True and 1.42 <= fx["final_mean_reproj_px"] <= 1.47
+    assert abs(fx["rmse_px"] - (2.0 * fx["final_cost"] / fx["n_active"]) ** 0.5) < 1e-6
+    assert sl["iterations"] == 13299 and sl["golden"]["within_1e-3"] is True, sl["golden"]

@@ -25,14 +25,14 @@ def test_header_declares_the_program_list():
 
 
 def test_library_exports_every_declared_symbol():
-    from gbp_poplar_amd import _lib
+    from gbp_poplar_amd import _cabi, _lib
     lib = _lib.load()
     names = declared_functions()
     assert len(names) >= 30
     for n in names:
         assert hasattr(lib, n), "libgbp_mi355x.so does not export %s" % n
     assert sorted(_lib.symbols()) == names, set(names) ^ set(_lib.symbols())
-    assert lib.gbp_abi_version() == 3
+    assert lib.gbp_abi_version() == _cabi.GBP_ABI_VERSION == 4
 
 
 def _exported(path):

@@ -54,31 +54,66 @@ def test_subwave_sweep_is_bit_identical_to_the_product_sweep(name):
     assert n_relin > 0
 
 
+_RECOVERY_CODE = """
+import sys, time
+import numpy as np
+sys.path.insert(0, %(root)r)
+from gbp_poplar_amd import _cabi, driver, hostlib
+from gbp_poplar_amd.engine import GbpEngine
+bal = hostlib.bal_read(%(seq)r)
+K, state, _ = driver.build_inputs(bal, driver.Options(), hostlib)
+def make(**kw):
+    e = GbpEngine(bal['cam_id'], bal['lmk_id'], bal['n_cams'], bal['n_lmks'], K, hooks='exp', params=_cabi.GbpParams.defaults(**kw))
+    e.upload(state); e.linearise(); e.iterate(1)
+    return e
+def flow(e):
+    out = []
+    e.iterate(20)                                   # mode 0: a plain burst
+    e.iterate_eval(15); out.append(e.eval_end())    # mode 1: burst + metric in one launch
+    e.iterate(7); e.iterate(5)                      # two bursts in flight behind each other
+    out += e.iterate_eval_each(12)                  # mode 2: the metric after every iteration (blocking)
+    e.sync()
+    return out, e.read()
+ref = make(persistent=-1)                            # the two-kernel path
+ref_ev, ref_state = flow(ref)
+eng = make(persistent=1, persist_coop=%(coop)d)
+assert eng.graph_state() == 2, eng.last_error()
+t0 = time.time()
+ev, st = flow(eng)
+dt = time.time() - t0
+assert eng.graph_state() != 2, 'the ctx should have left the persistent path'
+for k in st:
+    assert np.array_equal(st[k], ref_state[k], equal_nan=True), k
+assert len(ev) == len(ref_ev) == 13
+for a, b in zip(ev, ref_ev):
+    assert a == b, (a, b)
+eng.upload(state)                                    # a new upload gives the ctx its persistent path back
+print('RECOVERED %%.1f s graph_state_after_upload %%d :: %%s' %% (dt, eng.graph_state(), eng.last_error()))
+"""
+
+
 @pytest.mark.skipif(not _exp_lib_present(), reason="experiments build absent (python -m gbp_poplar_amd.build --experiments)")
-def test_persistent_kernel_gives_up_instead_of_hanging():
-    """A k_persist launch whose workgroups can NOT all be resident (forced here: every 8th dispatch slot = one XCD = 32 CUs for
-    the 52 workgroups of fr1xyz) must end by itself — bounded barrier wait, abort word — and surface as an error at the
-    next synchronisation, not hang the GPU."""
+@pytest.mark.parametrize("coop", [-1, 0])
+def test_persistent_kernel_time_out_is_recovered(coop):
+    """A k_persist launch whose workgroups can NOT all be resident (forced: every 8th dispatch slot = one XCD = 32 CUs for the
+    52 workgroups of fr1xyz; experiments build) must not hang and must not lose the run:
+      * plain launch (persist_coop = -1): the barrier gives up after 1.5 s, later launches return at once, the library restores
+        the snapshot taken before the failed launch and replays the bursts on the two-kernel path;
+      * cooperative launch (persist_coop = 0): the runtime refuses the grid before anything runs, same fallback.
+    Either way: rc 0 everywhere, every belief / damping / counter and every metric equal to the two-kernel path's, a warning in
+    gbp_last_error, and the persistent path back after the next gbp_upload."""
     import subprocess
     import sys
     import time
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = ("import sys, time\n"
-            "sys.path.insert(0, %r)\n"
-            "from gbp_poplar_amd import _cabi, driver, hostlib\n"
-            "from gbp_poplar_amd.engine import GbpEngine, GbpError\n"
-            "bal = hostlib.bal_read(%r)\n"
-            "K, state, _ = driver.build_inputs(bal, driver.Options(), hostlib)\n"
-            "eng = GbpEngine(bal['cam_id'], bal['lmk_id'], bal['n_cams'], bal['n_lmks'], K, hooks='exp', params=_cabi.GbpParams.defaults(persistent=1))\n"
-            "eng.upload(state); eng.linearise(); eng.iterate(1)\n"
-            "t0 = time.time()\n"
-            "try:\n"
-            "    eng.iterate(50); eng.sync(); print('NO ERROR')\n"
-            "except GbpError as e:\n"
-            "    print('ERROR', round(time.time() - t0, 1), e)\n") % (root, seq_path("fr1xyz"))
+    code = _RECOVERY_CODE % {"root": root, "seq": seq_path("fr1xyz"), "coop": coop}
     env = dict(os.environ, GBP_PERSIST_SPREAD="8")
     t0 = time.time()
-    p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
-    assert p.returncode == 0, p.stderr[-2000:]
-    assert "ERROR" in p.stdout and "barrier timed out" in p.stdout, p.stdout
-    assert time.time() - t0 < 60
+    p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=180)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    line = [l for l in p.stdout.splitlines() if l.startswith("RECOVERED")][-1]
+    # a time-out may have been a passing condition (another process): the next upload re-arms the persistent path; a refused
+    # cooperative grid will be refused again: the ctx stays on the two-kernel path
+    assert ("graph_state_after_upload 2" in line) == (coop == -1), line
+    assert "warning:" in line and ("timed out" in line if coop == -1 else "refused" in line), line
+    assert time.time() - t0 < 90

@@ -1194,6 +1194,74 @@ def test_full_size_s1_bit_exact_first_sweeps(s1, oracle_mod):
         oracle_mod.set_trig_mode(0)
 
 
+def test_full_size_s1_bit_exact_through_the_lockstep_relinearisation(s1, oracle_mod):
+    """The ./ba flow on the 1M-factor graph through its FIRST LOCK-STEP RELINEARISATION: damping_count starts at -15
+    (ba.cpp:581), so sweep 17 (0-based) is the first in which count > min_linear_iters - num_undamped_iters
+    (gbp_codelets.cpp:280) and — the graph converges — nearly every factor relinearises in the same launch (all lanes in
+    relin_core, every potential written back, the camera-only Jacobian terms taken from the per-camera CAM_LIN records).
+    LINEARISE + 20 sweeps, prior weakening on 1,3,5,7,9; oracle in the device's conventions.
+      * after sweep 17: factor potentials (eta 9 + Lambda 81 per factor), every belief, damping, damping_count, robust_flag
+        bit for bit, n_relin > 900 000 (so the test cannot pass vacuously);
+      * after sweep 19: state bit for bit again (the sweeps that consume the relinearised potentials);
+      * a second engine (product library) runs sweeps 10..19 as ONE gbp_iterate(10) = one replay of the captured hipGraph:
+        same final state."""
+    from gbp_poplar_amd.engine import GbpEngine
+    bal, opts, K, state = s1
+    state_keys = ("cam_beliefs_eta", "cam_beliefs_lambda", "lmk_beliefs_eta", "lmk_beliefs_lambda", "damping", "damping_count",
+                  "robust_flag")
+    oracle_mod.set_trig_mode(1)
+    try:
+        eng = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K, hooks=True)
+        orc = oracle_mod.Oracle(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K)
+        orc.set_sum_order(1)
+        for e in (eng, orc):
+            e.upload(state)
+            e.linearise()
+
+        def sweeps(e, first, last):
+            for it in range(first, last + 1):
+                if ((it + 1) % 2 == 0) and (it < opts.steps * 2):
+                    e.weaken_priors()
+                e.iterate(1)
+
+        sweeps(eng, 0, 16)
+        sweeps(orc, 0, 16)
+        assert eng.eval()["n_relin"] == orc.eval()["n_relin"]           # before the lock-step sweep: (almost) nobody yet
+        sweeps(eng, 17, 17)
+        sweeps(orc, 17, 17)
+        eg, eo = eng.eval(), orc.eval()
+        assert eg["n_relin"] == eo["n_relin"] and eg["n_relin"] > 900000, (eg["n_relin"], eo["n_relin"])
+        assert eg["n_robust"] == eo["n_robust"]
+        ge, gl = eng.factor_potentials()
+        oe, ol = orc.factor_potentials()
+        assert np.array_equal(ge, oe), "potential eta after the lock-step relinearisation"
+        assert np.array_equal(gl, ol), "potential Lambda after the lock-step relinearisation"
+        del ge, gl, oe, ol
+        g, o = eng.read(), orc.read()
+        for k in state_keys:
+            assert np.array_equal(g[k], o[k]), ("after sweep 17", k)
+        assert int((g["damping_count"] == -8).sum()) == eg["n_relin"]
+        sweeps(eng, 18, 19)
+        sweeps(orc, 18, 19)
+        g, o = eng.read(), orc.read()
+        for k in state_keys:
+            assert np.array_equal(g[k], o[k]), ("after sweep 19", k)
+        eng.close()
+
+        eng2 = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K)     # the product library
+        eng2.upload(state)
+        eng2.linearise()
+        sweeps(eng2, 0, 9)
+        eng2.iterate(10)                         # sweeps 10..19 (the lock-step one included) from the hipGraph
+        assert eng2.graph_state() == 1
+        g2 = eng2.read()
+        for k in state_keys:
+            assert np.array_equal(g2[k], o[k]), ("hipGraph burst", k)
+        eng2.close()
+    finally:
+        oracle_mod.set_trig_mode(0)
+
+
 def test_full_size_s1_properties(s1):
     """Size-independent properties at full size: run-to-run determinism, hipGraph replay == direct launches,
     hoisted == per-factor mu, monotone convergence to the noise floor, healthy beliefs."""
