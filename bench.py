@@ -99,6 +99,9 @@ def parse(argv=None):
                     help="camera ranges of the pipelined all-gather (default: 1)")
     ap.add_argument("--tile-order", type=int, default=0, help="gbp_params.tile_order: 0 = default, 1 = sequential, 2 = sweep tiles XCD-aware too")
     ap.add_argument("--master-port", type=int, default=0, help="self-launch: rendezvous port (0 = pick a free one)")
+    ap.add_argument("--preflight", type=int, default=1,
+                    help="N > 1 (and --force-sharded), native communicator: the un-timed self-validation block (GPU identities, peer access, "
+                         "librccl path/version, all-gather probe, one-stream vs two-stream schedule measured and chosen); 0 = off")
     ap.add_argument("--small-configs", choices=["auto", "on", "off"], default="auto",
                     help="the fr1xyz (./ba) and fr2robot2 (./slam) halves of the metric through the C++ CLIs (auto: with the default N = 1 workload)")
     # internal modes
@@ -485,6 +488,48 @@ def gpu_accuracy_run(bal, K, state, opts, n):
     return {"rmse_px": float((2.0 * ev["sum_half_sq"] / max(ev["n_active"], 1)) ** 0.5), "mean_reproj_px": traj[-1][1]}
 
 
+def preflight(eng, dist, torch, rank, world, local_rank, fence, probe_reps=50, sched_iters=20):
+    """Un-timed self-validation of a multi-rank run, carried in the JSON line (`config.preflight`): which GPUs the ranks sit on
+    (N distinct PCI bus ids), who can reach whom (hipDeviceCanAccessPeer), which librccl every rank resolved (path + version),
+    what ONE all-gather of the camera partial buffers costs with these N ranks, and — instead of trusting the ">= 4 ranks: second
+    stream" rule — 20 iterations each of the one-stream and the two-stream schedule of the sharded iteration, the faster one
+    (MAX over ranks) kept for the timed region.  Returns (dict, extra iterations executed)."""
+    info = eng.comm_describe()
+    n_dev = torch.cuda.device_count()
+    info["peer_access_from_this_device"] = [bool(j == local_rank or torch.cuda.can_device_access_peer(local_rank, j)) for j in range(n_dev)]
+    info["visible_devices"] = n_dev
+    infos = [None] * world
+    dist.all_gather_object(infos, info)
+
+    def max_over_ranks(x):
+        t = torch.tensor([float(x)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    probe_us = max_over_ranks(eng.comm_probe(probe_reps))
+    sched, extra = {}, 0
+    for two in (0, 1):
+        eng.comm_set_schedule(two)
+        eng.iterate(5)
+        fence()
+        t0 = time.perf_counter()
+        eng.iterate(sched_iters)
+        fence()
+        sched["two_streams" if two else "one_stream"] = round(max_over_ranks((time.perf_counter() - t0) / sched_iters * 1e3), 4)
+        extra += 5 + sched_iters
+    chosen = "two_streams" if sched["two_streams"] < sched["one_stream"] else "one_stream"
+    eng.comm_set_schedule(chosen == "two_streams")
+    buses = [i["pci_bus_id"] for i in infos]
+    out = {"ranks": infos, "distinct_pci_bus_ids": len(set(buses)), "all_ranks_on_distinct_gpus": len(set(buses)) == world,
+           "same_library_on_every_rank": len({(i["library"], i["library_version"]) for i in infos}) == 1,
+           "exchange_probe_us": round(probe_us, 2),
+           "exchange_probe_is": "one all-gather of the [cameras x 44] fp32 partial buffers over %d ranks, mean of %d back to back, MAX over ranks" % (world, probe_reps),
+           "schedule_ms_per_iteration": sched, "stream_mode_chosen": chosen,
+           "schedule_is": "%d iterations each (MAX over ranks, un-timed region); the library's own rule would have picked %s"
+                          % (sched_iters, "two_streams" if world >= 4 else "one_stream")}
+    return out, extra
+
+
 def workload_name(a, world, C, L, E):
     if world == 1:
         base = "S1 synthetic" if (a.cams, a.lmks, a.obs) == (1000, 100000, 10) else "synthetic"
@@ -621,8 +666,17 @@ def main(argv=None):
     ev0 = run_eval()
     warm_start(run, opts, a.warmup)
     extra_warm = 0
+    pre = None
+    if sharded and a.comm == "native" and run is eng and a.preflight:
+        def _fence():
+            run.sync()
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+        pre, n_pre = preflight(eng, dist, torch, rank, world, local_rank, _fence)
+        extra_warm += n_pre
     if getattr(run, "use_graph", False):
-        extra_warm = run.graph_unroll + 3
+        extra_warm += run.graph_unroll + 3
         run.iterate(extra_warm)                # un-timed: triggers the one-off capture of the sharded iteration graph
 
     def fence():
@@ -744,7 +798,7 @@ def main(argv=None):
                        "nonfinite_beliefs": int(ev1["n_nonfinite"]),
                        "exchange_chunks": getattr(run, "chunks", None),
                        "iteration_graph": graph_used, "exchange": exchange_kind, "comm_error": comm_error,
-                       "sharded_graph_error": getattr(run, "graph_error", None)},
+                       "sharded_graph_error": getattr(run, "graph_error", None), "preflight": pre},
         }
         if roof:
             out["roofline"] = roof

@@ -60,6 +60,9 @@ _SIGS = {
     "gbp_comm_init_rccl": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gbp_comm_transport": (C.c_char_p, [C.c_void_p]),
     "gbp_graph_state": (C.c_int, [C.c_void_p]),
+    "gbp_comm_describe": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
+    "gbp_comm_set_schedule": (C.c_int, [C.c_void_p, C.c_int]),
+    "gbp_comm_probe": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
     "gbp_comm_barrier": (C.c_int, [C.c_void_p]),
     "gbp_eval_global": (C.c_int, [C.c_void_p, C.POINTER(cabi.GbpEvalOut)]),
     "gbp_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -521,7 +522,7 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
     const char* pe = prm ? nullptr : std::getenv("GBP_PERSIST");     // measurements through the CLIs (they pass no params): -1 / 0 / 1 like gbp_params.persistent
     const int mode = pe ? std::atoi(pe) : c->prm.persistent;
     const char* pc = prm ? nullptr : std::getenv("GBP_PERSIST_COOP");
-    const int coop_mode = pc ? std::atoi(pc) : c->prm.persist_coop;  // 0 = cooperative launch where the device offers it, 1 = insist, -1 = plain launch + probe
+    const int coop_mode = pc ? std::atoi(pc) : c->prm.persist_coop;  // 1 = cooperative launch, else (default) plain launch + probe + recovery
     const uint32_t nb = persist_blocks(c->n_tiles, c->C, c->L_loc);
     // measured (profiles/r03_small_graphs.md): the shipped sequences (19 - 61 workgroups, relinearising in every sweep) run
     // 1.55 - 1.82x faster in k_persist; converging synthetic graphs 1.21x at 63 workgroups, break even at 125
@@ -540,25 +541,29 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
           g_create_error = c->err;
         }
         if (rc == GBP_OK) {
-          // Co-residency.  Cooperative launch (default where the device reports it): the runtime refuses a grid that cannot be
-          // resident at once and the driver never runs two cooperative grids side by side, whichever process they belong to.
-          // Plain launch: the occupancy query says the workgroups fit; a probe (the placement + three barriers, no work) checks
-          // that THIS device's dispatcher keeps them resident together — under the process-wide lock and behind the device's
-          // last k_persist launch, so that it does not compete with one.  Either probe failing leaves the ctx on the two-kernel
-          // path and says so in gbp_last_error.
+          // Co-residency.  Plain launch (default): the occupancy query says the workgroups fit; a probe (the placement + three
+          // barriers, no work) checks that THIS device's dispatcher keeps them resident together — under the process-wide lock
+          // and behind the device's last k_persist launch, so that it does not compete with one; what another PROCESS does to
+          // the GPU later is caught by the bounded barrier wait and undone by persist_recover.  Cooperative launch (persist_coop
+          // = 1): the runtime refuses a grid that cannot be resident at once and the driver never runs two cooperative grids
+          // side by side, whichever process they belong to — measured on MI355X: two concurrent `ba fr1xyz` then take turns
+          // (44 ms each instead of 22), and every launch costs 30-60 us more (profiles/r04_persist_launch.md), which is why
+          // it is the option and not the default.  A failing probe leaves the ctx on the two-kernel path and says so in
+          // gbp_last_error.
           int dev = 0, coop_attr = 0;
           (void)hipGetDevice(&dev);
           (void)hipDeviceGetAttribute(&coop_attr, hipDeviceAttributeCooperativeLaunch, dev);
           std::lock_guard<std::mutex> lock(g_persist_mu);
           if (g_persist_event[dev & 15] && g_persist_last_ctx[dev & 15]) (void)hipStreamWaitEvent(c->stream, g_persist_event[dev & 15], 0);
           bool ok = false;
-          if (coop_mode >= 0 && coop_attr) {
+          if (coop_mode > 0 && coop_attr) {
             ok = persist_probe(c->n_tiles, c->C, c->L_loc, P<unsigned>(c->psync), static_cast<unsigned*>(c->pstatus_dev),
                                static_cast<volatile unsigned*>(c->pstatus_host), true, c->stream);
             c->persist_coop = ok;
             if (!ok) c->err = "k_persist: the cooperative launch was refused or its barriers timed out";
           }
-          if (!ok && coop_mode <= 0) {
+          if (coop_mode > 0 && !coop_attr) c->err = "k_persist: this device does not offer cooperative launches";
+          if (coop_mode <= 0) {
             ok = persist_probe(c->n_tiles, c->C, c->L_loc, P<unsigned>(c->psync), static_cast<unsigned*>(c->pstatus_dev),
                                static_cast<volatile unsigned*>(c->pstatus_host), false, c->stream);
             if (!ok) c->err = "k_persist: the workgroups of this graph are not co-resident under the spread placement on this device (probe timed out)";
@@ -1099,8 +1104,10 @@ static int launch_persist_burst(gbp_ctx* c, const SweepArgs& a, int n, const Per
     if (!e) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (g_persist_last_ctx[dev & 15] && (g_persist_last_ctx[dev & 15] != c || g_persist_last_stream[dev & 15] != c->stream))
       HIPCHK(c, hipStreamWaitEvent(c->stream, e, 0));
+#ifndef GBP_PERSIST_NO_SNAPSHOT     // (defined only in a measurement build: what does the snapshot cost per launch?  profiles/r04_persist_launch.md)
     launch_copy_segments(c->snap_save, P<unsigned>(c->psync) + 32, c->stream);       // skipped on the device once the abort word is set
     HIPCHK(c, hipGetLastError());
+#endif
     const hipError_t le = launch_persist(A, c->persist_coop, c->stream);
     if (le != hipSuccess) {
       (void)hipGetLastError();
@@ -1751,6 +1758,63 @@ int gbp_comm_init_rccl(gbp_ctx* c, const void* id128) {
   gbp::Comm* comm = gbp::comm_create_rccl(id128, c->rank, c->world, err);
   if (!comm) return fail(c, GBP_ERR_COMM, "gbp_comm_init_rccl: " + err);
   return comm_attach(c, comm);
+}
+
+// ---- what a first multi-GPU run wants on record (bench.py preflight) ---------------------------------------------------
+int gbp_comm_describe(gbp_ctx* c, char* buf, size_t cap) {
+  if (!c || !buf || cap == 0) return GBP_ERR_INVALID;
+  int dev = 0;
+  char bus[64] = {0};
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetPCIBusId(bus, sizeof(bus), dev);
+  const std::string lib = c->comm ? c->comm->library_path() : "";
+  std::snprintf(buf, cap, "{\"rank\": %d, \"world\": %d, \"device\": %d, \"pci_bus_id\": \"%s\", \"transport\": \"%s\", \"library\": \"%s\", "
+                          "\"library_version\": %d, \"two_streams\": %s}",
+                c->rank, c->world, dev, bus, c->comm ? c->comm->name() : "none", lib.c_str(), c->comm ? c->comm->library_version() : 0,
+                (c->comm && !c->comm_single_stream) ? "true" : "false");
+  return GBP_OK;
+}
+
+// 0: the whole sharded iteration on ONE stream (sweep, beliefs + local partials, all-gather, combine); 1: the camera side of
+// the exchange (local partials, all-gather) on a second, highest-priority stream beside the landmark beliefs.  Results are
+// identical; which is faster depends on what the all-gather costs against ~10 us of second-queue overhead — measure
+// (bench.py does, 20 iterations each) instead of guessing.
+int gbp_comm_set_schedule(gbp_ctx* c, int two_streams) {
+  if (!c || !c->comm) return fail(c, GBP_ERR_STATE, "gbp_comm_set_schedule: the ctx has no communicator");
+  if (int rc = settle(c)) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->comm_stream) HIPCHK(c, hipStreamSynchronize(c->comm_stream));
+  drop_graph(c);
+  c->comm_single_stream = two_streams == 0;
+  if (!c->comm_stream && !c->comm_single_stream) {
+    int least = 0, greatest = 0;
+    HIPCHK(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIPCHK(c, hipStreamCreateWithPriority(&c->comm_stream, hipStreamNonBlocking, greatest));
+  }
+  return GBP_OK;
+}
+
+// `reps` all-gathers of the camera partial buffers back to back on the ctx's stream (collective: every rank calls it);
+// *avg_us = mean duration between two events.  The buffers keep their content (the gather of the same partials).
+int gbp_comm_probe(gbp_ctx* c, int reps, double* avg_us) {
+  if (!c || !c->comm || !avg_us || reps < 1) return fail(c, GBP_ERR_STATE, "gbp_comm_probe: needs a communicator, reps >= 1");
+  if (!c->comm->stream_ordered()) {      // host-staged: wall clock around blocking exchanges
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < reps; ++i)
+      if (int rc = exchange_now(c)) return rc;
+    *avg_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
+    return GBP_OK;
+  }
+  if (int rc = exchange_now(c)) return rc;     // warm (lazy channel set-up)
+  HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+  for (int i = 0; i < reps; ++i)
+    if (int rc = exchange_now(c)) return rc;
+  HIPCHK(c, hipEventRecord(c->ev2, c->stream));
+  HIPCHK(c, hipEventSynchronize(c->ev2));
+  float ms = 0;
+  HIPCHK(c, hipEventElapsedTime(&ms, c->ev1, c->ev2));
+  *avg_us = 1e3 * ms / reps;
+  return GBP_OK;
 }
 
 int gbp_graph_state(const gbp_ctx* c) { return !c ? 0 : (c->persist_ok ? 2 : (c->graph_exec ? 1 : (c->graph_failed ? -1 : 0))); }

@@ -24,6 +24,8 @@ struct RcclApi {
   decltype(&ncclAllGather) AllGather = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclGetVersion) GetVersion = nullptr;     // optional
+  std::string path;                                    // resolved file the symbols come from (dladdr)
   std::string error;
 };
 
@@ -64,6 +66,9 @@ RcclApi& rccl() {
   api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(h, "ncclAllGather"));
   api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
   api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+  api.GetVersion = reinterpret_cast<decltype(api.GetVersion)>(dlsym(h, "ncclGetVersion"));
+  Dl_info info;
+  if (api.AllGather && dladdr(reinterpret_cast<void*>(api.AllGather), &info) && info.dli_fname) api.path = info.dli_fname;
   if (!api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.CommDestroy || !api.GetErrorString) {
     api.error = "librccl lacks an expected symbol";
     api.handle = nullptr;
@@ -164,6 +169,12 @@ class RcclComm : public Comm {
     return all_gather_host(&x, all, 1, err);
   }
   const char* name() const override { return "rccl"; }
+  std::string library_path() const override { return rccl().path; }
+  int library_version() const override {
+    int v = 0;
+    if (rccl().GetVersion && rccl().GetVersion(&v) == ncclSuccess) return v;
+    return 0;
+  }
 };
 
 // ---- host-staged transport (ranks sharing a GPU) -----------------------------------------------------------------------

@@ -36,6 +36,10 @@ class Comm {
   virtual int all_gather_host(const double* mine, double* all, int n, std::string& err) = 0;
   virtual int barrier(std::string& err) = 0;
   virtual const char* name() const = 0;
+  // where the collective library was loaded from and its version ("" / 0 for the host-staged transport): what a first
+  // multi-GPU run wants on record next to its numbers
+  virtual std::string library_path() const { return ""; }
+  virtual int library_version() const { return 0; }
   int rank = 0, world = 1;
 };
 

@@ -449,14 +449,28 @@ GBP_DEV void sweep_tile(const SweepArgs& a, const uint32_t wslot) {
   bool relin;
   factor_update<HOIST, ABL>(fac, cm, mu, lm, cb, lb, K, a.hp, damping, count, flags, var, active, oc_eta, oc_lam, ol, relin,
                             [&](float (&x0c)[6], float (&x0l)[3], CamLin& cl) {   // rare path: loaded only by relinearising lanes
+                              // camera side: the hoisted mean and its CAM_LIN record — per-camera tables (C x 144 B) that live in L2
                               const float4 m0 = a.cam_mu[(size_t)cam_i * 4], m1 = a.cam_mu[(size_t)cam_i * 4 + 1];
-                              const float4 l0 = a.lmk_mu[(size_t)lmk_i * 2];
                               float4 q[kCamLin4];
                               GBP_UNROLL
                               for (int g = 0; g < kCamLin4; ++g) q[g] = a.cam_lin[(size_t)cam_i * kCamLin4 + g];
                               x0c[0] = m0.x; x0c[1] = m0.y; x0c[2] = m0.z; x0c[3] = m0.w; x0c[4] = m1.x; x0c[5] = m1.y;
-                              x0l[0] = l0.x; x0l[1] = l0.y; x0l[2] = l0.z;
                               cam_lin_unpack(q, cl);
+                              // landmark side: the mean is RECOMPUTED from the belief record the lane holds anyway — inf2mean3x3
+                              // (bafuncs.cpp:11-15) with the operations k_beliefs used for LMK_MU, so the same bits — instead of
+                              // gathered: a second random gather (a 128-B line fill per factor for 12 useful bytes) made the
+                              // lock-step relinearising sweep move 104 MB more than it has to (profiles/r04_relin_dispatches.csv)
+                              float B[9], S3[9];
+                              GBP_UNROLL
+                              for (int i = 0; i < 9; ++i) B[i] = lb[4 + i];
+                              inv3x3(B, S3);
+                              GBP_UNROLL
+                              for (int i = 0; i < 3; ++i) {
+                                float a2 = 0.f;
+                                GBP_UNROLL
+                                for (int k = 0; k < 3; ++k) a2 += S3[i * 3 + k] * lb[k];
+                                x0l[i] = a2;
+                              }
                             });
 
   // ---- outputs --------------------------------------------------------------------------------
@@ -1537,11 +1551,34 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
     // ================= phase B: the belief update (arithmetic of k_beliefs, roll = 1) =================
     if (cam_wave) {
       float acc = 0.f;
+#ifndef GBP_PERSIST_ROW_ROUNDS
+#define GBP_PERSIST_ROW_ROUNDS 3
+#endif
       if (cam_live && r1 > r0) {
         const uint32_t row = r0 * (uint32_t)kCamRec + cj;           // float index into ROWP
+        const uint32_t n = r1 - r0;
+#if GBP_PERSIST_ROW_ROUNDS == 1
+        {  // measurement variant: rows 0 .. 32 in ONE round of loads (profiles/r04_small_graphs.md: not faster)
+          float v[33];
+          GBP_UNROLL
+          for (int k = 0; k < 33; ++k) v[k] = X_rowp.ld1(row + ((uint32_t)k < n ? (uint32_t)k : n - 1u) * (uint32_t)kCamRec);
+          acc = v[0];
+          GBP_UNROLL
+          for (int k = 1; k < 33; ++k)
+            if ((uint32_t)k < n) acc = acc + v[k];
+        }
+        for (uint32_t r = 33; r < n; r += 16) {
+          float v[16];
+          const uint32_t m = n - r;
+          GBP_UNROLL
+          for (int k = 0; k < 16; ++k) v[k] = X_rowp.ld1(row + ((uint32_t)k < m ? r + (uint32_t)k : n - 1u) * (uint32_t)kCamRec);
+          GBP_UNROLL
+          for (int k = 0; k < 16; ++k)
+            if ((uint32_t)k < m) acc = acc + v[k];
+        }
+#else
         acc = X_rowp.ld1(row);
         uint32_t r = 1;
-        const uint32_t n = r1 - r0;
         for (; r + 16 <= n; r += 16) {
           float v[16];
           GBP_UNROLL
@@ -1559,6 +1596,7 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
           for (int k = 0; k < 16; ++k)
             if ((uint32_t)k < m) acc = acc + v[k];
         }
+#endif
       }
       if (cam_live) {
         b.cam_local[(size_t)v * kCamRec + cj] = acc;

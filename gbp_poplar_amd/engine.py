@@ -180,6 +180,22 @@ class GbpEngine:
         buf = C.create_string_buffer(bytes(id128), 128)
         self._chk(self.lib.gbp_comm_init_rccl(self.h, buf), "gbp_comm_init_rccl")
 
+    def comm_describe(self):
+        """dict: rank, world, device, pci_bus_id, transport, library (resolved path of librccl), library_version, two_streams"""
+        import json
+        buf = C.create_string_buffer(1024)
+        self._chk(self.lib.gbp_comm_describe(self.h, buf, 1024), "gbp_comm_describe")
+        return json.loads(buf.value.decode())
+
+    def comm_set_schedule(self, two_streams):
+        self._chk(self.lib.gbp_comm_set_schedule(self.h, int(bool(two_streams))), "gbp_comm_set_schedule")
+
+    def comm_probe(self, reps=50):
+        """mean duration (us) of one all-gather of the camera partial buffers, `reps` back to back (collective)"""
+        us = C.c_double(0.0)
+        self._chk(self.lib.gbp_comm_probe(self.h, int(reps), C.byref(us)), "gbp_comm_probe")
+        return us.value
+
     def comm_transport(self):
         return self.lib.gbp_comm_transport(self.h).decode()
 

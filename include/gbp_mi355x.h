@@ -91,12 +91,13 @@ typedef struct {
                                   affected bursts on the two-kernel path (identical results), returns GBP_OK and leaves a warning in
                                   gbp_last_error; the ctx then stays on the two-kernel path until the next gbp_upload. */
   int32_t reserved[1];
-  int32_t persist_coop;        /* how the persistent kernel is launched: 0 (default) = hipLaunchCooperativeKernel where the device
-                                  offers it (the runtime refuses a grid that cannot be co-resident, the driver never runs two
-                                  cooperative grids side by side — also not those of two PROCESSES), else a plain launch vouched for
-                                  by a creation-time probe of the placement (this process only; its launches are serialised);
-                                  1 = cooperative or not at all, -1 = plain launch + probe.  Not capturable: while the ctx's stream
-                                  is being captured gbp_iterate uses the two-kernel path. */
+  int32_t persist_coop;        /* how the persistent kernel is launched: 0 (default) = plain launch, vouched for by a creation-time probe
+                                  of the placement (the launches of one process are serialised by the library; a second process that
+                                  takes CUs away is caught by the time-out + recovery above);  1 = hipLaunchCooperativeKernel, or the
+                                  two-kernel path where the device refuses it: the runtime rejects a grid that cannot be co-resident
+                                  and the driver never runs two cooperative grids side by side, also not those of two PROCESSES — a
+                                  guarantee instead of a way back, for 30-60 us more per launch (measured, profiles/r04_persist_launch.md).
+                                  Not capturable either way: while the ctx's stream is being captured gbp_iterate uses the two-kernel path. */
 } gbp_params;
 
 /* Landmark shard of a multi-GPU run (one process per GPU).  The global problem is passed to
@@ -277,6 +278,15 @@ int gbp_comm_unique_id(void* id128);
 int gbp_comm_init_rccl(gbp_ctx* ctx, const void* id128);
 const char* gbp_comm_transport(const gbp_ctx* ctx);            /* "rccl", "host-staged" or "none" */
 int gbp_comm_barrier(gbp_ctx* ctx);
+/* What a first multi-GPU run puts on record next to its numbers (bench.py's preflight block): gbp_comm_describe writes one
+ * JSON object (rank, world, device, PCI bus id, transport, the collective library's resolved path and version, schedule);
+ * gbp_comm_probe times `reps` all-gathers of the camera partial buffers back to back (collective); gbp_comm_set_schedule
+ * switches between the one-stream and the two-stream form of the sharded iteration (identical results) so that a launcher can
+ * MEASURE both and keep the faster one instead of trusting the ">= 4 ranks" rule (ba.cpp:617-649 has no such choice to make:
+ * Poplar compiles the exchange into the program). */
+int gbp_comm_describe(gbp_ctx* ctx, char* json_buf, size_t cap);
+int gbp_comm_set_schedule(gbp_ctx* ctx, int two_streams);
+int gbp_comm_probe(gbp_ctx* ctx, int reps, double* avg_us);
 int gbp_graph_state(const gbp_ctx* ctx);                       /* 2 = bursts run inside the persistent kernel (small graph), 1 = gbp_iterate replays a captured hipGraph, 0 = not captured (yet), -1 = capture failed: direct launches */
 int gbp_eval_global(gbp_ctx* ctx, gbp_eval_out* out);          /* gbp_eval summed over all shards */
 

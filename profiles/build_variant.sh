@@ -1,0 +1,11 @@
+#!/bin/bash
+# A product-library variant for A/B measurements:  bash profiles/build_variant.sh <name> <extra hipcc flags...>
+#   -> profiles/_bin/<name>/libgbp_mi355x.so   (run a CLI against it with LD_LIBRARY_PATH=profiles/_bin/<name>)
+set -e
+NAME=$1; shift
+REPO=$(cd $(dirname $0)/.. && pwd)
+mkdir -p $REPO/profiles/_bin/$NAME
+C=$REPO/gbp_poplar_amd/csrc
+hipcc -shared -o $REPO/profiles/_bin/$NAME/libgbp_mi355x.so -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wall -Wno-unused-function "$@" \
+  -x hip $C/gbp_kernels.hip $C/gbp_capi.cpp $C/gbp_comm.cpp $C/gbp_host.cpp -ldl
+echo built profiles/_bin/$NAME

@@ -67,7 +67,7 @@ def test_bench_sharded_code_path_on_one_gpu(comm):
     """bench.py --force-sharded: the N > 1 code path (shard ctx, RCCL all-gather, overlap; the library's own communicator
     or torch.distributed) with one rank on one GPU — same contract fields, same convergence as the plain path."""
     plain = _bench_gpu("--pmc", "off")
-    out = _bench_gpu("--force-sharded", "--comm", comm, "--sharded-graph", "1" if comm == "native" else "0", "--pmc", "off")
+    out = _bench_gpu("--force-sharded", "--comm", comm, "--sharded-graph", "1" if comm == "native" else "0", "--pmc", "off", "--preflight", "0")
     assert out["config"]["iterations_run"] == plain["config"]["iterations_run"] == 24
     assert out["n_gpus"] == 1 and out["steps"] == 12 and out["value"] > 0 and out["higher_is_better"] is True
     assert out["config"]["comm_error"] is None
@@ -103,6 +103,17 @@ def test_bench_sharded_line_is_complete_on_the_config5_shard_shape():
     assert "shard shape" in r["traffic_source"]
     assert r["exchange_avg_us"] > 0 and r["rank_step_ms_max"] >= r["rank_step_ms_min"] > 0
     assert out["config"]["factors"] == 1250000 and out["steps"] == 20
+    # the first multi-GPU run validates itself — the preflight block rides in the line
+    pre = out["config"]["preflight"]
+    assert pre["all_ranks_on_distinct_gpus"] is True and pre["distinct_pci_bus_ids"] == 1 and pre["same_library_on_every_rank"] is True
+    rk = pre["ranks"][0]
+    assert rk["transport"] == "rccl" and "librccl" in rk["library"] and rk["library_version"] > 20000 and rk["pci_bus_id"]
+    assert rk["peer_access_from_this_device"][0] is True
+    assert pre["exchange_probe_us"] > 0
+    sched = pre["schedule_ms_per_iteration"]
+    assert sched["one_stream"] > 0 and sched["two_streams"] > 0
+    assert pre["stream_mode_chosen"] == min(sched, key=sched.get)
+    assert out["config"]["iterations_run"] == 5 + 50 + 20
 
 
 @pytest.mark.gpu

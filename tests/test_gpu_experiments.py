@@ -93,13 +93,13 @@ print('RECOVERED %%.1f s graph_state_after_upload %%d :: %%s' %% (dt, eng.graph_
 
 
 @pytest.mark.skipif(not _exp_lib_present(), reason="experiments build absent (python -m gbp_poplar_amd.build --experiments)")
-@pytest.mark.parametrize("coop", [-1, 0])
+@pytest.mark.parametrize("coop", [0, 1])
 def test_persistent_kernel_time_out_is_recovered(coop):
     """A k_persist launch whose workgroups can NOT all be resident (forced: every 8th dispatch slot = one XCD = 32 CUs for the
     52 workgroups of fr1xyz; experiments build) must not hang and must not lose the run:
-      * plain launch (persist_coop = -1): the barrier gives up after 1.5 s, later launches return at once, the library restores
+      * plain launch (persist_coop = 0, the default): the barrier gives up after 1.5 s, later launches return at once, the library restores
         the snapshot taken before the failed launch and replays the bursts on the two-kernel path;
-      * cooperative launch (persist_coop = 0): the runtime refuses the grid before anything runs, same fallback.
+      * cooperative launch (persist_coop = 1): the runtime refuses the grid before anything runs, same fallback.
     Either way: rc 0 everywhere, every belief / damping / counter and every metric equal to the two-kernel path's, a warning in
     gbp_last_error, and the persistent path back after the next gbp_upload."""
     import subprocess
@@ -114,6 +114,6 @@ def test_persistent_kernel_time_out_is_recovered(coop):
     line = [l for l in p.stdout.splitlines() if l.startswith("RECOVERED")][-1]
     # a time-out may have been a passing condition (another process): the next upload re-arms the persistent path; a refused
     # cooperative grid will be refused again: the ctx stays on the two-kernel path
-    assert ("graph_state_after_upload 2" in line) == (coop == -1), line
-    assert "warning:" in line and ("timed out" in line if coop == -1 else "refused" in line), line
+    assert ("graph_state_after_upload 2" in line) == (coop == 0), line
+    assert "warning:" in line and ("timed out" in line if coop == 0 else "refused" in line), line
     assert time.time() - t0 < 90
