@@ -523,7 +523,7 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
     const int mode = pe ? std::atoi(pe) : c->prm.persistent;
     const char* pc = prm ? nullptr : std::getenv("GBP_PERSIST_COOP");
     const int coop_mode = pc ? std::atoi(pc) : c->prm.persist_coop;  // 1 = cooperative launch, else (default) plain launch + probe + recovery
-    const uint32_t nb = persist_blocks(c->n_tiles, c->C, c->L_loc);
+    const uint32_t nb = persist_blocks(c->n_tiles, c->C, c->L_loc, true);
     // measured (profiles/r03_small_graphs.md): the shipped sequences (19 - 61 workgroups, relinearising in every sweep) run
     // 1.55 - 1.82x faster in k_persist; converging synthetic graphs 1.21x at 63 workgroups, break even at 125
     const uint32_t auto_limit = 96;
@@ -1123,7 +1123,7 @@ static int launch_persist_burst(gbp_ctx* c, const SweepArgs& a, int n, const Per
     g_persist_last_ctx[dev & 15] = c;
     g_persist_last_stream[dev & 15] = c->stream;
   }
-  const unsigned nb = persist_blocks(c->n_tiles, c->C, c->L_loc);
+  const unsigned nb = persist_blocks(c->n_tiles, c->C, c->L_loc, ev != nullptr && ev->each != 0);      // the grid launch_persist used
   c->persist_epoch_base += nb * (unsigned)(2 * n - 1 + (ev ? 1 : 0));      // n <= kPersistChunk; the counter wraps, grid_sync compares wrap-safe
   c->persist_seq += 1;
   c->persist_log.push_back(gbp_ctx::Burst{c->persist_seq, n, mode, area});
@@ -1648,7 +1648,7 @@ int gbp_debug_div_redo(unsigned long long* out4, int reset) { debug_div_redo(out
 // arm (out = NULL), run gbp_iterate(n), call again with `out` to read.  Returns the number of waves.
 int gbp_debug_persist_trace(gbp_ctx* c, unsigned long long* out, int cap_waves) {
   if (!c || !c->persist_ok) return GBP_ERR_STATE;
-  const int waves = (int)persist_blocks(c->n_tiles, c->C, c->L_loc) * 4;
+  const int waves = (int)persist_blocks(c->n_tiles, c->C, c->L_loc, true) * 4;
   const size_t bytes = (size_t)waves * kPersistTraceIters * 8 * sizeof(unsigned long long);
   if (!c->ptrace.p) { if (int rc = dev_alloc(c, c->ptrace, bytes)) return rc; }
   HIPCHK(c, hipStreamSynchronize(c->stream));

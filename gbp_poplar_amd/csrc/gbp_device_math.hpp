@@ -151,7 +151,17 @@ GBP_DEV void so3exp(const float (&v)[3], float (&R)[9]) {
     // sin/cos are taken correctly rounded (fp64 evaluation rounded once to fp32): the reference's
     // own std::sin/std::cos resolve to whatever libm its target ships (Poplar's on the IPU), so no
     // libm is "the" reference; a correctly rounded value is the one every good libm approximates.
+#ifdef GBP_SINCOS_SEPARATE
     const float s = FAST_TRIG ? __sinf(theta) : (float)sin((double)theta), c = FAST_TRIG ? __cosf(theta) : (float)cos((double)theta);
+#else
+    float s, c;
+    if (FAST_TRIG) { s = __sinf(theta); c = __cosf(theta); }
+    else {            // one argument reduction for both (the device library's sincos): the same fp64 values as sin() and cos()
+      double sd, cd;
+      sincos((double)theta, &sd, &cd);
+      s = (float)sd; c = (float)cd;
+    }
+#endif
     const float H[9] = {0.f, -v[2], v[1], v[2], 0.f, -v[0], -v[1], v[0], 0.f};
     const float a = s / theta;
     const float b = (1 - c) / (theta * theta);

@@ -156,7 +156,8 @@ void launch_sweep_blocks(SweepArgs a, uint32_t block0, uint32_t block1, bool hoi
 bool launch_sweep_ablated(const SweepArgs& a, uint32_t n_tiles, int abl, hipStream_t s);  // timing experiments; false = not built in
 void launch_linearise(const SweepArgs& a, uint32_t n_tiles, hipStream_t s);
 void launch_beliefs(BeliefArgs b, bool do_cam, bool do_lmk, hipStream_t s);
-uint32_t persist_blocks(uint32_t n_tiles, uint32_t n_cams, uint32_t n_lmks);   // workgroups k_persist needs for a graph
+// workgroups of a k_persist launch for a graph; with_metric: + one wave per camera for the metric roles where the placement allows
+uint32_t persist_blocks(uint32_t n_tiles, uint32_t n_cams, uint32_t n_lmks, bool with_metric);
 int persist_max_resident_blocks();                                            // how many of them this GPU keeps resident at once
 // cooperative != 0: hipLaunchCooperativeKernel — the runtime refuses a grid that cannot be co-resident on the device and the
 // driver never runs two cooperative grids (of any process) side by side; 0: plain launch (the creation-time probe vouches for

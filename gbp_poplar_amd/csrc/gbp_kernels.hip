@@ -1370,17 +1370,32 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
   // ---- phase-B role: camera v (lanes 0..43 = the record), or landmarks 16 (v - C) .. + 15 (4 lanes each).  Roles are
   // numbered ACROSS the workgroups (v = wave-in-workgroup * workgroups + workgroup): the camera waves, whose lane 0 runs long
   // serial fp64 chains when the metric rides along, land one per CU instead of four
+  // Third kind of role, used only while the metric rides in the launch: waves [C + G, 2C + G) — where the grid has them
+  // (persist_blocks) — take the METRIC mean of camera v - (C + G): they sum the camera's rows themselves (same loads, same
+  // order: same belief) and run the fp64 pivoted solve + the fp64 LDL check that would otherwise sit behind the hoisted mean
+  // and CAM_LIN on the camera wave's single working lane (belief phase of a camera wave 6.1 us, of everyone else <= 4.0 us:
+  // profiles/r04_small_graphs.md).
   const uint32_t v = wib * nblk + bid;
   const bool cam_wave = v < b.n_cams;
   const bool lmk_wave = !cam_wave && (v - b.n_cams) < A.n_lmk_groups;
+  const uint32_t v_met0 = b.n_cams + A.n_lmk_groups;
+#ifdef GBP_PERSIST_NO_METRIC_ROLES     // (measurement build only)
+  const bool met_wave = false, cam_has_met_wave = false;
+#else
+  const bool met_wave = A.ev.on && v >= v_met0 && v - v_met0 < b.n_cams;
+  const bool cam_has_met_wave = cam_wave && v_met0 + v < nblk * 4u;       // this camera's metric mean is solved by wave v_met0 + v
+#endif
+  const uint32_t camv = met_wave ? v - v_met0 : v;                          // the camera of either role
   const uint32_t cj = lane;                                   // camera role: element of the 44-float record
-  const bool cam_live = cam_wave && cj < (uint32_t)kCamRec;
+  const bool cam_live = (cam_wave || met_wave) && cj < (uint32_t)kCamRec;
   uint32_t r0 = 0, r1 = 0;
   float cam_prior_j = 0.f;
   float4 cam_cur0 = make_float4(0.f, 0.f, 0.f, 0.f), cam_cur1 = cam_cur0;   // mean of the belief the next sweep consumes
+  if (cam_wave || met_wave) {
+    r0 = b.cam_row_ptr[camv]; r1 = b.cam_row_ptr[camv + 1];
+    if (cam_live) cam_prior_j = b.cam_prior[(size_t)camv * kCamRec + cj];
+  }
   if (cam_wave) {
-    r0 = b.cam_row_ptr[v]; r1 = b.cam_row_ptr[v + 1];
-    if (cam_live) cam_prior_j = b.cam_prior[(size_t)v * kCamRec + cj];
     // (sc1 like EVERY access of this launch to an array that crosses waves: a plain load could leave a copy in this XCD's L2
     // that goes stale when another XCD rewrites the neighbouring half of the 128-B line)
     cam_cur0 = X_cmu.ld4(v * 4u); cam_cur1 = X_cmu.ld4(v * 4u + 1u);
@@ -1466,7 +1481,9 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
     // ================= phase A: the sweep of this wave's tile =================
     if (has_tile) {
       float cb[44], lb[16], mu[12];
-      // the linearisation point of a relinearising lane is fetched with the beliefs (one round of loads per phase)
+      // One round of loads per phase: the beliefs AND what a relinearising lane needs (hoisted means, CAM_LIN) go out together.
+      // (measured and dropped, profiles/r04_small_graphs.md: fetching the camera's 18 float4 once per 16-lane row and handing
+      // them round through LDS instead of 18 loads per lane — 3x fewer L1 accesses — changes nothing: 21.5 vs 21.5 ms)
       const float4 l0 = X_lmu.ld4(lmu_rec4);
       const float4 m0 = X_cmu.ld4(cmu_rec4), m1 = X_cmu.ld4(cmu_rec4 + 1u);
       float4 clq[kCamLin4];
@@ -1549,34 +1566,13 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
     GBP_TRACE(2);
 
     // ================= phase B: the belief update (arithmetic of k_beliefs, roll = 1) =================
-    if (cam_wave) {
+    if (cam_wave || (met_wave && ev_means)) {
       float acc = 0.f;
-#ifndef GBP_PERSIST_ROW_ROUNDS
-#define GBP_PERSIST_ROW_ROUNDS 3
-#endif
       if (cam_live && r1 > r0) {
         const uint32_t row = r0 * (uint32_t)kCamRec + cj;           // float index into ROWP
         const uint32_t n = r1 - r0;
-#if GBP_PERSIST_ROW_ROUNDS == 1
-        {  // measurement variant: rows 0 .. 32 in ONE round of loads (profiles/r04_small_graphs.md: not faster)
-          float v[33];
-          GBP_UNROLL
-          for (int k = 0; k < 33; ++k) v[k] = X_rowp.ld1(row + ((uint32_t)k < n ? (uint32_t)k : n - 1u) * (uint32_t)kCamRec);
-          acc = v[0];
-          GBP_UNROLL
-          for (int k = 1; k < 33; ++k)
-            if ((uint32_t)k < n) acc = acc + v[k];
-        }
-        for (uint32_t r = 33; r < n; r += 16) {
-          float v[16];
-          const uint32_t m = n - r;
-          GBP_UNROLL
-          for (int k = 0; k < 16; ++k) v[k] = X_rowp.ld1(row + ((uint32_t)k < m ? r + (uint32_t)k : n - 1u) * (uint32_t)kCamRec);
-          GBP_UNROLL
-          for (int k = 0; k < 16; ++k)
-            if ((uint32_t)k < m) acc = acc + v[k];
-        }
-#else
+        // (measured, profiles/r04_small_graphs.md: all 33 rows of a fr1xyz camera in ONE round of loads, or 17 + 16, are SLOWER than
+        // this 1 + 16 + tail shape — 21.5 -> 22.1 / 23.2 ms per 1 500 iterations — so the shape stays)
         acc = X_rowp.ld1(row);
         uint32_t r = 1;
         for (; r + 16 <= n; r += 16) {
@@ -1596,16 +1592,24 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
           for (int k = 0; k < 16; ++k)
             if ((uint32_t)k < m) acc = acc + v[k];
         }
-#endif
       }
       if (cam_live) {
-        b.cam_local[(size_t)v * kCamRec + cj] = acc;
+        if (cam_wave) b.cam_local[(size_t)v * kCamRec + cj] = acc;
         sh[wib][cj] = cam_prior_j + acc;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (lane == 0) {
+      if (lane == 0 && !cam_wave) {   // metric role: what k_means computes for this camera, from the belief in LDS
+        float xm[6];                  // (the fp64 pivoted solve only: the fp64 LDL check stays with the camera wave, which has the slack)
+        solve_pivot<6>(sh[wib] + 8, 6, sh[wib], xm);
+        bool finite = true;
+        GBP_UNROLL
+        for (int i = 0; i < 6; ++i) { X_emc.st1(camv * 6u + (uint32_t)i, xm[i]); finite &= (xm[i] - xm[i] == 0.f); }
+        if (!finite) atomicAdd(&A.ev.health[0], 1ull);
+      }
+      if (lane == 0 && cam_wave) {
+        const bool ev_here = ev_means && !cam_has_met_wave;     // no wave to spare for this camera's metric mean: solved here
         float cb[44], x0c[6];
         GBP_UNROLL
         for (int i = 0; i < 44; ++i) cb[i] = sh[wib][i];
@@ -1613,8 +1617,11 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
         // LDL pivots): computed together, before any store or branch, so that the scheduler can interleave them
         float xm[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         bool pd = true;
-        if (ev_means) {   // metric means of this camera (what k_means computes), from the belief in LDS
+        if (ev_here) {   // metric means of this camera (what k_means computes), from the belief in LDS
           solve_pivot<6>(sh[wib] + 8, 6, sh[wib], xm);
+          pd = ldl_pivots_positive<6>(sh[wib] + 8, 6);
+          cam_mean(cb, x0c);
+        } else if (ev_means) {   // the solve runs on this camera's metric wave; the health check here
           pd = ldl_pivots_positive<6>(sh[wib] + 8, 6);
           cam_mean(cb, x0c);
         } else {
@@ -1638,19 +1645,19 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
           GBP_UNROLL
           for (int g = 0; g < kCamLin4; ++g) X_clin.st4(v * (uint32_t)kCamLin4 + (uint32_t)g, q[g]);
         }
-        if (ev_means) {
+        if (ev_here) {
           bool finite = true;
           GBP_UNROLL
           for (int i = 0; i < 6; ++i) { X_emc.st1(v * 6u + (uint32_t)i, xm[i]); finite &= (xm[i] - xm[i] == 0.f); }
           if (!finite) atomicAdd(&A.ev.health[0], 1ull);
-          if (!pd) atomicAdd(&A.ev.health[1], 1ull);
         }
+        if (ev_means && !pd) atomicAdd(&A.ev.health[1], 1ull);
         sh[wib][6] = S;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (cam_live) X_camb.st1(v * (uint32_t)kCamRec + cj, sh[wib][cj]);
+      if (cam_live && cam_wave) X_camb.st1(v * (uint32_t)kCamRec + cj, sh[wib][cj]);
     } else if (lmk_wave) {
       float4 acc = lmk_prior4;
       {  // both batches of loads are issued before the first add (one memory round trip for up to 30 slots: the
@@ -2189,7 +2196,7 @@ static int persist_spread(uint32_t nb) { return nb <= 64 ? 4 : nb <= 128 ? 2 : 1
 
 bool persist_probe(uint32_t n_tiles, uint32_t n_cams, uint32_t n_lmks, unsigned* sync, unsigned* status_dev, volatile unsigned* status_host,
                    bool cooperative, hipStream_t s) {
-  const uint32_t nb = persist_blocks(n_tiles, n_cams, n_lmks);
+  const uint32_t nb = persist_blocks(n_tiles, n_cams, n_lmks, true);     // the larger of the two grids this graph is launched with
   const int spread = persist_spread(nb);
   if (hipMemsetAsync(sync, 0, kPersistSyncWords * sizeof(unsigned), s) != hipSuccess) return false;
   // 96 KiB of dynamic LDS per workgroup: at most ONE workgroup per CU (160 KiB), like k_persist's ~450 registers per lane
@@ -2211,10 +2218,21 @@ bool persist_probe(uint32_t n_tiles, uint32_t n_cams, uint32_t n_lmks, unsigned*
   return ok;
 }
 
-uint32_t persist_blocks(uint32_t n_tiles, uint32_t n_cams, uint32_t n_lmks) {
+uint32_t persist_blocks(uint32_t n_tiles, uint32_t n_cams, uint32_t n_lmks, bool with_metric) {
   const uint64_t waves_b = (uint64_t)n_cams + ((uint64_t)n_lmks + 15) / 16;
   const uint64_t waves = waves_b > n_tiles ? waves_b : n_tiles;
-  return (uint32_t)((waves + 3) / 4);
+  const uint32_t nb = (uint32_t)((waves + 3) / 4);
+  if (!with_metric) return nb;
+  // a launch that carries the metric after EVERY iteration gets one more wave per camera for the metric roles — as long as that does not cost the
+  // placement (every 4th dispatch slot holds up to 64 working workgroups): fr1xyz 52 -> 56 workgroups, fr2robot2 19 -> 24;
+  // fr1desk would go 61 -> 77 and stays.  Launches without the metric keep the smaller grid (4 more workgroups cost them
+  // 0.45 us per iteration on fr1xyz, profiles/r04_small_graphs.md).
+  const uint64_t waves_m = waves_b + n_cams > n_tiles ? waves_b + n_cams : n_tiles;
+  const uint32_t nb_m = (uint32_t)((waves_m + 3) / 4);
+#ifdef GBP_PERSIST_NO_METRIC_ROLES
+  return nb;
+#endif
+  return nb_m <= 64u ? nb_m : nb;
 }
 int persist_max_resident_blocks() {
   int dev = 0, per_cu = 0;
@@ -2231,7 +2249,7 @@ void launch_copy_segments(const CopySegs& t, const unsigned* guard, hipStream_t 
 }
 hipError_t launch_persist(PersistArgs A, bool cooperative, hipStream_t s) {
   A.n_lmk_groups = (A.b.n_lmks + 15) / 16;
-  const uint32_t nb = persist_blocks(A.n_tiles, A.b.n_cams, A.b.n_lmks);
+  const uint32_t nb = persist_blocks(A.n_tiles, A.b.n_cams, A.b.n_lmks, A.ev.on != 0 && A.ev.each != 0);   // (one final metric: not worth 4 more workgroups in every barrier)
   // Placement: the grid is 4x the work and only every 4th workgroup works (the fillers leave at once).  Measured
   // (profiles/persist_placement.py, profiles/r03_small_graphs.md): with the working workgroups in consecutive dispatch slots a
   // few of them — always all four waves of a workgroup, on a CU next to another working CU — run their fp64-heavy sections

@@ -9,7 +9,7 @@ exec > $OUT/run.log 2>&1
 BA=gbp_poplar_amd/bin/ba; SLAM=gbp_poplar_amd/bin/slam
 $BA --bal_file data/sequences/fr1xyz.txt --eval_every 100 > /dev/null 2>&1   # warm the box
 for round in 1 2 3; do
-for v in default rows3 rows1 nosnap; do
+for v in ${VARIANTS:-default}; do
   if [ $v = default ]; then L=""; else L=$REPO/profiles/_bin/$v; fi
   for ev in 100 1; do
     echo -n "$v fr1xyz every$ev: "; LD_LIBRARY_PATH=$L $BA --bal_file data/sequences/fr1xyz.txt --eval_every $ev 2>&1 | grep -E "Total time" | sed 's/.*device time in GBP iterations: //' | cut -c1-60

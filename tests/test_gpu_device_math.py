@@ -72,6 +72,32 @@ def test_so3exp_vs_reference():
     assert np.max(np.abs(out.astype(np.float64) - ref)) <= 2.4e-7   # 2 ulp of an entry of magnitude <= 1
 
 
+def test_so3exp_is_the_correctly_rounded_trig_oracle_bit_for_bit(oracle_mod):
+    """so3exp on the device evaluates sin / cos in fp64 (ONE argument reduction for both: the device library's sincos) and
+    rounds once to fp32; the oracle's trig mode 1 does the same with glibc's fp64 sin / cos.  200 000 rotation vectors over the
+    range the sequences and the synthetic graphs use (|w| from 1e-5 to 3.3 rad, plus a few hundred up to 50 rad): every one of
+    the nine entries bit for bit (what lets whole chaotic runs with millions of relinearisations be bit-identical)."""
+    import ctypes as C
+    rng = np.random.default_rng(21)
+    n = 200000
+    d = rng.standard_normal((n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    mag = np.concatenate([10.0 ** rng.uniform(-5, 0, n // 4), rng.uniform(0.0, 3.3, n - n // 4 - 400), rng.uniform(3.3, 50.0, 400)])
+    w = (d * mag[:, None]).astype(np.float32)
+    dev = _run(2, w, 9)
+    lib = oracle_mod.load("restatement")
+    ref = np.zeros((n, 9), np.float32)
+    oracle_mod.set_trig_mode(1)
+    try:
+        fp = C.POINTER(C.c_float)
+        for i in range(n):
+            lib.om_so3exp(w[i].ctypes.data_as(fp), ref[i].ctypes.data_as(fp))
+    finally:
+        oracle_mod.set_trig_mode(0)
+    bad = np.nonzero((dev != ref).any(axis=1))[0]
+    assert bad.size == 0, (bad[:5], w[bad[:5]], dev[bad[:5]], ref[bad[:5]])
+
+
 def test_hfunc_and_jac_vs_reference():
     n = G["proj_cam"].shape[0]
     inp = np.concatenate([G["proj_cam"], G["proj_lmk"], np.tile(G["proj_K"], (n, 1))], axis=1)
