@@ -516,6 +516,51 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
     else g_create_error = c->err;
     c->use_tile_perm = rc == GBP_OK;
   }
+  // (0 = the library's choice: this order for graphs of at least 2 048 tiles — below that the whole landmark table sits in every
+  //  L2 anyway, and small graphs run in k_persist, which keeps the plain order)
+  if (rc == GBP_OK && (c->prm.tile_order == 3 || (c->prm.tile_order == 0 && c->n_tiles >= 2048))) {
+    // XCD-aware execution order of the sweep, LOCAL version: workgroup w lands on XCD (w mod 8) and should find the landmark
+    // records its factors gather in THAT XCD's L2.  Tiles are classed by the landmark octile of their median factor; the
+    // wave slots of workgroup w are filled with the earliest not yet placed tiles of class (w mod 8), looking at most
+    // `window` tiles ahead of the oldest unplaced one (else: the oldest unplaced tile, whatever its class).  A camera's
+    // factors are sorted by landmark, so its ~16 tiles walk through the octiles in order and the permutation only shuffles
+    // tiles of two or three neighbouring cameras: every stream keeps ONE compact front (tile_order = 2 gave every XCD a
+    // front of its own and lost more in the streams than it won in the gathers), while each private L2 serves 1/8 of the
+    // gathered landmark table.
+    const uint32_t nt = c->n_tiles;
+    std::vector<uint8_t> cls(nt, 8);
+    for (uint32_t t = 0; t < nt; ++t) {
+      uint32_t l[kTile], n = 0;
+      for (uint32_t i = 0; i < kTile; ++i) {
+        const size_t p = (size_t)t * kTile + i;
+        if (c->pos_edge[p] != ~0u) l[n++] = c->pos_lmk_loc[p];
+      }
+      if (n) {
+        std::nth_element(l, l + n / 2, l + n);
+        cls[t] = (uint8_t)std::min<uint64_t>(7u, (uint64_t)l[n / 2] * 8u / std::max<uint32_t>(c->L_loc, 1u));
+      }
+    }
+    const uint32_t window = 96;                   // tiles: about six cameras of the 1M-factor graph
+    std::vector<uint32_t> perm(nt);
+    std::vector<uint8_t> placed(nt, 0);
+    std::vector<uint32_t> next_of_class(9, 0);    // per class: where to continue looking
+    uint32_t oldest = 0;
+    for (uint32_t slot = 0; slot < nt; ++slot) {
+      while (oldest < nt && placed[oldest]) ++oldest;
+      const uint32_t want = (slot / 4) % 8;
+      uint32_t& cur = next_of_class[want];
+      if (cur < oldest) cur = oldest;
+      while (cur < nt && cur < oldest + window && (placed[cur] || cls[cur] != want)) ++cur;
+      uint32_t pick = oldest;
+      if (cur < nt && cur < oldest + window && !placed[cur] && cls[cur] == want) pick = cur;
+      perm[slot] = pick;
+      placed[pick] = 1;
+    }
+    rc = dev_alloc(c, c->tile_perm, (size_t)nt * 4);
+    if (rc == GBP_OK) CK(hipMemcpy(c->tile_perm.p, perm.data(), (size_t)nt * 4, hipMemcpyHostToDevice), "copy tile_perm");
+    else g_create_error = c->err;
+    c->use_tile_perm = rc == GBP_OK;
+  }
   if (rc != GBP_OK) return rc;
   // ---- persistent iteration kernel: only where every workgroup of the graph is resident at once ----
   {

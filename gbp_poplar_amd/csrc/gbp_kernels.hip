@@ -382,7 +382,9 @@ GBP_DEV void factor_update(float (&fac)[56], const float (&cm)[28], float (&mu)[
 constexpr int kWpb = GBP_SWEEP_WPB;
 template <bool HOIST, int ABL>
 GBP_DEV void sweep_tile(const SweepArgs& a, const uint32_t wslot) {
-  const uint32_t tile = a.tile_perm ? (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tile_perm[wslot]) : wslot;
+  // (the slot is wave-uniform: as an SGPR it turns the permutation look-up into one scalar load)
+  const uint32_t ws = (uint32_t)__builtin_amdgcn_readfirstlane((int)wslot);
+  const uint32_t tile = a.tile_perm ? a.tile_perm[ws] : ws;
   const uint32_t lane = threadIdx.x & 63, p = tile * 64 + lane;
 
   const uint32_t cam_i = a.row_cam[p >> 4];

@@ -73,12 +73,16 @@ typedef struct {
                                   uploaded mu/oldmu to be zero as in ba.cpp:582-583); 1: keep the literal
                                   per-factor mu/oldmu tensors                                            */
   int32_t tile_order;          /* XCD-aware execution order (results are identical in every mode):
-                                  0 (default) = the landmark blocks of the belief kernel that share an XCD take one
-                                      contiguous landmark range (both 64-B halves of a 128-B message line then meet in
-                                      one L2), sweep tiles run in device order;
+                                  0 (default) = the landmark blocks of the belief kernel that share an XCD take one contiguous
+                                      landmark range (both 64-B halves of a 128-B message line then meet in one L2); on graphs of
+                                      2 048 tiles (131 072 factor positions) or more the sweep runs in order 3, below in device order;
                                   1 = everything sequential;
-                                  2 = as 0, and each XCD also sweeps the tiles of one landmark range (11 % less fabric
-                                      traffic, slightly slower: kept for measurements)                              */
+                                  2 = as 0, and each XCD sweeps the tiles of one landmark range (global permutation: every XCD
+                                      gets a stream front of its own; kept for measurements);
+                                  3 = as 0, and the sweep's tiles are permuted LOCALLY (within a few cameras) so that workgroup w —
+                                      which lands on XCD w mod 8 — holds factors of landmark octile w mod 8: each private L2 then
+                                      serves 1/8 of the gathered landmark-belief table while every stream keeps one compact front
+                                      (S1: 689 -> 614 MB per sweep, 7 920 -> 8 200 iterations/s, profiles/r04_tile_order.md)          */
   int32_t persistent;          /* gbp_iterate(n >= 2) on a graph small enough that all of its workgroups are resident at once
                                   (BASELINE configs 1-3) runs the n iterations inside ONE kernel launch (k_persist: per-factor
                                   state in registers, device-wide barriers instead of kernel boundaries; identical results):

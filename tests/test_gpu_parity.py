@@ -1038,9 +1038,9 @@ def test_random_graph_structures_bit_exact(seed, oracle_mod):
 
 
 def test_xcd_aware_tile_order_is_unobservable():
-    """gbp_params.tile_order only changes which XCD works on which landmark blocks (0) and sweep tiles (2: a permutation
-    table read once per wave): every tensor is identical to the sequential order (1), here on a graph of ~100
-    workgroups / 49 landmark blocks (not multiples of 8)."""
+    """gbp_params.tile_order only changes which XCD works on which landmark blocks (0) and sweep tiles (2, 3: a permutation
+    table read once per wave; 3 — the local permutation — is what 0 selects by itself on large graphs): every tensor is
+    identical to the sequential order (1), here on a graph of ~100 workgroups / 49 landmark blocks (not multiples of 8)."""
     from gbp_poplar_amd import _cabi, driver, hostlib
     from gbp_poplar_amd.engine import GbpEngine
     bal = small_synth(n_cams=37, n_lmks=3100, obs=8, seed=21)
@@ -1048,14 +1048,14 @@ def test_xcd_aware_tile_order_is_unobservable():
     opts.undamped_start = 2
     K, state, _ = driver.build_inputs(bal, opts, hostlib)
     snaps = []
-    for order in (1, 0, 2):
+    for order in (1, 0, 2, 3):
         eng = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K,
                         params=_cabi.GbpParams.defaults(tile_order=order, dmu_threshold=0.05, min_linear_iters=3), hooks=True)
         traj = driver.run_ba(eng, state, opts, n_iters=25, eval_every=5)
         d = _gpu_snapshot(eng)
         d["mu"] = eng.mu()[0]
         snaps.append((traj, d))
-    assert snaps[0][0] == snaps[1][0] == snaps[2][0]
+    assert snaps[0][0] == snaps[1][0] == snaps[2][0] == snaps[3][0]
     assert sum(t[3] for t in snaps[0][0]) > 0                      # relinearisations happened
     for other in snaps[1:]:
         for k, v in snaps[0][1].items():
