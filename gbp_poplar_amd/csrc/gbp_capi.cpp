@@ -98,6 +98,7 @@ struct gbp_ctx {
   void* series_host = nullptr;         // gbp_iterate_eval_each: [kSeriesMax metrics][1 + workgroups] slots, same kind of memory
   void* series_dev = nullptr;
   int eval_parity = 0, eval_pending = 0;
+  bool eval_per_wave[2] = {false, false};   // result area written by k_persist (one record per tile wave) or by k_eval (one per workgroup)
   hipEvent_t eval_ev[2] = {nullptr, nullptr};
   bool profile_stages = false;
   // k_persist (small graphs): n iterations in one launch
@@ -451,7 +452,8 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
   A(c->rowp, (Ep / kRow) * kCamRec * 4);
   A(c->d_cam_row_ptr, (size_t)(C + 1) * 4); A(c->d_lmk_ptr, (size_t)(c->L_loc + 1) * 4);
   A(c->cwf, (size_t)C * 4); A(c->lwf, (size_t)c->L_loc * 4); A(c->cscale, (size_t)C * 4); A(c->lscale, (size_t)c->L_loc * 4);
-  A(c->cam_mu, (size_t)C * 6 * 4); A(c->lmk_mu, (size_t)c->L_loc * 3 * 4); A(c->dK, 16 * 4);
+  A(c->cam_mu, (size_t)C * 6 * 4 * 2); A(c->lmk_mu, (size_t)c->L_loc * 3 * 4 * 2);   // metric means; k_persist alternates between the two halves
+  A(c->dK, 16 * 4);
   A(c->evalp, sizeof(DeviceEval) * 16); A(c->health, 32);
   A(c->hmu_c, (size_t)C * 4 * 16); A(c->hmu_l, (size_t)c->L_loc * 2 * 16); A(c->clin, (size_t)C * 5 * 16);
   A(c->st_a, Ep * 4); A(c->st_b, Ep * 4);
@@ -1398,6 +1400,7 @@ static int eval_enqueue(gbp_ctx* c, int area) {
               P<float>(c->dK), c->prm.num_undamped_iters, slots + 1, h_cur, reinterpret_cast<unsigned long long*>(slots), c->n_tiles, c->stream);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->eval_ev[area], c->stream));
+  c->eval_per_wave[area] = false;
   return GBP_OK;
 }
 
@@ -1413,11 +1416,25 @@ static int eval_begin_impl(gbp_ctx* c) {
   return GBP_OK;
 }
 
-static int sum_eval(gbp_ctx* c, const DeviceEval* part, uint32_t nb, gbp_eval_out* o) {
+// part[0] = the two health counters; then one record per workgroup of k_eval (per_wave = false: nb of them), or one per tile
+// wave of k_persist (per_wave = true: n_tiles of them) — the four waves of a workgroup added as k_eval's block reduction adds
+// them, ((w0 + w1) + w2) + w3, then the workgroups in order: the same fp64 additions in the same order either way.
+static int sum_eval(gbp_ctx* c, const DeviceEval* part, uint32_t nb, gbp_eval_out* o, bool per_wave = false) {
   std::memset(o, 0, sizeof(*o));
-  for (uint32_t b = 1; b <= nb; ++b) {
-    o->sum_norm += part[b].sum_norm; o->sum_half_sq += part[b].sum_half_sq;
-    o->n_active += part[b].n_active; o->n_relin += part[b].n_relin; o->n_robust += part[b].n_robust;
+  if (per_wave) {
+    for (uint32_t b = 0; b < nb; ++b) {
+      DeviceEval w[4] = {};
+      for (uint32_t k = 0; k < 4; ++k)
+        if (b * 4 + k < c->n_tiles) w[k] = part[1 + b * 4 + k];
+      o->sum_norm += ((w[0].sum_norm + w[1].sum_norm) + w[2].sum_norm) + w[3].sum_norm;
+      o->sum_half_sq += ((w[0].sum_half_sq + w[1].sum_half_sq) + w[2].sum_half_sq) + w[3].sum_half_sq;
+      for (uint32_t k = 0; k < 4; ++k) { o->n_active += w[k].n_active; o->n_relin += w[k].n_relin; o->n_robust += w[k].n_robust; }
+    }
+  } else {
+    for (uint32_t b = 1; b <= nb; ++b) {
+      o->sum_norm += part[b].sum_norm; o->sum_half_sq += part[b].sum_half_sq;
+      o->n_active += part[b].n_active; o->n_relin += part[b].n_relin; o->n_robust += part[b].n_robust;
+    }
   }
   // non-finite guard (replaces the Poplar FP traps of ba.cpp:888-891) + non-PD belief count;
   // cameras are replicated, so only rank 0 counts them
@@ -1446,7 +1463,7 @@ static int eval_end_impl(gbp_ctx* c, gbp_eval_out* o) {
     if (failed) HIPCHK(c, hipEventSynchronize(c->eval_ev[area]));
   }
   c->eval_pending -= 1;
-  return sum_eval(c, static_cast<const DeviceEval*>(c->eval_host) + 1025 * area, eval_blocks(c->n_tiles), o);
+  return sum_eval(c, static_cast<const DeviceEval*>(c->eval_host) + 1025 * area, eval_blocks(c->n_tiles), o, c->eval_per_wave[area]);
 }
 
 static int eval_impl(gbp_ctx* c, gbp_eval_out* o) {
@@ -1463,7 +1480,7 @@ static int iterate_eval_impl(gbp_ctx* c, int n) {
   if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "gbp_iterate_eval: upload first");
   if (n <= 0) return eval_begin_impl(c);
   bool fused = false;
-  if (c->eval_pending < 2 && n <= kPersistChunk && eval_blocks(c->n_tiles) == (c->n_tiles + 3) / 4)
+  if (c->eval_pending < 2 && n <= kPersistChunk && c->n_tiles <= 1024)
     if (int rc = persist_ready(c, &fused)) return rc;
   if (fused) {
     if (int rc = eval_alloc(c)) return rc;
@@ -1473,9 +1490,10 @@ static int iterate_eval_impl(gbp_ctx* c, int n) {
     ev.on = 1;
     ev.cam_mu = P<float>(c->cam_mu); ev.lmk_mu = P<float>(c->lmk_mu);
     ev.num_undamped = c->prm.num_undamped_iters;
-    ev.slots = slots;                    // [0] = health copy, [1 + workgroup] = partial sums (the layout gbp_eval_end reads)
+    ev.slots = slots;                    // [0] = health copy, [1 + tile wave] = partial sums
     ev.health = P<unsigned long long>(c->health) + 2 * area;
     ev.health_next = P<unsigned long long>(c->health) + 2 * (area ^ 1);
+    ev.health_each = P<unsigned long long>(c->health);
     gbp_ctx::Span sp{};
     if (int rc = span_begin(c, sp)) return rc;
     const int lrc = launch_persist_burst(c, sweep_args(c), n, &ev, 1, area);
@@ -1484,6 +1502,7 @@ static int iterate_eval_impl(gbp_ctx* c, int n) {
       c->timed_iters += (uint64_t)n;
       c->beliefs_valid = true;
       HIPCHK(c, hipEventRecord(c->eval_ev[area], c->stream));
+      c->eval_per_wave[area] = true;
       c->eval_parity ^= 1;
       c->eval_pending += 1;
       return GBP_OK;
@@ -1510,7 +1529,7 @@ static int iterate_eval_each_impl(gbp_ctx* c, int n, gbp_eval_out* out) {
     if (int rc = persist_ready(c, &fused)) return rc;
   int done = 0;
   if (fused) {
-    const uint32_t stride = nb + 1;
+    const uint32_t stride = c->n_tiles + 1;          // [0] = health copy, then one record per tile wave
     if (!c->series_host) {
       HIPCHK(c, hipHostMalloc(&c->series_host, sizeof(DeviceEval) * (size_t)stride * kSeriesMax, hipHostMallocMapped));
       HIPCHK(c, hipHostGetDevicePointer(&c->series_dev, c->series_host, 0));
@@ -1525,6 +1544,7 @@ static int iterate_eval_each_impl(gbp_ctx* c, int n, gbp_eval_out* out) {
       ev.slots = static_cast<DeviceEval*>(c->series_dev);
       ev.health = P<unsigned long long>(c->health) + 2 * area;
       ev.health_next = P<unsigned long long>(c->health) + 2 * (area ^ 1);
+      ev.health_each = P<unsigned long long>(c->health);
       gbp_ctx::Span sp{};
       if (int rc = span_begin(c, sp)) return rc;
       const int lrc = launch_persist_burst(c, sweep_args(c), m, &ev, 2, area);
@@ -1541,7 +1561,7 @@ static int iterate_eval_each_impl(gbp_ctx* c, int n, gbp_eval_out* out) {
       if (failed) { fused = false; break; }             // ... which the plain loop below now runs
       c->timed_iters += (uint64_t)m;
       c->beliefs_valid = true;
-      for (int k = 0; k < m; ++k) sum_eval(c, static_cast<const DeviceEval*>(c->series_host) + (size_t)k * stride, nb, out + done + k);
+      for (int k = 0; k < m; ++k) sum_eval(c, static_cast<const DeviceEval*>(c->series_host) + (size_t)k * stride, nb, out + done + k, true);
       done += m;
     }
   }

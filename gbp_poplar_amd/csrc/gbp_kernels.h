@@ -111,12 +111,13 @@ struct DeviceEval;
 struct PersistEval {
   int on;
   int each;                            // 0: one metric, after the last iteration;  1: after EVERY iteration (gbp_iterate_eval_each)
-  uint32_t stride;                     // DeviceEval slots per metric: [0] = health copy, [1 + workgroup] = partial sums
-  float* cam_mu;                       // [C][6] metric means (util.cpp:103-108), written by the camera waves
-  float* lmk_mu;                       // [L][3]
+  uint32_t stride;                     // DeviceEval slots per metric: [0] = health copy, [1 + tile wave] = that wave's partial sums
+  float* cam_mu;                       // [2][C][6] metric means (util.cpp:103-108) of iteration k in half k & 1, written by the camera / metric waves
+  float* lmk_mu;                       // [2][L][3]
   int num_undamped;
   DeviceEval* slots;                   // [metrics][stride], host-mapped memory; metric k of the launch -> slots + k * stride
-  unsigned long long* health;          // [2] non-finite means / non-PD beliefs of THIS evaluation (zero on entry)
+  unsigned long long* health;          // [2] non-finite means / non-PD beliefs of THIS evaluation (zero on entry); each == 0
+  unsigned long long* health_each;     // [2][2] each == 1: the counters of iteration k in pair k & 1 (all zero on entry and on exit)
   unsigned long long* health_next;     // zeroed for the next evaluation
 };
 struct PersistArgs {

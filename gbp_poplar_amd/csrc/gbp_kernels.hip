@@ -1436,7 +1436,14 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
   // write the metric means in phase B; after the next device-wide hand-off every tile wave adds its factors' residuals and the
   // workgroup reduces them in k_eval's order (a workgroup holds the same 256 positions as a block of k_eval).  `packed` is the
   // factor's state word as the sweep of the evaluated iteration left it.
-  const bool tile_block = bid * 4u < A.n_tiles;              // uniform per workgroup
+  // Where the pieces of metric k live: the belief owners write the metric means of iteration k into half (k & 1) of the two
+  // mean buffers during phase B of k; the tile waves evaluate their factors' residuals at the END of phase B of k + 1 — behind
+  // their own belief-phase role, where all but the slowest waves have slack (in phase A the same work sat on the iteration's
+  // critical path: +2.1 us on fr1xyz) — reading half (k & 1) while the owners write half ((k + 1) & 1).  The health counters of
+  // an every-iteration launch alternate the same way.  Each tile wave stores its own partial sums (slot 1 + wave); the host adds
+  // the four waves of a workgroup as k_eval's block reduction does, ((w0 + w1) + w2) + w3, then the workgroups in order.
+  const uint32_t emc_half = b.n_cams * 6u, eml_half = b.n_lmks * 3u;
+  auto health_of = [&](uint32_t k) -> unsigned long long* { return A.ev.each ? A.ev.health_each + 2u * (k & 1u) : A.ev.health; };
   auto metric = [&](uint32_t k, int packed, const float (&cmv)[6], const float (&lmu)[3]) {
     double s_norm = 0, s_half = 0;
     unsigned long long n_act = 0, n_rel = 0, n_rob = 0;
@@ -1451,23 +1458,38 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
         }
       }
     }
-    DeviceEval* slots = A.ev.slots + (size_t)k * A.ev.stride;
-    if (tile_block) eval_block_reduce(s_norm, s_half, n_act, n_rel, n_rob, slots + 1 + bid);
+    DeviceEval* slots = A.ev.slots + (size_t)(A.ev.each ? k : 0u) * A.ev.stride;
+    if (has_tile) {     // the lane tree of eval_block_reduce, then one record per wave
+      for (int off = 32; off > 0; off >>= 1) {
+        s_norm += __shfl_down(s_norm, off);
+        s_half += __shfl_down(s_half, off);
+        n_act += __shfl_down(n_act, off);
+        n_rel += __shfl_down(n_rel, off);
+        n_rob += __shfl_down(n_rob, off);
+      }
+      if (lane == 0) {
+        DeviceEval o;
+        o.sum_norm = s_norm; o.sum_half_sq = s_half; o.n_active = n_act; o.n_relin = n_rel; o.n_robust = n_rob; o.pad = 0;
+        slots[1 + w] = o;
+      }
+    }
     if (bid == 0 && threadIdx.x == 0) {
+      unsigned long long* h = health_of(k);
       unsigned long long* out = reinterpret_cast<unsigned long long*>(slots);
-      out[0] = __hip_atomic_load(&A.ev.health[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      out[1] = __hip_atomic_load(&A.ev.health[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (A.ev.each) {   // the next phase B counts from zero (it starts behind the next hand-off)
-        __hip_atomic_store(&A.ev.health[0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&A.ev.health[1], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      out[0] = __hip_atomic_load(&h[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      out[1] = __hip_atomic_load(&h[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (A.ev.each) {   // this half counts from zero again when its turn comes (two hand-offs from now)
+        __hip_atomic_store(&h[0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&h[1], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   };
-  auto metric_means = [&](float (&cmv)[6], float (&lmu)[3]) {
+  auto metric_means = [&](uint32_t k, float (&cmv)[6], float (&lmu)[3]) {
+    const uint32_t oc = (k & 1u) * emc_half + cam_i * 6u, ol_ = (k & 1u) * eml_half + lmk_i * 3u;
     GBP_UNROLL
-    for (int i = 0; i < 6; ++i) cmv[i] = X_emc.ld1(cam_i * 6u + (uint32_t)i);
+    for (int i = 0; i < 6; ++i) cmv[i] = X_emc.ld1(oc + (uint32_t)i);
     GBP_UNROLL
-    for (int i = 0; i < 3; ++i) lmu[i] = X_eml.ld1(lmk_i * 3u + (uint32_t)i);
+    for (int i = 0; i < 3; ++i) lmu[i] = X_eml.ld1(ol_ + (uint32_t)i);
   };
 
   unsigned epoch = 0;
@@ -1477,9 +1499,7 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
     // the metric of iteration it - 1 rides in this phase A (both only READ what phase B left): its loads go out with the
     // sweep's, its arithmetic runs behind the sweep's stores
     const bool ev_prev = A.ev.on && A.ev.each && it > 0;
-    float ev_cm[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ev_lm[3] = {0.f, 0.f, 0.f};
-    int ev_packed = 0;
-    if (ev_prev && has_tile) { metric_means(ev_cm, ev_lm); ev_packed = __float_as_int(lm[13]); }
+    const int ev_packed = __float_as_int(lm[13]);      // the factor's state word as the sweep of iteration it - 1 left it
     // ================= phase A: the sweep of this wave's tile =================
     if (has_tile) {
       float cb[44], lb[16], mu[12];
@@ -1562,12 +1582,15 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
         }
       }
     }
-    if (ev_prev) metric((uint32_t)it - 1u, ev_packed, ev_cm, ev_lm);
     GBP_TRACE(1);
     grid_sync(A.sync, A.epoch_base + (++epoch) * nblk, A.status, A.seq);
     GBP_TRACE(2);
 
     // ================= phase B: the belief update (arithmetic of k_beliefs, roll = 1) =================
+    float ev_cm[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ev_lm[3] = {0.f, 0.f, 0.f};
+    if (ev_prev && has_tile) metric_means((uint32_t)it - 1u, ev_cm, ev_lm);     // in flight with the role's own loads
+    unsigned long long* const hw = health_of((uint32_t)it);                      // what this phase's owners count into
+    const uint32_t emc_w = ((uint32_t)it & 1u) * emc_half, eml_w = ((uint32_t)it & 1u) * eml_half;
     if (cam_wave || (met_wave && ev_means)) {
       float acc = 0.f;
       if (cam_live && r1 > r0) {
@@ -1607,8 +1630,8 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
         solve_pivot<6>(sh[wib] + 8, 6, sh[wib], xm);
         bool finite = true;
         GBP_UNROLL
-        for (int i = 0; i < 6; ++i) { X_emc.st1(camv * 6u + (uint32_t)i, xm[i]); finite &= (xm[i] - xm[i] == 0.f); }
-        if (!finite) atomicAdd(&A.ev.health[0], 1ull);
+        for (int i = 0; i < 6; ++i) { X_emc.st1(emc_w + camv * 6u + (uint32_t)i, xm[i]); finite &= (xm[i] - xm[i] == 0.f); }
+        if (!finite) atomicAdd(&hw[0], 1ull);
       }
       if (lane == 0 && cam_wave) {
         const bool ev_here = ev_means && !cam_has_met_wave;     // no wave to spare for this camera's metric mean: solved here
@@ -1650,10 +1673,10 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
         if (ev_here) {
           bool finite = true;
           GBP_UNROLL
-          for (int i = 0; i < 6; ++i) { X_emc.st1(v * 6u + (uint32_t)i, xm[i]); finite &= (xm[i] - xm[i] == 0.f); }
-          if (!finite) atomicAdd(&A.ev.health[0], 1ull);
+          for (int i = 0; i < 6; ++i) { X_emc.st1(emc_w + v * 6u + (uint32_t)i, xm[i]); finite &= (xm[i] - xm[i] == 0.f); }
+          if (!finite) atomicAdd(&hw[0], 1ull);
         }
-        if (ev_means && !pd) atomicAdd(&A.ev.health[1], 1ull);
+        if (ev_means && !pd) atomicAdd(&hw[1], 1ull);
         sh[wib][6] = S;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1727,9 +1750,9 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
           solve_pivot<3>(rec + 4, 3, rec, x);
           bool finite = true;
           GBP_UNROLL
-          for (int i = 0; i < 3; ++i) { X_eml.st1(l * 3u + (uint32_t)i, x[i]); finite &= (x[i] - x[i] == 0.f); }
-          if (!finite) atomicAdd(&A.ev.health[0], 1ull);
-          if (!ldl_pivots_positive<3>(rec + 4, 3)) atomicAdd(&A.ev.health[1], 1ull);
+          for (int i = 0; i < 3; ++i) { X_eml.st1(eml_w + l * 3u + (uint32_t)i, x[i]); finite &= (x[i] - x[i] == 0.f); }
+          if (!finite) atomicAdd(&hw[0], 1ull);
+          if (!ldl_pivots_positive<3>(rec + 4, 3)) atomicAdd(&hw[1], 1ull);
         }
       }
       const float u0 = __shfl(u[0], 0, 4), u1 = __shfl(u[1], 0, 4), u2 = __shfl(u[2], 0, 4);
@@ -1737,6 +1760,7 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
       if (q4 == 3) { acc.y = u1; acc.z = u2; }       // record slots 13, 14
       if (lmk_live) X_lmkb.st4(l * 4u + q4, acc);
     }
+    if (ev_prev) metric((uint32_t)it - 1u, ev_packed, ev_cm, ev_lm);     // the residuals of the PREVIOUS iteration, behind this wave's role
     GBP_TRACE(3);
     if (it + 1 < A.n_iters) grid_sync(A.sync, A.epoch_base + (++epoch) * nblk, A.status, A.seq);
     GBP_TRACE(4);
@@ -1745,11 +1769,11 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
 
   // ---- the metric of the last iteration: one more hand-off, then as above ----
   if (A.ev.on) {
-    if (bid == 0 && threadIdx.x == 0) { A.ev.health_next[0] = 0ull; A.ev.health_next[1] = 0ull; }
+    if (!A.ev.each && bid == 0 && threadIdx.x == 0) { A.ev.health_next[0] = 0ull; A.ev.health_next[1] = 0ull; }   // (each: both pairs end at zero by themselves)
     grid_sync(A.sync, A.epoch_base + (++epoch) * nblk, A.status, A.seq);
     float cmv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, lmu[3] = {0.f, 0.f, 0.f};
-    if (has_tile) metric_means(cmv, lmu);
-    metric(A.ev.each ? (uint32_t)A.n_iters - 1u : 0u, __float_as_int(lm[13]), cmv, lmu);
+    if (has_tile) metric_means((uint32_t)A.n_iters - 1u, cmv, lmu);
+    metric((uint32_t)A.n_iters - 1u, __float_as_int(lm[13]), cmv, lmu);
   }
 
   // ---- what stayed in registers goes back to its arrays ----
