@@ -1308,8 +1308,11 @@ __global__ __launch_bounds__(256) void k_copy_segments(const CopySegs t, const u
   }
 }
 
-template <int ABL = 0>   // ABL: timing experiments only (see k_sweep)
+// EV: does the launch carry the metric (A.ev.on)?  A launch without it runs an instantiation that holds none of the metric's
+// code or registers (plain bursts 14.3 -> 14.0 us per iteration on fr1xyz, profiles/r04_small_graphs.md).
+template <int ABL = 0, bool EV = true>   // ABL: timing experiments only (see k_sweep)
 __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
+  const bool ev_on = EV && A.ev.on != 0;
   const SweepArgs& a = A.s;
   const BeliefArgs& b = A.b;
   const uint32_t wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1384,7 +1387,7 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
 #ifdef GBP_PERSIST_NO_METRIC_ROLES     // (measurement build only)
   const bool met_wave = false, cam_has_met_wave = false;
 #else
-  const bool met_wave = A.ev.on && v >= v_met0 && v - v_met0 < b.n_cams;
+  const bool met_wave = ev_on && v >= v_met0 && v - v_met0 < b.n_cams;
   const bool cam_has_met_wave = cam_wave && v_met0 + v < nblk * 4u;       // this camera's metric mean is solved by wave v_met0 + v
 #endif
   const uint32_t camv = met_wave ? v - v_met0 : v;                          // the camera of either role
@@ -1495,10 +1498,10 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
   unsigned epoch = 0;
   for (int it = 0; it < A.n_iters; ++it) {
     GBP_TRACE(0);
-    const bool ev_means = A.ev.on && (A.ev.each || it + 1 == A.n_iters);     // this iteration's beliefs are evaluated
+    const bool ev_means = ev_on && (A.ev.each || it + 1 == A.n_iters);     // this iteration's beliefs are evaluated
     // the metric of iteration it - 1 rides in this phase A (both only READ what phase B left): its loads go out with the
     // sweep's, its arithmetic runs behind the sweep's stores
-    const bool ev_prev = A.ev.on && A.ev.each && it > 0;
+    const bool ev_prev = ev_on && A.ev.each && it > 0;
     const int ev_packed = __float_as_int(lm[13]);      // the factor's state word as the sweep of iteration it - 1 left it
     // ================= phase A: the sweep of this wave's tile =================
     if (has_tile) {
@@ -1768,7 +1771,7 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
 #undef GBP_TRACE
 
   // ---- the metric of the last iteration: one more hand-off, then as above ----
-  if (A.ev.on) {
+  if (ev_on) {
     if (!A.ev.each && bid == 0 && threadIdx.x == 0) { A.ev.health_next[0] = 0ull; A.ev.health_next[1] = 0ull; }   // (each: both pairs end at zero by themselves)
     grid_sync(A.sync, A.epoch_base + (++epoch) * nblk, A.status, A.seq);
     float cmv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, lmu[3] = {0.f, 0.f, 0.f};
@@ -2264,7 +2267,7 @@ int persist_max_resident_blocks() {
   int dev = 0, per_cu = 0;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_persist<0>, 256, 0) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (k_persist<0, true>), 256, 0) != hipSuccess) return 0;
   return per_cu * prop.multiProcessorCount;
 }
 void launch_copy_segments(const CopySegs& t, const unsigned* guard, hipStream_t s) {
@@ -2291,18 +2294,20 @@ hipError_t launch_persist(PersistArgs A, bool cooperative, hipStream_t s) {
   static const int env_abl = std::getenv("GBP_PERSIST_ABL") ? std::atoi(std::getenv("GBP_PERSIST_ABL")) : 0;
   if (env_abl) {
     A.spread = 1;
-    if (env_abl == 256) { hipLaunchKernelGGL(k_persist<256>, dim3(nb), dim3(256), 0, s, A); return hipGetLastError(); }
-    if (env_abl == 64) { hipLaunchKernelGGL(k_persist<64>, dim3(nb), dim3(256), 0, s, A); return hipGetLastError(); }
-    if (env_abl == 768) { hipLaunchKernelGGL(k_persist<768>, dim3(nb), dim3(256), 0, s, A); return hipGetLastError(); }
+    if (env_abl == 256) { hipLaunchKernelGGL((k_persist<256, true>), dim3(nb), dim3(256), 0, s, A); return hipGetLastError(); }
+    if (env_abl == 64) { hipLaunchKernelGGL((k_persist<64, true>), dim3(nb), dim3(256), 0, s, A); return hipGetLastError(); }
+    if (env_abl == 768) { hipLaunchKernelGGL((k_persist<768, true>), dim3(nb), dim3(256), 0, s, A); return hipGetLastError(); }
   }
 #endif
   A.spread = (uint32_t)spread;
   const uint32_t grid = spread > 1 ? nb * (uint32_t)spread : spread < -1 ? ((nb + 7) / 8) * (uint32_t)(-spread) * 8 : nb;
   if (cooperative) {
     void* args[] = {&A};
-    return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_persist<0>), dim3(grid), dim3(256), args, 0, s);
+    return hipLaunchCooperativeKernel(A.ev.on ? reinterpret_cast<const void*>(k_persist<0, true>) : reinterpret_cast<const void*>(k_persist<0, false>),
+                                      dim3(grid), dim3(256), args, 0, s);
   }
-  hipLaunchKernelGGL(k_persist<0>, dim3(grid), dim3(256), 0, s, A);
+  if (A.ev.on) hipLaunchKernelGGL((k_persist<0, true>), dim3(grid), dim3(256), 0, s, A);
+  else hipLaunchKernelGGL((k_persist<0, false>), dim3(grid), dim3(256), 0, s, A);
   return hipGetLastError();
 }
 void launch_weaken(float4* prior, const float* scaling, uint32_t* flag, uint32_t n, int rec4, hipStream_t s) {
