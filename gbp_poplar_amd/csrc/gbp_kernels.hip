@@ -2285,7 +2285,7 @@ hipError_t launch_persist(PersistArgs A, bool cooperative, hipStream_t s) {
   // 2-2.7x slower and set the barrier-to-barrier time; every 2nd or 4th slot removes those outliers (fr1xyz 22.0 -> 19.3 us
   // per iteration in the traced build), every 3rd does not.
   // Workgroup b runs on XCD b % 8 (round-robin dispatch), so every spread-th workgroup lands on 8 / spread XCDs of 32 CUs:
-  // the working workgroups stay co-resident (one per CU: 340 registers per lane) only while nb <= 32 * 8 / spread.
+  // the working workgroups stay co-resident (one per CU: 256 VGPRs + 160-215 AGPRs per lane, profiles/r04_resources.md) only while nb <= 32 * 8 / spread.
   int spread = persist_spread(nb);
   A.n_work_blocks = nb;
 #ifdef GBP_BUILD_ABLATIONS
