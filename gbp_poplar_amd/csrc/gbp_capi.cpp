@@ -1194,6 +1194,14 @@ static int iterate_impl(gbp_ctx* c, int n) {
   if (!persist)
     if (int rc = settle(c)) return rc;
   const SweepArgs a = sweep_args(c);
+  if (c->stream != c->own_stream && stream_is_capturing(c)) {
+    // the caller is capturing its own stream (gbp_set_stream) into a graph: plain kernel launches only — no persistent kernel
+    // (host-computed barrier targets), no timing events that would become graph nodes, no capture of our own inside theirs
+    for (int i = 0; i < n; ++i) enqueue_iteration(c, a);
+    HIPCHK(c, hipGetLastError());
+    c->beliefs_valid = true;
+    return GBP_OK;
+  }
   gbp_ctx::Span sp{};
   if (int rc = span_begin(c, sp)) return rc;
   if (c->profile_stages) {

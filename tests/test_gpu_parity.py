@@ -1723,3 +1723,44 @@ def test_config3_slam_fr2robot2_full_run_bit_exact(oracle_mod):
     assert np.array_equal(tg[:, [0, 4, 5, 6]], to[:, [0, 4, 5, 6]])
     gold = _golden("trajectories.npz")
     _check_against_golden_trajectory(tg, ig, gold["slam_fr2robot2"], gold["slam_fr2robot2_initial"], 2e-4)   # measured 5e-5
+
+
+def test_iterations_captured_into_a_callers_graph_use_the_two_kernel_path(oracle_mod):
+    """the persistent kernel's barrier targets are launch arguments computed by the host, so a launch replayed from
+    a graph would find its barriers already passed.  While the stream a caller handed over (gbp_set_stream) is being captured,
+    gbp_iterate therefore queues plain k_sweep / k_beliefs launches: the caller's graph replays to the same state as the
+    persistent path reaches."""
+    import torch
+    from gbp_poplar_amd import driver, hostlib
+    from gbp_poplar_amd.engine import GbpEngine
+    bal = _bal("fr2robot2")
+    K, state, _ = driver.build_inputs(bal, driver.Options(), hostlib)
+
+    def make():
+        e = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K)
+        e.upload(state)
+        e.linearise()
+        e.iterate(3)
+        e.sync()
+        return e
+
+    ref, eng = make(), make()
+    assert eng.graph_state() == 2                      # small graph: bursts normally run inside k_persist
+    ref.iterate(12)
+    stream = torch.cuda.Stream()
+    eng.set_stream(stream.cuda_stream)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=stream):
+        eng.iterate(4)
+    for _ in range(3):
+        graph.replay()
+    stream.synchronize()
+    eng.set_stream(0)
+    g, o = eng.read(), ref.read()
+    for k in g:
+        assert np.array_equal(g[k], o[k], equal_nan=True), k
+    eng.iterate(5)                                     # and the ctx is back on its own stream and path afterwards
+    ref.iterate(5)
+    g, o = eng.read(), ref.read()
+    for k in g:
+        assert np.array_equal(g[k], o[k], equal_nan=True), k
