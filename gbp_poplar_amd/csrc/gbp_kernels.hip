@@ -1270,11 +1270,15 @@ GBP_DEV float4 lmsg_piece_xw(const XwBuf& lmsg, uint32_t pos, uint32_t q) {
 }
 
 constexpr unsigned long long kBarrierTimeoutTicks = 150000000ull;   // 1.5 s of the 100 MHz wall clock
-GBP_DEV void grid_sync(unsigned* sync, unsigned target /* arrivals to wait for */, unsigned* status, unsigned seq /* what a time-out writes to *status */) {
+// The hand-off in two halves, so that work which needs nothing from the other workgroups can run between the arrival and the
+// wait (the metric's residuals of the previous iteration: they then cost nothing while the arrivals are in flight).
+GBP_DEV void grid_arrive(unsigned* sync) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's write-through stores have been acknowledged
   __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+GBP_DEV void grid_wait(unsigned* sync, unsigned target /* arrivals to wait for */, unsigned* status, unsigned seq /* what a time-out writes to *status */) {
   if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned spin = 0;
     unsigned long long t0 = 0;
     while ((int)(__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {   // wrap-safe
@@ -1294,6 +1298,10 @@ GBP_DEV void grid_sync(unsigned* sync, unsigned target /* arrivals to wait for *
     }
   }
   __syncthreads();
+}
+GBP_DEV void grid_sync(unsigned* sync, unsigned target, unsigned* status, unsigned seq) {
+  grid_arrive(sync);
+  grid_wait(sync, target, status, seq);
 }
 
 // Snapshot / restore of the arrays a k_persist launch mutates (one launch for all of them): taken before every launch so that
@@ -1763,9 +1771,16 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
       if (q4 == 3) { acc.y = u1; acc.z = u2; }       // record slots 13, 14
       if (lmk_live) X_lmkb.st4(l * 4u + q4, acc);
     }
-    if (ev_prev) metric((uint32_t)it - 1u, ev_packed, ev_cm, ev_lm);     // the residuals of the PREVIOUS iteration, behind this wave's role
+    // the residuals of the PREVIOUS iteration: behind this wave's role, and — where a hand-off follows — between its arrival and
+    // its wait (they read what the previous belief phase left and the factor's own registers: nothing of this phase)
     GBP_TRACE(3);
-    if (it + 1 < A.n_iters) grid_sync(A.sync, A.epoch_base + (++epoch) * nblk, A.status, A.seq);
+    if (it + 1 < A.n_iters) {
+      grid_arrive(A.sync);
+      if (ev_prev) metric((uint32_t)it - 1u, ev_packed, ev_cm, ev_lm);
+      grid_wait(A.sync, A.epoch_base + (++epoch) * nblk, A.status, A.seq);
+    } else if (ev_prev) {
+      metric((uint32_t)it - 1u, ev_packed, ev_cm, ev_lm);
+    }
     GBP_TRACE(4);
   }
 #undef GBP_TRACE
