@@ -40,8 +40,11 @@ roofline (dominant kernel k_sweep; `kernels` carries the same figures for k_beli
   traffic / achieved_traffic    HBM bytes per launch from rocprofv3 PMC passes of this same build and workload
                                 (FETCH_SIZE, WRITE_SIZE in separate passes, read side doubled: gfx950 tallies wide
                                 streaming reads at 1/2 — MI355X_MICROARCH.md, HBM), taken LIVE by this script
-                                (rank 0, N = 1) in child processes before the parent touches the GPU; a stamped
-                                profiles/traffic_S1.json is used only if the live passes fail and its stamp matches.
+                                (rank 0, N = 1) in child processes before the parent touches the GPU.  The child replays
+                                the parent's run and the counters are averaged over the launches the parent brackets
+                                (the `--profile-steps` iterations behind the timed region), so bytes and time belong to
+                                the same launches; a third child pass gives their rocprofv3 durations (`roofline.rocprof`).
+                                A stamped profiles/traffic_S1.json is used only if the live passes fail and its stamp matches.
   frac                          achieved_traffic / peak — the physically meaningful HBM fraction (headline).
   N > 1 (and --force-sharded)   the PMC passes run on rank 0's SHARD SHAPE — the same generator with all C = 1000 N cameras
                                 and one rank's share of the landmarks, one process, before rank 0 touches its GPU — so the
@@ -99,6 +102,7 @@ def parse(argv=None):
                     help="camera ranges of the pipelined all-gather (default: 1)")
     ap.add_argument("--tile-order", type=int, default=0, help="gbp_params.tile_order: 0 = default, 1 = sequential, 2 = sweep tiles XCD-aware too")
     ap.add_argument("--master-port", type=int, default=0, help="self-launch: rendezvous port (0 = pick a free one)")
+    ap.add_argument("--graph-unroll", type=int, default=0, help="gbp_params.graph_unroll of the single-GPU ctx (0 = library default)")
     ap.add_argument("--preflight", type=int, default=1,
                     help="N > 1 (and --force-sharded), native communicator: the un-timed self-validation block (GPU identities, peer access, "
                          "librccl path/version, all-gather probe, one-stream vs two-stream schedule measured and chosen); 0 = off")
@@ -182,6 +186,13 @@ def launch_selftest(a):
 
 # ---- HBM traffic from rocprofv3 PMC passes ----------------------------------------------------------------------
 
+def extra_untimed_iterations(a, world):
+    """Iterations a run executes between its warm-up and its timed region besides the W warm-up steps (the preflight of a
+    sharded run with the library's communicator: 2 x (5 + 20))."""
+    sharded = world > 1 or a.force_sharded
+    return 50 if (sharded and a.comm == "native" and a.preflight) else 0
+
+
 def pmc_shape(a, world):
     """(cameras, landmarks) of the graph the PMC child runs: S1 itself at N = 1; at N > 1 one rank's shard shape —
     every camera of the global graph, one rank's share of the landmarks, drawn by the same generator."""
@@ -197,10 +208,12 @@ def build_stamp(a, world=1):
     return {"source_sha16": h.hexdigest()[:16], "workload": [cams, lmks, a.obs, a.seed], "tile_order": a.tile_order}
 
 
-def parse_pmc_csv(directory, counter):
-    """{kernel short name: mean counter value per dispatch} from a rocprofv3 counter_collection CSV."""
+def parse_pmc_csv(directory, counter, last=None):
+    """{kernel short name: (mean counter value per dispatch, dispatches)} from a rocprofv3 counter_collection CSV; `last`: only
+    the last `last` dispatches of each kernel (the child replays the parent's whole run: these are the launches the parent
+    brackets with hipEvents)."""
     import csv
-    agg = {}
+    per = {}
     for f in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if r.get("Counter_Name") != counter:
@@ -208,10 +221,14 @@ def parse_pmc_csv(directory, counter):
             name = r.get("Kernel_Name", "")
             for short in ("k_sweep", "k_beliefs", "k_relin"):
                 if short in name:
-                    v = agg.setdefault(short, [0, 0.0])
-                    v[0] += 1
-                    v[1] += float(r.get("Counter_Value", 0))
-    return {k: (s / n, n) for k, (n, s) in agg.items() if n}
+                    per.setdefault(short, []).append((int(r.get("Dispatch_Id", 0)), float(r.get("Counter_Value", 0))))
+    out = {}
+    for k, v in per.items():
+        v.sort()
+        if last:
+            v = v[-last:]
+        out[k] = (sum(x for _, x in v) / len(v), len(v))
+    return out
 
 
 def measure_traffic_live(a, keep_dir=None, world=1):
@@ -230,7 +247,10 @@ def measure_traffic_live(a, keep_dir=None, world=1):
     cams, lmks = pmc_shape(a, world)
     # the program after `--` is the interpreter binary itself (no PATH lookup, no shim script: a re-exec behind
     # rocprofv3 --pmc is refused on this pool)
-    child = [os.path.realpath(sys.executable), os.path.abspath(__file__), "--pmc-child", "--steps", "4", "--warmup", "12",
+    # the child replays the parent's run up to and including its profiled iterations (same flow, same iteration numbers: the
+    # launches whose counters are averaged are the launches the parent brackets — lock-step relinearising sweeps included)
+    child = [os.path.realpath(sys.executable), os.path.abspath(__file__), "--pmc-child", "--steps", str(a.profile_steps),
+             "--warmup", str(a.warmup + a.steps + extra_untimed_iterations(a, world)),
              "--cams", str(cams), "--lmks", str(lmks), "--obs", str(a.obs), "--seed", str(a.seed), "--tile-order", str(a.tile_order)]
     vals = {}
     rocprof_us = {}
@@ -242,19 +262,23 @@ def measure_traffic_live(a, keep_dir=None, world=1):
         p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
         if p.returncode == 0:
             import csv
-            for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
+            per = {}
+            for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
                     for short in ("k_sweep", "k_beliefs"):
-                        if short in r.get("Name", ""):
-                            rocprof_us[short] = {"avg_us": round(float(r["AverageNs"]) / 1e3, 2), "min_us": round(float(r["MinNs"]) / 1e3, 2),
-                                                 "max_us": round(float(r["MaxNs"]) / 1e3, 2), "calls": int(r["Calls"])}
+                        if short in r.get("Kernel_Name", ""):
+                            per.setdefault(short, []).append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+            for short, v in per.items():
+                v.sort()
+                v = [x for _, x in v[-a.profile_steps:]]
+                rocprof_us[short] = {"avg_us": round(sum(v) / len(v), 2), "min_us": round(min(v), 2), "max_us": round(max(v), 2), "calls": len(v)}
         for counter, tag in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
             d = os.path.join(tmp, tag)
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", tag, "--"] + child
             p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
             if p.returncode != 0:
                 return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (counter, p.returncode, p.stderr[-300:])
-            vals[tag] = parse_pmc_csv(d, counter)
+            vals[tag] = parse_pmc_csv(d, counter, last=a.profile_steps)
             if "k_sweep" not in vals[tag]:
                 return None, "no k_sweep dispatch in the %s pass" % counter
     except Exception as exc:       # noqa: BLE001 — the bench line must still be produced
@@ -632,7 +656,7 @@ def main(argv=None):
     opts = driver.Options()
     K, state, _ = driver.build_inputs(bal, opts, hostlib)
 
-    prm = _cabi.GbpParams.defaults(tile_order=a.tile_order)
+    prm = _cabi.GbpParams.defaults(tile_order=a.tile_order, graph_unroll=a.graph_unroll)
     if a.sharded_graph is None:
         a.sharded_graph = 0
     if sharded and a.comm == "native":
@@ -759,14 +783,16 @@ def main(argv=None):
                 "layout_bytes_per_factor": LAYOUT_BYTES_PER_FACTOR,
                 "frac_layout": round(layout / sweep_s / 1e9 / HBM_PEAK_GBS, 4),
                 "traffic_over_layout": round(tr_bytes / layout, 3) if tr_bytes else None,
+                "traffic_is": "mean over the launches the live brackets cover (a child process replays the run under rocprofv3 --pmc; lock-step "
+                              "relinearising sweeps — 840 MB instead of 614 MB — are averaged in when the window holds them)",
                 "traffic_source": traffic_src, "traffic_error": None if tr_bytes else traffic_err,
                 "avg_launch_us": round(sweep_s * 1e6, 2),
                 "avg_launch_us_is": "mean live hipEvent bracket on the kernel's stream (kernel + dependent-launch gap); `frac` is priced with it",
                 "rocprof": ({"avg_launch_us": tr["rocprof"]["avg_us"], "min_us": tr["rocprof"]["min_us"], "max_us": tr["rocprof"]["max_us"],
                              "launches": tr["rocprof"]["calls"],
                              "frac": round(tr_bytes / (tr["rocprof"]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                             "is": "rocprofv3 --kernel-trace --stats durations of a child pass of this build and workload (the first sweeps of the "
-                                   "./ba flow, lock-step launches included when the window holds one); the figure profiles/*_kernel_stats.csv carries"}
+                             "is": "rocprofv3 --kernel-trace durations of the SAME launches in a child pass (the child replays this run: the profiled "
+                                   "iterations, lock-step relinearising sweeps included where the window holds them)"}
                             if tr and tr.get("rocprof") else None),
                 "belief_kernels_avg_us": round(belief_s * 1e6, 2) if belief_s is not None else None,
                 "exchange_avg_us": round(tm.get("exchange_ms", 0.0) * 1e3 / a.profile_steps, 2) if sharded and run is eng else None,
