@@ -205,7 +205,8 @@ def build_stamp(a, world=1):
     for f in ("gbp_kernels.hip", "gbp_kernels.h", "gbp_device_math.hpp"):
         h.update(open(os.path.join(ROOT, "gbp_poplar_amd", "csrc", f), "rb").read())
     cams, lmks = pmc_shape(a, world)
-    return {"source_sha16": h.hexdigest()[:16], "workload": [cams, lmks, a.obs, a.seed], "tile_order": a.tile_order}
+    return {"source_sha16": h.hexdigest()[:16], "workload": [cams, lmks, a.obs, a.seed], "tile_order": a.tile_order,
+            "window": [a.warmup + a.steps + extra_untimed_iterations(a, world), a.profile_steps]}     # which launches the mean is over
 
 
 def parse_pmc_csv(directory, counter, last=None):

@@ -872,9 +872,14 @@ __global__ __launch_bounds__(256) void k_linearise(const SweepArgs a) {
 // and the dmu^2 pieces of the next sweep are computed here once per variable (see k_sweep<HOIST>).
 // =================================================================================================
 // float4 #q of the landmark-message record at device position pos, with the per-factor state that rides in
-// the record's pad slots (3, 13, 14, 15) blanked so that it never enters a belief sum
-GBP_DEV float4 lmsg_piece(const float4* lmsg, uint32_t pos, uint32_t q) {
-  float4 m = lmsg[(size_t)pos * 4 + q];   // default cache policy: a non-temporal hint here costs 4 us (the 128-B line's other half is a neighbour's record)
+// the record's pad slots (3, 13, 14, 15) blanked so that it never enters a belief sum.  Two steps, and the loads of a batch are
+// issued UNCONDITIONALLY (unused slots hold position 0: a valid record) before anything looks at a loaded value: written as
+// `k < deg ? load : 0` every gather became a branch with its own `s_waitcnt vmcnt(0)` at the join — ten dependent round trips
+// per wave instead of ten loads in flight (the ISA showed it; `k_persist` had hit the same thing with its sc1 loads).
+GBP_DEV float4 lmsg_load(const float4* lmsg, uint32_t pos, uint32_t q) {
+  return lmsg[(size_t)pos * 4 + q];   // default cache policy: a non-temporal hint here costs 4 us (the 128-B line's other half is a neighbour's record)
+}
+GBP_DEV float4 lmsg_blank(float4 m, uint32_t q) {
   if (q == 0) m.w = 0.f;
   if (q == 3) { m.y = 0.f; m.z = 0.f; m.w = 0.f; }
   return m;
@@ -906,7 +911,14 @@ __global__ __launch_bounds__(256) void k_beliefs(const BeliefArgs b) {
         const uint32_t c0 = b.chunk_start[ch], n_i = b.chunk_start[ch + 1] - c0;
         const float* g = b.gathered + (size_t)b.world * c0 * kCamRec + (size_t)(c - c0) * kCamRec + j;
         float acc = b.cam_prior[(size_t)c * kCamRec + j];
-        for (int r = 0; r < b.world; ++r) acc = acc + g[(size_t)r * n_i * kCamRec];
+        for (int r0 = 0; r0 < b.world; r0 += 8) {      // the partials of eight ranks in flight at once (clamped, unconditional), added in rank order
+          float v[8];
+          GBP_UNROLL
+          for (int k = 0; k < 8; ++k) v[k] = g[(size_t)(r0 + k < b.world ? r0 + k : b.world - 1) * n_i * kCamRec];
+          GBP_UNROLL
+          for (int k = 0; k < 8; ++k)
+            if (r0 + k < b.world) acc = acc + v[k];
+        }
         bel = acc;
       } else {
         const uint32_t r0 = b.cam_row_ptr[c], r1 = b.cam_row_ptr[c + 1];
@@ -923,11 +935,12 @@ __global__ __launch_bounds__(256) void k_beliefs(const BeliefArgs b) {
             GBP_UNROLL
             for (int k = 0; k < 16; ++k) acc = acc + v[k];
           }
-          {  // tail (< 16 rows) in one predicated batch as well: this chain is pure load latency
+          {  // tail (< 16 rows) in one batch as well, the loads unconditional (row clamped, value dropped: a conditional load is a
+             // branch with its own wait): this chain is pure load latency
             float v[16];
             const uint32_t m = n - r;
             GBP_UNROLL
-            for (int k = 0; k < 16; ++k) v[k] = (uint32_t)k < m ? row[(size_t)(r + k) * kCamRec] : 0.f;
+            for (int k = 0; k < 16; ++k) v[k] = row[(size_t)((uint32_t)k < m ? r + k : n - 1u) * kCamRec];
             GBP_UNROLL
             for (int k = 0; k < 16; ++k)
               if ((uint32_t)k < m) acc = acc + v[k];
@@ -991,9 +1004,13 @@ __global__ __launch_bounds__(256) void k_beliefs(const BeliefArgs b) {
   // are, so the whole sum is two dependent round trips (index record -> up to 15 message records in flight) instead
   // of four (lmk_ptr -> fpos -> 8 records -> tail).  Slots beyond 15 (rare) go through lmk_ptr / lmk_fpos.
   uint4 ix = make_uint4(0u, 0u, 0u, 0u);
+  float4 used_mu = make_float4(0.f, 0.f, 0.f, 0.f);
   if (live) {
     ix = reinterpret_cast<const uint4*>(b.lmk_ix)[(size_t)l * 4 + q];
     acc = b.lmk_prior[(size_t)l * 4 + q];
+    // the mean the last sweep used (roll: the current one becomes it) goes out with the first round of loads: fetched where it
+    // is consumed — behind the gathers — it was a third dependent round trip of every wave
+    if (b.hoist && q == 0) used_mu = b.lmk_mu[(size_t)l * 2 + (b.roll ? 0 : 1)];
   }
 #ifdef GBP_BUILD_EXPERIMENTS
   if (b.abl == 2) ix = make_uint4(live ? 10u : 0u, 0u, 0u, 0u);   // degree without waiting for the record (S1: 10 everywhere)
@@ -1014,16 +1031,20 @@ __global__ __launch_bounds__(256) void k_beliefs(const BeliefArgs b) {
     // instead of 60 staging registers (S1: k_beliefs 20.4 -> 18.8 us; profiles/r03_beliefs.md).
     float4 m[10];
     GBP_UNROLL
-    for (int k = 0; k < 10; ++k) m[k] = (uint32_t)k < deg ? lmsg_piece(b.lmsg, slot_pos(k), q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < 10; ++k) m[k] = lmsg_load(b.lmsg, slot_pos(k), q);      // all ten in flight (see lmsg_load)
     GBP_UNROLL
-    for (int k = 0; k < 10; ++k)     // adds in slot order
-      if ((uint32_t)k < deg) { acc.x = acc.x + m[k].x; acc.y = acc.y + m[k].y; acc.z = acc.z + m[k].z; acc.w = acc.w + m[k].w; }
+    for (int k = 0; k < 10; ++k) {   // adds in slot order
+      const float4 v = lmsg_blank(m[k], q);
+      if ((uint32_t)k < deg) { acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z; acc.w = acc.w + v.w; }
+    }
     if (__any(deg > 10u)) {
       GBP_UNROLL
-      for (int k = 10; k < 15; ++k) m[k - 10] = (uint32_t)k < deg ? lmsg_piece(b.lmsg, slot_pos(k), q) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int k = 10; k < 15; ++k) m[k - 10] = lmsg_load(b.lmsg, slot_pos(k), q);
       GBP_UNROLL
-      for (int k = 10; k < 15; ++k)
-        if ((uint32_t)k < deg) { acc.x = acc.x + m[k - 10].x; acc.y = acc.y + m[k - 10].y; acc.z = acc.z + m[k - 10].z; acc.w = acc.w + m[k - 10].w; }
+      for (int k = 10; k < 15; ++k) {
+        const float4 v = lmsg_blank(m[k - 10], q);
+        if ((uint32_t)k < deg) { acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z; acc.w = acc.w + v.w; }
+      }
     }
   }
   if (deg > 15u) {   // slots 16.. : positions from lmk_fpos, 8 record gathers in flight per round, adds in slot order
@@ -1033,12 +1054,14 @@ __global__ __launch_bounds__(256) void k_beliefs(const BeliefArgs b) {
       float4 m[8];
       const uint32_t nleft = s1 - s;
       GBP_UNROLL
-      for (int k = 0; k < 8; ++k) pos[k] = (uint32_t)k < nleft ? b.lmk_fpos[s + k] : 0u;
+      for (int k = 0; k < 8; ++k) pos[k] = b.lmk_fpos[(uint32_t)k < nleft ? s + k : s1 - 1u];     // clamped, unconditional
       GBP_UNROLL
-      for (int k = 0; k < 8; ++k) m[k] = (uint32_t)k < nleft ? lmsg_piece(b.lmsg, pos[k], q) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int k = 0; k < 8; ++k) m[k] = lmsg_load(b.lmsg, pos[k], q);
       GBP_UNROLL
-      for (int k = 0; k < 8; ++k)
-        if ((uint32_t)k < nleft) { acc.x = acc.x + m[k].x; acc.y = acc.y + m[k].y; acc.z = acc.z + m[k].z; acc.w = acc.w + m[k].w; }
+      for (int k = 0; k < 8; ++k) {
+        const float4 v = lmsg_blank(m[k], q);
+        if ((uint32_t)k < nleft) { acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z; acc.w = acc.w + v.w; }
+      }
     }
   }
   if (b.hoist) {
@@ -1063,8 +1086,8 @@ __global__ __launch_bounds__(256) void k_beliefs(const BeliefArgs b) {
         x0l[i] = a2;
       }
       float4* mu = b.lmk_mu + (size_t)l * 2;  // [0] = mean of the current belief, [1] = mean the last sweep used
-      float4 used = mu[1];
-      if (b.roll) { used = mu[0]; mu[1] = used; }
+      const float4 used = used_mu;
+      if (b.roll) mu[1] = used;
       u[0] = (used.x - x0l[0]) * (used.x - x0l[0]);
       u[1] = (used.y - x0l[1]) * (used.y - x0l[1]);
       u[2] = (used.z - x0l[2]) * (used.z - x0l[2]);
