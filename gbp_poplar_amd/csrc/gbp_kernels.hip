@@ -1464,7 +1464,10 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
   // single round of loads; slots beyond 30 go through lmk_fpos every iteration
   uint32_t pos2[15];
   GBP_UNROLL
-  for (int k = 0; k < 15; ++k) pos2[k] = (lmk_live && 15u + (uint32_t)k < deg) ? b.lmk_fpos[lp0 + 15u + (uint32_t)k] : 0u;
+  for (int k = 0; k < 15; ++k) {   // unconditional loads (slot clamped, value dropped): fifteen conditional ones were fifteen round trips per launch
+    const uint32_t p2 = b.lmk_fpos[lp0 + (15u + (uint32_t)k < deg ? 15u + (uint32_t)k : 0u)];
+    pos2[k] = (lmk_live && 15u + (uint32_t)k < deg) ? p2 : 0u;
+  }
 
   // ---- the metric (gbp_iterate_eval / gbp_iterate_eval_each): what k_means + k_eval compute, same bits.  The belief owners
   // write the metric means in phase B; after the next device-wide hand-off every tile wave adds its factors' residuals and the
@@ -1744,7 +1747,7 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
           float4 m[8];
           const uint32_t nleft = lp1 - s;
           GBP_UNROLL
-          for (int k = 0; k < 8; ++k) ps[k] = (uint32_t)k < nleft ? b.lmk_fpos[s + k] : 0u;
+          for (int k = 0; k < 8; ++k) ps[k] = b.lmk_fpos[(uint32_t)k < nleft ? s + k : lp1 - 1u];     // clamped, unconditional
           GBP_UNROLL
           for (int k = 0; k < 8; ++k) m[k] = lmsg_piece_xw(X_lmsg, ps[k], q4);
           GBP_UNROLL
