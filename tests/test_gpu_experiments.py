@@ -68,10 +68,13 @@ def make(**kw):
     return e
 def flow(e):
     out = []
-    e.iterate(20)                                   # mode 0: a plain burst
-    e.iterate_eval(15); out.append(e.eval_end())    # mode 1: burst + metric in one launch
+    steps = {"plain": lambda: e.iterate(20),                                        # mode 0: a plain burst
+             "eval": lambda: (e.iterate_eval(15), out.append(e.eval_end())),        # mode 1: burst + metric in one launch
+             "each": lambda: out.extend(e.iterate_eval_each(12))}                   # mode 2: the metric after every iteration (blocking)
+    order = {"plain": ("plain", "eval", "each"), "eval": ("eval", "each", "plain"), "each": ("each", "plain", "eval")}[%(first)r]
+    for k in order:                                 # the FIRST of them is the launch that times out / is refused
+        steps[k]()
     e.iterate(7); e.iterate(5)                      # two bursts in flight behind each other
-    out += e.iterate_eval_each(12)                  # mode 2: the metric after every iteration (blocking)
     e.sync()
     return out, e.read()
 ref = make(persistent=-1)                            # the two-kernel path
@@ -93,20 +96,21 @@ print('RECOVERED %%.1f s graph_state_after_upload %%d :: %%s' %% (dt, eng.graph_
 
 
 @pytest.mark.skipif(not _exp_lib_present(), reason="experiments build absent (python -m gbp_poplar_amd.build --experiments)")
-@pytest.mark.parametrize("coop", [0, 1])
-def test_persistent_kernel_time_out_is_recovered(coop):
+@pytest.mark.parametrize("coop,first", [(0, "plain"), (0, "eval"), (0, "each"), (1, "plain")])
+def test_persistent_kernel_time_out_is_recovered(coop, first):
     """A k_persist launch whose workgroups can NOT all be resident (forced: every 8th dispatch slot = one XCD = 32 CUs for the
     52 workgroups of fr1xyz; experiments build) must not hang and must not lose the run:
       * plain launch (persist_coop = 0, the default): the barrier gives up after 1.5 s, later launches return at once, the library restores
         the snapshot taken before the failed launch and replays the bursts on the two-kernel path;
       * cooperative launch (persist_coop = 1): the runtime refuses the grid before anything runs, same fallback.
+    The launch that fails is a plain burst, a burst with the metric at its end, or an every-iteration burst (`first`).
     Either way: rc 0 everywhere, every belief / damping / counter and every metric equal to the two-kernel path's, a warning in
     gbp_last_error, and the persistent path back after the next gbp_upload."""
     import subprocess
     import sys
     import time
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = _RECOVERY_CODE % {"root": root, "seq": seq_path("fr1xyz"), "coop": coop}
+    code = _RECOVERY_CODE % {"root": root, "seq": seq_path("fr1xyz"), "coop": coop, "first": first}
     env = dict(os.environ, GBP_PERSIST_SPREAD="8")
     t0 = time.time()
     p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=180)
