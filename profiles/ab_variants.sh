@@ -1,5 +1,6 @@
 #!/bin/bash
-# A/B of product-library variants through the CLIs (same box, same run): profiles/_bin/<variant>/libgbp_mi355x.so
+# A/B of product-library variants through the CLIs (same box, same run, alternating): profiles/_bin/<variant>/libgbp_mi355x.so built by
+# profiles/build_variant.sh; VARIANTS="default rows3 ..." bash profiles/ab_variants.sh <tag>  -> gpurun_out/<tag>/run.log
 TAG=${1:-r04d}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/$TAG
