@@ -76,6 +76,7 @@ _SIGS = {
                                      cabi.c_f32p, cabi.c_f32p]),
     "gbp_init_add_noise": (C.c_int, [C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_uint64, cabi.c_f32p, cabi.c_f32p]),
     "gbp_init_av_depth": (C.c_int, [C.POINTER(cabi.GbpProblem), cabi.c_f32p, cabi.c_f32p]),
+    "gbp_tile_order_local": (C.c_int, [C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32, cabi.c_u32p]),
     "gbp_slam_create_flags": (C.c_int, [C.POINTER(cabi.GbpProblem), C.c_uint32] + [cabi.c_u32p] * 4),
     "gbp_slam_update_flags": (C.c_int, [C.POINTER(cabi.GbpProblem), C.c_uint32, C.c_uint32] + [cabi.c_u32p] * 4
                               + [cabi.c_i32p]),

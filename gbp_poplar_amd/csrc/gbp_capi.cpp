@@ -542,22 +542,12 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
         cls[t] = (uint8_t)std::min<uint64_t>(7u, (uint64_t)l[n / 2] * 8u / std::max<uint32_t>(c->L_loc, 1u));
       }
     }
-    const uint32_t window = 96;                   // tiles: about six cameras of the 1M-factor graph
+#ifndef GBP_TILE_WINDOW
+#define GBP_TILE_WINDOW 96
+#endif
+    const uint32_t window = GBP_TILE_WINDOW;      // tiles: about six cameras of the 1M-factor graph (32 / 48 / 192 measured: no difference, profiles/r04_tile_order.md)
     std::vector<uint32_t> perm(nt);
-    std::vector<uint8_t> placed(nt, 0);
-    std::vector<uint32_t> next_of_class(9, 0);    // per class: where to continue looking
-    uint32_t oldest = 0;
-    for (uint32_t slot = 0; slot < nt; ++slot) {
-      while (oldest < nt && placed[oldest]) ++oldest;
-      const uint32_t want = (slot / 4) % 8;
-      uint32_t& cur = next_of_class[want];
-      if (cur < oldest) cur = oldest;
-      while (cur < nt && cur < oldest + window && (placed[cur] || cls[cur] != want)) ++cur;
-      uint32_t pick = oldest;
-      if (cur < nt && cur < oldest + window && !placed[cur] && cls[cur] == want) pick = cur;
-      perm[slot] = pick;
-      placed[pick] = 1;
-    }
+    (void)gbp_tile_order_local(cls.data(), nt, window, perm.data());     // host helper (gbp_host.cpp): a bijection, tested on the CPU
     rc = dev_alloc(c, c->tile_perm, (size_t)nt * 4);
     if (rc == GBP_OK) CK(hipMemcpy(c->tile_perm.p, perm.data(), (size_t)nt * 4, hipMemcpyHostToDevice), "copy tile_perm");
     else g_create_error = c->err;

@@ -182,3 +182,12 @@ def eval_host(cam_id, lmk_id, n_cams, n_lmks, K9, active, meas, cbe, cbl, lbe, l
     _chk(lib.gbp_eval_host(C.byref(p), cabi.ptr(a, cabi.c_u32p), *[cabi.ptr(x, cabi.c_f32p) for x in arrs],
                            C.byref(sn), C.byref(sh), C.byref(na)), "gbp_eval_host")
     return sn.value, sh.value, na.value
+
+
+def tile_order_local(tile_class, window=96):
+    """perm[wave slot] = tile of the local XCD-aware sweep order (gbp_params.tile_order = 3) for tiles of the given classes 0..7."""
+    cls = np.ascontiguousarray(tile_class, np.uint8)
+    perm = np.zeros(cls.size, np.uint32)
+    _chk(load().gbp_tile_order_local(cls.ctypes.data_as(C.POINTER(C.c_uint8)), cls.size, int(window), cabi.ptr(perm, cabi.c_u32p)),
+         "gbp_tile_order_local")
+    return perm

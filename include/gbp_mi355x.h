@@ -345,6 +345,11 @@ int gbp_prior_scalings(uint32_t n_cams, uint32_t n_lmks, const float* cam_priors
 int gbp_init_add_noise(uint32_t n_cams, uint32_t n_lmks, float trans_std, float rot_std_deg, float lmk_std,
                        uint64_t seed, float* cam_mean /*[6C] in/out*/, float* lmk_mean /*[3L] in/out*/);
 int gbp_init_av_depth(const gbp_problem* problem, const float* cam_mean /*[6C]*/, float* lmk_mean /*[3L] out*/);
+/* The local XCD-aware execution order of the sweep (gbp_params.tile_order = 3), as a pure function of the tiles' landmark
+ * classes (0..7): perm[wave slot] = tile.  What gbp_create builds internally; exported so that the construction — a
+ * bijection that keeps every tile within `window` + 32 slots of its sequential place — can be tested without a device.  No reference counterpart
+ * (Poplar places vertices on tiles explicitly, ba.cpp:243-366). */
+int gbp_tile_order_local(const uint8_t* tile_class /*[n_tiles]*/, uint32_t n_tiles, uint32_t window, uint32_t* perm /*[n_tiles]*/);
 /* SLAM flag bookkeeping (dataio.cpp:455-475, 477-508).  update returns n_new_lmks via out. */
 int gbp_slam_create_flags(const gbp_problem* problem, uint32_t steps, uint32_t* active_flag,
                           uint32_t* cam_weaken_flag, uint32_t* lmk_weaken_flag,

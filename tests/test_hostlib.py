@@ -366,3 +366,29 @@ def test_belief_means_solve_the_information_form():
     le = np.einsum("lij,lj->li", ll, lmk_mu)
     cams, pts = hostlib.belief_means(C, L, ce.ravel(), cl.ravel(), le.ravel(), ll.ravel())
     assert cams.dtype == np.float64 and np.allclose(cams.reshape(C, 6), cam_mu, atol=2e-5) and np.allclose(pts.reshape(L, 3), lmk_mu, atol=2e-5)
+
+
+def test_local_tile_order_is_a_bounded_bijection():
+    """gbp_tile_order_local (the XCD-aware sweep order, gbp_params.tile_order = 3): every tile exactly once; no tile runs more
+    than `window` slots away from its place in the sequential order; on camera-major classes (a camera's 16 tiles walk through
+    the 8 landmark octiles, as on the 1M-factor graph) nearly every wave slot gets a tile of its workgroup's XCD class; on
+    adversarial classes (all tiles of one class) it degenerates to the sequential order."""
+    from gbp_poplar_amd import hostlib
+    rng = np.random.default_rng(3)
+    n = 16 * 1000 + 7                                            # not a multiple of anything
+    cls = ((np.arange(n) % 16) // 2).astype(np.uint8)            # 0 0 1 1 ... 7 7 per "camera"
+    jitter = rng.random(n) < 0.1                                  # 10 % of the tiles straddle into a neighbouring octile
+    cls[jitter] = (cls[jitter] + rng.integers(0, 2, jitter.sum()) * 2 - 1) % 8
+    for window in (8, 32, 96, 500):
+        perm = hostlib.tile_order_local(cls, window)
+        assert np.array_equal(np.sort(perm), np.arange(n)), window
+        slot = np.arange(n)
+        assert np.max(np.abs(perm.astype(np.int64) - slot)) <= window + 32, window      # (+ 32: the oldest tile waits for the next workgroup of its class)
+        want = (slot // 4) % 8
+        hit = (cls[perm] == want).mean()
+        assert hit > (0.85 if window >= 32 else 0.3), (window, hit)
+    same = np.zeros(n, np.uint8)
+    perm = hostlib.tile_order_local(same, 96)
+    assert np.array_equal(np.sort(perm), np.arange(n))
+    assert np.max(np.abs(perm.astype(np.int64) - np.arange(n))) <= 96 + 32
+    assert np.array_equal(hostlib.tile_order_local(np.zeros(0, np.uint8)), np.zeros(0, np.uint32))
