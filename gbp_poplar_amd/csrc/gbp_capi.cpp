@@ -537,6 +537,9 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
         const size_t p = (size_t)t * kTile + i;
         if (c->pos_edge[p] != ~0u) l[n++] = c->pos_lmk_loc[p];
       }
+#ifdef GBP_TILE_IDENTITY       // (measurement build only: what does the table look-up itself cost?  all tiles of one class -> identity)
+      n = 0; cls[t] = 0;
+#endif
       if (n) {
         std::nth_element(l, l + n / 2, l + n);
         cls[t] = (uint8_t)std::min<uint64_t>(7u, (uint64_t)l[n / 2] * 8u / std::max<uint32_t>(c->L_loc, 1u));
