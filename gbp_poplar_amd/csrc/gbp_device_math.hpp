@@ -15,6 +15,17 @@ namespace gbpdev {
 #define GBP_UNROLL _Pragma("unroll")
 #define GBP_DEV __device__ __forceinline__
 
+// SLP fence: an empty asm the value passes through (no instruction).  hipcc's SLP vectoriser pairs independent fp32 adds /
+// multiplies into v_pk_* instructions and prices the register shuffles that build the operand pairs at nothing; where the
+// operands come from differently laid-out records (a packed triangle against a full matrix) it spends up to four v_mov on
+// one saved add.  The fence ends the vectoriser's tree at this value, so the arithmetic that feeds it stays scalar
+// (measured per site with the executed-instruction counters, profiles/r04_alu_diet.md).
+#ifdef GBP_NO_SLP_FENCE
+#define GBP_SLP_FENCE(x) do { } while (0)
+#else
+#define GBP_SLP_FENCE(x) asm("" : "+v"(x))
+#endif
+
 // packed lower-triangle index, i >= j
 GBP_DEV constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }
 GBP_DEV constexpr int trisym(int i, int j) { return i >= j ? tri(i, j) : tri(j, i); }
@@ -45,12 +56,17 @@ GBP_DEV void div_shared(const float (&v)[N], float m, float (&q)[N]) {
     q[i] = (float)((double)v[i] * r);
     redo |= (__builtin_fabsf(q[i]) < 1.17549435e-38f) != (v[i] == 0.f);
   }
-  if (redo) {
+  // The slow path behind a WAVE-UNIFORM test: a per-lane `if (redo)` over nine divisions is small enough for the compiler to
+  // if-convert — both paths evaluated by every lane, the 9 x 11 instructions of the IEEE divisions thrown away by selects
+  // (measured: 15 divisions executed per ordinary sweep wave instead of 6, profiles/r04_alu_diet.md).
+  if (__builtin_amdgcn_ballot_w64(redo) != 0ull) {
+    if (redo) {
 #ifdef GBP_BUILD_EXPERIMENTS
-    atomicAdd(&g_div_redo[N == 54 ? 0 : N == 9 ? 1 : 2], 1ull);   // how often does the slow path run? (profiles/persist_trace.py)
+      atomicAdd(&g_div_redo[N == 54 ? 0 : N == 9 ? 1 : 2], 1ull);   // how often does the slow path run? (profiles/persist_trace.py)
 #endif
-    GBP_UNROLL
-    for (int i = 0; i < N; ++i) q[i] = v[i] / m;
+      GBP_UNROLL
+      for (int i = 0; i < N; ++i) q[i] = v[i] / m;
+    }
   }
 }
 
@@ -79,6 +95,9 @@ GBP_DEV void ldl6_lower(AF&& A, float (&rD)[6], float (&Ui)[6][6]) {
     float d = A(j, j);
     GBP_UNROLL
     for (int k = 0; k < j; ++k) d -= U[k][j] * U[k][j] * D[k];
+#ifdef F_D
+    GBP_SLP_FENCE(d);
+#endif
     D[j] = d;
     rD[j] = 1 / d;
     GBP_UNROLL
@@ -86,6 +105,9 @@ GBP_DEV void ldl6_lower(AF&& A, float (&rD)[6], float (&Ui)[6][6]) {
       float u = rD[j] * A(i, j);
       GBP_UNROLL
       for (int k = 0; k < j; ++k) u -= rD[j] * U[k][i] * U[k][j] * D[k];
+#ifdef F_U
+      GBP_SLP_FENCE(u);
+#endif
       U[j][i] = u;
     }
   }
@@ -97,6 +119,9 @@ GBP_DEV void ldl6_lower(AF&& A, float (&rD)[6], float (&Ui)[6][6]) {
       acc += U[i][j];  // k = i: LTinv(i,i) * LT(i,j) = 1 * LT(i,j)
       GBP_UNROLL
       for (int k = i + 1; k < j; ++k) acc += Ui[i][k] * U[k][j];
+#ifdef F_UI
+      GBP_SLP_FENCE(acc);
+#endif
       Ui[i][j] = acc / -1.f;   // Ui[i][j], j > i : LTinv(i,j)
     }
   }
@@ -120,7 +145,12 @@ GBP_DEV void inv6x6_lower(const float (&A)[21], float (&Ainv)[36]) {
   GBP_UNROLL
   for (int i = 0; i < 6; ++i) {
     GBP_UNROLL
-    for (int j = 0; j < 6; ++j) Ainv[i * 6 + j] = inv6_entry(rD, Ui, i, j);
+    for (int j = 0; j < 6; ++j) {
+      Ainv[i * 6 + j] = inv6_entry(rD, Ui, i, j);
+#ifdef F_AINV
+      GBP_SLP_FENCE(Ainv[i * 6 + j]);
+#endif
+    }
   }
 }
 // inf2mean6x6 (bafuncs.cpp:2-9) without materialising the inverse: x = A^-1 eta, every entry of A^-1 and every partial sum

@@ -68,6 +68,110 @@ GBP_DEV float row16_sum(float x) {
   return x;
 }
 
+// The 44-float ROWP record of every 16-lane row of a tile: the sums of the camera messages (6 eta + 36 Lambda entries, two
+// pad slots) over the row's 16 factors, each the balanced binary tree in lane order of row16_sum, handed to `st(g, float4)`
+// (float4 group g of the row's record) by the lanes that end up holding them.
+//
+// row16_sum leaves all 42 sums in all 16 lanes — 4 x 42 tree nodes, each evaluated by sixteen lanes, as v_mov_b32_dpp +
+// (packed) v_add: 252 instructions.  Here a node is ONE v_add_f32 with a DPP operand, and the two intra-quad steps HALVE the
+// set a lane carries (lane%4 = q ends up with the float4 groups g = q, q+4, q+8 of the record): the partners of a step keep
+// different halves, each sends the half the other keeps (two selects per pair of values), so the steps cost 60 + 36 + 12 +
+// 12 = 120 instructions and the record leaves in three stores of 64 contiguous bytes per row (lanes 12..15) instead of
+// eleven 16-byte ones (lane 0).  Every node adds the same two operands as row16_sum's (own + partner, commutative): the
+// same bits.
+//   step 1 (lane ^ 1): even lanes keep groups {0,2} mod 4, odd lanes groups {1,3} mod 4      -> t[2k], t[2k+1]
+//   step 2 (lane ^ 2): lane%4 in {0,1} keep t[2k] (groups 4j, 4j+1), {2,3} keep t[2k+1]      -> u[k], k = 4j + component
+//   steps 3, 4: row_shr:4 then row_shr:8 — quad 1 = Q0+Q1 and quad 3 = Q2+Q3, then quad 3 = (Q0+Q1)+(Q2+Q3)
+// A DPP operand must have been written >= 2 instructions earlier and inline asm is invisible to the hazard recogniser:
+// the DPP adds go in blocks of <= 6 behind one s_nop, reading only registers produced before their block (a copy or
+// AGPR read-back the register allocator might place in front of a block is covered by the nop as well).  Call with every
+// lane of the wave active.
+#define GBP_DPP6(ctrl, o, s0, s1)                                                                                         \
+  asm volatile("s_nop 1\n\t"                                                                                              \
+               "v_add_f32_dpp %0, %6, %12 " ctrl "\n\tv_add_f32_dpp %1, %7, %13 " ctrl "\n\tv_add_f32_dpp %2, %8, %14 " ctrl "\n\t" \
+               "v_add_f32_dpp %3, %9, %15 " ctrl "\n\tv_add_f32_dpp %4, %10, %16 " ctrl "\n\tv_add_f32_dpp %5, %11, %17 " ctrl      \
+               : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5])                              \
+               : "v"(s0[0]), "v"(s0[1]), "v"(s0[2]), "v"(s0[3]), "v"(s0[4]), "v"(s0[5]),                                   \
+                 "v"(s1[0]), "v"(s1[1]), "v"(s1[2]), "v"(s1[3]), "v"(s1[4]), "v"(s1[5]))
+#define GBP_DPP_QP1 "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+#define GBP_DPP_QP2 "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+#define GBP_DPP_SHR4 "row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+#define GBP_DPP_SHR8 "row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+template <class Store>
+GBP_DEV void row16_sums_store(const float (&oc_eta)[6], const float (&oc_lam)[36], const uint32_t lane, Store&& st) {
+  float x[48];      // the record's slots as this lane's terms (6, 7: pads; 44..47: the group that does not exist)
+  GBP_UNROLL
+  for (int i = 0; i < 6; ++i) x[i] = oc_eta[i];
+  GBP_UNROLL
+  for (int i = 0; i < 36; ++i) x[8 + i] = oc_lam[i];
+  x[6] = x[2]; x[7] = x[3];                      // (any defined value: what the pad / missing slots sum to is never stored)
+  GBP_UNROLL
+  for (int c = 0; c < 4; ++c) x[44 + c] = x[40 + c];
+  const bool odd = (lane & 1u) != 0, hi = (lane & 2u) != 0;
+  float t[24], u[12], w[12], r[12];
+  {  // step 1: t[m], m = 2k + h, pairs the groups 4j + 2h (kept by even lanes) and 4j + 2h + 1 (kept by odd lanes)
+    float keep[24], send[24];
+    GBP_UNROLL
+    for (int m = 0; m < 24; ++m) {
+      const int k = m / 2, h = m % 2, j = k / 4, c = k % 4;
+      const float a = x[4 * (4 * j + 2 * h) + c], b = x[4 * (4 * j + 2 * h + 1) + c];
+      keep[m] = odd ? b : a;
+      send[m] = odd ? a : b;
+    }
+    GBP_UNROLL
+    for (int m = 0; m < 24; m += 6) {
+      float o[6], s0[6], s1[6];
+      GBP_UNROLL
+      for (int i = 0; i < 6; ++i) { s0[i] = send[m + i]; s1[i] = keep[m + i]; }
+      GBP_DPP6(GBP_DPP_QP1, o, s0, s1);
+      GBP_UNROLL
+      for (int i = 0; i < 6; ++i) t[m + i] = o[i];
+    }
+  }
+  {  // step 2
+    float keep[12], send[12];
+    GBP_UNROLL
+    for (int k = 0; k < 12; ++k) {
+      keep[k] = hi ? t[2 * k + 1] : t[2 * k];
+      send[k] = hi ? t[2 * k] : t[2 * k + 1];
+    }
+    GBP_UNROLL
+    for (int k = 0; k < 12; k += 6) {
+      float o[6], s0[6], s1[6];
+      GBP_UNROLL
+      for (int i = 0; i < 6; ++i) { s0[i] = send[k + i]; s1[i] = keep[k + i]; }
+      GBP_DPP6(GBP_DPP_QP2, o, s0, s1);
+      GBP_UNROLL
+      for (int i = 0; i < 6; ++i) u[k + i] = o[i];
+    }
+  }
+  GBP_UNROLL
+  for (int k = 0; k < 12; k += 6) {   // step 3: lanes 4..7 <- 0..3, 12..15 <- 8..11
+    float o[6], s0[6];
+    GBP_UNROLL
+    for (int i = 0; i < 6; ++i) s0[i] = u[k + i];
+    GBP_DPP6(GBP_DPP_SHR4, o, s0, s0);
+    GBP_UNROLL
+    for (int i = 0; i < 6; ++i) w[k + i] = o[i];
+  }
+  GBP_UNROLL
+  for (int k = 0; k < 12; k += 6) {   // step 4: lanes 12..15 <- 4..7
+    float o[6], s0[6];
+    GBP_UNROLL
+    for (int i = 0; i < 6; ++i) s0[i] = w[k + i];
+    GBP_DPP6(GBP_DPP_SHR8, o, s0, s0);
+    GBP_UNROLL
+    for (int i = 0; i < 6; ++i) r[k + i] = o[i];
+  }
+  if ((lane & 12u) == 12u) {
+    const uint32_t q = lane & 3u;
+    if (q == 1u) { r[2] = 0.f; r[3] = 0.f; }      // the pad slots of group 1
+    GBP_UNROLL
+    for (int j = 0; j < 3; ++j)
+      if (j < 2 || q < 3u) st(q + 4u * (uint32_t)j, make_float4(r[4 * j], r[4 * j + 1], r[4 * j + 2], r[4 * j + 3]));
+  }
+}
+
 // belief means: inf2mean6x6 / inf2mean3x3 (bafuncs.cpp:2-15) on CAMB / LMKB records
 GBP_DEV void belief_means(const float (&cb)[44], const float (&lb)[16], float (&x0c)[6], float (&x0l)[3]) {
   float Al[21], S6[36], B[9], S3[9];
@@ -192,14 +296,17 @@ GBP_DEV void factor_update(float (&fac)[56], const float (&cm)[28], float (&mu)[
                            const float (&lb)[16], const float (&K)[9], const Hyper& hp, float& damping, int& count, uint32_t& flags,
                            const float var, const bool active, float (&oc_eta)[6], float (&oc_lam)[36], float (&ol)[16], bool& relin,
                            Means&& means) {
+  relin = false;
+#ifdef GBP_ZERO_INIT_FIRST       // measurement: the outputs zeroed in front of the branch
   GBP_UNROLL
   for (int i = 0; i < 6; ++i) oc_eta[i] = 0.f;
   GBP_UNROLL
   for (int i = 0; i < 36; ++i) oc_lam[i] = 0.f;
   GBP_UNROLL
   for (int i = 0; i < 16; ++i) ol[i] = 0.f;
-  relin = false;
-
+#endif
+  // (zero messages of an inactive factor are written in the ELSE branch at the bottom: 58 v_mov the wavefronts of a graph
+  // with every factor active never execute, instead of an initialisation in front of the branch that all of them do)
   if (ABL & 4) {  // keep every load alive, no algebra
     GBP_UNROLL
     for (int i = 0; i < 16; ++i) ol[i] = lm[i] + lb[i];
@@ -207,8 +314,8 @@ GBP_DEV void factor_update(float (&fac)[56], const float (&cm)[28], float (&mu)[
     for (int i = 0; i < 6; ++i) oc_eta[i] = cm[i] + fac[i];
     GBP_UNROLL
     for (int i = 0; i < 36; ++i) oc_lam[i] = fac[9 + i] + cb[8 + i] + cm[6 + (i % 21)];
-  }
-  if (active && !(ABL & 4)) {
+  } else if (active) {
+    ol[3] = 0.f; ol[13] = 0.f; ol[14] = 0.f; ol[15] = 0.f;      // (3, 13, 14: the caller's per-factor scalars)
     // ---- PrepMessageVertex, gbp_codelets.cpp:241-378 ----
     if (0 == count) damping = hp.maxeta_damping;
     count += 1;
@@ -274,6 +381,7 @@ GBP_DEV void factor_update(float (&fac)[56], const float (&cm)[28], float (&mu)[
         for (int j = 0; j <= i; ++j) {
           float t = fac[9 + tri(i, j)] + cb[8 + i * 6 + j];
           t = t - cm[6 + tri(i, j)];
+          GBP_SLP_FENCE(t);
           Ap[tri(i, j)] = t;
         }
       }
@@ -285,6 +393,9 @@ GBP_DEV void factor_update(float (&fac)[56], const float (&cm)[28], float (&mu)[
           float acc = 0.f;
           GBP_UNROLL
           for (int k = 0; k < 6; ++k) acc += fac[30 + k * 3 + i] * Ainv[k * 6 + j];  // Lambda_lc(i,k) = Lambda_cl(k,i)
+#ifdef F_G
+          GBP_SLP_FENCE(acc);
+#endif
           G[i * 6 + j] = acc;
         }
       }
@@ -308,6 +419,9 @@ GBP_DEV void factor_update(float (&fac)[56], const float (&cm)[28], float (&mu)[
           float t = 0.f;
           GBP_UNROLL
           for (int k = 0; k < 6; ++k) t += G[i * 6 + k] * fac[30 + k * 3 + j];
+#ifdef F_OL
+          GBP_SLP_FENCE(t);
+#endif
           ol[4 + i * 3 + j] = fac[48 + trisym(i, j)] - t;
         }
       }
@@ -320,7 +434,11 @@ GBP_DEV void factor_update(float (&fac)[56], const float (&cm)[28], float (&mu)[
         GBP_UNROLL
         for (int j = 0; j < 3; ++j) {
           float t = fac[48 + trisym(i, j)] + lb[4 + i * 3 + j];
-          Bp[i * 3 + j] = t - lm[4 + i * 3 + j];
+          t = t - lm[4 + i * 3 + j];
+#ifdef F_BP
+          GBP_SLP_FENCE(t);
+#endif
+          Bp[i * 3 + j] = t;
         }
       }
       inv3x3(Bp, Bi);
@@ -347,6 +465,28 @@ GBP_DEV void factor_update(float (&fac)[56], const float (&cm)[28], float (&mu)[
         const float h = fac[i] - s;
         oc_eta[i] = h * omd + cm[i] * damping;
       }
+#ifdef GBP_PK_OCLAM
+      {  // the same sums, two columns (j, j+1) per packed instruction: Lambda_cl gathered once as column pairs
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        v2f LT[3][3];
+        GBP_UNROLL
+        for (int k = 0; k < 3; ++k) {
+          GBP_UNROLL
+          for (int jp = 0; jp < 3; ++jp) LT[k][jp] = (v2f){fac[30 + (2 * jp) * 3 + k], fac[30 + (2 * jp + 1) * 3 + k]};
+        }
+        GBP_UNROLL
+        for (int i = 0; i < 6; ++i) {
+          GBP_UNROLL
+          for (int jp = 0; jp < 3; ++jp) {
+            v2f t = (v2f){0.f, 0.f};
+            GBP_UNROLL
+            for (int k = 0; k < 3; ++k) t = t + (v2f){G2[i * 3 + k], G2[i * 3 + k]} * LT[k][jp];
+            oc_lam[i * 6 + 2 * jp] = fac[9 + trisym(i, 2 * jp)] - t.x;
+            oc_lam[i * 6 + 2 * jp + 1] = fac[9 + trisym(i, 2 * jp + 1)] - t.y;
+          }
+        }
+      }
+#else
       GBP_UNROLL
       for (int i = 0; i < 6; ++i) {
         GBP_UNROLL
@@ -354,10 +494,26 @@ GBP_DEV void factor_update(float (&fac)[56], const float (&cm)[28], float (&mu)[
           float t = 0.f;
           GBP_UNROLL
           for (int k = 0; k < 3; ++k) t += G2[i * 3 + k] * fac[30 + j * 3 + k];  // Lambda_lc(k,j) = Lambda_cl(j,k)
+#ifdef F_OCLAM
+          GBP_SLP_FENCE(t);
+#endif
           oc_lam[i * 6 + j] = fac[9 + trisym(i, j)] - t;
+#ifdef F_OCLAM2
+          GBP_SLP_FENCE(oc_lam[i * 6 + j]);
+#endif
         }
       }
+#endif
     }
+  } else {
+#ifndef GBP_ZERO_INIT_FIRST
+    GBP_UNROLL
+    for (int i = 0; i < 6; ++i) oc_eta[i] = 0.f;
+    GBP_UNROLL
+    for (int i = 0; i < 36; ++i) oc_lam[i] = 0.f;
+    GBP_UNROLL
+    for (int i = 0; i < 16; ++i) ol[i] = 0.f;
+#endif
   }
 }
 
@@ -508,6 +664,7 @@ GBP_DEV void sweep_tile(const SweepArgs& a, const uint32_t wslot) {
   }
   // camera half of the belief reduction: per-row (16 factors of one camera) tree sums
   {
+#ifdef GBP_ROWSUM_PLAIN      // measurement: the 4 x 42-node butterfly of row16_sum, record stored by lane 0 of the row
     float rs[44];
     GBP_UNROLL
     for (int i = 0; i < 6; ++i) rs[i] = row16_sum(oc_eta[i]);
@@ -519,6 +676,10 @@ GBP_DEV void sweep_tile(const SweepArgs& a, const uint32_t wslot) {
       GBP_UNROLL
       for (int g = 0; g < kCamRec4; ++g) rp[g] = make_float4(rs[4 * g], rs[4 * g + 1], rs[4 * g + 2], rs[4 * g + 3]);
     }
+#else
+    float4* rp = a.rowp + (size_t)(p >> 4) * kCamRec4;
+    row16_sums_store(oc_eta, oc_lam, lane, [&](uint32_t g, float4 v) { rp[g] = v; });
+#endif
   }
   if (active) {
     if (!HOIST) store_tile<kMuG>(a.mu, tile, lane, mu);
@@ -1606,6 +1767,8 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
       }
       cm[27] = 0.f;
       {  // camera half of the belief reduction: per-row tree sums, as in k_sweep
+        const uint32_t rp4 = (p >> 4) * (uint32_t)kCamRec4;
+#ifdef GBP_ROWSUM_PLAIN
         float rs[44];
         GBP_UNROLL
         for (int i = 0; i < 6; ++i) rs[i] = row16_sum(oc_eta[i]);
@@ -1613,10 +1776,12 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
         GBP_UNROLL
         for (int i = 0; i < 36; ++i) rs[8 + i] = row16_sum(oc_lam[i]);
         if ((lane & 15) == 0) {
-          const uint32_t rp4 = (p >> 4) * (uint32_t)kCamRec4;
           GBP_UNROLL
           for (int g = 0; g < kCamRec4; ++g) X_rowp.st4(rp4 + (uint32_t)g, make_float4(rs[4 * g], rs[4 * g + 1], rs[4 * g + 2], rs[4 * g + 3]));
         }
+#else
+        row16_sums_store(oc_eta, oc_lam, lane, [&](uint32_t g, float4 v) { X_rowp.st4(rp4 + g, v); });
+#endif
       }
     }
     GBP_TRACE(1);
