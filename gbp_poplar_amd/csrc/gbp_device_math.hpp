@@ -36,10 +36,17 @@ GBP_DEV constexpr int trisym(int i, int j) { return i >= j ? tri(i, j) : tri(j, 
 // significands is never a midpoint of two fp32 numbers and lies at least 2^-49 (relative) away from the nearest one
 // (|X 2^(24+s) - (2k+1) M| >= 1 for integers X, M < 2^24), so the fp64 value and the exact quotient sit on the same
 // side of every fp32 rounding boundary and round alike.  Zeros, infinities and NaNs behave like the division.  The
-// bound needs a NORMAL fp32 result: a quotient that is subnormal (or underflows to zero from a non-zero numerator)
-// raises `redo` and the whole set is divided the slow way.  An fp32 IEEE division costs 11 instructions, five of them
-// quarter-rate; this costs 3 full-rate ones per value (measured in situ on fr1xyz: 29.9 -> 26.4 us per iteration for
-// the 54 divisions of the Huber rescale alone, profiles/r03_small_graphs.md).
+// bound needs a NORMAL fp32 result: a set that may hold a subnormal quotient (or one that underflows to zero from a
+// non-zero numerator) is divided the slow way.  That is decided BEFORE the quotients, from the numerators alone:
+//   |v| >= thr, thr >= FLT_MIN |m| (1 + 2^-10)   =>   |v / m| >= FLT_MIN (1 + 2^-10): a normal quotient
+// with thr = (|m| (1 + 2^-9)) FLT_MIN rounded + 2 ulps (the first product rounds once, the scaling is exact unless it is
+// subnormal, where it loses < 1 ulp: hence the 2).  "Some non-zero |v| < thr" is one integer comparison of the smallest
+// u = 2 bits(|v|) - 1 (zero -> 0xffffffff; fp32 magnitudes order like their bit patterns) — v_lshl_add + half a v_min3
+// per value instead of two compares and two scalar mask operations on every quotient; an infinite or NaN threshold
+// (m infinite / NaN) compares as huge and takes the slow path, which is the division itself.  An fp32 IEEE division
+// costs 11 instructions, five of them quarter-rate; this costs 3 full-rate ones per value + 1.5 for the test (measured
+// in situ on fr1xyz: 29.9 -> 26.4 us per iteration for the 54 divisions of the Huber rescale alone,
+// profiles/r03_small_graphs.md; the test: profiles/r04_alu_diet.md).
 #ifdef GBP_BUILD_EXPERIMENTS
 __device__ unsigned long long g_div_redo[4];
 __device__ unsigned long long* g_tick_buf;     // [wave][16] wall-clock stamps inside the relinearisation path (last iteration wins)
@@ -50,15 +57,26 @@ __device__ unsigned long long* g_tick_buf;     // [wave][16] wall-clock stamps i
 template <int N>
 GBP_DEV void div_shared(const float (&v)[N], float m, float (&q)[N]) {
   const double r = 1.0 / (double)m;
+#ifdef GBP_DIV_CHECK_QUOTIENTS      // measurement: the test on every quotient (rounds 3 and 4 up to here)
   bool redo = false;
   GBP_UNROLL
   for (int i = 0; i < N; ++i) {
     q[i] = (float)((double)v[i] * r);
     redo |= (__builtin_fabsf(q[i]) < 1.17549435e-38f) != (v[i] == 0.f);
   }
-  // The slow path behind a WAVE-UNIFORM test: a per-lane `if (redo)` over nine divisions is small enough for the compiler to
-  // if-convert — both paths evaluated by every lane, the 9 x 11 instructions of the IEEE divisions thrown away by selects
-  // (measured: 15 divisions executed per ordinary sweep wave instead of 6, profiles/r04_alu_diet.md).
+#else
+  uint32_t least = 0xffffffffu;
+  GBP_UNROLL
+  for (int i = 0; i < N; ++i) {
+    q[i] = (float)((double)v[i] * r);
+    const uint32_t u = (__float_as_uint(v[i]) << 1) - 1u;
+    least = u < least ? u : least;
+  }
+  const float thr = (__builtin_fabsf(m) * 1.001953125f) * 1.17549435e-38f;
+  const bool redo = least < 2u * (__float_as_uint(thr) + 2u) - 1u;
+#endif
+  // (the slow path behind a WAVE-UNIFORM test, so that it is a branch no wavefront takes instead of nine divisions the
+  // compiler might if-convert into every lane's instruction stream)
   if (__builtin_amdgcn_ballot_w64(redo) != 0ull) {
     if (redo) {
 #ifdef GBP_BUILD_EXPERIMENTS
@@ -95,9 +113,6 @@ GBP_DEV void ldl6_lower(AF&& A, float (&rD)[6], float (&Ui)[6][6]) {
     float d = A(j, j);
     GBP_UNROLL
     for (int k = 0; k < j; ++k) d -= U[k][j] * U[k][j] * D[k];
-#ifdef F_D
-    GBP_SLP_FENCE(d);
-#endif
     D[j] = d;
     rD[j] = 1 / d;
     GBP_UNROLL
@@ -105,9 +120,6 @@ GBP_DEV void ldl6_lower(AF&& A, float (&rD)[6], float (&Ui)[6][6]) {
       float u = rD[j] * A(i, j);
       GBP_UNROLL
       for (int k = 0; k < j; ++k) u -= rD[j] * U[k][i] * U[k][j] * D[k];
-#ifdef F_U
-      GBP_SLP_FENCE(u);
-#endif
       U[j][i] = u;
     }
   }
@@ -119,9 +131,6 @@ GBP_DEV void ldl6_lower(AF&& A, float (&rD)[6], float (&Ui)[6][6]) {
       acc += U[i][j];  // k = i: LTinv(i,i) * LT(i,j) = 1 * LT(i,j)
       GBP_UNROLL
       for (int k = i + 1; k < j; ++k) acc += Ui[i][k] * U[k][j];
-#ifdef F_UI
-      GBP_SLP_FENCE(acc);
-#endif
       Ui[i][j] = acc / -1.f;   // Ui[i][j], j > i : LTinv(i,j)
     }
   }
@@ -147,9 +156,6 @@ GBP_DEV void inv6x6_lower(const float (&A)[21], float (&Ainv)[36]) {
     GBP_UNROLL
     for (int j = 0; j < 6; ++j) {
       Ainv[i * 6 + j] = inv6_entry(rD, Ui, i, j);
-#ifdef F_AINV
-      GBP_SLP_FENCE(Ainv[i * 6 + j]);
-#endif
     }
   }
 }

@@ -393,16 +393,14 @@ GBP_DEV void factor_update(float (&fac)[56], const float (&cm)[28], float (&mu)[
           float acc = 0.f;
           GBP_UNROLL
           for (int k = 0; k < 6; ++k) acc += fac[30 + k * 3 + i] * Ainv[k * 6 + j];  // Lambda_lc(i,k) = Lambda_cl(k,i)
-#ifdef F_G
-          GBP_SLP_FENCE(acc);
-#endif
           G[i * 6 + j] = acc;
         }
       }
       GBP_UNROLL
       for (int k = 0; k < 6; ++k) {
         float t = fac[k] + cb[k];
-        ed[k] = t - cm[k];
+        t = t - cm[k];
+        ed[k] = t;
       }
       GBP_UNROLL
       for (int i = 0; i < 3; ++i) {
@@ -419,9 +417,6 @@ GBP_DEV void factor_update(float (&fac)[56], const float (&cm)[28], float (&mu)[
           float t = 0.f;
           GBP_UNROLL
           for (int k = 0; k < 6; ++k) t += G[i * 6 + k] * fac[30 + k * 3 + j];
-#ifdef F_OL
-          GBP_SLP_FENCE(t);
-#endif
           ol[4 + i * 3 + j] = fac[48 + trisym(i, j)] - t;
         }
       }
@@ -435,9 +430,6 @@ GBP_DEV void factor_update(float (&fac)[56], const float (&cm)[28], float (&mu)[
         for (int j = 0; j < 3; ++j) {
           float t = fac[48 + trisym(i, j)] + lb[4 + i * 3 + j];
           t = t - lm[4 + i * 3 + j];
-#ifdef F_BP
-          GBP_SLP_FENCE(t);
-#endif
           Bp[i * 3 + j] = t;
         }
       }
@@ -455,7 +447,8 @@ GBP_DEV void factor_update(float (&fac)[56], const float (&cm)[28], float (&mu)[
       GBP_UNROLL
       for (int k = 0; k < 3; ++k) {
         float t = fac[6 + k] + lb[k];
-        el[k] = t - lm[k];
+        t = t - lm[k];
+        el[k] = t;
       }
       GBP_UNROLL
       for (int i = 0; i < 6; ++i) {
@@ -465,28 +458,6 @@ GBP_DEV void factor_update(float (&fac)[56], const float (&cm)[28], float (&mu)[
         const float h = fac[i] - s;
         oc_eta[i] = h * omd + cm[i] * damping;
       }
-#ifdef GBP_PK_OCLAM
-      {  // the same sums, two columns (j, j+1) per packed instruction: Lambda_cl gathered once as column pairs
-        typedef float v2f __attribute__((ext_vector_type(2)));
-        v2f LT[3][3];
-        GBP_UNROLL
-        for (int k = 0; k < 3; ++k) {
-          GBP_UNROLL
-          for (int jp = 0; jp < 3; ++jp) LT[k][jp] = (v2f){fac[30 + (2 * jp) * 3 + k], fac[30 + (2 * jp + 1) * 3 + k]};
-        }
-        GBP_UNROLL
-        for (int i = 0; i < 6; ++i) {
-          GBP_UNROLL
-          for (int jp = 0; jp < 3; ++jp) {
-            v2f t = (v2f){0.f, 0.f};
-            GBP_UNROLL
-            for (int k = 0; k < 3; ++k) t = t + (v2f){G2[i * 3 + k], G2[i * 3 + k]} * LT[k][jp];
-            oc_lam[i * 6 + 2 * jp] = fac[9 + trisym(i, 2 * jp)] - t.x;
-            oc_lam[i * 6 + 2 * jp + 1] = fac[9 + trisym(i, 2 * jp + 1)] - t.y;
-          }
-        }
-      }
-#else
       GBP_UNROLL
       for (int i = 0; i < 6; ++i) {
         GBP_UNROLL
@@ -494,16 +465,9 @@ GBP_DEV void factor_update(float (&fac)[56], const float (&cm)[28], float (&mu)[
           float t = 0.f;
           GBP_UNROLL
           for (int k = 0; k < 3; ++k) t += G2[i * 3 + k] * fac[30 + j * 3 + k];  // Lambda_lc(k,j) = Lambda_cl(j,k)
-#ifdef F_OCLAM
-          GBP_SLP_FENCE(t);
-#endif
           oc_lam[i * 6 + j] = fac[9 + trisym(i, j)] - t;
-#ifdef F_OCLAM2
-          GBP_SLP_FENCE(oc_lam[i * 6 + j]);
-#endif
         }
       }
-#endif
     }
   } else {
 #ifndef GBP_ZERO_INIT_FIRST
