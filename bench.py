@@ -102,7 +102,10 @@ def parse(argv=None):
                     help="camera ranges of the pipelined all-gather (default: 1)")
     ap.add_argument("--tile-order", type=int, default=0, help="gbp_params.tile_order: 0 = default, 1 = sequential, 2 = sweep tiles XCD-aware too")
     ap.add_argument("--master-port", type=int, default=0, help="self-launch: rendezvous port (0 = pick a free one)")
-    ap.add_argument("--graph-unroll", type=int, default=0, help="gbp_params.graph_unroll of the single-GPU ctx (0 = library default)")
+    ap.add_argument("--graph-unroll", type=int, default=20,
+                    help="gbp_params.graph_unroll of the single-GPU ctx (0 = library default, 10).  20: one hipGraphLaunch per 20 iterations "
+                         "— a replay costs 10-20 us of launch work, 1 %% of ten 1M-factor iterations (measured, alternating on one box: "
+                         "8 336 / 8 436 / 8 402 iterations/s with 10 / 20 / 50)")
     ap.add_argument("--preflight", type=int, default=1,
                     help="N > 1 (and --force-sharded), native communicator: the un-timed self-validation block (GPU identities, peer access, "
                          "librccl path/version, all-gather probe, one-stream vs two-stream schedule measured and chosen); 0 = off")
@@ -658,7 +661,7 @@ def main(argv=None):
     opts = driver.Options()
     K, state, _ = driver.build_inputs(bal, opts, hostlib)
 
-    prm = _cabi.GbpParams.defaults(tile_order=a.tile_order, graph_unroll=a.graph_unroll)
+    prm = _cabi.GbpParams.defaults(tile_order=a.tile_order, graph_unroll=a.graph_unroll if not sharded else 0)   # (a sharded ctx captures only on request: below)
     if a.sharded_graph is None:
         a.sharded_graph = 0
     if sharded and a.comm == "native":
@@ -843,7 +846,7 @@ def main(argv=None):
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload_name(a, world, C, L, E),
                        "cams": C, "lmks": L, "factors": E, "iters_per_sec": round(ips, 2),
-                       "parallelism": "1 GPU, hipGraph x10 iterations" if not sharded else "landmark shards x%d + all_gather(cam partials)" % world,
+                       "parallelism": ("1 GPU, hipGraph x%d iterations" % (a.graph_unroll if a.graph_unroll > 0 else 10)) if not sharded else "landmark shards x%d + all_gather(cam partials)" % world,
                        "reproj_rmse_px_initial": round(m0[2], 6), "reproj_rmse_px_final": round(m1[2], 6),
                        "mean_reproj_px_final": round(m1[0], 6), "iterations_run": a.warmup + extra_warm + a.steps,
                        "nonfinite_beliefs": int(ev1["n_nonfinite"]),
