@@ -1,7 +1,7 @@
 #!/bin/bash
 # Executed-instruction mix of k_sweep per wave (ordinary sweep 5 and the lock-step sweep 18 of the ./ba flow on S1):
-#   [GBP_LIB=<variant .so>] bash profiles/inst_mix.sh <tag>   -> gpurun_out/<tag>_inst_mix.txt
-TAG=${1:-r04}
+#   [GBP_LIB=<variant .so>] bash profiles/inst_mix.sh <tag> [k_sweep|k_beliefs]  -> gpurun_out/<tag>_inst_mix.txt
+TAG=${1:-r04}; export KERN=${2:-k_sweep}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/${TAG}_inst_mix
 mkdir -p $OUT
@@ -13,11 +13,11 @@ for SET in "SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_V
   rocprofv3 --pmc $SET --output-format csv -d $OUT/p$i -o c -- python3 $R/profiles/relin_hump_b2b.py 20 > /dev/null 2> $OUT/p$i.err
 done
 python3 - $OUT > $R/gpurun_out/${TAG}_inst_mix.txt <<'PY'
-import csv, glob, sys, collections
+import csv, glob, os, sys, collections
 out = sys.argv[1]
 per = collections.OrderedDict()
 for f in sorted(glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True)):
-    rows = [r for r in csv.DictReader(open(f)) if "k_sweep" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(f)) if os.environ.get("KERN", "k_sweep") in r["Kernel_Name"]]
     ids = sorted({int(r["Dispatch_Id"]) for r in rows})
     for r in rows:
         per.setdefault(r["Counter_Name"], {})[ids.index(int(r["Dispatch_Id"]))] = float(r["Counter_Value"])
