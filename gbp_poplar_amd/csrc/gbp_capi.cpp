@@ -167,6 +167,7 @@ SweepArgs sweep_args(gbp_ctx* c) {
   a.block0 = 0;
   a.variant = c->prm.reserved[0];      // read by the experiments build only
   a.tile_perm = c->use_tile_perm ? P<uint32_t>(c->tile_perm) : nullptr;
+  a.cmsg_cached = c->C <= 2048u ? 1u : 0u;
   return a;
 }
 

@@ -72,6 +72,11 @@ struct SweepArgs {
                              // order (gbp_params.tile_order = 2): workgroups are dealt round-robin over the 8 XCDs, the
                              // table hands every XCD the tiles of one landmark range so that its private L2 holds that
                              // slice of the gathered landmark tables
+  uint32_t cmsg_cached;      // 1: the camera-message tiles are LOADED with the default cache policy instead of the non-temporal
+                             // hint (the stores keep the hint).  Measured on 1 M factors x 100 000 landmarks: +1.3 % iterations/s
+                             // with 500 cameras, +0.6 % with 1 000, +0.25 % with 2 000, -0.1 % with 4 000, -0.3 % with 8 000
+                             // (-1.4 % on the config-5 shard shape): set while the camera belief table (C x 176 B) is small
+                             // beside an XCD's 4 MiB L2 (C <= 2 048), profiles/r04_alu_diet.md section 6
 };
 
 constexpr int kMaxChunks = 8;

@@ -500,7 +500,7 @@ GBP_DEV void factor_update(float (&fac)[56], const float (&cm)[28], float (&mu)[
 #define GBP_SWEEP_WPB 4      // wavefronts per workgroup of the sweep (1, 2 or 4; the waves of a workgroup share nothing)
 #endif
 constexpr int kWpb = GBP_SWEEP_WPB;
-template <bool HOIST, int ABL>
+template <bool HOIST, int ABL, bool CMC = false>     // CMC: SweepArgs.cmsg_cached (camera messages loaded with the default cache policy)
 GBP_DEV void sweep_tile(const SweepArgs& a, const uint32_t wslot) {
   // (the slot is wave-uniform: as an SGPR it turns the permutation look-up into one scalar load)
   const uint32_t ws = (uint32_t)__builtin_amdgcn_readfirstlane((int)wslot);
@@ -508,11 +508,23 @@ GBP_DEV void sweep_tile(const SweepArgs& a, const uint32_t wslot) {
   const uint32_t lane = threadIdx.x & 63, p = tile * 64 + lane;
 
   const uint32_t cam_i = a.row_cam[p >> 4];
+#ifdef GBP_IDX_LOAD_CACHED
+  const uint32_t lmk_i = a.lmk_idx[p];
+#else
   const uint32_t lmk_i = __builtin_nontemporal_load(a.lmk_idx + p);
+#endif
 
   float fac[56], cm[28], mu[12], lm[16], cb[44], lb[16];
+#ifdef GBP_FAC_LOAD_CACHED
+  load_tile<kFacG, false>(a.fac, tile, lane, fac);
+#else
   load_tile<kFacG>(a.fac, tile, lane, fac);
-  load_tile<kCmsgG>(a.cmsg, tile, lane, cm);
+#endif
+  // The camera messages: non-temporal like the potentials, or — SweepArgs.cmsg_cached, graphs with few cameras — with the
+  // default policy like the landmark messages below (both are rewritten in place by this tile).  The potentials, which an
+  // ordinary sweep only reads, keep the hint on every graph: with default-policy loads they cost 3 %.
+  // (a template parameter, not a branch on the flag: with both load sequences behind a branch the nt path lost 1.2 %)
+  load_tile<kCmsgG, !CMC>(a.cmsg, tile, lane, cm);
   if (!HOIST) load_tile<kMuG>(a.mu, tile, lane, mu);
   // Landmark messages live as 64-byte records in DEVICE (camera-major) order: the wave's 64 records are one
   // contiguous 4 KiB block, moved with four coalesced 1 KiB accesses and transposed through a wave-private
@@ -534,7 +546,14 @@ GBP_DEV void sweep_tile(const SweepArgs& a, const uint32_t wslot) {
   } else {
     GBP_UNROLL
     for (int k = 0; k < 4; ++k) {
+#ifdef GBP_LMSG_LOAD_NT     // measurement: the hint rounds 1-4 used here too
       const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(lm_tile) + k * 64 + lane);
+#else
+      // (DEFAULT policy for this one stream: the tile is rewritten in place ten microseconds later and gathered by k_beliefs
+      // right after the sweep — measured +1.5 % iterations/s on S1 against the non-temporal hint, with either store policy;
+      // the potentials and the camera messages keep the hint: profiles/r04_alu_diet.md section 6)
+      const v4f v = (reinterpret_cast<const v4f*>(lm_tile))[k * 64 + lane];
+#endif
       const uint32_t r = k * 16 + rec_t;
       stage[r * 4 + ((lane & 3u) ^ (((r >> 2) & 3u) ^ (r & 2u)))] = make_float4(v.x, v.y, v.z, v.w);
     }
@@ -611,7 +630,12 @@ GBP_DEV void sweep_tile(const SweepArgs& a, const uint32_t wslot) {
     GBP_UNROLL
     for (int k = 0; k < 4; ++k) {
       const uint32_t r = k * 16 + rec_t;
+#ifdef GBP_LMSG_STORE_NT
+      { const float4 f = stage[r * 4 + ((lane & 3u) ^ (((r >> 2) & 3u) ^ (r & 2u)))]; const v4f v = {f.x, f.y, f.z, f.w};
+        __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(lm_tile) + k * 64 + lane); }
+#else
       lm_tile[k * 64 + lane] = stage[r * 4 + ((lane & 3u) ^ (((r >> 2) & 3u) ^ (r & 2u)))];
+#endif
     }
   }
   {
@@ -624,7 +648,11 @@ GBP_DEV void sweep_tile(const SweepArgs& a, const uint32_t wslot) {
       for (int j = 0; j <= i; ++j) cmo[6 + tri(i, j)] = oc_lam[i * 6 + j];
     }
     cmo[27] = 0.f;
+#ifdef GBP_CMSG_STORE_CACHED
+    store_tile<kCmsgG, false>(a.cmsg, tile, lane, cmo);
+#else
     store_tile<kCmsgG>(a.cmsg, tile, lane, cmo);
+#endif
   }
   // camera half of the belief reduction: per-row (16 factors of one camera) tree sums
   {
@@ -651,9 +679,9 @@ GBP_DEV void sweep_tile(const SweepArgs& a, const uint32_t wslot) {
   }
 }
 
-template <bool HOIST, int ABL = 0>
+template <bool HOIST, int ABL = 0, bool CMC = false>
 __global__ __launch_bounds__(64 * kWpb) void k_sweep(const SweepArgs a) {
-  sweep_tile<HOIST, ABL>(a, (blockIdx.x + a.block0 * (4 / kWpb)) * kWpb + (threadIdx.x >> 6));
+  sweep_tile<HOIST, ABL, CMC>(a, (blockIdx.x + a.block0 * (4 / kWpb)) * kWpb + (threadIdx.x >> 6));
 }
 
 #ifdef GBP_BUILD_EXPERIMENTS
@@ -2222,7 +2250,8 @@ void launch_sweep_blocks(SweepArgs a, uint32_t block0, uint32_t block1, bool hoi
     }
   }
 #endif
-  if (hoist) hipLaunchKernelGGL(k_sweep<true>, g, b, 0, s, a);
+  if (hoist && a.cmsg_cached) hipLaunchKernelGGL((k_sweep<true, 0, true>), g, b, 0, s, a);
+  else if (hoist) hipLaunchKernelGGL(k_sweep<true>, g, b, 0, s, a);
   else hipLaunchKernelGGL(k_sweep<false>, g, b, 0, s, a);
 }
 // Timing-only ablations of the sweep (profiles/ablate_sweep.py): compiled only with -DGBP_BUILD_ABLATIONS, the product

@@ -16,7 +16,7 @@ for v in ${VARIANTS:-default}; do
 import json,sys
 d=json.loads(sys.stdin.read())
 k={x['kernel'].split('<')[0].split('(')[0]:x for x in d['roofline'].get('kernels',[])} if isinstance(d['roofline'].get('kernels'),list) else {}
-print(d['value'], d['ms_per_step'], d['roofline'].get('avg_launch_us'), d['roofline'].get('min_us'), d['roofline'].get('max_us'), {n:v.get('avg_launch_us') for n,v in k.items()})
+print(d['value'], d['ms_per_step'], 'sweep', d['roofline'].get('avg_launch_us'), 'beliefs', d['roofline'].get('belief_kernels_avg_us'))
 "
 done
 done
