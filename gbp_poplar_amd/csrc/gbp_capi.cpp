@@ -167,7 +167,14 @@ SweepArgs sweep_args(gbp_ctx* c) {
   a.block0 = 0;
   a.variant = c->prm.reserved[0];      // read by the experiments build only
   a.tile_perm = c->use_tile_perm ? P<uint32_t>(c->tile_perm) : nullptr;
-  a.cmsg_cached = c->C <= 2048u ? 1u : 0u;
+#ifdef GBP_CMSG_CACHED_OFF       // measurement
+  a.cmsg_cached = 0u;
+#else
+  // few cameras (their belief table small beside an XCD's L2) AND both message streams of this rank (176 B per factor slot)
+  // within ~3/4 of the 256 MiB Infinity Cache, where the lines loaded this sweep are still found by the next: measured
+  // +1.4 % at 0.5 M factors, +0...2 % at 1 M (the edge), -0.5 % at 1.25 M, -2 % at 1.5 M, -5.5 % at 2 M (r04_alu_diet.md section 6)
+  a.cmsg_cached = (c->C <= 2048u && (uint64_t)c->n_tiles * 64u * 176u <= 200000000ull) ? 1u : 0u;
+#endif
   return a;
 }
 

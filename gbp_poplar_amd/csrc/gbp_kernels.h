@@ -75,8 +75,10 @@ struct SweepArgs {
   uint32_t cmsg_cached;      // 1: the camera-message tiles are LOADED with the default cache policy instead of the non-temporal
                              // hint (the stores keep the hint).  Measured on 1 M factors x 100 000 landmarks: +1.3 % iterations/s
                              // with 500 cameras, +0.6 % with 1 000, +0.25 % with 2 000, -0.1 % with 4 000, -0.3 % with 8 000
-                             // (-1.4 % on the config-5 shard shape): set while the camera belief table (C x 176 B) is small
-                             // beside an XCD's 4 MiB L2 (C <= 2 048), profiles/r04_alu_diet.md section 6
+                             // (-1.4 % on the config-5 shard shape); 1 000 cameras, factor count scanned: +1.4 % at 0.5 M, +0...2 % at
+                             // 1 M, -0.5 % at 1.25 M, -2 % at 1.5 M, -5.5 % at 2 M.  Set while the camera belief table (C x 176 B) is
+                             // small beside an XCD's 4 MiB L2 (C <= 2 048) and the two message streams (176 B per factor) fit the
+                             // Infinity Cache with room to spare (<= 200 MB), profiles/r04_alu_diet.md section 6
 };
 
 constexpr int kMaxChunks = 8;
