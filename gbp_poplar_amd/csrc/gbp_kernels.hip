@@ -1785,6 +1785,11 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
     if (ev_prev && has_tile) metric_means((uint32_t)it - 1u, ev_cm, ev_lm);     // in flight with the role's own loads
     unsigned long long* const hw = health_of((uint32_t)it);                      // what this phase's owners count into
     const uint32_t emc_w = ((uint32_t)it & 1u) * emc_half, eml_w = ((uint32_t)it & 1u) * eml_half;
+#ifdef GBP_LDL_INLINE          // measurement: the health check of the camera belief on the critical path of the belief phase
+    const bool ldl_deferred = false;
+#else
+    const bool ldl_deferred = it + 1 < A.n_iters;      // a hand-off follows this belief phase
+#endif
     if (cam_wave || (met_wave && ev_means)) {
       float acc = 0.f;
       if (cam_live && r1 > r0) {
@@ -1840,8 +1845,9 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
           solve_pivot<6>(sh[wib] + 8, 6, sh[wib], xm);
           pd = ldl_pivots_positive<6>(sh[wib] + 8, 6);
           cam_mean(cb, x0c);
-        } else if (ev_means) {   // the solve runs on this camera's metric wave; the health check here
-          pd = ldl_pivots_positive<6>(sh[wib] + 8, 6);
+        } else if (ev_means) {   // the solve runs on this camera's metric wave; the health check here — or, where a hand-off
+          // follows, behind the arrival on the NEXT wave of the workgroup (ldl_deferred, below): it feeds nothing in this iteration
+          if (!ldl_deferred) pd = ldl_pivots_positive<6>(sh[wib] + 8, 6);
           cam_mean(cb, x0c);
         } else {
           cam_mean(cb, x0c);
@@ -1959,6 +1965,18 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
     GBP_TRACE(3);
     if (it + 1 < A.n_iters) {
       grid_arrive(A.sync);
+      {
+        // The fp64 LDL health check a camera wave left out above (with the metric every iteration it is the slowest wave of the
+        // belief phase), made by the NEXT wave of the workgroup from the camera's record in LDS (Lambda at sh[.] + 8: untouched
+        // until the next belief phase, visible since the arrival's workgroup barrier) — not by the camera wave itself: that is
+        // wave 0, which polls the hand-off, and polling from any other wave costs 0.9 us per hand-off (measured; so does the check
+        // in front of the polling).  Counted into this iteration's pair of counters, which block 0 reads one iteration from now.
+        // fr1xyz, metric every iteration: 14.75 -> 14.60 us per iteration (profiles/r04_alu_diet.md section 3).
+        const uint32_t pw = (wib + 3u) & 3u, pv = pw * nblk + bid;
+        if (ldl_deferred && ev_means && lane == 0 && pv < b.n_cams && v_met0 + pv < nblk * 4u) {
+          if (!ldl_pivots_positive<6>(sh[pw] + 8, 6)) atomicAdd(&hw[1], 1ull);
+        }
+      }
       if (ev_prev) metric((uint32_t)it - 1u, ev_packed, ev_cm, ev_lm);
       grid_wait(A.sync, A.epoch_base + (++epoch) * nblk, A.status, A.seq);
     } else if (ev_prev) {
