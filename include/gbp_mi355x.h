@@ -67,7 +67,9 @@ typedef struct {
                                   and PrepMessageVertex does not zero, gbp_codelets.cpp:285-336);
                                   1 = reset (zero first)                                          */
   int32_t graph_unroll;        /* GBP iterations captured per hipGraph (>=1); 0 = library default (10 on a single-GPU ctx;
-                                  direct launches on a sharded ctx, where the graph is slower); < 0 = never capture */
+                                  direct launches on a sharded ctx, where the graph is slower); < 0 = never capture.
+                                  A replay costs 10-20 us of launch work: on a 1M-factor graph 20 per graph are 1 % faster
+                                  than 10 (bench.py passes 20), calls of fewer than graph_unroll iterations launch directly */
   int32_t per_factor_mu;       /* 0 (default): belief means are computed once per variable (bit-identical
                                   to the per-factor recomputation of gbp_codelets.cpp:264-277, requires the
                                   uploaded mu/oldmu to be zero as in ba.cpp:582-583); 1: keep the literal
