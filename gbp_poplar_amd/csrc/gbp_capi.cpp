@@ -56,11 +56,13 @@ struct gbp_ctx {
   std::vector<uint32_t> pos_edge;     // [Ep] device position -> global file edge index, ~0u = pad
   std::vector<uint32_t> pos_cam, pos_lmk_loc, pos_lpos;
   std::vector<uint32_t> cam_row_ptr;  // [C+1] rows of each camera
+  std::vector<uint32_t> row_slot;     // [n_rows] device row of logical row r (empty: identity).  See kRowWindow in create_impl.
+  uint32_t row_window = 0;            // cameras per window of the row placement (0: identity)
   std::vector<uint32_t> lmk_ptr;      // [L_loc+1] records of each local landmark in LMSG
   uint32_t Ep = 0, n_tiles = 0, n_rows = 0;
   // device memory
   std::vector<DevBuf*> all;
-  DevBuf row_cam, lmk_idx, fac, cmsg, mu, lmsg, camb, camp, lmkb, lmkp, rowp, local, d_cam_row_ptr, d_lmk_ptr, cwf, lwf,
+  DevBuf row_cam, lmk_idx, fac, cmsg, mu, lmsg, camb, camp, lmkb, lmkp, rowp, local, d_cam_row_ptr, d_row_slot, d_lmk_ptr, cwf, lwf,
       cscale, lscale, cam_mu, lmk_mu, dK, evalp, hmu_c, hmu_l, clin, d_lmk_fpos, d_lmk_ix, health, tile_perm;
   DevBuf st_a, st_b;                   // [Ep] scratch of the per-factor state get / set kernels
   std::vector<uint8_t> active_host;    // [Ep] host shadow of the active flags (hoist guard of gbp_new_keyframe)
@@ -187,6 +189,7 @@ void drop_graph(gbp_ctx* c) {
 BeliefArgs belief_args(gbp_ctx* c) {
   BeliefArgs b{};
   b.rowp = P<float>(c->rowp); b.cam_row_ptr = P<uint32_t>(c->d_cam_row_ptr); b.cam_prior = P<float>(c->camp);
+  b.row_slot = c->row_slot.empty() ? nullptr : P<uint32_t>(c->d_row_slot);
   b.cam_local = P<float>(c->local); b.gathered = nullptr; b.world = c->world;
   b.camb = P<float>(c->camb); b.cam_mu = P<float4>(c->hmu_c); b.cam_lin = P<float4>(c->clin); b.n_cams = c->C;
   b.lmk_prior = P<float4>(c->lmkp); b.lmsg = P<float4>(c->lmsg); b.lmk_ptr = P<uint32_t>(c->d_lmk_ptr);
@@ -432,16 +435,61 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
   c->pos_cam.assign(c->Ep, 0);
   c->pos_lmk_loc.assign(c->Ep, 0);
   c->pos_lpos.assign(c->Ep, c->E_loc);  // pads point at the dump record
+  // ---- row placement (graphs of many cameras with few factors each: BASELINE config 5 has 156 per camera and rank) ----
+  // A row — 16 consecutive factors of one camera, in file order: the unit of the camera sums, never split or reordered — may sit in
+  // any device row: the sweep writes its sums where the row sits, the camera part of k_beliefs finds a camera's rows through
+  // row_slot and adds them in the camera's own order (same sums, same bits).  The file lists a camera's factors by landmark,
+  // so a row covers 16 / deg of the landmark range, but the four rows of a TILE cover four times that: 41 % on config 5 — no tile
+  // belongs to one landmark octile, the XCD-aware tile order has nothing to work with, and nearly every landmark-belief gather
+  // misses its L2 (14-17 us of the 135 us sweep against 4.7 of 98 on S1: profiles/ablate_sweep.py).  Inside windows of
+  // kRowWindow cameras the rows are therefore placed by the landmark octile of their first factor (stable: file order within an
+  // octile), so that a tile holds rows of neighbouring cameras from ONE octile.  Only where it is needed (few factors per
+  // camera) and where the tile order is on (>= 2 048 tiles, tile_order 0 / 3); chunk boundaries of a pipelined exchange are
+  // snapped to the windows (set_exchange_chunks_impl).
+#ifndef GBP_ROW_WINDOW
+#define GBP_ROW_WINDOW 32
+#endif
+#ifndef GBP_ROW_KEY_LANE
+#define GBP_ROW_KEY_LANE 0
+#endif
+  constexpr uint32_t kRowWindow = GBP_ROW_WINDOW;
+  c->row_slot.clear(); c->row_window = 0;
+#ifndef GBP_ROW_PLACEMENT_OFF     // measurement
+  if ((c->prm.tile_order == 0 || c->prm.tile_order == 3) && c->n_tiles >= 2048 && C >= 2 * kRowWindow && c->L_loc >= 8 &&
+      (uint64_t)c->E_loc < (uint64_t)C * 512u) {
+    std::vector<uint8_t> key(c->n_rows, 0);
+    {
+      std::vector<uint32_t> cfill(C, 0);
+      for (uint32_t e = 0; e < E; ++e) {
+        const uint32_t cam = pr->cam_id[e], l = pr->lmk_id[e];
+        if (l < c->lmk_begin || l >= c->lmk_end) continue;
+        const uint32_t i = cfill[cam]++;
+        if (i % kRow == GBP_ROW_KEY_LANE || i % kRow == 0) key[c->cam_row_ptr[cam] + i / kRow] = (uint8_t)(((uint64_t)(l - c->lmk_begin) * 8u) / c->L_loc);
+      }
+    }
+    c->row_slot.assign(c->n_rows, 0);
+    for (uint32_t c0 = 0; c0 < C; c0 += kRowWindow) {
+      const uint32_t c1 = std::min<uint32_t>(C, c0 + kRowWindow), R0 = c->cam_row_ptr[c0], R1 = c->cam_row_ptr[c1];
+      uint32_t cnt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      for (uint32_t r = R0; r < R1; ++r) cnt[key[r] + 1]++;
+      for (int k = 0; k < 8; ++k) cnt[k + 1] += cnt[k];
+      for (uint32_t r = R0; r < R1; ++r) c->row_slot[r] = R0 + cnt[key[r]]++;      // counting sort: stable
+    }
+    c->row_window = kRowWindow;
+  }
+#endif
+  auto dev_row = [&](uint32_t r) -> uint32_t { return c->row_slot.empty() ? r : c->row_slot[r]; };
   for (uint32_t k = 0; k < C; ++k)
     for (uint32_t r = c->cam_row_ptr[k]; r < c->cam_row_ptr[k + 1]; ++r)
-      for (int i = 0; i < kRow; ++i) c->pos_cam[(size_t)r * kRow + i] = k;
+      for (int i = 0; i < kRow; ++i) c->pos_cam[(size_t)dev_row(r) * kRow + i] = k;
   {
     std::vector<uint32_t> cfill(C, 0), lfill(c->L_loc, 0);
     for (uint32_t e = 0; e < E; ++e) {
       const uint32_t cam = pr->cam_id[e], l = pr->lmk_id[e];
       if (l < c->lmk_begin || l >= c->lmk_end) continue;
       const uint32_t ll = l - c->lmk_begin;
-      const uint32_t p = c->cam_row_ptr[cam] * kRow + cfill[cam]++;
+      const uint32_t ci = cfill[cam]++;
+      const uint32_t p = dev_row(c->cam_row_ptr[cam] + ci / kRow) * kRow + ci % kRow;
       c->pos_edge[p] = e;
       c->pos_lmk_loc[p] = ll;
       c->pos_lpos[p] = c->lmk_ptr[ll] + lfill[ll]++;
@@ -459,6 +507,7 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
   A(c->lmkb, (size_t)c->L_loc * 64); A(c->lmkp, (size_t)c->L_loc * 64);
   A(c->rowp, (Ep / kRow) * kCamRec * 4);
   A(c->d_cam_row_ptr, (size_t)(C + 1) * 4); A(c->d_lmk_ptr, (size_t)(c->L_loc + 1) * 4);
+  A(c->d_row_slot, c->row_slot.size() * 4);
   A(c->cwf, (size_t)C * 4); A(c->lwf, (size_t)c->L_loc * 4); A(c->cscale, (size_t)C * 4); A(c->lscale, (size_t)c->L_loc * 4);
   A(c->cam_mu, (size_t)C * 6 * 4 * 2); A(c->lmk_mu, (size_t)c->L_loc * 3 * 4 * 2);   // metric means; k_persist alternates between the two halves
   A(c->dK, 16 * 4);
@@ -475,6 +524,7 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
   CK(hipEventCreate(&c->ev2), "hipEventCreate"); CK(hipEventCreate(&c->ev3), "hipEventCreate");
   CK(hipMemcpy(c->d_cam_row_ptr.p, c->cam_row_ptr.data(), (size_t)(C + 1) * 4, hipMemcpyHostToDevice), "copy cam_row_ptr");
   CK(hipMemcpy(c->d_lmk_ptr.p, c->lmk_ptr.data(), (size_t)(c->L_loc + 1) * 4, hipMemcpyHostToDevice), "copy lmk_ptr");
+  if (!c->row_slot.empty()) CK(hipMemcpy(c->d_row_slot.p, c->row_slot.data(), c->row_slot.size() * 4, hipMemcpyHostToDevice), "copy row_slot");
   CK(hipMemcpy(c->dK.p, c->K, 9 * 4, hipMemcpyHostToDevice), "copy K");
   {
     std::vector<uint32_t> fpos(c->E_loc ? c->E_loc : 1, 0u);  // landmark-major slot list -> device position
@@ -957,6 +1007,8 @@ static int set_exchange_chunks_impl(gbp_ctx* c, int n) {
   c->exch_chunks = n;
   c->chunk_start.assign(n + 1, 0u);
   for (int i = 0; i <= n; ++i) c->chunk_start[i] = (uint32_t)(((uint64_t)c->C * (uint64_t)i) / (uint64_t)n);
+  if (c->row_window)      // the rows of a window of cameras are interleaved (create_impl): a piece ends where a window ends
+    for (int i = 1; i < n; ++i) c->chunk_start[i] = std::min<uint32_t>(c->C, ((c->chunk_start[i] + c->row_window / 2) / c->row_window) * c->row_window);
   return GBP_OK;
 }
 

@@ -86,6 +86,7 @@ constexpr int kMaxChunks = 8;
 struct BeliefArgs {
   // camera part
   const float* rowp; const uint32_t* cam_row_ptr; const float* cam_prior;
+  const uint32_t* row_slot;  // [n_rows] device row of the camera-major row r, or NULL: rows sit in camera-major order (gbp_capi.cpp: row placement)
   float* cam_local;          // [C][44] local row sums (kept for prior-only refreshes / the exchange buffer)
   const float* gathered;     // != nullptr: belief = prior + sum_r gathered[r] instead of the row sums
   int world;

@@ -1076,7 +1076,7 @@ __global__ __launch_bounds__(256) void k_beliefs(const BeliefArgs b) {
       } else {
         const uint32_t r0 = b.cam_row_ptr[c], r1 = b.cam_row_ptr[c + 1];
         float acc = 0.f;
-        if (r1 > r0) {
+        if (r1 > r0 && !b.row_slot) {
           const float* row = b.rowp + (size_t)r0 * kCamRec + j;
           acc = row[0];
           uint32_t r = 1;
@@ -1094,6 +1094,24 @@ __global__ __launch_bounds__(256) void k_beliefs(const BeliefArgs b) {
             const uint32_t m = n - r;
             GBP_UNROLL
             for (int k = 0; k < 16; ++k) v[k] = row[(size_t)((uint32_t)k < m ? r + k : n - 1u) * kCamRec];
+            GBP_UNROLL
+            for (int k = 0; k < 16; ++k)
+              if ((uint32_t)k < m) acc = acc + v[k];
+          }
+        } else if (r1 > r0) {
+          // the camera's rows sit where the row placement put them (gbp_capi.cpp): the same sums in the same order, each row
+          // found through row_slot (wave-uniform indices: one round of scalar loads in front of the rows')
+          const float* base = b.rowp + j;
+          const uint32_t n = r1 - r0;
+          acc = base[(size_t)b.row_slot[r0] * kCamRec];
+          for (uint32_t r = 1; r < n; r += 16) {
+            uint32_t sl[16];
+            float v[16];
+            const uint32_t m = n - r;
+            GBP_UNROLL
+            for (int k = 0; k < 16; ++k) sl[k] = b.row_slot[r0 + ((uint32_t)k < m ? r + k : n - 1u)];      // clamped, unconditional
+            GBP_UNROLL
+            for (int k = 0; k < 16; ++k) v[k] = base[(size_t)sl[k] * kCamRec];
             GBP_UNROLL
             for (int k = 0; k < 16; ++k)
               if ((uint32_t)k < m) acc = acc + v[k];
