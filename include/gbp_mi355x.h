@@ -84,7 +84,12 @@ typedef struct {
                                   3 = as 0, and the sweep's tiles are permuted LOCALLY (within a few cameras) so that workgroup w —
                                       which lands on XCD w mod 8 — holds factors of landmark octile w mod 8: each private L2 then
                                       serves 1/8 of the gathered landmark-belief table while every stream keeps one compact front
-                                      (S1: 689 -> 614 MB per sweep, 7 920 -> 8 200 iterations/s, profiles/r04_tile_order.md)          */
+                                      (S1: 689 -> 614 MB per sweep, 7 920 -> 8 200 iterations/s, profiles/r04_tile_order.md).
+                                      Where order 3 applies and cameras are small (fewer than 512 factors per camera and rank on
+                                      average: BASELINE config 5) the 16-factor ROWS of 32 neighbouring cameras are laid out by
+                                      landmark octile as well (a row stays whole, a camera's rows are added in the camera's own
+                                      order: same sums; +2.4 % on the config-5 shard shape); the pieces of a pipelined exchange
+                                      (gbp_set_exchange_chunks) then end on multiples of 32 cameras                                 */
   int32_t persistent;          /* gbp_iterate(n >= 2) on a graph small enough that all of its workgroups are resident at once
                                   (BASELINE configs 1-3) runs the n iterations inside ONE kernel launch (k_persist: per-factor
                                   state in registers, device-wide barriers instead of kernel boundaries; identical results):
