@@ -444,8 +444,8 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
   // misses its L2 (14-17 us of the 135 us sweep against 4.7 of 98 on S1: profiles/ablate_sweep.py).  Inside windows of
   // kRowWindow cameras the rows are therefore placed by the landmark octile of their first factor (stable: file order within an
   // octile), so that a tile holds rows of neighbouring cameras from ONE octile.  Only where it is needed (few factors per
-  // camera) and where the tile order is on (>= 2 048 tiles, tile_order 0 / 3); chunk boundaries of a pipelined exchange are
-  // snapped to the windows (set_exchange_chunks_impl).
+  // camera) and where the tile order is on (>= 2 048 tiles, tile_order 0 / 3); a piece of a pipelined exchange sweeps to the
+  // end of the window its camera range ends in (gbp_iterate_begin_chunk).
 #ifndef GBP_ROW_WINDOW
 #define GBP_ROW_WINDOW 32
 #endif
@@ -1007,8 +1007,6 @@ static int set_exchange_chunks_impl(gbp_ctx* c, int n) {
   c->exch_chunks = n;
   c->chunk_start.assign(n + 1, 0u);
   for (int i = 0; i <= n; ++i) c->chunk_start[i] = (uint32_t)(((uint64_t)c->C * (uint64_t)i) / (uint64_t)n);
-  if (c->row_window)      // the rows of a window of cameras are interleaved (create_impl): a piece ends where a window ends
-    for (int i = 1; i < n; ++i) c->chunk_start[i] = std::min<uint32_t>(c->C, ((c->chunk_start[i] + c->row_window / 2) / c->row_window) * c->row_window);
   return GBP_OK;
 }
 
@@ -1024,7 +1022,11 @@ int gbp_iterate_begin_chunk(gbp_ctx* c, int chunk) {
   const uint32_t n_blocks = c->n_tiles / 4;
   auto block_end = [&](int i) -> uint32_t {  // first block boundary at/after the last row of the cameras of range i
     if (i + 1 >= c->exch_chunks) return n_blocks;
-    const uint64_t pos = (uint64_t)c->cam_row_ptr[c->chunk_start[i + 1]] * kRow;
+    // (with the row placement of create_impl the rows of a window of cameras are interleaved: the piece runs to the end of the
+    // window its last camera sits in — a few rows of the next range are swept early, as with the block rounding below)
+    uint32_t cam_end = c->chunk_start[i + 1];
+    if (c->row_window) cam_end = std::min<uint32_t>(c->C, ((cam_end + c->row_window - 1) / c->row_window) * c->row_window);
+    const uint64_t pos = (uint64_t)c->cam_row_ptr[cam_end] * kRow;
     return (uint32_t)std::min<uint64_t>(n_blocks, (pos + 255) / 256);
   };
   const uint32_t b0 = chunk == 0 ? 0u : block_end(chunk - 1), b1 = block_end(chunk);

@@ -88,8 +88,7 @@ typedef struct {
                                       Where order 3 applies and cameras are small (fewer than 512 factors per camera and rank on
                                       average: BASELINE config 5) the 16-factor ROWS of 32 neighbouring cameras are laid out by
                                       landmark octile as well (a row stays whole, a camera's rows are added in the camera's own
-                                      order: same sums; +2.4 % on the config-5 shard shape); the pieces of a pipelined exchange
-                                      (gbp_set_exchange_chunks) then end on multiples of 32 cameras                                 */
+                                      order: same sums; +2.4 % on the config-5 shard shape)                                                */
   int32_t persistent;          /* gbp_iterate(n >= 2) on a graph small enough that all of its workgroups are resident at once
                                   (BASELINE configs 1-3) runs the n iterations inside ONE kernel launch (k_persist: per-factor
                                   state in registers, device-wide barriers instead of kernel boundaries; identical results):

@@ -812,6 +812,49 @@ def test_sharded_kernels_on_one_gpu_match_sharded_oracle(world, chunks, oracle_m
     assert abs(tot["sum_norm"] - eo["sum_norm"]) <= 1e-5 * eo["sum_norm"]
 
 
+@pytest.mark.parametrize("chunks", [1, 3])
+def test_row_placement_is_unobservable(chunks):
+    """Graphs of many small cameras (fewer than 512 factors per camera, >= 2 048 tiles: BASELINE config 5's shape) get their
+    16-factor rows laid out by landmark octile inside windows of 32 cameras (gbp_capi.cpp, row placement).  A row stays whole
+    and a camera's rows are added in the camera's own order, so nothing may change: the default engine against tile_order = 1
+    (camera-major rows, sequential tiles) on a 4 096-camera x 40 000-landmark x 400 000-factor graph, bit for bit through the
+    start of a BA run; and the same through the sharded C-ABI path of a 1-shard ctx with the sweep issued in `chunks` pieces
+    (camera ranges that do NOT end on window boundaries: a piece sweeps to the end of the window its range ends in)."""
+    from gbp_poplar_amd import _cabi, driver, hostlib
+    from gbp_poplar_amd.distributed import ShardedGbp
+    from gbp_poplar_amd.engine import GbpEngine
+    bal = hostlib.synth_generate(4096, 40000, 10, 7)
+    opts = driver.Options()
+    K, state, _ = driver.build_inputs(bal, opts, hostlib)
+    ref = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K, params=_cabi.GbpParams.defaults(tile_order=1))
+    eng = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K, shard=(0, 1, 0, bal["n_lmks"]))
+    sh = ShardedGbp(eng, bal["n_cams"], 0, 1, dist=None, device="cuda", chunks=chunks)
+    fake = _FakeDist()
+    fake.members.append(sh)
+    sh._exchange = lambda: None
+    for e in (ref, eng):
+        e.upload(state)
+    ref.linearise()
+    eng.refresh_begin(); fake.gather_all(); eng.refresh_end(); eng.linearise_factors()
+    for it in range(14):
+        if (it + 1) % 2 == 0 and it < 10:
+            ref.weaken_priors()
+            eng.weaken_priors()
+        ref.iterate(1)
+        if chunks > 1:
+            for i in range(chunks):
+                eng.iterate_begin_chunk(i)
+        else:
+            eng.iterate_begin()
+        fake.gather_all()
+        eng.iterate_end()
+    a, b = ref.read(), sh.read()
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    ea, eb = ref.eval(), eng.eval()
+    assert ea["n_relin"] == eb["n_relin"] and ea["n_robust"] == eb["n_robust"] and ea["sum_norm"] == eb["sum_norm"]
+
+
 def test_sharded_slam_keyframes_on_one_gpu(oracle_mod):
     """READ_PRIORS / NEW_KEYFRAME on landmark-shard contexts (two shards on one GPU, exchange by device copies): the
     incremental SLAM flow of slam.cpp:1018-1055 with a keyframe every 12 sweeps == the oracle in 2-shard order."""
