@@ -449,6 +449,9 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
 #ifndef GBP_ROW_WINDOW
 #define GBP_ROW_WINDOW 32
 #endif
+#ifndef GBP_ROW_PLACE_MAX_DEG
+#define GBP_ROW_PLACE_MAX_DEG 512u      // average factors per camera (and rank) below which the rows are placed by octile
+#endif
 #ifndef GBP_ROW_KEY_LANE
 #define GBP_ROW_KEY_LANE 0
 #endif
@@ -456,7 +459,7 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
   c->row_slot.clear(); c->row_window = 0;
 #ifndef GBP_ROW_PLACEMENT_OFF     // measurement
   if ((c->prm.tile_order == 0 || c->prm.tile_order == 3) && c->n_tiles >= 2048 && C >= 2 * kRowWindow && c->L_loc >= 8 &&
-      (uint64_t)c->E_loc < (uint64_t)C * 512u) {
+      (uint64_t)c->E_loc < (uint64_t)C * GBP_ROW_PLACE_MAX_DEG) {
     std::vector<uint8_t> key(c->n_rows, 0);
     {
       std::vector<uint32_t> cfill(C, 0);
