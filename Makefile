@@ -8,12 +8,12 @@ ARCH    ?= gfx950
 PKG     := gbp_poplar_amd
 CSRC    := $(PKG)/csrc
 LIB     := $(PKG)/libgbp_mi355x.so
-HIPFLAGS := -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=$(ARCH) -Wall -Wno-unused-function
+HIPFLAGS := -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden --offload-arch=$(ARCH) -Wall -Wno-unused-function
 
 all: $(LIB) $(PKG)/bin/ba $(PKG)/bin/slam $(PKG)/bin/bal_convert
 
-$(LIB): $(CSRC)/gbp_kernels.hip $(CSRC)/gbp_capi.cpp $(CSRC)/gbp_comm.cpp $(CSRC)/gbp_comm.hpp $(CSRC)/gbp_host.cpp $(CSRC)/gbp_kernels.h $(CSRC)/gbp_device_math.hpp include/gbp_mi355x.h
-	$(HIPCC) -shared -o $@ $(HIPFLAGS) -x hip $(CSRC)/gbp_kernels.hip $(CSRC)/gbp_capi.cpp $(CSRC)/gbp_comm.cpp $(CSRC)/gbp_host.cpp -ldl
+$(LIB): $(CSRC)/gbp_kernels.hip $(CSRC)/gbp_capi.cpp $(CSRC)/gbp_layout.cpp $(CSRC)/gbp_layout.hpp $(CSRC)/gbp_comm.cpp $(CSRC)/gbp_comm.hpp $(CSRC)/gbp_host.cpp $(CSRC)/gbp_kernels.h $(CSRC)/gbp_device_math.hpp include/gbp_mi355x.h
+	$(HIPCC) -shared -o $@ $(HIPFLAGS) -x hip $(CSRC)/gbp_kernels.hip $(CSRC)/gbp_capi.cpp $(CSRC)/gbp_layout.cpp $(CSRC)/gbp_comm.cpp $(CSRC)/gbp_host.cpp -ldl -Wl,--version-script=$(CSRC)/gbp_exports.map
 
 $(PKG)/bin/%: $(CSRC)/%_main.cpp $(CSRC)/cli_common.hpp $(LIB)
 	@mkdir -p $(PKG)/bin

@@ -98,8 +98,6 @@ def parse(argv=None):
     ap.add_argument("--sharded-graph", type=int, default=None,
                     help="capture the sharded iteration (kernels + the RCCL all-gather) in a hipGraph (default off: measured "
                          "slower than direct launches, 0.191 vs 0.186 ms per iteration on the config-5 shard shape)")
-    ap.add_argument("--exchange-chunks", type=int, default=None,
-                    help="camera ranges of the pipelined all-gather (default: 1)")
     ap.add_argument("--tile-order", type=int, default=0, help="gbp_params.tile_order: 0 = default, 1 = sequential, 2 = sweep tiles XCD-aware too")
     ap.add_argument("--master-port", type=int, default=0, help="self-launch: rendezvous port (0 = pick a free one)")
     ap.add_argument("--graph-unroll", type=int, default=20,
@@ -703,7 +701,7 @@ def main(argv=None):
             exchange_kind = "native: ncclAllGather issued by libgbp_mi355x.so (C++ host; beside the landmark beliefs from 4 ranks on)"
         else:
             run = ShardedGbp(eng, C, rank, world, dist=dist, device="cuda", always_collective=a.force_sharded,
-                             use_graph=bool(a.sharded_graph), chunks=a.exchange_chunks)
+                             use_graph=bool(a.sharded_graph))
             run_eval = run.eval
             exchange_kind = "torch.distributed all_gather_into_tensor around the split-phase C-ABI (--comm torch)"
     run.upload(state)
@@ -850,7 +848,6 @@ def main(argv=None):
                        "reproj_rmse_px_initial": round(m0[2], 6), "reproj_rmse_px_final": round(m1[2], 6),
                        "mean_reproj_px_final": round(m1[0], 6), "iterations_run": a.warmup + extra_warm + a.steps,
                        "nonfinite_beliefs": int(ev1["n_nonfinite"]),
-                       "exchange_chunks": getattr(run, "chunks", None),
                        "iteration_graph": graph_used, "exchange": exchange_kind, "comm_error": comm_error,
                        "sharded_graph_error": getattr(run, "graph_error", None), "preflight": pre},
         }

@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-GBP_ABI_VERSION = 4          # include/gbp_mi355x.h
+GBP_ABI_VERSION = 5          # include/gbp_mi355x.h
 
 c_f32p = C.POINTER(C.c_float)
 c_f64p = C.POINTER(C.c_double)
@@ -34,6 +34,13 @@ class GbpParams(C.Structure):
         for k, v in kw.items():
             setattr(p, k, v)
         return p
+
+
+class GbpLayoutOptions(C.Structure):
+    """include/gbp_mi355x_debug.h: knobs of the device-order construction (test-hooks build only)."""
+    _fields_ = [("row_placement", C.c_uint32), ("row_window", C.c_uint32), ("row_place_max_deg", C.c_uint32),
+                ("row_key_lane", C.c_uint32), ("classes", C.c_uint32), ("tile_window", C.c_uint32),
+                ("tile_min_tiles", C.c_uint32), ("tile_identity", C.c_uint32)]
 
 
 class GbpShard(C.Structure):

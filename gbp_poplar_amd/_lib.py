@@ -41,8 +41,6 @@ _SIGS = {
     "gbp_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gbp_set_exchange_buffers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "gbp_iterate_begin": (C.c_int, [C.c_void_p]),
-    "gbp_set_exchange_chunks": (C.c_int, [C.c_void_p, C.c_int]),
-    "gbp_iterate_begin_chunk": (C.c_int, [C.c_void_p, C.c_int]),
     "gbp_iterate_local": (C.c_int, [C.c_void_p]),
     "gbp_iterate_end": (C.c_int, [C.c_void_p]),
     "gbp_refresh_begin": (C.c_int, [C.c_void_p]),
@@ -76,7 +74,6 @@ _SIGS = {
                                      cabi.c_f32p, cabi.c_f32p]),
     "gbp_init_add_noise": (C.c_int, [C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_uint64, cabi.c_f32p, cabi.c_f32p]),
     "gbp_init_av_depth": (C.c_int, [C.POINTER(cabi.GbpProblem), cabi.c_f32p, cabi.c_f32p]),
-    "gbp_tile_order_local": (C.c_int, [C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32, cabi.c_u32p]),
     "gbp_slam_create_flags": (C.c_int, [C.POINTER(cabi.GbpProblem), C.c_uint32] + [cabi.c_u32p] * 4),
     "gbp_slam_update_flags": (C.c_int, [C.POINTER(cabi.GbpProblem), C.c_uint32, C.c_uint32] + [cabi.c_u32p] * 4
                               + [cabi.c_i32p]),
@@ -95,6 +92,15 @@ _DEBUG_SIGS = {
     "gbp_debug_set_factor_potentials": (C.c_int, [C.c_void_p, cabi.c_f32p, cabi.c_f32p]),
     "gbp_debug_math": (C.c_int, [C.c_int, cabi.c_f32p, cabi.c_f32p, C.c_int]),
     "gbp_debug_math_timed": (C.c_int, [C.c_int, cabi.c_f32p, cabi.c_f32p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "gbp_debug_layout_default_options": (None, [C.POINTER(cabi.GbpLayoutOptions)]),
+    "gbp_debug_layout_options": (C.c_int, [C.POINTER(cabi.GbpLayoutOptions)]),
+    "gbp_debug_force_sweep_policy": (C.c_int, [C.c_int]),
+    "gbp_debug_layout_build": (C.c_int, [C.POINTER(cabi.GbpProblem), C.c_int, C.POINTER(cabi.GbpShard),
+                                         C.POINTER(cabi.GbpLayoutOptions), C.POINTER(C.c_void_p)]),
+    "gbp_debug_layout_dims": (C.c_int, [C.c_void_p, cabi.c_u32p]),
+    "gbp_debug_layout_array": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(cabi.c_u32p), C.POINTER(C.c_size_t)]),
+    "gbp_debug_layout_free": (None, [C.c_void_p]),
+    "gbp_debug_tile_order_local": (C.c_int, [C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32, C.c_uint32, cabi.c_u32p]),
 }
 
 

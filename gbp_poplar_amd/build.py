@@ -4,8 +4,8 @@
                                              gbp_poplar_amd/libgbp_mi355x_test.so  the same sources + the test hooks of
                                                                                    include/gbp_mi355x_debug.h (tests/ only)
     python -m gbp_poplar_amd.build --experiments
-                                          -> gbp_poplar_amd/libgbp_mi355x_exp.so   + timing ablations / mapping experiments
-                                                                                   (profiles/*.py only)
+                                          -> gbp_poplar_amd/libgbp_mi355x_exp.so   + csrc/experiments/: timing ablations / mapping
+                                                                                   experiments (profiles/*.py only)
 
 hipcc cross-compiles for gfx950 without a GPU.  -ffp-contract=off: results are compared
 bit-for-bit with the CPU oracle, so no FMA contraction on either side.
@@ -22,8 +22,9 @@ TEST_LIB = os.path.join(HERE, "libgbp_mi355x_test.so")  # + gbp_debug_* (include
 EXP_LIB = os.path.join(HERE, "libgbp_mi355x_exp.so")    # + timing ablations and mapping experiments (profiles/*.py only)
 BIN = os.path.join(HERE, "bin")
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function"]
-LIB_SRCS = ["gbp_kernels.hip", "gbp_capi.cpp", "gbp_comm.cpp", "gbp_host.cpp"]
+# -fvisibility=hidden: the library exports the gbp_* functions of include/*.h (GBP_API) and nothing else
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function"]
+LIB_SRCS = ["gbp_kernels.hip", "gbp_capi.cpp", "gbp_layout.cpp", "gbp_comm.cpp", "gbp_host.cpp"]
 CLI_SRCS = {"ba": "ba_main.cpp", "slam": "slam_main.cpp", "bal_convert": "bal_convert_main.cpp"}
 
 
@@ -43,14 +44,14 @@ def _stale(target, deps):
 
 def _deps():
     inc = os.path.join(HERE, "..", "include")
-    return [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(inc, f) for f in os.listdir(inc)]
+    srcs = [os.path.join(d, f) for d, _, fs in os.walk(CSRC) for f in fs]          # csrc/, csrc/hooks/, csrc/experiments/
+    return srcs + [os.path.join(inc, f) for f in os.listdir(inc)]
 
 
 def _build_lib(target, defines, force, verbose):
     if force or _stale(target, _deps()):
-        extra = os.environ.get("GBP_EXTRA_HIPFLAGS", "").split()     # experiments only (e.g. -DGBP_FAC_TEMPORAL)
-        cmd = [hipcc(), "-shared", "-o", target] + FLAGS + defines + extra + ["-x", "hip"] + \
-              [os.path.join(CSRC, s) for s in LIB_SRCS] + ["-ldl"]
+        cmd = [hipcc(), "-shared", "-o", target] + FLAGS + defines + ["-x", "hip"] + \
+              [os.path.join(CSRC, s) for s in LIB_SRCS] + ["-ldl", "-Wl,--version-script=" + os.path.join(CSRC, "gbp_exports.map")]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
@@ -81,7 +82,7 @@ def build(force=False, verbose=False, test_hooks=True):
 def build_experiments(force=False, verbose=False):
     """The measurement build: the product sources + test hooks + the ablated / experimental kernel instantiations.
     Loaded only by profiles/*.py (GBP_LIB)."""
-    return _build_lib(EXP_LIB, ["-DGBP_BUILD_ABLATIONS", "-DGBP_BUILD_EXPERIMENTS", "-DGBP_BUILD_TEST_HOOKS"], force, verbose)
+    return _build_lib(EXP_LIB, ["-DGBP_BUILD_EXPERIMENTS", "-DGBP_BUILD_TEST_HOOKS"], force, verbose)
 
 
 if __name__ == "__main__":

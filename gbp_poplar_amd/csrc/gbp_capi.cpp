@@ -12,6 +12,7 @@
 #endif
 #include "gbp_comm.hpp"
 #include "gbp_kernels.h"
+#include "gbp_layout.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -44,6 +45,24 @@ struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
 };
+static_assert(kLayoutTile == (uint32_t)kTile && kLayoutRow == (uint32_t)kRow, "gbp_layout.hpp and gbp_kernels.h disagree on the tile shape");
+// The construction knobs of the device order and the cache policy of the sweep: the defaults are the product.  Only the
+// test-hooks build can change them (gbp_debug_layout_options / gbp_debug_force_sweep_policy: measurements and tests).
+LayoutOptions g_layout_options;
+int g_force_sweep_policy = -1;
+
+// Cache policy of the sweep's two message streams for a graph of C cameras and n_tiles tiles (SweepArgs.policy).
+// Camera messages loaded with the default policy instead of the non-temporal hint: few cameras (their belief table small beside
+// an XCD's 4 MiB L2) AND both message streams of this rank (176 B per factor slot) within ~3/4 of the 256 MiB Infinity Cache,
+// where the lines loaded this sweep are still found by the next: measured on 1 M factors x 100 000 landmarks +1.3 % iterations/s
+// with 500 cameras, +0.6 % with 1 000, +0.25 % with 2 000, -0.1 % with 4 000, -0.3 % with 8 000 (-1.4 % on the config-5 shard
+// shape); 1 000 cameras, factor count scanned: +1.4 % at 0.5 M, +0...2 % at 1 M (the edge), -0.5 % at 1.25 M, -2 % at 1.5 M,
+// -5.5 % at 2 M (profiles/r04_alu_diet.md section 6).
+uint32_t sweep_policy_for(uint32_t C, uint32_t n_tiles) {
+  uint32_t pol = 0;
+  if (C <= 2048u && (uint64_t)n_tiles * 64u * 176u <= 200000000ull) pol |= kPolCmsgLoadCached;
+  return pol;
+}
 }  // namespace
 
 struct gbp_ctx {
@@ -52,13 +71,7 @@ struct gbp_ctx {
   int rank = 0, world = 1;
   float K[9];
   gbp_params prm;
-  // device-order maps (host)
-  std::vector<uint32_t> pos_edge;     // [Ep] device position -> global file edge index, ~0u = pad
-  std::vector<uint32_t> pos_cam, pos_lmk_loc, pos_lpos;
-  std::vector<uint32_t> cam_row_ptr;  // [C+1] rows of each camera
-  std::vector<uint32_t> row_slot;     // [n_rows] device row of logical row r (empty: identity).  See kRowWindow in create_impl.
-  uint32_t row_window = 0;            // cameras per window of the row placement (0: identity)
-  std::vector<uint32_t> lmk_ptr;      // [L_loc+1] records of each local landmark in LMSG
+  Layout lay;                         // device order (host side): position <-> file edge, rows, slots, tile order
   uint32_t Ep = 0, n_tiles = 0, n_rows = 0;
   // device memory
   std::vector<DevBuf*> all;
@@ -67,6 +80,7 @@ struct gbp_ctx {
   DevBuf st_a, st_b;                   // [Ep] scratch of the per-factor state get / set kernels
   std::vector<uint8_t> active_host;    // [Ep] host shadow of the active flags (hoist guard of gbp_new_keyframe)
   bool use_tile_perm = false;
+  uint32_t sweep_policy = 0;           // kPol* bits of SweepArgs.policy for this graph's shape (sweep_policy_for)
   bool hoist = true;  // per-variable belief means (k_sweep<true>); false = literal per-factor mu/oldmu tensors
   void* send_dev = nullptr;
   void* recv_dev = nullptr;
@@ -86,8 +100,6 @@ struct gbp_ctx {
   bool sharded_graph = false;          // gbp_params.graph_unroll > 0 was asked for explicitly (see iterate_sharded)
   bool uploaded = false, beliefs_valid = false;
   bool lmk_half_done = false;          // gbp_iterate_local already refreshed the landmark beliefs of this iteration
-  int exch_chunks = 1;                 // camera ranges of the pipelined exchange (gbp_set_exchange_chunks)
-  std::vector<uint32_t> chunk_start;   // [exch_chunks + 1] camera index where each chunk starts
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
   // gbp_iterate does not block the host: each call is bracketed by an event pair that is read later (gbp_timing, or
   // when the ring is full), so a caller that evaluates the metric every iteration pays ONE host synchronisation per
@@ -119,7 +131,6 @@ struct gbp_ctx {
   std::string warn;                    // text of the last recovered incident (also left in `err`, the call returns GBP_OK)
   uint64_t persist_recoveries = 0;
   DevBuf psync;                        // barrier words
-  DevBuf ptrace;                       // experiments build: per-phase time stamps of k_persist (gbp_debug_persist_trace)
   void* pstatus_host = nullptr;        // pinned + device-mapped: raised by the kernel if a barrier gave up
   void* pstatus_dev = nullptr;
   uint64_t persist_launches = 0;
@@ -166,17 +177,9 @@ SweepArgs sweep_args(gbp_ctx* c) {
   a.hp.maxeta_damping = c->prm.maxeta_damping; a.hp.num_undamped_iters = c->prm.num_undamped_iters;
   a.hp.dmu_threshold = c->prm.dmu_threshold; a.hp.min_linear_iters = c->prm.min_linear_iters;
   a.hp.nstds = c->prm.nstds; a.hp.relin_mode = c->prm.relin_mode;
-  a.block0 = 0;
   a.variant = c->prm.reserved[0];      // read by the experiments build only
   a.tile_perm = c->use_tile_perm ? P<uint32_t>(c->tile_perm) : nullptr;
-#ifdef GBP_CMSG_CACHED_OFF       // measurement
-  a.cmsg_cached = 0u;
-#else
-  // few cameras (their belief table small beside an XCD's L2) AND both message streams of this rank (176 B per factor slot)
-  // within ~3/4 of the 256 MiB Infinity Cache, where the lines loaded this sweep are still found by the next: measured
-  // +1.4 % at 0.5 M factors, +0...2 % at 1 M (the edge), -0.5 % at 1.25 M, -2 % at 1.5 M, -5.5 % at 2 M (r04_alu_diet.md section 6)
-  a.cmsg_cached = (c->C <= 2048u && (uint64_t)c->n_tiles * 64u * 176u <= 200000000ull) ? 1u : 0u;
-#endif
+  a.policy = c->sweep_policy;
   return a;
 }
 
@@ -189,17 +192,14 @@ void drop_graph(gbp_ctx* c) {
 BeliefArgs belief_args(gbp_ctx* c) {
   BeliefArgs b{};
   b.rowp = P<float>(c->rowp); b.cam_row_ptr = P<uint32_t>(c->d_cam_row_ptr); b.cam_prior = P<float>(c->camp);
-  b.row_slot = c->row_slot.empty() ? nullptr : P<uint32_t>(c->d_row_slot);
+  b.row_slot = c->lay.row_slot.empty() ? nullptr : P<uint32_t>(c->d_row_slot);
   b.cam_local = P<float>(c->local); b.gathered = nullptr; b.world = c->world;
   b.camb = P<float>(c->camb); b.cam_mu = P<float4>(c->hmu_c); b.cam_lin = P<float4>(c->clin); b.n_cams = c->C;
   b.lmk_prior = P<float4>(c->lmkp); b.lmsg = P<float4>(c->lmsg); b.lmk_ptr = P<uint32_t>(c->d_lmk_ptr);
   b.lmk_fpos = P<uint32_t>(c->d_lmk_fpos); b.lmk_ix = P<uint32_t>(c->d_lmk_ix);
   b.lmkb = P<float4>(c->lmkb); b.lmk_mu = P<float4>(c->hmu_l); b.n_lmks = c->L_loc;
   b.partial_only = 0; b.hoist = c->hoist ? 1 : 0; b.roll = 0;
-  b.cam0 = 0; b.cam1 = 0;
   b.lmk_blocks = 0; b.lmk_xcd_order = c->prm.tile_order != 1 ? 1 : 0;
-  b.n_chunks = c->exch_chunks;
-  for (int i = 0; i <= c->exch_chunks; ++i) b.chunk_start[i] = c->chunk_start[i];
   return b;
 }
 
@@ -388,11 +388,20 @@ void gbp_destroy(gbp_ctx* c) {
 static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_shard* sh, gbp_ctx** out) {
   if (!pr || !out || !pr->cam_id || !pr->lmk_id || pr->n_cams == 0 || pr->n_lmks == 0 || pr->n_edges == 0)
     return fail(nullptr, GBP_ERR_INVALID, "gbp_create: null or empty problem");
+  // ---- device order: pure host code (gbp_layout.cpp), built and validated before anything touches the GPU ----
+  Layout lay;
+  {
+    gbp_params dflt;
+    gbp_default_params(&dflt);
+    std::string lerr;
+    if (int lrc = layout_build(pr, (prm ? prm : &dflt)->tile_order, sh, g_layout_options, lay, lerr)) return fail(nullptr, lrc, lerr);
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     return fail(nullptr, GBP_ERR_NO_DEVICE, "gbp_create: no HIP device (the product has no CPU fallback)");
   gbp_ctx* c = new gbp_ctx();
   struct Owner { gbp_ctx* p; ~Owner() { if (p) gbp_destroy(p); } } owner{c};   // released on success only
+  c->lay = std::move(lay);
   c->C = pr->n_cams; c->L = pr->n_lmks; c->E = pr->n_edges;
   std::memcpy(c->K, pr->K, sizeof(c->K));
   if (prm) c->prm = *prm; else gbp_default_params(&c->prm);
@@ -404,100 +413,12 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
   c->world = sh ? sh->world : 1;
   c->lmk_begin = sh ? sh->lmk_begin : 0;
   c->lmk_end = sh ? sh->lmk_end : c->L;
-  if (c->world < 1 || c->rank < 0 || c->rank >= c->world || c->lmk_begin > c->lmk_end || c->lmk_end > c->L)
-    return fail(nullptr, GBP_ERR_INVALID, "gbp_create: bad shard");
-  c->L_loc = c->lmk_end - c->lmk_begin;
-  c->chunk_start = {0u, c->C};
+  c->L_loc = c->lmk_end - c->lmk_begin;      // (the shard was validated by layout_build)
 
-  // ---- device order: camera-major, file order inside a camera, rows of 16, tiles of 64 ----
-  const uint32_t C = c->C, E = c->E;
-  std::vector<uint32_t> deg(C, 0), ldeg(c->L_loc, 0);
-  for (uint32_t e = 0; e < E; ++e) {
-    const uint32_t cam = pr->cam_id[e], l = pr->lmk_id[e];
-    if (cam >= C || l >= c->L) return fail(nullptr, GBP_ERR_INVALID, "gbp_create: index out of range");
-    if (l >= c->lmk_begin && l < c->lmk_end) { deg[cam]++; ldeg[l - c->lmk_begin]++; c->E_loc++; }
-  }
-  c->cam_row_ptr.assign(C + 1, 0);
-  for (uint32_t k = 0; k < C; ++k) c->cam_row_ptr[k + 1] = c->cam_row_ptr[k] + (deg[k] + kRow - 1) / kRow;
-  {  // device positions are 32-bit: rows of 16 per camera, padded to whole 256-factor blocks
-    uint64_t rows = 0;
-    for (uint32_t k = 0; k < C; ++k) rows += (deg[k] + kRow - 1) / kRow;
-    if (((rows * kRow + 255) / 256) * 256 >= (1ull << 32))
-      return fail(nullptr, GBP_ERR_INVALID, "gbp_create: more than 2^32 padded factor positions on one GPU; shard by landmark (gbp_shard)");
-  }
-  c->n_rows = c->cam_row_ptr[C];
-  c->Ep = ((c->n_rows * kRow + 255) / 256) * 256;
-  if (c->Ep == 0) c->Ep = 256;
-  c->n_tiles = c->Ep / kTile;
-  c->lmk_ptr.assign(c->L_loc + 1, 0);
-  for (uint32_t l = 0; l < c->L_loc; ++l) c->lmk_ptr[l + 1] = c->lmk_ptr[l] + ldeg[l];
-  c->pos_edge.assign(c->Ep, ~0u);
-  c->pos_cam.assign(c->Ep, 0);
-  c->pos_lmk_loc.assign(c->Ep, 0);
-  c->pos_lpos.assign(c->Ep, c->E_loc);  // pads point at the dump record
-  // ---- row placement (graphs of many cameras with few factors each: BASELINE config 5 has 156 per camera and rank) ----
-  // A row — 16 consecutive factors of one camera, in file order: the unit of the camera sums, never split or reordered — may sit in
-  // any device row: the sweep writes its sums where the row sits, the camera part of k_beliefs finds a camera's rows through
-  // row_slot and adds them in the camera's own order (same sums, same bits).  The file lists a camera's factors by landmark,
-  // so a row covers 16 / deg of the landmark range, but the four rows of a TILE cover four times that: 41 % on config 5 — no tile
-  // belongs to one landmark octile, the XCD-aware tile order has nothing to work with, and nearly every landmark-belief gather
-  // misses its L2 (14-17 us of the 135 us sweep against 4.7 of 98 on S1: profiles/ablate_sweep.py).  Inside windows of
-  // kRowWindow cameras the rows are therefore placed by the landmark octile of their first factor (stable: file order within an
-  // octile), so that a tile holds rows of neighbouring cameras from ONE octile.  Only where it is needed (few factors per
-  // camera) and where the tile order is on (>= 2 048 tiles, tile_order 0 / 3); a piece of a pipelined exchange sweeps to the
-  // end of the window its camera range ends in (gbp_iterate_begin_chunk).
-#ifndef GBP_ROW_WINDOW
-#define GBP_ROW_WINDOW 32
-#endif
-#ifndef GBP_ROW_PLACE_MAX_DEG
-#define GBP_ROW_PLACE_MAX_DEG 512u      // average factors per camera (and rank) below which the rows are placed by octile
-#endif
-#ifndef GBP_ROW_KEY_LANE
-#define GBP_ROW_KEY_LANE 0
-#endif
-  constexpr uint32_t kRowWindow = GBP_ROW_WINDOW;
-  c->row_slot.clear(); c->row_window = 0;
-#ifndef GBP_ROW_PLACEMENT_OFF     // measurement
-  if ((c->prm.tile_order == 0 || c->prm.tile_order == 3) && c->n_tiles >= 2048 && C >= 2 * kRowWindow && c->L_loc >= 8 &&
-      (uint64_t)c->E_loc < (uint64_t)C * GBP_ROW_PLACE_MAX_DEG) {
-    std::vector<uint8_t> key(c->n_rows, 0);
-    {
-      std::vector<uint32_t> cfill(C, 0);
-      for (uint32_t e = 0; e < E; ++e) {
-        const uint32_t cam = pr->cam_id[e], l = pr->lmk_id[e];
-        if (l < c->lmk_begin || l >= c->lmk_end) continue;
-        const uint32_t i = cfill[cam]++;
-        if (i % kRow == GBP_ROW_KEY_LANE || i % kRow == 0) key[c->cam_row_ptr[cam] + i / kRow] = (uint8_t)(((uint64_t)(l - c->lmk_begin) * 8u) / c->L_loc);
-      }
-    }
-    c->row_slot.assign(c->n_rows, 0);
-    for (uint32_t c0 = 0; c0 < C; c0 += kRowWindow) {
-      const uint32_t c1 = std::min<uint32_t>(C, c0 + kRowWindow), R0 = c->cam_row_ptr[c0], R1 = c->cam_row_ptr[c1];
-      uint32_t cnt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-      for (uint32_t r = R0; r < R1; ++r) cnt[key[r] + 1]++;
-      for (int k = 0; k < 8; ++k) cnt[k + 1] += cnt[k];
-      for (uint32_t r = R0; r < R1; ++r) c->row_slot[r] = R0 + cnt[key[r]]++;      // counting sort: stable
-    }
-    c->row_window = kRowWindow;
-  }
-#endif
-  auto dev_row = [&](uint32_t r) -> uint32_t { return c->row_slot.empty() ? r : c->row_slot[r]; };
-  for (uint32_t k = 0; k < C; ++k)
-    for (uint32_t r = c->cam_row_ptr[k]; r < c->cam_row_ptr[k + 1]; ++r)
-      for (int i = 0; i < kRow; ++i) c->pos_cam[(size_t)dev_row(r) * kRow + i] = k;
-  {
-    std::vector<uint32_t> cfill(C, 0), lfill(c->L_loc, 0);
-    for (uint32_t e = 0; e < E; ++e) {
-      const uint32_t cam = pr->cam_id[e], l = pr->lmk_id[e];
-      if (l < c->lmk_begin || l >= c->lmk_end) continue;
-      const uint32_t ll = l - c->lmk_begin;
-      const uint32_t ci = cfill[cam]++;
-      const uint32_t p = dev_row(c->cam_row_ptr[cam] + ci / kRow) * kRow + ci % kRow;
-      c->pos_edge[p] = e;
-      c->pos_lmk_loc[p] = ll;
-      c->pos_lpos[p] = c->lmk_ptr[ll] + lfill[ll]++;
-    }
-  }
+  const Layout& y = c->lay;
+  c->E_loc = y.E_loc; c->n_rows = y.n_rows; c->Ep = y.Ep; c->n_tiles = y.n_tiles;
+  const uint32_t C = c->C;
+  c->sweep_policy = g_force_sweep_policy >= 0 ? (uint32_t)g_force_sweep_policy : sweep_policy_for(c->C, c->n_tiles);
 
   // ---- device allocations ----
   int rc = GBP_OK;
@@ -510,7 +431,7 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
   A(c->lmkb, (size_t)c->L_loc * 64); A(c->lmkp, (size_t)c->L_loc * 64);
   A(c->rowp, (Ep / kRow) * kCamRec * 4);
   A(c->d_cam_row_ptr, (size_t)(C + 1) * 4); A(c->d_lmk_ptr, (size_t)(c->L_loc + 1) * 4);
-  A(c->d_row_slot, c->row_slot.size() * 4);
+  A(c->d_row_slot, y.row_slot.size() * 4);
   A(c->cwf, (size_t)C * 4); A(c->lwf, (size_t)c->L_loc * 4); A(c->cscale, (size_t)C * 4); A(c->lscale, (size_t)c->L_loc * 4);
   A(c->cam_mu, (size_t)C * 6 * 4 * 2); A(c->lmk_mu, (size_t)c->L_loc * 3 * 4 * 2);   // metric means; k_persist alternates between the two halves
   A(c->dK, 16 * 4);
@@ -525,95 +446,18 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
   c->stream = c->own_stream;
   CK(hipEventCreate(&c->ev0), "hipEventCreate"); CK(hipEventCreate(&c->ev1), "hipEventCreate");
   CK(hipEventCreate(&c->ev2), "hipEventCreate"); CK(hipEventCreate(&c->ev3), "hipEventCreate");
-  CK(hipMemcpy(c->d_cam_row_ptr.p, c->cam_row_ptr.data(), (size_t)(C + 1) * 4, hipMemcpyHostToDevice), "copy cam_row_ptr");
-  CK(hipMemcpy(c->d_lmk_ptr.p, c->lmk_ptr.data(), (size_t)(c->L_loc + 1) * 4, hipMemcpyHostToDevice), "copy lmk_ptr");
-  if (!c->row_slot.empty()) CK(hipMemcpy(c->d_row_slot.p, c->row_slot.data(), c->row_slot.size() * 4, hipMemcpyHostToDevice), "copy row_slot");
+  CK(hipMemcpy(c->d_cam_row_ptr.p, y.cam_row_ptr.data(), (size_t)(C + 1) * 4, hipMemcpyHostToDevice), "copy cam_row_ptr");
+  CK(hipMemcpy(c->d_lmk_ptr.p, y.lmk_ptr.data(), (size_t)(c->L_loc + 1) * 4, hipMemcpyHostToDevice), "copy lmk_ptr");
+  if (!y.row_slot.empty()) CK(hipMemcpy(c->d_row_slot.p, y.row_slot.data(), y.row_slot.size() * 4, hipMemcpyHostToDevice), "copy row_slot");
   CK(hipMemcpy(c->dK.p, c->K, 9 * 4, hipMemcpyHostToDevice), "copy K");
-  {
-    std::vector<uint32_t> fpos(c->E_loc ? c->E_loc : 1, 0u);  // landmark-major slot list -> device position
-    for (size_t p = 0; p < Ep; ++p)
-      if (c->pos_edge[p] != ~0u) fpos[c->pos_lpos[p]] = (uint32_t)p;
-    CK(hipMemcpy(c->d_lmk_fpos.p, fpos.data(), (size_t)c->E_loc * 4, hipMemcpyHostToDevice), "copy lmk_fpos");
-    std::vector<uint32_t> ix((size_t)c->L_loc * 16 + 16, 0u);   // per landmark: degree + positions of its first 15 slots
-    for (uint32_t l = 0; l < c->L_loc; ++l) {
-      const uint32_t s0 = c->lmk_ptr[l], d = c->lmk_ptr[l + 1] - s0;
-      ix[(size_t)l * 16] = d;
-      for (uint32_t k = 0; k < d && k < 15u; ++k) ix[(size_t)l * 16 + 1 + k] = fpos[s0 + k];
-    }
-    CK(hipMemcpy(c->d_lmk_ix.p, ix.data(), (size_t)c->L_loc * 64, hipMemcpyHostToDevice), "copy lmk_ix");
-  }
-  {
-    std::vector<uint32_t> rc_(Ep / kRow);
-    for (size_t r = 0; r < Ep / kRow; ++r) rc_[r] = c->pos_cam[r * kRow];
-    CK(hipMemcpy(c->row_cam.p, rc_.data(), rc_.size() * 4, hipMemcpyHostToDevice), "copy row_cam");
-    CK(hipMemcpy(c->lmk_idx.p, c->pos_lmk_loc.data(), Ep * 4, hipMemcpyHostToDevice), "copy lmk_idx");
-  }
-  if (rc == GBP_OK && c->prm.tile_order == 2) {
-    // XCD-aware execution order of the sweep (optional: 11 % less fabric traffic, but ~2 % slower than the sequential
-    // order on S1 — consecutive tiles of an XCD then sit ~200 KB apart in every stream; profiles/r01_ablation.md).  Workgroup w lands on XCD (w mod 8) (observed placement; only speed
-    // depends on it) and its wave v runs tile perm[4w + v].  Tiles are ranked by the octile of their lowest landmark
-    // index (memory order inside an octile) and the ranking is cut into 8 equal runs, one per XCD, so each private 4 MiB L2 serves one slice of the gathered
-    // landmark tables (beliefs + hoisted means) instead of a random 4 MiB / table-size share of all of them.
-    const uint32_t nt = c->n_tiles, nb = nt / 4;
-    std::vector<uint64_t> key(nt);
-    for (uint32_t t = 0; t < nt; ++t) {
-      uint32_t lo = ~0u;
-      for (uint32_t i = 0; i < kTile; ++i) {
-        const size_t p = (size_t)t * kTile + i;
-        if (c->pos_edge[p] != ~0u) lo = std::min(lo, c->pos_lmk_loc[p]);
-      }
-      const uint64_t run = lo == ~0u ? 8u : (uint64_t)lo * 8u / std::max<uint32_t>(c->L_loc, 1u);  // landmark octile
-      key[t] = (run << 32) | t;   // memory order inside a run
-    }
-    std::sort(key.begin(), key.end());
-    std::vector<uint32_t> perm(nt);
-    const uint32_t q = nb / 8, r = nb % 8;   // XCD group g owns q+1 workgroups if g < r, else q (bijective for any nb)
-    uint32_t next = 0;
-    for (uint32_t g = 0; g < 8; ++g) {
-      const uint32_t n_wg = q + (g < r ? 1u : 0u);
-      for (uint32_t k = 0; k < n_wg; ++k)
-        for (uint32_t v = 0; v < 4; ++v) perm[(size_t)(8 * k + g) * 4 + v] = (uint32_t)(key[next++] & 0xffffffffu);
-    }
-    rc = dev_alloc(c, c->tile_perm, (size_t)nt * 4);
-    if (rc == GBP_OK) CK(hipMemcpy(c->tile_perm.p, perm.data(), (size_t)nt * 4, hipMemcpyHostToDevice), "copy tile_perm");
-    else g_create_error = c->err;
-    c->use_tile_perm = rc == GBP_OK;
-  }
-  // (0 = the library's choice: this order for graphs of at least 2 048 tiles — below that the whole landmark table sits in every
-  //  L2 anyway, and small graphs run in k_persist, which keeps the plain order)
-  if (rc == GBP_OK && (c->prm.tile_order == 3 || (c->prm.tile_order == 0 && c->n_tiles >= 2048))) {
-    // XCD-aware execution order of the sweep, LOCAL version: workgroup w lands on XCD (w mod 8) and should find the landmark
-    // records its factors gather in THAT XCD's L2.  Tiles are classed by the landmark octile of their median factor; the
-    // wave slots of workgroup w are filled with the earliest not yet placed tiles of class (w mod 8), looking at most
-    // `window` tiles ahead of the oldest unplaced one (else: the oldest unplaced tile, whatever its class).  A camera's
-    // factors are sorted by landmark, so its ~16 tiles walk through the octiles in order and the permutation only shuffles
-    // tiles of two or three neighbouring cameras: every stream keeps ONE compact front (tile_order = 2 gave every XCD a
-    // front of its own and lost more in the streams than it won in the gathers), while each private L2 serves 1/8 of the
-    // gathered landmark table.
-    const uint32_t nt = c->n_tiles;
-    std::vector<uint8_t> cls(nt, 8);
-    for (uint32_t t = 0; t < nt; ++t) {
-      uint32_t l[kTile], n = 0;
-      for (uint32_t i = 0; i < kTile; ++i) {
-        const size_t p = (size_t)t * kTile + i;
-        if (c->pos_edge[p] != ~0u) l[n++] = c->pos_lmk_loc[p];
-      }
-#ifdef GBP_TILE_IDENTITY       // (measurement build only: what does the table look-up itself cost?  all tiles of one class -> identity)
-      n = 0; cls[t] = 0;
-#endif
-      if (n) {
-        std::nth_element(l, l + n / 2, l + n);
-        cls[t] = (uint8_t)std::min<uint64_t>(7u, (uint64_t)l[n / 2] * 8u / std::max<uint32_t>(c->L_loc, 1u));
-      }
-    }
-#ifndef GBP_TILE_WINDOW
-#define GBP_TILE_WINDOW 96
-#endif
-    const uint32_t window = GBP_TILE_WINDOW;      // tiles: about six cameras of the 1M-factor graph (32 / 48 / 192 measured: no difference, profiles/r04_tile_order.md)
-    std::vector<uint32_t> perm(nt);
-    (void)gbp_tile_order_local(cls.data(), nt, window, perm.data());     // host helper (gbp_host.cpp): a bijection, tested on the CPU
-    rc = dev_alloc(c, c->tile_perm, (size_t)nt * 4);
-    if (rc == GBP_OK) CK(hipMemcpy(c->tile_perm.p, perm.data(), (size_t)nt * 4, hipMemcpyHostToDevice), "copy tile_perm");
+  if (c->E_loc) CK(hipMemcpy(c->d_lmk_fpos.p, y.lmk_fpos.data(), (size_t)c->E_loc * 4, hipMemcpyHostToDevice), "copy lmk_fpos");
+  if (c->L_loc) CK(hipMemcpy(c->d_lmk_ix.p, y.lmk_ix.data(), (size_t)c->L_loc * 64, hipMemcpyHostToDevice), "copy lmk_ix");
+  CK(hipMemcpy(c->row_cam.p, y.row_cam.data(), y.row_cam.size() * 4, hipMemcpyHostToDevice), "copy row_cam");
+  CK(hipMemcpy(c->lmk_idx.p, y.pos_lmk_loc.data(), Ep * 4, hipMemcpyHostToDevice), "copy lmk_idx");
+  if (rc == GBP_OK && !y.tile_perm.empty()) {
+    // the XCD-aware execution order of the sweep: wave slot -> tile (gbp_layout.cpp); read once per wave with a scalar load
+    rc = dev_alloc(c, c->tile_perm, (size_t)y.n_tiles * 4);
+    if (rc == GBP_OK) CK(hipMemcpy(c->tile_perm.p, y.tile_perm.data(), (size_t)y.n_tiles * 4, hipMemcpyHostToDevice), "copy tile_perm");
     else g_create_error = c->err;
     c->use_tile_perm = rc == GBP_OK;
   }
@@ -628,7 +472,10 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
     // measured (profiles/r03_small_graphs.md): the shipped sequences (19 - 61 workgroups, relinearising in every sweep) run
     // 1.55 - 1.82x faster in k_persist; converging synthetic graphs 1.21x at 63 workgroups, break even at 125
     const uint32_t auto_limit = 96;
-    if (mode >= 0 && !sh && c->hoist && !c->use_tile_perm && nb <= (mode > 0 ? 1u << 30 : auto_limit)) {
+    // (k_persist sweeps tile w on wave w and its camera role adds rows cam_row_ptr[c] .. cam_row_ptr[c + 1] where camera-major order
+    // puts them: a graph with a tile permutation or with rows placed by landmark class never runs in it, whatever the size
+    // thresholds of the three features say)
+    if (mode >= 0 && !sh && c->hoist && !c->use_tile_perm && c->lay.row_slot.empty() && nb <= (mode > 0 ? 1u << 30 : auto_limit)) {
       const int resident = persist_max_resident_blocks();
       if (resident > 0 && nb <= (uint32_t)resident) {
         rc = dev_alloc(c, c->psync, kPersistSyncWords * sizeof(unsigned));
@@ -708,8 +555,12 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
 static int persist_check(gbp_ctx* c, unsigned upto);
 // Every entry point that enqueues other device work, or changes what the launches in flight depend on, first makes sure
 // they completed without a barrier time-out (and repairs the state if one did): free when nothing is in flight.
+static bool stream_is_capturing(gbp_ctx* c);
 static int settle(gbp_ctx* c) {
   if (c->persist_log.empty()) return GBP_OK;
+  // unvalidated k_persist launches and a caller who has begun capturing the stream: synchronising would invalidate their capture
+  if (stream_is_capturing(c))
+    return fail(c, GBP_ERR_STATE, "bursts of the persistent kernel are still in flight on this stream: call gbp_sync before beginning a stream capture");
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return persist_check(c, 0);
 }
@@ -764,7 +615,7 @@ static int upload_impl(gbp_ctx* c, const gbp_state_in* in) {
   std::vector<float> rec0(Ep * 16, 0.f), fac(Ep * kFacG * 4, 0.f), mu(c->hoist ? 0 : Ep * kMuG * 4, 0.f);
   c->active_host.assign(Ep, 0);
   for (size_t p = 0; p < Ep; ++p) {
-    const uint32_t e = c->pos_edge[p];
+    const uint32_t e = c->lay.pos_edge[p];
     HostState h{0.f, 0, kFlagPad, 0.f};
     if (e != ~0u) {
       h.flags = (in->active_flag[e] == 1) ? kFlagActive : 0u;
@@ -1003,47 +854,6 @@ static int iterate_begin_impl(gbp_ctx* c) {
   return GBP_OK;
 }
 
-// Layout of the exchange buffers: n camera ranges [i*C/n, (i+1)*C/n), identical on every rank.  send_dev stays
-// [C][44]; recv_dev holds, for range i, [world][n_i][44] behind world * start_i * 44 floats (n = 1: [world][C][44]).
-static int set_exchange_chunks_impl(gbp_ctx* c, int n) {
-  if (!c || n < 1 || n > kMaxChunks) return fail(c, GBP_ERR_INVALID, "gbp_set_exchange_chunks: 1..8 chunks");
-  c->exch_chunks = n;
-  c->chunk_start.assign(n + 1, 0u);
-  for (int i = 0; i <= n; ++i) c->chunk_start[i] = (uint32_t)(((uint64_t)c->C * (uint64_t)i) / (uint64_t)n);
-  return GBP_OK;
-}
-
-// Piece `chunk` of a pipelined iteration: sweep the 256-factor blocks that complete the cameras of range `chunk`
-// (device order is camera-major) and reduce those cameras' local partial sums into send_dev.  After the call the
-// caller may start exchanging that range while the next piece runs.  Pieces must be issued in order 0..n-1.
-int gbp_iterate_begin_chunk(gbp_ctx* c, int chunk) {
-  if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "upload first");
-  if (chunk < 0 || chunk >= c->exch_chunks) return fail(c, GBP_ERR_INVALID, "gbp_iterate_begin_chunk: bad chunk");
-  if (int rc = settle(c)) return rc;
-  float* dst = exch(c) ? static_cast<float*>(c->send_dev) : P<float>(c->local);
-  if (!dst) return fail(c, GBP_ERR_STATE, "exchange buffers not set");
-  const uint32_t n_blocks = c->n_tiles / 4;
-  auto block_end = [&](int i) -> uint32_t {  // first block boundary at/after the last row of the cameras of range i
-    if (i + 1 >= c->exch_chunks) return n_blocks;
-    // (with the row placement of create_impl the rows of a window of cameras are interleaved: the piece runs to the end of the
-    // window its last camera sits in — a few rows of the next range are swept early, as with the block rounding below)
-    uint32_t cam_end = c->chunk_start[i + 1];
-    if (c->row_window) cam_end = std::min<uint32_t>(c->C, ((cam_end + c->row_window - 1) / c->row_window) * c->row_window);
-    const uint64_t pos = (uint64_t)c->cam_row_ptr[cam_end] * kRow;
-    return (uint32_t)std::min<uint64_t>(n_blocks, (pos + 255) / 256);
-  };
-  const uint32_t b0 = chunk == 0 ? 0u : block_end(chunk - 1), b1 = block_end(chunk);
-  SweepArgs sa = sweep_args(c);
-  sa.tile_perm = nullptr;   // a piece must sweep exactly the blocks of its camera range
-  launch_sweep_blocks(sa, b0, b1, c->hoist, c->stream);
-  BeliefArgs b = belief_args(c);
-  b.cam_local = dst; b.partial_only = 1;
-  b.cam0 = c->chunk_start[chunk]; b.cam1 = c->chunk_start[chunk + 1];
-  if (b.cam1 > b.cam0) launch_beliefs(b, true, false, c->stream);
-  HIPCHK(c, hipGetLastError());
-  return GBP_OK;
-}
-
 // The landmark half of the belief update needs nothing from other ranks: a caller may run it while the
 // all-gather of the camera partials is in flight (between gbp_iterate_begin and gbp_iterate_end).
 int gbp_iterate_local(gbp_ctx* c) {
@@ -1146,6 +956,9 @@ static int persist_recover(gbp_ctx* c) {
     if (b.mode == 1)
       if (int rc = eval_enqueue(c, b.area)) return rc;
   }
+  // the replay has completed when this returns: the callers (gbp_sync, gbp_read*, gbp_new_keyframe, gbp_set_stream, the debug
+  // accessors) go on to blocking copies on the NULL stream, which a non-blocking stream does not order against
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   c->warn = "warning: a device-wide barrier of the persistent kernel timed out in launch " + std::to_string(first) +
             " of this ctx (its workgroups were not co-resident: is another process using the GPU?); the state was restored and " +
             std::to_string(iters) + " iterations were replayed on the two-kernel path (identical results); the ctx stays on that path until the next gbp_upload";
@@ -1175,9 +988,10 @@ static bool stream_is_capturing(gbp_ctx* c) {
 static int persist_ready(gbp_ctx* c, bool* yes) {
   *yes = false;
   if (!c->persist_ok || c->comm || c->world != 1 || c->profile_stages) return GBP_OK;
+  if (stream_is_capturing(c)) return GBP_OK;
   if (c->persist_log.size() >= kPersistLogMax)
     if (int rc = settle(c)) return rc;
-  *yes = c->persist_ok && !stream_is_capturing(c);
+  *yes = c->persist_ok;
   return GBP_OK;
 }
 
@@ -1194,7 +1008,6 @@ static int launch_persist_burst(gbp_ctx* c, const SweepArgs& a, int n, const Per
   A.n_iters = n;
   A.sync = P<unsigned>(c->psync);
   A.status = static_cast<unsigned*>(c->pstatus_dev);
-  A.trace = static_cast<unsigned long long*>(c->ptrace.p);      // NULL outside the experiments build
   A.epoch_base = c->persist_epoch_base;
   A.seq = c->persist_seq + 1;
   if (ev) A.ev = *ev;
@@ -1209,10 +1022,8 @@ static int launch_persist_burst(gbp_ctx* c, const SweepArgs& a, int n, const Per
     if (!e) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (g_persist_last_ctx[dev & 15] && (g_persist_last_ctx[dev & 15] != c || g_persist_last_stream[dev & 15] != c->stream))
       HIPCHK(c, hipStreamWaitEvent(c->stream, e, 0));
-#ifndef GBP_PERSIST_NO_SNAPSHOT     // (defined only in a measurement build: what does the snapshot cost per launch?  profiles/r04_persist_launch.md)
-    launch_copy_segments(c->snap_save, P<unsigned>(c->psync) + 32, c->stream);       // skipped on the device once the abort word is set
+    launch_copy_segments(c->snap_save, P<unsigned>(c->psync) + 32, c->stream);       // skipped on the device once the abort word is set (5-7 us per launch)
     HIPCHK(c, hipGetLastError());
-#endif
     const hipError_t le = launch_persist(A, c->persist_coop, c->stream);
     if (le != hipSuccess) {
       (void)hipGetLastError();
@@ -1358,7 +1169,7 @@ static int read_impl(gbp_ctx* c, gbp_state_out* o) {
     HIPCHK(c, hipMemcpy(damp.data(), c->st_a.p, (size_t)c->Ep * 4, hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(packed.data(), c->st_b.p, (size_t)c->Ep * 4, hipMemcpyDeviceToHost));
     for (size_t p = 0; p < c->Ep; ++p) {
-      const uint32_t e = c->pos_edge[p];
+      const uint32_t e = c->lay.pos_edge[p];
       if (e == ~0u) continue;
       if (o->damping) o->damping[e] = damp[p];
       if (o->damping_count) o->damping_count[e] = packed[p] >> 3;
@@ -1399,7 +1210,7 @@ static int new_keyframe_impl(gbp_ctx* c, const gbp_kf_update* u) {
     std::vector<uint32_t> ctl(c->Ep, 0u);
     const int thr = c->prm.min_linear_iters - c->prm.num_undamped_iters;
     for (size_t p = 0; p < c->Ep; ++p) {
-      const uint32_t e = c->pos_edge[p];
+      const uint32_t e = c->lay.pos_edge[p];
       if (e == ~0u) continue;
       if (u->damping_count) { cnt[p] = u->damping_count[e]; ctl[p] |= 1u; }
       if (u->active_flag) {
@@ -1421,7 +1232,7 @@ static int new_keyframe_impl(gbp_ctx* c, const gbp_kf_update* u) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (u->active_flag)
       for (size_t p = 0; p < c->Ep; ++p)
-        if (c->pos_edge[p] != ~0u) c->active_host[p] = u->active_flag[c->pos_edge[p]] == 1;
+        if (c->lay.pos_edge[p] != ~0u) c->active_host[p] = u->active_flag[c->lay.pos_edge[p]] == 1;
   }
   if (u->cam_priors_eta && u->cam_priors_lambda) {
     std::vector<float> rec;
@@ -1675,7 +1486,7 @@ static int debug_get_impl(gbp_ctx* c, int what, float* a, float* b) {
     std::vector<float> f((size_t)c->Ep * kFacG * 4);
     HIPCHK(c, hipMemcpy(f.data(), c->fac.p, f.size() * 4, hipMemcpyDeviceToHost));
     for (size_t p = 0; p < c->Ep; ++p) {
-      const uint32_t e = c->pos_edge[p];
+      const uint32_t e = c->lay.pos_edge[p];
       if (e == ~0u) continue;
       auto F = [&](int i) { return f[tile_off((uint32_t)p, kFacG, i)]; };
       for (int i = 0; i < 9; ++i) a[(size_t)e * 9 + i] = F(i);
@@ -1688,7 +1499,7 @@ static int debug_get_impl(gbp_ctx* c, int what, float* a, float* b) {
     std::vector<float> f((size_t)c->Ep * kCmsgG * 4);
     HIPCHK(c, hipMemcpy(f.data(), c->cmsg.p, f.size() * 4, hipMemcpyDeviceToHost));
     for (size_t p = 0; p < c->Ep; ++p) {
-      const uint32_t e = c->pos_edge[p];
+      const uint32_t e = c->lay.pos_edge[p];
       if (e == ~0u) continue;
       for (int i = 0; i < 6; ++i) a[(size_t)e * 6 + i] = f[tile_off((uint32_t)p, kCmsgG, i)];
       for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j)
@@ -1698,7 +1509,7 @@ static int debug_get_impl(gbp_ctx* c, int what, float* a, float* b) {
     std::vector<float> f((size_t)c->Ep * 16);
     HIPCHK(c, hipMemcpy(f.data(), c->lmsg.p, f.size() * 4, hipMemcpyDeviceToHost));
     for (size_t p = 0; p < c->Ep; ++p) {
-      const uint32_t e = c->pos_edge[p];
+      const uint32_t e = c->lay.pos_edge[p];
       if (e == ~0u) continue;
       const float* r = &f[p * 16];
       for (int i = 0; i < 3; ++i) a[(size_t)e * 3 + i] = r[i];
@@ -1712,18 +1523,18 @@ static int debug_get_impl(gbp_ctx* c, int what, float* a, float* b) {
     std::vector<float> rec;
     if (int rc = download_lmsg(c, rec)) return rc;
     for (size_t p = 0; p < c->Ep; ++p) {
-      const uint32_t e = c->pos_edge[p];
+      const uint32_t e = c->lay.pos_edge[p];
       if (e == ~0u) continue;
       if (!(get_state(rec, p).flags & kFlagActive)) continue;  // inactive factors never update mu (gbp_codelets.cpp:242)
-      for (int i = 0; i < 6; ++i) a[(size_t)e * 9 + i] = mc[(size_t)c->pos_cam[p] * 16 + 8 + i];
-      for (int i = 0; i < 3; ++i) a[(size_t)e * 9 + 6 + i] = ml[(size_t)c->pos_lmk_loc[p] * 8 + 4 + i];
+      for (int i = 0; i < 6; ++i) a[(size_t)e * 9 + i] = mc[(size_t)c->lay.pos_cam[p] * 16 + 8 + i];
+      for (int i = 0; i < 3; ++i) a[(size_t)e * 9 + 6 + i] = ml[(size_t)c->lay.pos_lmk_loc[p] * 8 + 4 + i];
       b[e] = 0.f;
     }
   } else if (what == 3) {
     std::vector<float> f((size_t)c->Ep * kMuG * 4);
     HIPCHK(c, hipMemcpy(f.data(), c->mu.p, f.size() * 4, hipMemcpyDeviceToHost));
     for (size_t p = 0; p < c->Ep; ++p) {
-      const uint32_t e = c->pos_edge[p];
+      const uint32_t e = c->lay.pos_edge[p];
       if (e == ~0u) continue;
       for (int i = 0; i < 9; ++i) a[(size_t)e * 9 + i] = f[tile_off((uint32_t)p, kMuG, i)];
       b[e] = f[tile_off((uint32_t)p, kMuG, 9)];
@@ -1742,16 +1553,20 @@ int gbp_debug_time_sweep(gbp_ctx* c, int ablation, int reps, double* avg_us) {
   const SweepArgs a = sweep_args(c);
   bool built = true;
   auto one = [&]() {
-    if (ablation >= 100 && ablation <= 104) {  // 100: k_beliefs, 101: camera part only, 102: landmark part only,
-      BeliefArgs b = belief_args(c);           // 103 / 104 (experiments build): landmark part with a streaming / an index-free gather
-      b.abl = ablation == 103 ? 1 : ablation == 104 ? 2 : 0;
-      launch_beliefs(b, ablation != 102 && ablation < 103, ablation != 101, c->stream);
+    if (ablation >= 100 && ablation <= 102) {  // 100: k_beliefs, 101: camera part only, 102: landmark part only
+      launch_beliefs(belief_args(c), ablation != 102, ablation != 101, c->stream);
+    } else if (ablation == 0) {
+      launch_sweep(a, c->n_tiles, c->hoist, c->stream);
     } else {
-      built = launch_sweep_ablated(a, c->n_tiles, ablation, c->stream) && built;
+#ifdef GBP_BUILD_EXPERIMENTS
+      built = lab_launch_sweep_ablated(a, c->n_tiles, ablation, c->stream) && built;
+#else
+      built = false;
+#endif
     }
   };
   one();
-  if (!built) return fail(c, GBP_ERR_INVALID, "gbp_debug_time_sweep: ablated sweeps are compiled only with -DGBP_BUILD_ABLATIONS");
+  if (!built) return fail(c, GBP_ERR_INVALID, "gbp_debug_time_sweep: ablated sweeps exist in the experiments build only (python -m gbp_poplar_amd.build --experiments)");
   HIPCHK(c, hipEventRecord(c->ev1, c->stream));
   for (int i = 0; i < reps; ++i) one();
   HIPCHK(c, hipEventRecord(c->ev2, c->stream));
@@ -1762,32 +1577,58 @@ int gbp_debug_time_sweep(gbp_ctx* c, int ablation, int reps, double* avg_us) {
   return GBP_OK;
 }
 
-#ifdef GBP_BUILD_EXPERIMENTS
-// arm (out == NULL) / read the [waves][16] stamps of the relinearisation path written by the last launch
-int gbp_debug_ticks(gbp_ctx* c, unsigned long long* out, int waves) {
-  static void* dev = nullptr;
-  if (!c) return GBP_ERR_INVALID;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (!dev) HIPCHK(c, hipMalloc(&dev, 4096 * 16 * 8));
-  if (!out) { HIPCHK(c, hipMemset(dev, 0, 4096 * 16 * 8)); debug_tick_buf(static_cast<unsigned long long*>(dev)); }
-  else { HIPCHK(c, hipMemcpy(out, dev, (size_t)waves * 16 * 8, hipMemcpyDeviceToHost)); debug_tick_buf(nullptr); }
+// ---- the device order without a device (gbp_layout.cpp): what gbp_create builds, handed out for CPU property tests ----
+struct gbp_layout { Layout y; };
+static LayoutOptions to_options(const gbp_layout_options* o) {
+  LayoutOptions r;
+  if (o) {
+    r.row_placement = o->row_placement; r.row_window = o->row_window; r.row_place_max_deg = o->row_place_max_deg;
+    r.row_key_lane = o->row_key_lane; r.classes = o->classes; r.tile_window = o->tile_window; r.tile_min_tiles = o->tile_min_tiles;
+    r.tile_identity = o->tile_identity;
+  }
+  return r;
+}
+void gbp_debug_layout_default_options(gbp_layout_options* o) {
+  if (!o) return;
+  const LayoutOptions d;
+  o->row_placement = d.row_placement; o->row_window = d.row_window; o->row_place_max_deg = d.row_place_max_deg;
+  o->row_key_lane = d.row_key_lane; o->classes = d.classes; o->tile_window = d.tile_window; o->tile_min_tiles = d.tile_min_tiles;
+  o->tile_identity = d.tile_identity;
+}
+int gbp_debug_layout_options(const gbp_layout_options* o) { g_layout_options = to_options(o); return GBP_OK; }
+int gbp_debug_force_sweep_policy(int policy) { g_force_sweep_policy = policy; return GBP_OK; }
+int gbp_debug_layout_build(const gbp_problem* pr, int tile_order, const gbp_shard* sh, const gbp_layout_options* o, gbp_layout** out) {
+  if (!out) return GBP_ERR_INVALID;
+  return guarded(nullptr, "gbp_debug_layout_build", [&] {
+    gbp_layout* h = new gbp_layout();
+    std::string err;
+    const int rc = layout_build(pr, tile_order, sh, o ? to_options(o) : g_layout_options, h->y, err);
+    if (rc != GBP_OK) { delete h; return fail(nullptr, rc, err); }
+    *out = h;
+    return (int)GBP_OK;
+  });
+}
+int gbp_debug_layout_dims(const gbp_layout* h, uint32_t* d) {
+  if (!h || !d) return GBP_ERR_INVALID;
+  const Layout& y = h->y;
+  const uint32_t v[11] = {y.C, y.L, y.E, y.lmk_begin, y.lmk_end, y.L_loc, y.E_loc, y.n_rows, y.n_tiles, y.Ep, y.row_window};
+  std::memcpy(d, v, sizeof(v));
   return GBP_OK;
 }
-int gbp_debug_div_redo(unsigned long long* out4, int reset) { debug_div_redo(out4, reset != 0); return GBP_OK; }
-// Per-phase wall-clock stamps (100 MHz ticks) of the first 16 iterations of the NEXT k_persist launches:
-// out[wave][iteration][8] = {iteration start, sweep done, barrier 1 passed, beliefs done, barrier 2 passed, sweep loads arrived, factor update done, wave had a relinearising lane}.  Call once to
-// arm (out = NULL), run gbp_iterate(n), call again with `out` to read.  Returns the number of waves.
-int gbp_debug_persist_trace(gbp_ctx* c, unsigned long long* out, int cap_waves) {
-  if (!c || !c->persist_ok) return GBP_ERR_STATE;
-  const int waves = (int)persist_blocks(c->n_tiles, c->C, c->L_loc, true) * 4;
-  const size_t bytes = (size_t)waves * kPersistTraceIters * 8 * sizeof(unsigned long long);
-  if (!c->ptrace.p) { if (int rc = dev_alloc(c, c->ptrace, bytes)) return rc; }
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (out) HIPCHK(c, hipMemcpy(out, c->ptrace.p, std::min(bytes, (size_t)cap_waves * kPersistTraceIters * 8 * sizeof(unsigned long long)), hipMemcpyDeviceToHost));
-  else HIPCHK(c, hipMemset(c->ptrace.p, 0, bytes));
-  return waves;
+int gbp_debug_layout_array(const gbp_layout* h, int which, const uint32_t** data, size_t* n) {
+  if (!h || !data || !n) return GBP_ERR_INVALID;
+  const Layout& y = h->y;
+  const std::vector<uint32_t>* a[11] = {&y.pos_edge, &y.pos_cam, &y.pos_lmk_loc, &y.pos_lpos, &y.cam_row_ptr, &y.row_slot, &y.row_cam,
+                                        &y.lmk_ptr, &y.lmk_fpos, &y.lmk_ix, &y.tile_perm};
+  if (which < 0 || which > 10) return GBP_ERR_INVALID;
+  *data = a[which]->data(); *n = a[which]->size();
+  return GBP_OK;
 }
-#endif
+void gbp_debug_layout_free(gbp_layout* h) { delete h; }
+int gbp_debug_tile_order_local(const uint8_t* tile_class, uint32_t n_tiles, uint32_t window, uint32_t n_classes, uint32_t* perm) {
+  if (!tile_class || !perm || window == 0 || n_classes == 0) return GBP_ERR_INVALID;
+  return guarded(nullptr, "gbp_debug_tile_order_local", [&] { tile_order_local(tile_class, n_tiles, window, n_classes, perm); return (int)GBP_OK; });
+}
 
 // Inverse of gbp_debug_get(what = 0): overwrite the factor potentials (lower triangles of the
 // symmetric blocks and Lambda_cl are taken; Lambda_lc is implied).  Test hook only.
@@ -1798,7 +1639,7 @@ static int debug_set_factor_potentials_impl(gbp_ctx* c, const float* eta9E, cons
   std::vector<float> f((size_t)c->Ep * kFacG * 4);
   HIPCHK(c, hipMemcpy(f.data(), c->fac.p, f.size() * 4, hipMemcpyDeviceToHost));
   for (size_t p = 0; p < c->Ep; ++p) {
-    const uint32_t e = c->pos_edge[p];
+    const uint32_t e = c->lay.pos_edge[p];
     if (e == ~0u) continue;
     const float* lam = lam81E + (size_t)e * 81;
     for (int i = 0; i < 9; ++i) f[tile_off((uint32_t)p, kFacG, i)] = eta9E[(size_t)e * 9 + i];
@@ -2029,7 +1870,6 @@ int gbp_create(const gbp_problem* pr, const gbp_params* prm, const gbp_shard* sh
   return guarded(nullptr, "gbp_create", [&] { return create_impl(pr, prm, sh, out); });
 }
 int gbp_upload(gbp_ctx* c, const gbp_state_in* in) { return guarded(c, "gbp_upload", [&] { return upload_impl(c, in); }); }
-int gbp_set_exchange_chunks(gbp_ctx* c, int n) { return guarded(c, "gbp_set_exchange_chunks", [&] { return set_exchange_chunks_impl(c, n); }); }
 int gbp_iterate(gbp_ctx* c, int n) { return guarded(c, "gbp_iterate", [&] { return iterate_impl(c, n); }); }
 int gbp_linearise(gbp_ctx* c) { return guarded(c, "gbp_linearise", [&] { return linearise_impl(c); }); }
 int gbp_iterate_begin(gbp_ctx* c) { return guarded(c, "gbp_iterate_begin", [&] { return iterate_begin_impl(c); }); }

@@ -20,11 +20,7 @@ namespace gbpdev {
 // operands come from differently laid-out records (a packed triangle against a full matrix) it spends up to four v_mov on
 // one saved add.  The fence ends the vectoriser's tree at this value, so the arithmetic that feeds it stays scalar
 // (measured per site with the executed-instruction counters, profiles/r04_alu_diet.md).
-#ifdef GBP_NO_SLP_FENCE
-#define GBP_SLP_FENCE(x) do { } while (0)
-#else
 #define GBP_SLP_FENCE(x) asm("" : "+v"(x))
-#endif
 
 // packed lower-triangle index, i >= j
 GBP_DEV constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }
@@ -47,24 +43,9 @@ GBP_DEV constexpr int trisym(int i, int j) { return i >= j ? tri(i, j) : tri(j, 
 // costs 11 instructions, five of them quarter-rate; this costs 3 full-rate ones per value + 1.5 for the test (measured
 // in situ on fr1xyz: 29.9 -> 26.4 us per iteration for the 54 divisions of the Huber rescale alone,
 // profiles/r03_small_graphs.md; the test: profiles/r04_alu_diet.md).
-#ifdef GBP_BUILD_EXPERIMENTS
-__device__ unsigned long long g_div_redo[4];
-__device__ unsigned long long* g_tick_buf;     // [wave][16] wall-clock stamps inside the relinearisation path (last iteration wins)
-#define GBP_TICK(slot) do { if (g_tick_buf) g_tick_buf[(size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (slot)] = wall_clock64(); } while (0)
-#else
-#define GBP_TICK(slot) do { } while (0)
-#endif
 template <int N>
 GBP_DEV void div_shared(const float (&v)[N], float m, float (&q)[N]) {
   const double r = 1.0 / (double)m;
-#ifdef GBP_DIV_CHECK_QUOTIENTS      // measurement: the test on every quotient (rounds 3 and 4 up to here)
-  bool redo = false;
-  GBP_UNROLL
-  for (int i = 0; i < N; ++i) {
-    q[i] = (float)((double)v[i] * r);
-    redo |= (__builtin_fabsf(q[i]) < 1.17549435e-38f) != (v[i] == 0.f);
-  }
-#else
   uint32_t least = 0xffffffffu;
   GBP_UNROLL
   for (int i = 0; i < N; ++i) {
@@ -74,14 +55,10 @@ GBP_DEV void div_shared(const float (&v)[N], float m, float (&q)[N]) {
   }
   const float thr = (__builtin_fabsf(m) * 1.001953125f) * 1.17549435e-38f;
   const bool redo = least < 2u * (__float_as_uint(thr) + 2u) - 1u;
-#endif
   // (the slow path behind a WAVE-UNIFORM test, so that it is a branch no wavefront takes instead of nine divisions the
   // compiler might if-convert into every lane's instruction stream)
   if (__builtin_amdgcn_ballot_w64(redo) != 0ull) {
     if (redo) {
-#ifdef GBP_BUILD_EXPERIMENTS
-      atomicAdd(&g_div_redo[N == 54 ? 0 : N == 9 ? 1 : 2], 1ull);   // how often does the slow path run? (profiles/persist_trace.py)
-#endif
       GBP_UNROLL
       for (int i = 0; i < N; ++i) q[i] = v[i] / m;
     }
@@ -178,7 +155,6 @@ GBP_DEV void solve6_lower(AF&& A, EF&& eta, float (&x)[6]) {
 // dropped; "0 + x" is kept (acc starts at 0.f) because 0 + (-0) = +0 in the reference too.
 
 // reference ba/bafuncs.cpp:31-55 — Rodrigues, identity if theta <= 1e-6.
-template <bool FAST_TRIG = false>   // FAST_TRIG: timing experiments only (hardware sin/cos approximations)
 GBP_DEV void so3exp(const float (&v)[3], float (&R)[9]) {
   const float theta = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
   GBP_UNROLL
@@ -187,17 +163,9 @@ GBP_DEV void so3exp(const float (&v)[3], float (&R)[9]) {
     // sin/cos are taken correctly rounded (fp64 evaluation rounded once to fp32): the reference's
     // own std::sin/std::cos resolve to whatever libm its target ships (Poplar's on the IPU), so no
     // libm is "the" reference; a correctly rounded value is the one every good libm approximates.
-#ifdef GBP_SINCOS_SEPARATE
-    const float s = FAST_TRIG ? __sinf(theta) : (float)sin((double)theta), c = FAST_TRIG ? __cosf(theta) : (float)cos((double)theta);
-#else
-    float s, c;
-    if (FAST_TRIG) { s = __sinf(theta); c = __cosf(theta); }
-    else {            // one argument reduction for both (the device library's sincos): the same fp64 values as sin() and cos()
-      double sd, cd;
-      sincos((double)theta, &sd, &cd);
-      s = (float)sd; c = (float)cd;
-    }
-#endif
+    double sd, cd;     // one argument reduction for both (the device library's sincos): the same fp64 values as sin() and cos()
+    sincos((double)theta, &sd, &cd);
+    const float s = (float)sd, c = (float)cd;
     const float H[9] = {0.f, -v[2], v[1], v[2], 0.f, -v[0], -v[1], v[0], 0.f};
     const float a = s / theta;
     const float b = (1 - c) / (theta * theta);
@@ -241,9 +209,8 @@ struct CamLin {
 };
 constexpr int kCamLin4 = 5;   // float4 per camera of the CAM_LIN array
 
-template <bool FAST_TRIG = false>
 GBP_DEV void cam_lin(const float (&v)[3], CamLin& c) {
-  so3exp<FAST_TRIG>(v, c.R);
+  so3exp(v, c.R);
   const float vh[9] = {0.f, -v[2], v[1], v[2], 0.f, -v[0], -v[1], v[0], 0.f};
   float RtI[9];
   GBP_UNROLL
@@ -289,7 +256,6 @@ GBP_DEV void cam_lin_unpack(const float4 (&q)[kCamLin4], CamLin& c) {
 // hfunc + Jac of one factor from the camera-only terms `cl` of its camera (cl == cam_lin(cam[3..5]))
 GBP_DEV void jac_hfunc_lin(const float (&cam)[6], const float (&lmk)[3], const float (&K)[9], const CamLin& cl, Lin& o) {
   const float (&R)[9] = cl.R;
-  GBP_TICK(2);
   float yc[3];
   GBP_UNROLL
   for (int i = 0; i < 3; ++i) {
@@ -364,12 +330,10 @@ GBP_DEV void jac_hfunc_lin(const float (&cam)[6], const float (&lmk)[3], const f
   }
 }
 
-template <bool FAST_TRIG = false>
 GBP_DEV void jac_hfunc(const float (&cam)[6], const float (&lmk)[3], const float (&K)[9], Lin& o) {
   CamLin cl;
   const float v[3] = {cam[3], cam[4], cam[5]};
-  GBP_TICK(1);
-  cam_lin<FAST_TRIG>(v, cl);
+  cam_lin(v, cl);
   jac_hfunc_lin(cam, lmk, K, cl, o);
 }
 

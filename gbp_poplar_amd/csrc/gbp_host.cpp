@@ -441,30 +441,6 @@ int gbp_landmark_partition(const gbp_problem* p, int world, uint32_t* bounds) {
   return GBP_OK;
 }
 
-// The LOCAL XCD-aware execution order of the sweep (gbp_params.tile_order = 3; gbp_capi.cpp builds the classes from the device
-// order): wave slot s belongs to workgroup s / 4, which lands on XCD (s / 4) mod 8; it is given the earliest not yet placed
-// tile of class (s / 4) mod 8 among the `window` tiles that follow the oldest unplaced one — else that oldest tile, whatever its
-// class.  A bijection by construction; no tile moves further than `window` slots from where a sequential order would run it,
-// (+ the 32 slots until the next workgroup of its class comes round), so every per-factor stream keeps one compact front.  Pure host code: testable without a GPU (tests/test_hostlib.py).
-int gbp_tile_order_local(const uint8_t* tile_class, uint32_t n_tiles, uint32_t window, uint32_t* perm) {
-  if (!tile_class || !perm || window == 0) return GBP_ERR_INVALID;
-  std::vector<uint8_t> placed(n_tiles, 0);
-  uint32_t next_of_class[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // per class: where to continue looking
-  uint32_t oldest = 0;
-  for (uint32_t slot = 0; slot < n_tiles; ++slot) {
-    while (oldest < n_tiles && placed[oldest]) ++oldest;
-    const uint32_t want = (slot / 4) % 8;
-    uint32_t& cur = next_of_class[want];
-    if (cur < oldest) cur = oldest;
-    while (cur < n_tiles && cur < oldest + window && (placed[cur] || tile_class[cur] != want)) ++cur;
-    uint32_t pick = oldest;
-    if (cur < n_tiles && cur < oldest + window && !placed[cur] && tile_class[cur] == want) pick = cur;
-    perm[slot] = pick;
-    placed[pick] = 1;
-  }
-  return GBP_OK;
-}
-
 // add_cam_trans_noise / add_cam_rot_noise / add_lmk_noise (dataio.cpp:330-415) with an explicit seed.  The first two
 // cameras anchor the gauge and stay exact (dataio.h:114-119, k = 2).  Draw order: translations, rotations, landmarks.
 int gbp_init_add_noise(uint32_t C, uint32_t L, float tn, float rn_deg, float ltn, uint64_t seed, float* cam, float* lmk) {

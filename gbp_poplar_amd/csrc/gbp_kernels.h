@@ -66,39 +66,31 @@ struct SweepArgs {
   const float4* cam_lin;  // [C][5]: camera-only Jacobian terms of the current hoisted mean (R 9, N 9, |w|^2; gbp_device_math.hpp CamLin)
   float K[9];
   Hyper hp;
-  uint32_t block0;           // first 256-factor block of this launch (pieces of a sweep: pipelined exchange)
-  int variant;               // experiments build only: 1 = k_sweep_coop16 (16 lanes per factor) instead of k_sweep
-  const uint32_t* tile_perm; // [n_tiles] or NULL (default): wave slot (4 * block + wave) -> tile.  Optional XCD-aware
-                             // order (gbp_params.tile_order = 2): workgroups are dealt round-robin over the 8 XCDs, the
-                             // table hands every XCD the tiles of one landmark range so that its private L2 holds that
-                             // slice of the gathered landmark tables
-  uint32_t cmsg_cached;      // 1: the camera-message tiles are LOADED with the default cache policy instead of the non-temporal
-                             // hint (the stores keep the hint).  Measured on 1 M factors x 100 000 landmarks: +1.3 % iterations/s
-                             // with 500 cameras, +0.6 % with 1 000, +0.25 % with 2 000, -0.1 % with 4 000, -0.3 % with 8 000
-                             // (-1.4 % on the config-5 shard shape); 1 000 cameras, factor count scanned: +1.4 % at 0.5 M, +0...2 % at
-                             // 1 M, -0.5 % at 1.25 M, -2 % at 1.5 M, -5.5 % at 2 M.  Set while the camera belief table (C x 176 B) is
-                             // small beside an XCD's 4 MiB L2 (C <= 2 048) and the two message streams (176 B per factor) fit the
-                             // Infinity Cache with room to spare (<= 200 MB), profiles/r04_alu_diet.md section 6
+  int variant;               // experiments build only (gbp_params.reserved[0]): a mapping experiment instead of k_sweep
+  const uint32_t* tile_perm; // [n_tiles] or NULL: wave slot (4 * block + wave) -> tile.  The XCD-aware execution order (gbp_layout.cpp):
+                             // workgroups are dealt round-robin over the 8 XCDs, the table hands every XCD the tiles of one landmark
+                             // class so that its private L2 holds that slice of the gathered landmark tables
+  uint32_t policy;           // kPol* bits: cache policy of the two message streams, chosen per graph shape (gbp_capi.cpp: sweep_policy)
 };
-
-constexpr int kMaxChunks = 8;
+// SweepArgs.policy.  The potentials (read once per sweep) and every tile STORE of the camera messages carry the non-temporal
+// hint on every graph; what varies with the shape is how the two message streams, which a tile reads and rewrites in place, are
+// loaded / stored:
+constexpr uint32_t kPolCmsgLoadCached = 1u;   // camera-message tiles LOADED with the default policy (few cameras, both streams within the Infinity Cache)
+constexpr uint32_t kPolLmsgLoadNt = 2u;       // landmark-message tiles loaded with the non-temporal hint (default: default policy — k_beliefs gathers them next)
+constexpr uint32_t kPolLmsgStoreNt = 4u;      // ... and stored with it
 
 struct BeliefArgs {
   // camera part
   const float* rowp; const uint32_t* cam_row_ptr; const float* cam_prior;
-  const uint32_t* row_slot;  // [n_rows] device row of the camera-major row r, or NULL: rows sit in camera-major order (gbp_capi.cpp: row placement)
+  const uint32_t* row_slot;  // [n_rows] device row of the camera-major row r, or NULL: rows sit in camera-major order (gbp_layout.cpp: row placement)
   float* cam_local;          // [C][44] local row sums (kept for prior-only refreshes / the exchange buffer)
-  const float* gathered;     // != nullptr: belief = prior + sum_r gathered[r] instead of the row sums
+  const float* gathered;     // != nullptr: belief = prior + sum_r gathered[r] ([world][C][44]) instead of the row sums
   int world;
   float* camb; float4* cam_mu; float4* cam_lin; uint32_t n_cams;
   // landmark part
   const float4* lmk_prior; const float4* lmsg; const uint32_t* lmk_ptr; const uint32_t* lmk_fpos;
   const uint32_t* lmk_ix;   // [L][16]: degree, device positions of slots 1..15 (one 64-B index record per landmark)
   float4* lmkb; float4* lmk_mu; uint32_t n_lmks;
-  // camera range of this launch [cam0, cam1) (0,0 = all) and chunk layout of `gathered` (see k_beliefs)
-  uint32_t cam0, cam1;
-  int n_chunks;
-  uint32_t chunk_start[kMaxChunks + 1];
   // control
   uint32_t cam_blocks;
   uint32_t lmk_blocks;       // landmark blocks of this launch
@@ -106,8 +98,6 @@ struct BeliefArgs {
   int partial_only;          // camera part writes cam_local only (multi-GPU: before the exchange)
   int hoist;                 // compute per-variable means + dmu^2 pieces
   int roll;                  // end of an iteration: "means used by the last sweep" := current means, then recompute
-  int abl;                   // experiments build only (timing, results are garbage): 1 = message records read in landmark-major
-                             // order (what a streaming gather would cost), 2 = random positions WITHOUT the index-record load
 };
 
 // k_persist: n GBP iterations in ONE launch for graphs small enough that every workgroup is resident at once
@@ -141,7 +131,6 @@ struct PersistArgs {
   unsigned* sync;          // [kPersistSyncWords] barrier words: [0] arrival counter (monotonic over launches), [32] abort word
   unsigned* status;        // host-mapped: set to `seq` by the first workgroup that gives up at a barrier (a workgroup was not resident)
   unsigned seq;            // number of this launch in the ctx (>= 1): tells the host WHICH launch failed first (later ones return at once)
-  unsigned long long* trace;  // experiments build only (else NULL): [wave][iteration < kPersistTraceIters][8] wall-clock ticks
 };
 // snapshot / restore of the arrays a k_persist launch mutates (k_copy_segments)
 constexpr int kMaxCopySegs = 12;
@@ -151,7 +140,6 @@ struct CopySegs {
   void* dst[kMaxCopySegs];
   size_t n4[kMaxCopySegs];     // float4 elements of each segment
 };
-constexpr int kPersistTraceIters = 16;
 constexpr int kSeriesMax = 128;         // metrics per launch of gbp_iterate_eval_each (longer bursts are split)
 constexpr int kPersistSyncWords = 16 * 32;
 
@@ -161,8 +149,6 @@ struct DeviceEval {  // per-block partials, summed on the host in block order
 };
 
 void launch_sweep(const SweepArgs& a, uint32_t n_tiles, bool hoist, hipStream_t s);
-void launch_sweep_blocks(SweepArgs a, uint32_t block0, uint32_t block1, bool hoist, hipStream_t s);
-bool launch_sweep_ablated(const SweepArgs& a, uint32_t n_tiles, int abl, hipStream_t s);  // timing experiments; false = not built in
 void launch_linearise(const SweepArgs& a, uint32_t n_tiles, hipStream_t s);
 void launch_beliefs(BeliefArgs b, bool do_cam, bool do_lmk, hipStream_t s);
 // workgroups of a k_persist launch for a graph; with_metric: + one wave per camera for the metric roles where the placement allows
@@ -187,8 +173,8 @@ void launch_eval(const uint32_t* row_cam, const uint32_t* lmk_idx, const float4*
                  const float* lmk_mu, const float* K9_dev, int num_undamped_iters, DeviceEval* partials /* may be mapped host memory */,
                  const unsigned long long* health2, unsigned long long* health2_out, uint32_t n_tiles, hipStream_t s);
 uint32_t eval_blocks(uint32_t n_tiles);
-void debug_div_redo(unsigned long long* out4, bool reset);
-void debug_tick_buf(unsigned long long* dev_buf);             // experiments build: stamps inside the relinearisation path   // experiments build: slow-path counts of div_shared
+// experiments build (csrc/experiments/gbp_lab_kernels.hip): timing ablations of the sweep; false = unknown ablation
+bool lab_launch_sweep_ablated(const SweepArgs& a, uint32_t n_tiles, int abl, hipStream_t s);
 bool debug_math_widths(int op, int* in_w, int* out_w);   // floats per vector of k_debug_math's op
 void launch_debug_math(int op, const float* in, float* out, int n, hipStream_t s);  // test hook
 

@@ -4,7 +4,8 @@
 //   k_sweep        PrepMessageVertex + Copy(mu,oldmu) + the four Compute*Message*Vertex classes
 //                  (gbp_codelets.cpp:215-710) + the camera half of popops::reduceWithOutput
 //                  (ba.cpp:129-132) as per-row partial sums + Copy(msg,pmsg) (in-place messages)
-//   k_cam_reduce / k_cam_combine / k_lmk_belief    the rest of buildUpdateBeliefsProg (ba.cpp:104-139)
+//   k_beliefs      the rest of buildUpdateBeliefsProg (ba.cpp:104-139): camera rows + prior, landmark messages + prior
+//   k_persist      n iterations of the two above inside ONE launch (graphs whose workgroups are all resident at once)
 //   k_linearise    RelineariseFactorVertex (gbp_codelets.cpp:20-172)
 //   k_weaken       WeakenPriorVertex (gbp_codelets.cpp:176-197)
 //   k_means/k_eval eval_reprojection_error (util.cpp:74-144) + counters (ba.cpp:1011-1020)
@@ -14,7 +15,6 @@
 // 6x6/3x3 algebra (no MFMA: the blocks are tiny and chains are serial) hides under the loads.
 // fp32 throughout, compiled with -ffp-contract=off so results are bit-comparable with the oracle.
 #include "gbp_kernels.h"
-#include <cstdlib>
 #include "gbp_device_math.hpp"
 
 namespace gbp {
@@ -53,32 +53,17 @@ GBP_DEV void load_rec(const float4* rec, float (&out)[G * 4]) {
   }
 }
 
-// sum over the 16 lanes of a DPP row as a balanced binary tree in lane order:
-// ((x0+x1)+(x2+x3)) + ... ; every lane ends with the same bits (fp32 add is commutative).
-GBP_DEV float row16_sum(float x) {
-  int t;
-  t = __builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-  x = x + __int_as_float(t);
-  t = __builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
-  x = x + __int_as_float(t);
-  t = __builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xF, 0xF, true);  // row_half_mirror
-  x = x + __int_as_float(t);
-  t = __builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x140, 0xF, 0xF, true);  // row_mirror
-  x = x + __int_as_float(t);
-  return x;
-}
-
 // The 44-float ROWP record of every 16-lane row of a tile: the sums of the camera messages (6 eta + 36 Lambda entries, two
 // pad slots) over the row's 16 factors, each the balanced binary tree in lane order of row16_sum, handed to `st(g, float4)`
 // (float4 group g of the row's record) by the lanes that end up holding them.
 //
-// row16_sum leaves all 42 sums in all 16 lanes — 4 x 42 tree nodes, each evaluated by sixteen lanes, as v_mov_b32_dpp +
+// A butterfly that leaves all 42 sums in all 16 lanes costs 4 x 42 tree nodes, each evaluated by sixteen lanes, as v_mov_b32_dpp +
 // (packed) v_add: 252 instructions.  Here a node is ONE v_add_f32 with a DPP operand, and the two intra-quad steps HALVE the
 // set a lane carries (lane%4 = q ends up with the float4 groups g = q, q+4, q+8 of the record): the partners of a step keep
 // different halves, each sends the half the other keeps (two selects per pair of values), so the steps cost 60 + 36 + 12 +
 // 12 = 120 instructions and the record leaves in three stores of 64 contiguous bytes per row (lanes 12..15) instead of
-// eleven 16-byte ones (lane 0).  Every node adds the same two operands as row16_sum's (own + partner, commutative): the
-// same bits.
+// eleven 16-byte ones (lane 0).  Every node adds the same two operands as the butterfly's ((x0+x1)+(x2+x3)) + ..., own +
+// partner, commutative: the same bits.
 //   step 1 (lane ^ 1): even lanes keep groups {0,2} mod 4, odd lanes groups {1,3} mod 4      -> t[2k], t[2k+1]
 //   step 2 (lane ^ 2): lane%4 in {0,1} keep t[2k] (groups 4j, 4j+1), {2,3} keep t[2k+1]      -> u[k], k = 4j + component
 //   steps 3, 4: row_shr:4 then row_shr:8 — quad 1 = Q0+Q1 and quad 3 = Q2+Q3, then quad 3 = (Q0+Q1)+(Q2+Q3)
@@ -202,13 +187,10 @@ GBP_DEV void belief_means(const float (&cb)[44], const float (&lb)[16], float (&
 
 // Shared body of gbp_codelets.cpp:90-168 and :294-373 on the packed FAC record: accumulate
 // J^T J / J^T (J x0 + z - h(x0)) onto the potential, Huber-rescale.  Returns the robust flag.
-template <int ABL = 0>   // ABL: timing experiments only (256 = hardware sin/cos, 512 = reciprocal multiply for the Huber rescale)
 GBP_DEV bool relin_core(float (&fac)[56], const float (&x0c)[6], const float (&x0l)[3], const float (&K)[9],
                         float var, float nstds, const CamLin& cl /* == cam_lin(x0c[3..5]) */) {
   Lin L;
-  GBP_TICK(0);
   jac_hfunc_lin(x0c, x0l, K, cl, L);
-  GBP_TICK(3);
   GBP_UNROLL
   for (int i = 0; i < 6; ++i) {
     GBP_UNROLL
@@ -259,7 +241,6 @@ GBP_DEV bool relin_core(float (&fac)[56], const float (&x0c)[6], const float (&x
     for (int k = 0; k < 2; ++k) acc += (i < 6 ? L.Jkf[k * 6 + i] : L.Jl[k * 3 + (i - 6)]) * buf[k];
     fac[i] = acc;
   }
-  GBP_TICK(4);
   // Huber (gbp_codelets.cpp:135-141): the 0.5 literal makes the denominator a double expression
   const float err = sqrtf((L.hx[0] - z0) * (L.hx[0] - z0) + (L.hx[1] - z1) * (L.hx[1] - z1));
   float mvar = var;
@@ -268,13 +249,6 @@ GBP_DEV bool relin_core(float (&fac)[56], const float (&x0c)[6], const float (&x
     const double den = 2 * ((double)(nstds * sqrtf(var) * err) - 0.5 * (double)nstds * (double)nstds * (double)var);
     mvar = (float)((double)(var * err * err) / den);
   }
-  if (ABL & 512) {
-    const float rm = 1 / mvar;
-    GBP_UNROLL
-    for (int i = 0; i < 54; ++i) fac[i] *= rm;
-    return robust;
-  }
-  GBP_TICK(5);
   {  // 54 divisions by one divisor (gbp_codelets.cpp:142-168, 343-373): exact through one fp64 reciprocal
     float num[54], quo[54];
     GBP_UNROLL
@@ -283,7 +257,6 @@ GBP_DEV bool relin_core(float (&fac)[56], const float (&x0c)[6], const float (&x
     GBP_UNROLL
     for (int i = 0; i < 54; ++i) fac[i] = quo[i];
   }
-  GBP_TICK(6);
   return robust;
 }
 
@@ -291,30 +264,15 @@ GBP_DEV bool relin_core(float (&fac)[56], const float (&x0c)[6], const float (&x
 // (gbp_codelets.cpp:215-710).  Shared by k_sweep (state streamed from HBM every launch) and k_persist (state kept in
 // registers across iterations).  `means(x0c, x0l, cl)` supplies the hoisted linearisation point and the camera-only Jacobian
 // terms of that point when a lane relinearises.
-template <bool HOIST, int ABL, class Means>
+template <bool HOIST, class Means>
 GBP_DEV void factor_update(float (&fac)[56], const float (&cm)[28], float (&mu)[12], const float (&lm)[16], const float (&cb)[44],
                            const float (&lb)[16], const float (&K)[9], const Hyper& hp, float& damping, int& count, uint32_t& flags,
                            const float var, const bool active, float (&oc_eta)[6], float (&oc_lam)[36], float (&ol)[16], bool& relin,
                            Means&& means) {
   relin = false;
-#ifdef GBP_ZERO_INIT_FIRST       // measurement: the outputs zeroed in front of the branch
-  GBP_UNROLL
-  for (int i = 0; i < 6; ++i) oc_eta[i] = 0.f;
-  GBP_UNROLL
-  for (int i = 0; i < 36; ++i) oc_lam[i] = 0.f;
-  GBP_UNROLL
-  for (int i = 0; i < 16; ++i) ol[i] = 0.f;
-#endif
   // (zero messages of an inactive factor are written in the ELSE branch at the bottom: 58 v_mov the wavefronts of a graph
   // with every factor active never execute, instead of an initialisation in front of the branch that all of them do)
-  if (ABL & 4) {  // keep every load alive, no algebra
-    GBP_UNROLL
-    for (int i = 0; i < 16; ++i) ol[i] = lm[i] + lb[i];
-    GBP_UNROLL
-    for (int i = 0; i < 6; ++i) oc_eta[i] = cm[i] + fac[i];
-    GBP_UNROLL
-    for (int i = 0; i < 36; ++i) oc_lam[i] = fac[9 + i] + cb[8 + i] + cm[6 + (i % 21)];
-  } else if (active) {
+  if (active) {
     ol[3] = 0.f; ol[13] = 0.f; ol[14] = 0.f; ol[15] = 0.f;      // (3, 13, 14: the caller's per-factor scalars)
     // ---- PrepMessageVertex, gbp_codelets.cpp:241-378 ----
     if (0 == count) damping = hp.maxeta_damping;
@@ -344,21 +302,12 @@ GBP_DEV void factor_update(float (&fac)[56], const float (&cm)[28], float (&mu)[
     const float dmu = sqrtf(d2);
     mu[9] = dmu;
     relin = (dmu < hp.dmu_threshold) && (count > hp.min_linear_iters - hp.num_undamped_iters);
-    if (ABL & 64) relin = false;    // timing experiments: no lane / every lane relinearises
-    if (ABL & 128) relin = true;
     if (relin) {
-      if (HOIST && (ABL & 1024)) {  // timing experiment: linearisation point without the dependent loads
-        GBP_UNROLL
-        for (int i = 0; i < 6; ++i) x0c[i] = cb[i] + 0.5f;
-        GBP_UNROLL
-        for (int i = 0; i < 3; ++i) x0l[i] = lb[i] + 0.5f;
-        const float w[3] = {x0c[3], x0c[4], x0c[5]};
-        cam_lin<(ABL & 256) != 0>(w, cl);
-      } else if (HOIST) {  // linearisation point = the hoisted means + the camera's CAM_LIN record (rare path: loaded only here)
+      if (HOIST) {  // linearisation point = the hoisted means + the camera's CAM_LIN record (rare path: loaded only here)
         means(x0c, x0l, cl);
       } else {
         const float w[3] = {x0c[3], x0c[4], x0c[5]};
-        cam_lin<(ABL & 256) != 0>(w, cl);
+        cam_lin(w, cl);
       }
       damping = 0.f;
       count = -hp.num_undamped_iters;
@@ -366,7 +315,7 @@ GBP_DEV void factor_update(float (&fac)[56], const float (&cm)[28], float (&mu)[
         GBP_UNROLL
         for (int i = 0; i < 54; ++i) fac[i] = 0.f;
       }
-      const bool robust = relin_core<ABL>(fac, x0c, x0l, K, var, hp.nstds, cl);
+      const bool robust = relin_core(fac, x0c, x0l, K, var, hp.nstds, cl);
       flags = robust ? (flags | kFlagRobust) : (flags & ~kFlagRobust);
     }
 
@@ -470,14 +419,12 @@ GBP_DEV void factor_update(float (&fac)[56], const float (&cm)[28], float (&mu)[
       }
     }
   } else {
-#ifndef GBP_ZERO_INIT_FIRST
     GBP_UNROLL
     for (int i = 0; i < 6; ++i) oc_eta[i] = 0.f;
     GBP_UNROLL
     for (int i = 0; i < 36; ++i) oc_lam[i] = 0.f;
     GBP_UNROLL
     for (int i = 0; i < 16; ++i) ol[i] = 0.f;
-#endif
   }
 }
 
@@ -493,14 +440,10 @@ GBP_DEV void factor_update(float (&fac)[56], const float (&cm)[28], float (&mu)[
 // fp32 operations in the same order, so the result is bit-identical while the per-factor MU stream and
 // two of the five small inverses disappear from the sweep.  HOIST = false keeps the literal per-factor
 // mu/oldmu tensors (needed only if a caller uploads non-zero oldmu).
-// ABL != 0 builds timing-only ablations of the same instruction stream (gbp_debug_time_sweep; results are
-// garbage): 1 = no landmark-message stream, 2 = no landmark-belief gather, 4 = no arithmetic (pass-through),
-// 16 / 32 = no landmark-message load / store.
-#ifndef GBP_SWEEP_WPB
-#define GBP_SWEEP_WPB 4      // wavefronts per workgroup of the sweep (1, 2 or 4; the waves of a workgroup share nothing)
-#endif
-constexpr int kWpb = GBP_SWEEP_WPB;
-template <bool HOIST, int ABL, bool CMC = false>     // CMC: SweepArgs.cmsg_cached (camera messages loaded with the default cache policy)
+constexpr int kWpb = 4;      // wavefronts per workgroup of the sweep (the waves of a workgroup share nothing)
+// POL: cache policy of the two message streams (SweepArgs.policy, chosen per graph shape by gbp_capi.cpp; a template parameter,
+// not a branch on the flag: with both load sequences behind a branch the non-temporal path lost 1.2 %)
+template <bool HOIST, uint32_t POL = 0>
 GBP_DEV void sweep_tile(const SweepArgs& a, const uint32_t wslot) {
   // (the slot is wave-uniform: as an SGPR it turns the permutation look-up into one scalar load)
   const uint32_t ws = (uint32_t)__builtin_amdgcn_readfirstlane((int)wslot);
@@ -508,23 +451,14 @@ GBP_DEV void sweep_tile(const SweepArgs& a, const uint32_t wslot) {
   const uint32_t lane = threadIdx.x & 63, p = tile * 64 + lane;
 
   const uint32_t cam_i = a.row_cam[p >> 4];
-#ifdef GBP_IDX_LOAD_CACHED
-  const uint32_t lmk_i = a.lmk_idx[p];
-#else
   const uint32_t lmk_i = __builtin_nontemporal_load(a.lmk_idx + p);
-#endif
 
   float fac[56], cm[28], mu[12], lm[16], cb[44], lb[16];
-#ifdef GBP_FAC_LOAD_CACHED
-  load_tile<kFacG, false>(a.fac, tile, lane, fac);
-#else
   load_tile<kFacG>(a.fac, tile, lane, fac);
-#endif
   // The camera messages: non-temporal like the potentials, or — SweepArgs.cmsg_cached, graphs with few cameras — with the
   // default policy like the landmark messages below (both are rewritten in place by this tile).  The potentials, which an
   // ordinary sweep only reads, keep the hint on every graph: with default-policy loads they cost 3 %.
-  // (a template parameter, not a branch on the flag: with both load sequences behind a branch the nt path lost 1.2 %)
-  load_tile<kCmsgG, !CMC>(a.cmsg, tile, lane, cm);
+  load_tile<kCmsgG, !(POL & kPolCmsgLoadCached)>(a.cmsg, tile, lane, cm);
   if (!HOIST) load_tile<kMuG>(a.mu, tile, lane, mu);
   // Landmark messages live as 64-byte records in DEVICE (camera-major) order: the wave's 64 records are one
   // contiguous 4 KiB block, moved with four coalesced 1 KiB accesses and transposed through a wave-private
@@ -532,47 +466,32 @@ GBP_DEV void sweep_tile(const SweepArgs& a, const uint32_t wslot) {
   // a permutation inside each 64-B record, so the tile-order accesses (whole records) and the record-order
   // accesses (one piece per lane) are both bank-conflict-free for ds_read_b128 (16-lane groups, 64 banks)
   // and ds_write_b128 (8-lane groups, 32 banks).  k_beliefs gathers the records of a landmark by position
-  // (random 64-B READS are ~2.3x cheaper than random 64-B writes, profiles/ablate_sweep.py).
+  // (random 64-B READS are ~2.3x cheaper than random 64-B writes: measured, profiles/HISTORY.md).
   __shared__ float4 lm_stage[kWpb][64 * 4];
   float4* stage = lm_stage[threadIdx.x >> 6];
   const uint32_t rec_t = lane >> 2;                                   // record handled in tile order (+16k)
   const uint32_t swz_own = ((lane >> 2) & 3u) ^ (lane & 2u);          // swizzle of the lane's own record
   float4* lm_tile = a.lmsg + (size_t)tile * 256;
-  if (ABL & (1 | 16)) {  // 16 = no LMSG load (store stays), 32 = no LMSG store (load stays)
-    GBP_UNROLL
-    for (int i = 0; i < 16; ++i) lm[i] = 0.f;
-    lm[13] = __int_as_float((int)((5u << 3) | kFlagActive));
-    lm[14] = 4.f;
-  } else {
-    GBP_UNROLL
-    for (int k = 0; k < 4; ++k) {
-#ifdef GBP_LMSG_LOAD_NT     // measurement: the hint rounds 1-4 used here too
-      const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(lm_tile) + k * 64 + lane);
-#else
-      // (DEFAULT policy for this one stream: the tile is rewritten in place ten microseconds later and gathered by k_beliefs
-      // right after the sweep — measured +1.5 % iterations/s on S1 against the non-temporal hint, with either store policy;
-      // the potentials and the camera messages keep the hint: profiles/r04_alu_diet.md section 6)
-      const v4f v = (reinterpret_cast<const v4f*>(lm_tile))[k * 64 + lane];
-#endif
-      const uint32_t r = k * 16 + rec_t;
-      stage[r * 4 + ((lane & 3u) ^ (((r >> 2) & 3u) ^ (r & 2u)))] = make_float4(v.x, v.y, v.z, v.w);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    GBP_UNROLL
-    for (int q = 0; q < 4; ++q) {
-      const float4 v = stage[lane * 4 + ((uint32_t)q ^ swz_own)];
-      lm[4 * q] = v.x; lm[4 * q + 1] = v.y; lm[4 * q + 2] = v.z; lm[4 * q + 3] = v.w;
-    }
+  GBP_UNROLL
+  for (int k = 0; k < 4; ++k) {
+    // (DEFAULT policy for this one stream unless the shape says otherwise: the tile is rewritten in place ten microseconds later
+    // and gathered by k_beliefs right after the sweep — measured +1.5 % iterations/s on the 1M-factor graph against the
+    // non-temporal hint, with either store policy; the potentials keep the hint on every graph)
+    const v4f* src = reinterpret_cast<const v4f*>(lm_tile) + k * 64 + lane;
+    const v4f v = (POL & kPolLmsgLoadNt) ? __builtin_nontemporal_load(src) : *src;
+    const uint32_t r = k * 16 + rec_t;
+    stage[r * 4 + ((lane & 3u) ^ (((r >> 2) & 3u) ^ (r & 2u)))] = make_float4(v.x, v.y, v.z, v.w);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  GBP_UNROLL
+  for (int q = 0; q < 4; ++q) {
+    const float4 v = stage[lane * 4 + ((uint32_t)q ^ swz_own)];
+    lm[4 * q] = v.x; lm[4 * q + 1] = v.y; lm[4 * q + 2] = v.z; lm[4 * q + 3] = v.w;
   }
   load_rec<kCamRec4>(a.camb + (size_t)cam_i * kCamRec4, cb);
-  if (ABL & 2) {
-    GBP_UNROLL
-    for (int i = 0; i < 16; ++i) lb[i] = (i == 4 || i == 8 || i == 12) ? 1.f : 0.f;
-  } else {
-    load_rec<kLmkRec4>(a.lmkb + (size_t)lmk_i * kLmkRec4, lb);
-  }
+  load_rec<kLmkRec4>(a.lmkb + (size_t)lmk_i * kLmkRec4, lb);
   // per-factor scalar state rides in the pad slots of the landmark-message record (read and rewritten
   // every sweep anyway): [3] damping, [13] (damping_count << 3) | flags, [14] measurement variance
   float damping = lm[3];
@@ -588,7 +507,7 @@ GBP_DEV void sweep_tile(const SweepArgs& a, const uint32_t wslot) {
 
   float oc_eta[6], oc_lam[36], ol[16];
   bool relin;
-  factor_update<HOIST, ABL>(fac, cm, mu, lm, cb, lb, K, a.hp, damping, count, flags, var, active, oc_eta, oc_lam, ol, relin,
+  factor_update<HOIST>(fac, cm, mu, lm, cb, lb, K, a.hp, damping, count, flags, var, active, oc_eta, oc_lam, ol, relin,
                             [&](float (&x0c)[6], float (&x0l)[3], CamLin& cl) {   // rare path: loaded only by relinearising lanes
                               // camera side: the hoisted mean and its CAM_LIN record — per-camera tables (C x 144 B) that live in L2
                               const float4 m0 = a.cam_mu[(size_t)cam_i * 4], m1 = a.cam_mu[(size_t)cam_i * 4 + 1];
@@ -600,7 +519,7 @@ GBP_DEV void sweep_tile(const SweepArgs& a, const uint32_t wslot) {
                               // landmark side: the mean is RECOMPUTED from the belief record the lane holds anyway — inf2mean3x3
                               // (bafuncs.cpp:11-15) with the operations k_beliefs used for LMK_MU, so the same bits — instead of
                               // gathered: a second random gather (a 128-B line fill per factor for 12 useful bytes) made the
-                              // lock-step relinearising sweep move 104 MB more than it has to (profiles/r04_relin_dispatches.csv)
+                              // lock-step relinearising sweep move 104 MB more than it has to
                               float B[9], S3[9];
                               GBP_UNROLL
                               for (int i = 0; i < 9; ++i) B[i] = lb[4 + i];
@@ -618,24 +537,23 @@ GBP_DEV void sweep_tile(const SweepArgs& a, const uint32_t wslot) {
   ol[3] = damping;
   ol[13] = __int_as_float((int)(((uint32_t)count << 3) | flags));
   ol[14] = var;
-  if (!(ABL & (1 | 32))) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    GBP_UNROLL
-    for (int q = 0; q < 4; ++q)
-      stage[lane * 4 + ((uint32_t)q ^ swz_own)] = make_float4(ol[4 * q], ol[4 * q + 1], ol[4 * q + 2], ol[4 * q + 3]);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    GBP_UNROLL
-    for (int k = 0; k < 4; ++k) {
-      const uint32_t r = k * 16 + rec_t;
-#ifdef GBP_LMSG_STORE_NT
-      { const float4 f = stage[r * 4 + ((lane & 3u) ^ (((r >> 2) & 3u) ^ (r & 2u)))]; const v4f v = {f.x, f.y, f.z, f.w};
-        __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(lm_tile) + k * 64 + lane); }
-#else
-      lm_tile[k * 64 + lane] = stage[r * 4 + ((lane & 3u) ^ (((r >> 2) & 3u) ^ (r & 2u)))];
-#endif
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  GBP_UNROLL
+  for (int q = 0; q < 4; ++q)
+    stage[lane * 4 + ((uint32_t)q ^ swz_own)] = make_float4(ol[4 * q], ol[4 * q + 1], ol[4 * q + 2], ol[4 * q + 3]);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  GBP_UNROLL
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t r = k * 16 + rec_t;
+    const float4 f = stage[r * 4 + ((lane & 3u) ^ (((r >> 2) & 3u) ^ (r & 2u)))];
+    if (POL & kPolLmsgStoreNt) {
+      const v4f v = {f.x, f.y, f.z, f.w};
+      __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(lm_tile) + k * 64 + lane);
+    } else {
+      lm_tile[k * 64 + lane] = f;
     }
   }
   {
@@ -648,342 +566,23 @@ GBP_DEV void sweep_tile(const SweepArgs& a, const uint32_t wslot) {
       for (int j = 0; j <= i; ++j) cmo[6 + tri(i, j)] = oc_lam[i * 6 + j];
     }
     cmo[27] = 0.f;
-#ifdef GBP_CMSG_STORE_CACHED
-    store_tile<kCmsgG, false>(a.cmsg, tile, lane, cmo);
-#else
     store_tile<kCmsgG>(a.cmsg, tile, lane, cmo);
-#endif
   }
   // camera half of the belief reduction: per-row (16 factors of one camera) tree sums
   {
-#ifdef GBP_ROWSUM_PLAIN      // measurement: the 4 x 42-node butterfly of row16_sum, record stored by lane 0 of the row
-    float rs[44];
-    GBP_UNROLL
-    for (int i = 0; i < 6; ++i) rs[i] = row16_sum(oc_eta[i]);
-    rs[6] = 0.f; rs[7] = 0.f;
-    GBP_UNROLL
-    for (int i = 0; i < 36; ++i) rs[8 + i] = row16_sum(oc_lam[i]);
-    if ((lane & 15) == 0) {
-      float4* rp = a.rowp + (size_t)(p >> 4) * kCamRec4;
-      GBP_UNROLL
-      for (int g = 0; g < kCamRec4; ++g) rp[g] = make_float4(rs[4 * g], rs[4 * g + 1], rs[4 * g + 2], rs[4 * g + 3]);
-    }
-#else
     float4* rp = a.rowp + (size_t)(p >> 4) * kCamRec4;
     row16_sums_store(oc_eta, oc_lam, lane, [&](uint32_t g, float4 v) { rp[g] = v; });
-#endif
   }
   if (active) {
     if (!HOIST) store_tile<kMuG>(a.mu, tile, lane, mu);
-    if (relin && !(ABL & 2048)) store_tile<kFacG>(a.fac, tile, lane, fac);
+    if (relin) store_tile<kFacG>(a.fac, tile, lane, fac);
   }
 }
 
-template <bool HOIST, int ABL = 0, bool CMC = false>
+template <bool HOIST, uint32_t POL = 0>
 __global__ __launch_bounds__(64 * kWpb) void k_sweep(const SweepArgs a) {
-  sweep_tile<HOIST, ABL, CMC>(a, (blockIdx.x + a.block0 * (4 / kWpb)) * kWpb + (threadIdx.x >> 6));
+  sweep_tile<HOIST, POL>(a, blockIdx.x * kWpb + (threadIdx.x >> 6));
 }
-
-#ifdef GBP_BUILD_EXPERIMENTS
-// Mapping experiment (profiles/time_mapping.py): the SAME sweep forced to three wavefronts per SIMD
-// (<= 168 VGPRs): what a third wave buys against what the spills cost.
-__global__ __launch_bounds__(64 * kWpb) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_sweep_w3(const SweepArgs a) {
-  sweep_tile<true, 0>(a, (blockIdx.x + a.block0 * (4 / kWpb)) * kWpb + (threadIdx.x >> 6));
-}
-// Mapping experiment (gbp_params.reserved[0] = 2): the same sweep as RESIDENT waves that loop over the tiles (grid = what
-// fits the chip at two waves per SIMD) instead of one wave per tile: a wave's stores overlap the next tile's loads, no
-// wave slot idles between a retiring wave and its successor.
-__global__ __launch_bounds__(256) void k_sweep_loop(const SweepArgs a, const uint32_t n_slots) {
-  for (uint32_t ws = blockIdx.x * 4 + (threadIdx.x >> 6); ws < n_slots; ws += gridDim.x * 4) sweep_tile<true, 0>(a, ws);
-}
-#endif
-
-#ifdef GBP_BUILD_EXPERIMENTS
-// =================================================================================================
-// k_sweep_coop16 — the sweep in the NORTH STAR's sub-wave mapping, built so that it can be measured against the product
-// kernel (profiles/time_mapping.py): 16 lanes (one DPP row) cooperate on ONE factor, the factor's blocks
-// (potential, both messages, both beliefs) are staged in LDS, every product / inverse is evaluated with lane = output
-// element in the reference's k order, the 6x6 inverse is the cooperative LDL^T of k_inv6_coop.  One wavefront = 4
-// factors, one workgroup = 16 factors = one camera row (its 44 row sums are a tree over the 16 factors, same order as
-// row16_sum).  Functionally complete and bit-identical to k_sweep (a relinearising factor runs relin_core on lane 0 of
-// its group); experiments build only.
-// =================================================================================================
-namespace coop {
-constexpr int kF = 0, kCm = 56, kLm = 84, kCb = 100, kLb = 144, kWs = 160;          // LDS floats of one factor
-constexpr int kAp = kWs, kU = kWs + 21, kUi = kWs + 36, kAinv = kWs + 51, kG = kWs + 87, kEd = kWs + 105, kBp = kWs + 111, kBi = kWs + 120,
-              kG2 = kWs + 129, kEl = kWs + 147, kOut = kWs + 150 /* ol 16 | oc_eta 6 | oc_lam 36 */, kStride = kWs + 150 + 58 + 2;   // 370 floats
-GBP_DEV void sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-// cooperative un-pivoted LDL^T inverse of the packed lower triangle at w[kAp..] -> w[kAinv..] (36), lane t of 16
-GBP_DEV void inv6(float* w, int t) {
-  auto uidx = [](int j, int i) { return kU + j * 5 - j * (j - 1) / 2 + (i - j - 1); };   // U[j][i], j < i   (15 entries)
-  float D[6], rD[6];
-  GBP_UNROLL
-  for (int j = 0; j < 6; ++j) {
-    float d = w[kAp + tri(j, j)];
-    GBP_UNROLL
-    for (int k = 0; k < j; ++k) { const float ukj = w[uidx(k, j)]; d -= ukj * ukj * D[k]; }
-    D[j] = d;
-    rD[j] = 1 / d;
-    const int i = j + 1 + t;
-    if (i < 6) {
-      float u = rD[j] * w[kAp + tri(i, j)];
-      GBP_UNROLL
-      for (int k = 0; k < j; ++k) u -= rD[j] * w[uidx(k, i)] * w[uidx(k, j)] * D[k];
-      w[uidx(j, i)] = u;
-    }
-    sync();
-  }
-  {
-    float ui[6];
-    GBP_UNROLL
-    for (int k = 0; k < 6; ++k) ui[k] = 0.f;
-    GBP_UNROLL
-    for (int j = 1; j < 6; ++j) {
-      if (t < j) {
-        float acc = 0.f;
-        acc += w[uidx(t, j)];
-        GBP_UNROLL
-        for (int k = 1; k < j; ++k)
-          if (k > t) acc += ui[k] * w[uidx(k, j)];
-        ui[j] = acc / -1.f;
-        w[kUi + (uidx(t, j) - kU)] = ui[j];
-      }
-    }
-  }
-  sync();
-  GBP_UNROLL
-  for (int r = 0; r < 3; ++r) {
-    const int e = t + 16 * r;
-    if (e < 36) {
-      const int i = e / 6, j = e - 6 * i;
-      const int k0 = i > j ? i : j;
-      float acc = 0.f;
-      GBP_UNROLL
-      for (int k = 0; k < 6; ++k) {
-        if (k >= k0) {
-          const float ww = (k == i) ? rD[k] : w[kUi + (uidx(i, k) - kU)] * rD[k];
-          if (k == j) acc += ww;
-          else acc += ww * w[kUi + (uidx(j, k) - kU)];
-        }
-      }
-      w[kAinv + e] = acc;
-    }
-  }
-  sync();
-}
-}  // namespace coop
-
-__global__ __launch_bounds__(256) void k_sweep_coop16(const SweepArgs a) {
-  using namespace coop;
-  __shared__ float lds[16][kStride];
-  const uint32_t f = threadIdx.x >> 4, t = threadIdx.x & 15;        // factor of the workgroup, lane of the factor
-  const uint32_t p = blockIdx.x * 16 + f, tile = p >> 6, lt = p & 63;
-  float* w = lds[f];
-  const uint32_t cam_i = a.row_cam[p >> 4], lmk_i = a.lmk_idx[p];
-  // ---- stage the factor's 160 input floats: 40 float4 over 16 lanes ----
-  GBP_UNROLL
-  for (int r = 0; r < 3; ++r) {
-    const int i = (int)t + 16 * r;
-    float4 v;
-    int dst = -1;
-    if (i < 14) { v = a.fac[((size_t)tile * kFacG + i) * 64 + lt]; dst = kF + 4 * i; }
-    else if (i < 21) { v = a.cmsg[((size_t)tile * kCmsgG + (i - 14)) * 64 + lt]; dst = kCm + 4 * (i - 14); }
-    else if (i < 25) { v = a.lmsg[(size_t)p * 4 + (i - 21)]; dst = kLm + 4 * (i - 21); }
-    else if (i < 36) { v = a.camb[(size_t)cam_i * kCamRec4 + (i - 25)]; dst = kCb + 4 * (i - 25); }
-    else if (i < 40) { v = a.lmkb[(size_t)lmk_i * kLmkRec4 + (i - 36)]; dst = kLb + 4 * (i - 36); }
-    if (dst >= 0) { w[dst] = v.x; w[dst + 1] = v.y; w[dst + 2] = v.z; w[dst + 3] = v.w; }
-  }
-  sync();
-  const float* fac = w + kF; const float* cm = w + kCm; const float* lm = w + kLm; const float* cb = w + kCb; const float* lb = w + kLb;
-  float damping = lm[3];
-  const int packed = __float_as_int(lm[13]);
-  int count = packed >> 3;
-  uint32_t flags = (uint32_t)packed & 7u;
-  const float var = lm[14];
-  const bool active = (flags & kFlagActive) != 0;
-  bool relin = false;
-  float* out = w + kOut;               // ol[0..15] | oc_eta[16..21] | oc_lam[22..57]
-  GBP_UNROLL
-  for (int r = 0; r < 4; ++r) { const int e = (int)t + 16 * r; if (e < 58) out[e] = 0.f; }
-  if (active) {    // uniform over the 16 lanes of a factor
-    if (0 == count) damping = a.hp.maxeta_damping;
-    count += 1;
-    float d2 = cb[6];
-    d2 += lb[3];
-    d2 += lb[13];
-    d2 += lb[14];
-    const float dmu = sqrtf(d2);
-    relin = (dmu < a.hp.dmu_threshold) && (count > a.hp.min_linear_iters - a.hp.num_undamped_iters);
-    if (relin) {
-      damping = 0.f;
-      count = -a.hp.num_undamped_iters;
-      if (t == 0) {                    // the rare path stays on one lane: relin_core as the product kernel runs it
-        float fr[56], x0c[6], x0l[3], K[9];
-        GBP_UNROLL
-        for (int i = 0; i < 56; ++i) fr[i] = fac[i];
-        GBP_UNROLL
-        for (int i = 0; i < 9; ++i) K[i] = a.K[i];
-        const float4 m0 = a.cam_mu[(size_t)cam_i * 4], m1 = a.cam_mu[(size_t)cam_i * 4 + 1];
-        const float4 l0 = a.lmk_mu[(size_t)lmk_i * 2];
-        x0c[0] = m0.x; x0c[1] = m0.y; x0c[2] = m0.z; x0c[3] = m0.w; x0c[4] = m1.x; x0c[5] = m1.y;
-        x0l[0] = l0.x; x0l[1] = l0.y; x0l[2] = l0.z;
-        if (a.hp.relin_mode == 1) {
-          GBP_UNROLL
-          for (int i = 0; i < 54; ++i) fr[i] = 0.f;
-        }
-        CamLin cl;
-        const float wv[3] = {x0c[3], x0c[4], x0c[5]};
-        cam_lin(wv, cl);
-        const bool robust = relin_core<0>(fr, x0c, x0l, K, var, a.hp.nstds, cl);
-        GBP_UNROLL
-        for (int i = 0; i < 54; ++i) w[kF + i] = fr[i];
-        w[kStride - 1] = robust ? 1.f : 0.f;
-      }
-      sync();
-      flags = w[kStride - 1] != 0.f ? (flags | kFlagRobust) : (flags & ~kFlagRobust);
-    }
-    const float omd = 1 - damping;
-    // ---- factor -> landmark message (gbp_codelets.cpp:503-562, 664-709) ----
-    GBP_UNROLL
-    for (int r = 0; r < 2; ++r) {
-      const int e = (int)t + 16 * r;
-      if (e < 21) {
-        int i = 0;
-        while ((i + 1) * (i + 2) / 2 <= e) ++i;
-        const int j = e - i * (i + 1) / 2;
-        float v = fac[9 + e] + cb[8 + i * 6 + j];
-        w[kAp + e] = v - cm[6 + e];
-      }
-    }
-    if (t < 6) { const float v = fac[t] + cb[t]; w[kEd + t] = v - cm[t]; }
-    sync();
-    inv6(w, (int)t);
-    GBP_UNROLL
-    for (int r = 0; r < 2; ++r) {
-      const int e = (int)t + 16 * r;
-      if (e < 18) {
-        const int i = e / 6, j = e - 6 * i;
-        float acc = 0.f;
-        GBP_UNROLL
-        for (int k = 0; k < 6; ++k) acc += fac[30 + k * 3 + i] * w[kAinv + k * 6 + j];
-        w[kG + e] = acc;
-      }
-    }
-    sync();
-    if (t < 3) {
-      float s = 0.f;
-      GBP_UNROLL
-      for (int k = 0; k < 6; ++k) s += w[kG + t * 6 + k] * w[kEd + k];
-      const float h = fac[6 + t] - s;
-      out[t] = h * omd + lm[t] * damping;
-    } else if (t < 12) {
-      const int e = (int)t - 3, i = e / 3, j = e - 3 * i;
-      float tt = 0.f;
-      GBP_UNROLL
-      for (int k = 0; k < 6; ++k) tt += w[kG + i * 6 + k] * fac[30 + k * 3 + j];
-      out[4 + e] = fac[48 + trisym(i, j)] - tt;
-    }
-    // ---- factor -> camera message (gbp_codelets.cpp:411-471, 592-637) ----
-    if (t < 9) {
-      const int i = (int)t / 3, j = (int)t - 3 * i;
-      const float v = fac[48 + trisym(i, j)] + lb[4 + t];
-      w[kBp + t] = v - lm[4 + t];
-    }
-    if (t < 3) { const float v = fac[6 + t] + lb[t]; w[kEl + t] = v - lm[t]; }
-    sync();
-    {
-      float M[9], I[9];
-      GBP_UNROLL
-      for (int i = 0; i < 9; ++i) M[i] = w[kBp + i];
-      inv3x3(M, I);                    // 50 operations: every lane runs it, lane t < 9 keeps entry t
-      if (t < 9) {
-        float v = I[0];
-        GBP_UNROLL
-        for (int i = 1; i < 9; ++i) v = ((int)t == i) ? I[i] : v;
-        w[kBi + t] = v;
-      }
-    }
-    sync();
-    GBP_UNROLL
-    for (int r = 0; r < 2; ++r) {
-      const int e = (int)t + 16 * r;
-      if (e < 18) {
-        const int i = e / 3, j = e - 3 * i;
-        float acc = 0.f;
-        GBP_UNROLL
-        for (int k = 0; k < 3; ++k) acc += fac[30 + i * 3 + k] * w[kBi + k * 3 + j];
-        w[kG2 + e] = acc;
-      }
-    }
-    sync();
-    if (t < 6) {
-      float s = 0.f;
-      GBP_UNROLL
-      for (int k = 0; k < 3; ++k) s += w[kG2 + t * 3 + k] * w[kEl + k];
-      const float h = fac[t] - s;
-      out[16 + t] = h * omd + cm[t] * damping;
-    }
-    GBP_UNROLL
-    for (int r = 0; r < 3; ++r) {
-      const int e = (int)t + 16 * r;
-      if (e < 36) {
-        const int i = e / 6, j = e - 6 * i;
-        float tt = 0.f;
-        GBP_UNROLL
-        for (int k = 0; k < 3; ++k) tt += w[kG2 + i * 3 + k] * fac[30 + j * 3 + k];
-        out[22 + e] = fac[9 + trisym(i, j)] - tt;
-      }
-    }
-  }
-  if (t == 0) {
-    out[3] = damping;
-    out[13] = __int_as_float((int)(((uint32_t)count << 3) | flags));
-    out[14] = var;
-  }
-  sync();
-  // ---- stores: landmark-message record (64 B), camera message (7 groups of the tile layout), potential if relinearised ----
-  if (t < 4) a.lmsg[(size_t)p * 4 + t] = make_float4(out[4 * t], out[4 * t + 1], out[4 * t + 2], out[4 * t + 3]);
-  if (t < 7) {
-    float c4[4];
-    GBP_UNROLL
-    for (int q = 0; q < 4; ++q) {
-      const int e = 4 * (int)t + q;            // cmo[e]: eta 0..5, lower triangle 6..26, pad
-      float v = 0.f;
-      if (e < 6) v = out[16 + e];
-      else if (e < 27) {
-        const int m = e - 6;
-        int i = 0;
-        while ((i + 1) * (i + 2) / 2 <= m) ++i;
-        const int j = m - i * (i + 1) / 2;
-        v = out[22 + i * 6 + j];
-      }
-      c4[q] = v;
-    }
-    a.cmsg[((size_t)tile * kCmsgG + t) * 64 + lt] = make_float4(c4[0], c4[1], c4[2], c4[3]);
-  }
-  if (active && relin && t < 14) a.fac[((size_t)tile * kFacG + t) * 64 + lt] = make_float4(w[kF + 4 * t], w[kF + 4 * t + 1], w[kF + 4 * t + 2], w[kF + 4 * t + 3]);
-  // ---- row sums over the 16 factors of the workgroup (= one camera row): the tree of row16_sum ----
-  __syncthreads();
-  if (threadIdx.x < 44) {
-    const int j = (int)threadIdx.x;
-    float r = 0.f;
-    if (j != 6 && j != 7) {
-      const int src = j < 6 ? kOut + 16 + j : kOut + 22 + (j - 8);
-      float x[16];
-      GBP_UNROLL
-      for (int q = 0; q < 16; ++q) x[q] = lds[q][src];
-      const float q0 = (x[0] + x[1]) + (x[2] + x[3]), q1 = (x[6] + x[7]) + (x[4] + x[5]);     // operand order of the DPP steps of lane 0 / lane 15
-      const float q2 = (x[8] + x[9]) + (x[10] + x[11]), q3 = (x[15] + x[14]) + (x[13] + x[12]);
-      r = (q0 + q1) + (q3 + q2);
-    }
-    reinterpret_cast<float*>(a.rowp)[(size_t)blockIdx.x * kCamRec + j] = r;
-  }
-}
-#endif  // GBP_BUILD_EXPERIMENTS
 
 // =================================================================================================
 // k_linearise: RelineariseFactorVertex on every factor (no active_flag test in the reference).
@@ -1044,30 +643,21 @@ GBP_DEV void cam_mean(REC&& cb, float (&x0c)[6]) {
   solve6_lower([&](int i, int j) { return cb[8 + i * 6 + j]; }, [&](int k) { return cb[k]; }, x0c);
 }
 
-#ifdef GBP_BELIEFS_WAVES   // occupancy experiment (profiles/r03_beliefs.md): -DGBP_BELIEFS_WAVES=7|8 through GBP_EXTRA_HIPFLAGS
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GBP_BELIEFS_WAVES, GBP_BELIEFS_WAVES))) void k_beliefs(const BeliefArgs b) {
-#else
 __global__ __launch_bounds__(256) void k_beliefs(const BeliefArgs b) {
-#endif
   __shared__ float sh[4][48];
   if (blockIdx.x < b.cam_blocks) {
     const uint32_t w = threadIdx.x >> 6, j = threadIdx.x & 63;
-    const uint32_t c = b.cam0 + blockIdx.x * 4 + w;
-    const bool live = c < b.cam1 && j < (uint32_t)kCamRec;
+    const uint32_t c = blockIdx.x * 4 + w;
+    const bool live = c < b.n_cams && j < (uint32_t)kCamRec;
     float bel = 0.f;
     if (live) {
       if (b.gathered) {
-        // exchange layout: chunk i (cameras [chunk_start[i], chunk_start[i+1])) is stored as [world][n_i][44]
-        // behind world * chunk_start[i] * 44 floats; one chunk == the plain [world][C][44] layout
-        int ch = 0;
-        while (ch + 1 < b.n_chunks && c >= b.chunk_start[ch + 1]) ++ch;
-        const uint32_t c0 = b.chunk_start[ch], n_i = b.chunk_start[ch + 1] - c0;
-        const float* g = b.gathered + (size_t)b.world * c0 * kCamRec + (size_t)(c - c0) * kCamRec + j;
+        const float* g = b.gathered + (size_t)c * kCamRec + j;      // exchange layout: [world][C][44]
         float acc = b.cam_prior[(size_t)c * kCamRec + j];
         for (int r0 = 0; r0 < b.world; r0 += 8) {      // the partials of eight ranks in flight at once (clamped, unconditional), added in rank order
           float v[8];
           GBP_UNROLL
-          for (int k = 0; k < 8; ++k) v[k] = g[(size_t)(r0 + k < b.world ? r0 + k : b.world - 1) * n_i * kCamRec];
+          for (int k = 0; k < 8; ++k) v[k] = g[(size_t)(r0 + k < b.world ? r0 + k : b.world - 1) * b.n_cams * kCamRec];
           GBP_UNROLL
           for (int k = 0; k < 8; ++k)
             if (r0 + k < b.world) acc = acc + v[k];
@@ -1099,7 +689,7 @@ __global__ __launch_bounds__(256) void k_beliefs(const BeliefArgs b) {
               if ((uint32_t)k < m) acc = acc + v[k];
           }
         } else if (r1 > r0) {
-          // the camera's rows sit where the row placement put them (gbp_capi.cpp): the same sums in the same order, each row
+          // the camera's rows sit where the row placement put them (gbp_layout.cpp): the same sums in the same order, each row
           // found through row_slot (wave-uniform indices: one round of scalar loads in front of the rows')
           const float* base = b.rowp + j;
           const uint32_t n = r1 - r0;
@@ -1128,8 +718,8 @@ __global__ __launch_bounds__(256) void k_beliefs(const BeliefArgs b) {
     // single stream (lanes 0..3 of wave 0) instead of issuing it from four wavefronts: with thousands of cameras the
     // camera part is bound by exactly these issue slots (8 000 cameras: 11 -> 4 us).
     if (b.hoist && w == 0 && j < 4) {
-      const uint32_t cj = b.cam0 + blockIdx.x * 4 + j;
-      if (cj < b.cam1) {
+      const uint32_t cj = blockIdx.x * 4 + j;
+      if (cj < b.n_cams) {
         float x0c[6];
         cam_mean(sh[j], x0c);                    // operands straight from LDS: the 44-float copy cost 14 VGPRs of occupancy
         float4* mu = b.cam_mu + (size_t)cj * 4;  // [0,1] = means of the current belief, [2,3] = means the last sweep used
@@ -1163,7 +753,7 @@ __global__ __launch_bounds__(256) void k_beliefs(const BeliefArgs b) {
     // XCD-aware order: the blocks that share an XCD (equal index mod 8 under round-robin placement) take one contiguous
     // run of landmarks.  The 64-B message records of two neighbouring factors share a 128-B line, and the partner's
     // landmark is a near neighbour (factors are sorted by landmark inside a camera): with both in one XCD's L2 about
-    // half of the partner fetches disappear (k_beliefs: 25.6 -> 21.3 us on S1, profiles/r01_ablation.md).
+    // half of the partner fetches disappear (k_beliefs: 25.6 -> 21.3 us on the 1M-factor graph).
     const uint32_t qn = b.lmk_blocks / 8, rn = b.lmk_blocks % 8, g = lb & 7u;
     lb = g * qn + (g < rn ? g : rn) + (lb >> 3);
   }
@@ -1183,23 +773,15 @@ __global__ __launch_bounds__(256) void k_beliefs(const BeliefArgs b) {
     // is consumed — behind the gathers — it was a third dependent round trip of every wave
     if (b.hoist && q == 0) used_mu = b.lmk_mu[(size_t)l * 2 + (b.roll ? 0 : 1)];
   }
-#ifdef GBP_BUILD_EXPERIMENTS
-  if (b.abl == 2) ix = make_uint4(live ? 10u : 0u, 0u, 0u, 0u);   // degree without waiting for the record (S1: 10 everywhere)
-#endif
   const uint32_t deg = (uint32_t)__shfl((int)ix.x, 0, 4);
   {
     // element k + 1 of the index record sits in lane (k + 1) / 4, component (k + 1) % 4 of the quad
     auto slot_pos = [&](int k) -> uint32_t {
       const uint32_t v = ((k + 1) & 3) == 0 ? ix.x : ((k + 1) & 3) == 1 ? ix.y : ((k + 1) & 3) == 2 ? ix.z : ix.w;
-      uint32_t pk = (uint32_t)__shfl((int)v, (k + 1) >> 2, 4);
-#ifdef GBP_BUILD_EXPERIMENTS   // timing only: where would the kernel be with a streaming / an index-free gather?
-      if (b.abl == 1) pk = b.lmk_ptr[0] + l * 10u + (uint32_t)k;
-      if (b.abl == 2) pk = (uint32_t)(((uint64_t)(l * 10u + (uint32_t)k) * 2654435761ull) % ((uint64_t)b.n_lmks * 10u));
-#endif
-      return pk;
+      return (uint32_t)__shfl((int)v, (k + 1) >> 2, 4);
     };
     // Ten gathers in flight, then (only where a landmark of the wave has more than ten factors) the other five: 40
-    // instead of 60 staging registers (S1: k_beliefs 20.4 -> 18.8 us; profiles/r03_beliefs.md).
+    // instead of 60 staging registers (1M-factor graph: k_beliefs 20.4 -> 18.8 us).
     float4 m[10];
     GBP_UNROLL
     for (int k = 0; k < 10; ++k) m[k] = lmsg_load(b.lmsg, slot_pos(k), q);      // all ten in flight (see lmsg_load)
@@ -1511,8 +1093,8 @@ __global__ __launch_bounds__(256) void k_copy_segments(const CopySegs t, const u
 }
 
 // EV: does the launch carry the metric (A.ev.on)?  A launch without it runs an instantiation that holds none of the metric's
-// code or registers (plain bursts 14.3 -> 14.0 us per iteration on fr1xyz, profiles/r04_small_graphs.md).
-template <int ABL = 0, bool EV = true>   // ABL: timing experiments only (see k_sweep)
+// code or registers (plain bursts 14.3 -> 14.0 us per iteration on fr1xyz).
+template <bool EV>
 __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
   const bool ev_on = EV && A.ev.on != 0;
   const SweepArgs& a = A.s;
@@ -1586,12 +1168,8 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
   const bool cam_wave = v < b.n_cams;
   const bool lmk_wave = !cam_wave && (v - b.n_cams) < A.n_lmk_groups;
   const uint32_t v_met0 = b.n_cams + A.n_lmk_groups;
-#ifdef GBP_PERSIST_NO_METRIC_ROLES     // (measurement build only)
-  const bool met_wave = false, cam_has_met_wave = false;
-#else
   const bool met_wave = ev_on && v >= v_met0 && v - v_met0 < b.n_cams;
   const bool cam_has_met_wave = cam_wave && v_met0 + v < nblk * 4u;       // this camera's metric mean is solved by wave v_met0 + v
-#endif
   const uint32_t camv = met_wave ? v - v_met0 : v;                          // the camera of either role
   const uint32_t cj = lane;                                   // camera role: element of the 44-float record
   const bool cam_live = (cam_wave || met_wave) && cj < (uint32_t)kCamRec;
@@ -1626,11 +1204,6 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
     pos[k] = (uint32_t)__shfl((int)v, (k + 1) >> 2, 4);
   }
 
-#ifdef GBP_BUILD_EXPERIMENTS   // per-phase wall-clock stamps of the first iterations (profiles/persist_trace.py)
-#define GBP_TRACE(slot) if (A.trace && it < kPersistTraceIters && lane == 0) A.trace[((size_t)w * kPersistTraceIters + it) * 8 + (slot)] = wall_clock64()
-#else
-#define GBP_TRACE(slot)
-#endif
   // slots 16 .. 30 of a landmark (fr1xyz: up to 30 factors per landmark): positions fetched ONCE, so that phase B stays a
   // single round of loads; slots beyond 30 go through lmk_fpos every iteration
   uint32_t pos2[15];
@@ -1702,7 +1275,6 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
 
   unsigned epoch = 0;
   for (int it = 0; it < A.n_iters; ++it) {
-    GBP_TRACE(0);
     const bool ev_means = ev_on && (A.ev.each || it + 1 == A.n_iters);     // this iteration's beliefs are evaluated
     // the metric of iteration it - 1 rides in this phase A (both only READ what phase B left): its loads go out with the
     // sweep's, its arithmetic runs behind the sweep's stores
@@ -1721,9 +1293,6 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
       for (int g = 0; g < kCamLin4; ++g) clq[g] = X_clin.ld4(clin_rec4 + (uint32_t)g);
       load_rec_xw<kLmkRec4>(X_lmkb, lb_rec4, lb);
       load_rec_xw<kCamRec4>(X_camb, cb_rec4, cb);
-#ifdef GBP_BUILD_EXPERIMENTS
-      if (A.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); GBP_TRACE(5); }
-#endif
       float damping = lm[3];
       const int packed = __float_as_int(lm[13]);
       int count = packed >> 3;
@@ -1732,23 +1301,13 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
       const bool active = (flags & kFlagActive) != 0;
       float oc_eta[6], oc_lam[36], ol[16];
       bool relin;
-      factor_update<true, ABL>(fac, cm, mu, lm, cb, lb, K, a.hp, damping, count, flags, var, active, oc_eta, oc_lam, ol, relin,
+      factor_update<true>(fac, cm, mu, lm, cb, lb, K, a.hp, damping, count, flags, var, active, oc_eta, oc_lam, ol, relin,
                              [&](float (&x0c)[6], float (&x0l)[3], CamLin& cl) {
                                x0c[0] = m0.x; x0c[1] = m0.y; x0c[2] = m0.z; x0c[3] = m0.w; x0c[4] = m1.x; x0c[5] = m1.y;
                                x0l[0] = l0.x; x0l[1] = l0.y; x0l[2] = l0.z;
                                cam_lin_unpack(clq, cl);
                              });
       fac_dirty = fac_dirty || (active && relin);
-#ifdef GBP_BUILD_EXPERIMENTS
-      if (A.trace) {
-        GBP_TRACE(6);
-        const unsigned long long any_relin = __ballot(active && relin);
-        // relinearising lanes | XCC_ID << 8 | HW_ID << 16  (hwreg 20 = XCC_ID, hwreg 4 = HW_ID: simd [5:4], cu [11:8], sh [12], se [15:13])
-        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20), hwid = __builtin_amdgcn_s_getreg((15 << 11) | 4);
-        if (it < kPersistTraceIters && lane == 0)
-          A.trace[((size_t)w * kPersistTraceIters + it) * 8 + 7] = (unsigned long long)__popcll(any_relin) | ((unsigned long long)xcc << 8) | ((unsigned long long)hwid << 16);
-      }
-#endif
       ol[3] = damping;
       ol[13] = __int_as_float((int)(((uint32_t)count << 3) | flags));
       ol[14] = var;
@@ -1778,36 +1337,17 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
       cm[27] = 0.f;
       {  // camera half of the belief reduction: per-row tree sums, as in k_sweep
         const uint32_t rp4 = (p >> 4) * (uint32_t)kCamRec4;
-#ifdef GBP_ROWSUM_PLAIN
-        float rs[44];
-        GBP_UNROLL
-        for (int i = 0; i < 6; ++i) rs[i] = row16_sum(oc_eta[i]);
-        rs[6] = 0.f; rs[7] = 0.f;
-        GBP_UNROLL
-        for (int i = 0; i < 36; ++i) rs[8 + i] = row16_sum(oc_lam[i]);
-        if ((lane & 15) == 0) {
-          GBP_UNROLL
-          for (int g = 0; g < kCamRec4; ++g) X_rowp.st4(rp4 + (uint32_t)g, make_float4(rs[4 * g], rs[4 * g + 1], rs[4 * g + 2], rs[4 * g + 3]));
-        }
-#else
         row16_sums_store(oc_eta, oc_lam, lane, [&](uint32_t g, float4 v) { X_rowp.st4(rp4 + g, v); });
-#endif
       }
     }
-    GBP_TRACE(1);
     grid_sync(A.sync, A.epoch_base + (++epoch) * nblk, A.status, A.seq);
-    GBP_TRACE(2);
 
     // ================= phase B: the belief update (arithmetic of k_beliefs, roll = 1) =================
     float ev_cm[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ev_lm[3] = {0.f, 0.f, 0.f};
     if (ev_prev && has_tile) metric_means((uint32_t)it - 1u, ev_cm, ev_lm);     // in flight with the role's own loads
     unsigned long long* const hw = health_of((uint32_t)it);                      // what this phase's owners count into
     const uint32_t emc_w = ((uint32_t)it & 1u) * emc_half, eml_w = ((uint32_t)it & 1u) * eml_half;
-#ifdef GBP_LDL_INLINE          // measurement: the health check of the camera belief on the critical path of the belief phase
-    const bool ldl_deferred = false;
-#else
     const bool ldl_deferred = it + 1 < A.n_iters;      // a hand-off follows this belief phase
-#endif
     if (cam_wave || (met_wave && ev_means)) {
       float acc = 0.f;
       if (cam_live && r1 > r0) {
@@ -1980,7 +1520,6 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
     }
     // the residuals of the PREVIOUS iteration: behind this wave's role, and — where a hand-off follows — between its arrival and
     // its wait (they read what the previous belief phase left and the factor's own registers: nothing of this phase)
-    GBP_TRACE(3);
     if (it + 1 < A.n_iters) {
       grid_arrive(A.sync);
       {
@@ -2000,9 +1539,7 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
     } else if (ev_prev) {
       metric((uint32_t)it - 1u, ev_packed, ev_cm, ev_lm);
     }
-    GBP_TRACE(4);
   }
-#undef GBP_TRACE
 
   // ---- the metric of the last iteration: one more hand-off, then as above ----
   if (ev_on) {
@@ -2132,310 +1669,32 @@ __global__ __launch_bounds__(256) void k_eval(const uint32_t* __restrict__ row_c
   eval_block_reduce(s_norm, s_half, n_act, n_rel, n_rob, partials + blockIdx.x);
 }
 
-#ifdef GBP_BUILD_TEST_HOOKS
-// =================================================================================================
-// k_debug_math: the device math layer (gbp_device_math.hpp) on caller-supplied vectors, one lane per
-// vector — lets a test compare HIP directly with the reference's own matlib.cpp / bafuncs.cpp outputs
-// (tests/golden/math_vectors.npz), without the restated vertex layer in between.  Test hook only.
-//   op 0 inv3x3      in 9        out 9      matlib.cpp:143-161
-//   op 1 inv6x6      in 36       out 36     matlib.cpp:180-222 (reads the lower triangle)
-//   op 2 so3exp      in 3        out 9      bafuncs.cpp:31-55
-//   op 3 hfunc+Jac   in 6+3+9    out 2+12+6 bafuncs.cpp:82-213
-//   op 4 P(6x3) += B(6x6) A(6x3)    in A18 B36 P18  out 18    matMul, matlib.cpp:47-56
-//   op 5 P(3x6) += A^T B            in A18 B36 P18  out 18    matMul transposeA, matlib.cpp:57-66
-//   op 6 P(6x6) += A A^T            in A18 P36      out 36    matMul transposeB, matlib.cpp:67-76
-//   op 7 inf2mean6x6 in eta6 L36  out 6 ; op 8 inf2mean3x3 in eta3 L9 out 3   bafuncs.cpp:2-15
-//   op 10 div_shared  in x9 m1     out 9      (gbp_device_math.hpp: IEEE quotients through one fp64 reciprocal)
-// =================================================================================================
-__global__ __launch_bounds__(64) void k_debug_math(int op, const float* __restrict__ in, float* __restrict__ out, int n,
-                                                   int in_w, int out_w) {
-  const int t = blockIdx.x * 64 + threadIdx.x;
-  if (t >= n) return;
-  const float* x = in + (size_t)t * in_w;
-  float* y = out + (size_t)t * out_w;
-  if (op == 0) {
-    float M[9], I[9];
-    GBP_UNROLL
-    for (int i = 0; i < 9; ++i) M[i] = x[i];
-    inv3x3(M, I);
-    GBP_UNROLL
-    for (int i = 0; i < 9; ++i) y[i] = I[i];
-  } else if (op == 1) {
-    float Al[21], I[36];
-    GBP_UNROLL
-    for (int i = 0; i < 6; ++i) {
-      GBP_UNROLL
-      for (int j = 0; j <= i; ++j) Al[tri(i, j)] = x[i * 6 + j];
-    }
-    inv6x6_lower(Al, I);
-    GBP_UNROLL
-    for (int i = 0; i < 36; ++i) y[i] = I[i];
-  } else if (op == 2) {
-    const float v[3] = {x[0], x[1], x[2]};
-    float R[9];
-    so3exp(v, R);
-    GBP_UNROLL
-    for (int i = 0; i < 9; ++i) y[i] = R[i];
-  } else if (op == 3) {
-    float cam[6], lmk[3], K[9];
-    GBP_UNROLL
-    for (int i = 0; i < 6; ++i) cam[i] = x[i];
-    GBP_UNROLL
-    for (int i = 0; i < 3; ++i) lmk[i] = x[6 + i];
-    GBP_UNROLL
-    for (int i = 0; i < 9; ++i) K[i] = x[9 + i];
-    Lin L;
-    jac_hfunc(cam, lmk, K, L);
-    y[0] = L.hx[0]; y[1] = L.hx[1];
-    GBP_UNROLL
-    for (int i = 0; i < 12; ++i) y[2 + i] = L.Jkf[i];
-    GBP_UNROLL
-    for (int i = 0; i < 6; ++i) y[14 + i] = L.Jl[i];
-  } else if (op == 4) {   // the same loop shape as the message products of k_sweep (k sequential, acc starts at P)
-    const float* A = x; const float* B = x + 18; const float* P0 = x + 54;
-    for (int i = 0; i < 6; ++i)
-      for (int j = 0; j < 3; ++j) {
-        float acc = P0[i * 3 + j];
-        for (int k = 0; k < 6; ++k) acc += B[i * 6 + k] * A[k * 3 + j];
-        y[i * 3 + j] = acc;
-      }
-  } else if (op == 5) {
-    const float* A = x; const float* B = x + 18; const float* P0 = x + 54;
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 6; ++j) {
-        float acc = P0[i * 6 + j];
-        for (int k = 0; k < 6; ++k) acc += A[k * 3 + i] * B[k * 6 + j];
-        y[i * 6 + j] = acc;
-      }
-  } else if (op == 6) {
-    const float* A = x; const float* P0 = x + 18;
-    for (int i = 0; i < 6; ++i)
-      for (int j = 0; j < 6; ++j) {
-        float acc = P0[i * 6 + j];
-        for (int k = 0; k < 3; ++k) acc += A[i * 3 + k] * A[j * 3 + k];
-        y[i * 6 + j] = acc;
-      }
-  } else if (op == 7 || op == 8) {
-    float cb[44], lb[16], x0c[6], x0l[3];
-    GBP_UNROLL
-    for (int i = 0; i < 44; ++i) cb[i] = 0.f;
-    GBP_UNROLL
-    for (int i = 0; i < 16; ++i) lb[i] = 0.f;
-    if (op == 7) {
-      GBP_UNROLL
-      for (int i = 0; i < 6; ++i) cb[i] = x[i];
-      GBP_UNROLL
-      for (int i = 0; i < 36; ++i) cb[8 + i] = x[6 + i];
-      lb[4] = lb[8] = lb[12] = 1.f;
-    } else {
-      GBP_UNROLL
-      for (int i = 0; i < 3; ++i) lb[i] = x[i];
-      GBP_UNROLL
-      for (int i = 0; i < 9; ++i) lb[4 + i] = x[3 + i];
-      GBP_UNROLL
-      for (int i = 0; i < 6; ++i) cb[8 + i * 7] = 1.f;
-    }
-    belief_means(cb, lb, x0c, x0l);
-    if (op == 7) { GBP_UNROLL for (int i = 0; i < 6; ++i) y[i] = x0c[i]; }
-    else { GBP_UNROLL for (int i = 0; i < 3; ++i) y[i] = x0l[i]; }
-  } else if (op == 10) {   // div_shared: 9 numerators, one divisor -> 9 quotients (must equal IEEE x / m bit for bit)
-    float num[9], quo[9];
-    GBP_UNROLL
-    for (int i = 0; i < 9; ++i) num[i] = x[i];
-    div_shared(num, x[9], quo);
-    GBP_UNROLL
-    for (int i = 0; i < 9; ++i) y[i] = quo[i];
-  }
-}
-
-#endif  // GBP_BUILD_TEST_HOOKS
 
 // =================================================================================================
 // launchers
 // =================================================================================================
 static inline uint32_t blocks_for(uint64_t threads) { return (uint32_t)((threads + 255) / 256); }
 
+#ifdef GBP_BUILD_EXPERIMENTS
+bool lab_launch_sweep(const SweepArgs& a, uint32_t n_tiles, bool hoist, hipStream_t s);   // experiments/gbp_lab_kernels.hip
+#endif
 void launch_sweep(const SweepArgs& a, uint32_t n_tiles, bool hoist, hipStream_t s) {
-  launch_sweep_blocks(a, 0, n_tiles / 4, hoist, s);
-}
-// blocks [block0, block1) of the device order (256 factors each): pieces of one sweep for the pipelined exchange
-void launch_sweep_blocks(SweepArgs a, uint32_t block0, uint32_t block1, bool hoist, hipStream_t s) {
-  if (block1 <= block0) return;
-  a.block0 = block0;
-  const dim3 g((block1 - block0) * (4 / kWpb)), b(64 * kWpb);
-#ifdef GBP_BUILD_EXPERIMENTS
-  if (a.variant == 1 && hoist) {   // gbp_params.reserved[0] = 1: the sub-wave mapping (mapping experiments, parity test)
-    hipLaunchKernelGGL(k_sweep_coop16, dim3((block1 - block0) * 16), dim3(256), 0, s, a);   // needs block0 == 0 (whole sweeps only)
-    return;
-  }
-  if (a.variant >= 2 && hoist && block0 == 0) {   // reserved[0] = 2 + k: resident looping waves, grid = (k ? k : 512) workgroups
-    const uint32_t nb = a.variant > 2 ? (uint32_t)a.variant : 512u;
-    hipLaunchKernelGGL(k_sweep_loop, dim3(nb < block1 ? nb : block1), dim3(256), 0, s, a, block1 * 4);
-    return;
-  }
-#endif
-#ifdef GBP_BUILD_ABLATIONS   // experiments build only: GBP_SWEEP_ABL swaps an ablated instantiation into the REAL iteration flow
-  static const int env_abl = std::getenv("GBP_SWEEP_ABL") ? std::atoi(std::getenv("GBP_SWEEP_ABL")) : 0;
-  if (env_abl && hoist) {
-    switch (env_abl) {
-#define GBP_ABL_CASE(N) case N: hipLaunchKernelGGL((k_sweep<true, N>), g, b, 0, s, a); return;
-      GBP_ABL_CASE(64) GBP_ABL_CASE(256) GBP_ABL_CASE(512) GBP_ABL_CASE(1024) GBP_ABL_CASE(2048) GBP_ABL_CASE(256 + 512)
-      GBP_ABL_CASE(256 + 512 + 1024 + 2048)
-#undef GBP_ABL_CASE
-      default: break;
-    }
-  }
-#endif
-  if (hoist && a.cmsg_cached) hipLaunchKernelGGL((k_sweep<true, 0, true>), g, b, 0, s, a);
-  else if (hoist) hipLaunchKernelGGL(k_sweep<true>, g, b, 0, s, a);
-  else hipLaunchKernelGGL(k_sweep<false>, g, b, 0, s, a);
-}
-// Timing-only ablations of the sweep (profiles/ablate_sweep.py): compiled only with -DGBP_BUILD_ABLATIONS, the product
-// library carries the one real instantiation.
-bool launch_sweep_ablated(const SweepArgs& a, uint32_t n_tiles, int abl, hipStream_t s) {
   const dim3 g(n_tiles / kWpb), b(64 * kWpb);
-#ifndef GBP_BUILD_ABLATIONS
-  if (abl != 0) return false;
-  hipLaunchKernelGGL((k_sweep<true, 0>), g, b, 0, s, a);
-#else
-  switch (abl) {
-    case 1: hipLaunchKernelGGL((k_sweep<true, 1>), g, b, 0, s, a); break;
-    case 2: hipLaunchKernelGGL((k_sweep<true, 2>), g, b, 0, s, a); break;
-    case 3: hipLaunchKernelGGL((k_sweep<true, 3>), g, b, 0, s, a); break;
-    case 4: hipLaunchKernelGGL((k_sweep<true, 4>), g, b, 0, s, a); break;
-    case 7: hipLaunchKernelGGL((k_sweep<true, 7>), g, b, 0, s, a); break;
-    case 16: hipLaunchKernelGGL((k_sweep<true, 16>), g, b, 0, s, a); break;
-    case 32: hipLaunchKernelGGL((k_sweep<true, 32>), g, b, 0, s, a); break;
-#define GBP_ABL_CASE(N) case N: hipLaunchKernelGGL((k_sweep<true, N>), g, b, 0, s, a); break;
-    GBP_ABL_CASE(64) GBP_ABL_CASE(128) GBP_ABL_CASE(128 + 256) GBP_ABL_CASE(128 + 512) GBP_ABL_CASE(128 + 1024)
-    GBP_ABL_CASE(128 + 2048) GBP_ABL_CASE(128 + 256 + 512 + 1024 + 2048) GBP_ABL_CASE(128 + 256 + 512)
-#undef GBP_ABL_CASE
 #ifdef GBP_BUILD_EXPERIMENTS
-    case 3000: hipLaunchKernelGGL(k_sweep_w3, g, b, 0, s, a); break;       // the product sweep at 3 waves / SIMD
-    case 3001: hipLaunchKernelGGL(k_sweep_coop16, dim3(n_tiles * 4), dim3(256), 0, s, a); break;   // 16 lanes per factor
+  if (lab_launch_sweep(a, n_tiles, hoist, s)) return;     // a mapping experiment / an ablated sweep was asked for (SweepArgs.variant)
 #endif
+  if (!hoist) { hipLaunchKernelGGL(k_sweep<false>, g, b, 0, s, a); return; }
+  switch (a.policy) {      // the instantiations gbp_capi.cpp's sweep_policy() can choose
+    case kPolCmsgLoadCached: hipLaunchKernelGGL((k_sweep<true, kPolCmsgLoadCached>), g, b, 0, s, a); break;
+    case kPolLmsgLoadNt | kPolLmsgStoreNt: hipLaunchKernelGGL((k_sweep<true, kPolLmsgLoadNt | kPolLmsgStoreNt>), g, b, 0, s, a); break;
     default: hipLaunchKernelGGL((k_sweep<true, 0>), g, b, 0, s, a); break;
   }
-#endif
-  return true;
 }
-#ifdef GBP_BUILD_TEST_HOOKS
-// =================================================================================================
-// k_inv6_coop: the SUB-WAVE mapping the north star sketches, built for the dominant routine so that it can be measured:
-// 16 lanes (one DPP row) cooperate on ONE 6x6 inverse, operands staged in LDS, lane = output element, every k-loop
-// in the reference's order (so the result is bit-identical to inv6x6_lower / matlib.cpp:180-222).  Four matrices per
-// wavefront instead of 64.  Test + measurement hook (gbp_debug_math op 9, gbp_debug_math_timed): DESIGN.md 2 quotes
-// its timing against the lane-per-matrix routine.
-// =================================================================================================
-__global__ __launch_bounds__(256) void k_inv6_coop(const float* __restrict__ in, float* __restrict__ out, int n) {
-  __shared__ float ws_all[16][64];                          // per 16-lane group: A lower 21 | U 15 | Ui 15
-  const int grp = (blockIdx.x * 256 + threadIdx.x) >> 4;    // matrix handled by this 16-lane group
-  const int t = threadIdx.x & 15;
-  float* ws = ws_all[threadIdx.x >> 4];
-  const bool live = grp < n;
-  const float* A = in + (size_t)(live ? grp : 0) * 36;
-  auto uidx = [](int j, int i) { return 21 + j * 5 - j * (j - 1) / 2 + (i - j - 1); };   // U[j][i], j < i   (15 entries)
-  auto sync = []() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  };
-  GBP_UNROLL
-  for (int r = 0; r < 2; ++r) {                             // stage the lower triangle
-    const int e = t + 16 * r;
-    if (e < 21) {
-      int i = 0;
-      while ((i + 1) * (i + 2) / 2 <= e) ++i;
-      const int j = e - i * (i + 1) / 2;
-      ws[e] = A[i * 6 + j];
-    }
-  }
-  sync();
-  float D[6], rD[6];
-  GBP_UNROLL
-  for (int j = 0; j < 6; ++j) {                             // un-pivoted LDL^T, column by column
-    float d = ws[tri(j, j)];
-    GBP_UNROLL
-    for (int k = 0; k < j; ++k) { const float ukj = ws[uidx(k, j)]; d -= ukj * ukj * D[k]; }
-    D[j] = d;
-    rD[j] = 1 / d;
-    const int i = j + 1 + t;                                // lane t owns U[j][j+1+t]
-    if (i < 6) {
-      float u = rD[j] * ws[tri(i, j)];
-      GBP_UNROLL
-      for (int k = 0; k < j; ++k) u -= rD[j] * ws[uidx(k, i)] * ws[uidx(k, j)] * D[k];
-      ws[uidx(j, i)] = u;
-    }
-    sync();
-  }
-  {                                                         // inverse of the unit upper factor: lane t < 5 owns row t
-    float ui[6];
-    GBP_UNROLL
-    for (int k = 0; k < 6; ++k) ui[k] = 0.f;
-    GBP_UNROLL
-    for (int j = 1; j < 6; ++j) {
-      if (t < j) {
-        float acc = 0.f;
-        acc += ws[uidx(t, j)];
-        GBP_UNROLL
-        for (int k = 1; k < j; ++k)
-          if (k > t) acc += ui[k] * ws[uidx(k, j)];
-        ui[j] = acc / -1.f;
-        ws[36 + (uidx(t, j) - 21)] = ui[j];
-      }
-    }
-  }
-  sync();
-  GBP_UNROLL
-  for (int r = 0; r < 3; ++r) {                             // Ainv = (LTinv Dinv) LTinv^T, lane = output element
-    const int e = t + 16 * r;
-    if (e < 36) {
-      const int i = e / 6, j = e - 6 * i;
-      const int k0 = i > j ? i : j;
-      float acc = 0.f;
-      GBP_UNROLL
-      for (int k = 0; k < 6; ++k) {
-        if (k >= k0) {
-          const float w = (k == i) ? rD[k] : ws[36 + (uidx(i, k) - 21)] * rD[k];
-          if (k == j) acc += w;
-          else acc += w * ws[36 + (uidx(j, k) - 21)];
-        }
-      }
-      if (live) out[(size_t)grp * 36 + e] = acc;
-    }
-  }
-}
-
-#ifdef GBP_BUILD_EXPERIMENTS
-void debug_tick_buf(unsigned long long* dev_buf) { (void)hipMemcpyToSymbol(HIP_SYMBOL(gbpdev::g_tick_buf), &dev_buf, sizeof(dev_buf)); }
-void debug_div_redo(unsigned long long* out4, bool reset) {
-  (void)hipMemcpyFromSymbol(out4, HIP_SYMBOL(gbpdev::g_div_redo), 4 * sizeof(unsigned long long));
-  if (reset) { const unsigned long long z[4] = {0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(gbpdev::g_div_redo), z, sizeof(z)); }
-}
-#endif
-bool debug_math_widths(int op, int* in_w, int* out_w) {
-  static const int iw[11] = {9, 36, 3, 18, 72, 72, 54, 42, 12, 36, 10}, ow[11] = {9, 36, 9, 20, 18, 18, 36, 6, 3, 36, 9};
-  if (op < 0 || op > 10) return false;
-  *in_w = iw[op]; *out_w = ow[op];
-  return true;
-}
-void launch_debug_math(int op, const float* in, float* out, int n, hipStream_t s) {
-  int in_w = 0, out_w = 0;
-  if (!debug_math_widths(op, &in_w, &out_w) || n <= 0) return;
-  if (op == 9) {   // 16 lanes per matrix
-    hipLaunchKernelGGL(k_inv6_coop, dim3(((size_t)n * 16 + 255) / 256), dim3(256), 0, s, in, out, n);
-    return;
-  }
-  hipLaunchKernelGGL(k_debug_math, dim3((n + 63) / 64), dim3(64), 0, s, op, in, out, n, in_w, out_w);
-}
-#endif  // GBP_BUILD_TEST_HOOKS
 void launch_linearise(const SweepArgs& a, uint32_t n_tiles, hipStream_t s) {
   hipLaunchKernelGGL(k_linearise, dim3(n_tiles / 4), dim3(256), 0, s, a);
 }
 void launch_beliefs(BeliefArgs b, bool do_cam, bool do_lmk, hipStream_t s) {
-  if (b.cam1 == 0 && b.cam0 == 0) b.cam1 = b.n_cams;  // default: all cameras
-  if (b.n_chunks <= 0) { b.n_chunks = 1; b.chunk_start[0] = 0; b.chunk_start[1] = b.n_cams; }
-  b.cam_blocks = do_cam ? (b.cam1 - b.cam0 + 3) / 4 : 0;
+  b.cam_blocks = do_cam ? (b.n_cams + 3) / 4 : 0;
   const uint32_t lmk_blocks = do_lmk ? blocks_for((uint64_t)b.n_lmks * 4) : 0;
   b.lmk_blocks = lmk_blocks;
   if (b.cam_blocks + lmk_blocks == 0) return;
@@ -2457,6 +1716,9 @@ __global__ __launch_bounds__(256) void k_persist_probe(unsigned* sync, unsigned*
 }
 
 static int persist_spread(uint32_t nb) { return nb <= 64 ? 4 : nb <= 128 ? 2 : 1; }
+#ifdef GBP_BUILD_EXPERIMENTS
+int lab_persist_spread(int spread);
+#endif
 
 bool persist_probe(uint32_t n_tiles, uint32_t n_cams, uint32_t n_lmks, unsigned* sync, unsigned* status_dev, volatile unsigned* status_host,
                    bool cooperative, hipStream_t s) {
@@ -2493,16 +1755,13 @@ uint32_t persist_blocks(uint32_t n_tiles, uint32_t n_cams, uint32_t n_lmks, bool
   // 0.45 us per iteration on fr1xyz, profiles/r04_small_graphs.md).
   const uint64_t waves_m = waves_b + n_cams > n_tiles ? waves_b + n_cams : n_tiles;
   const uint32_t nb_m = (uint32_t)((waves_m + 3) / 4);
-#ifdef GBP_PERSIST_NO_METRIC_ROLES
-  return nb;
-#endif
   return nb_m <= 64u ? nb_m : nb;
 }
 int persist_max_resident_blocks() {
   int dev = 0, per_cu = 0;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (k_persist<0, true>), 256, 0) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (k_persist<true>), 256, 0) != hipSuccess) return 0;
   return per_cu * prop.multiProcessorCount;
 }
 void launch_copy_segments(const CopySegs& t, const unsigned* guard, hipStream_t s) {
@@ -2522,27 +1781,19 @@ hipError_t launch_persist(PersistArgs A, bool cooperative, hipStream_t s) {
   // Workgroup b runs on XCD b % 8 (round-robin dispatch), so every spread-th workgroup lands on 8 / spread XCDs of 32 CUs:
   // the working workgroups stay co-resident (one per CU: 256 VGPRs + 160-215 AGPRs per lane, profiles/r04_resources.md) only while nb <= 32 * 8 / spread.
   int spread = persist_spread(nb);
-  A.n_work_blocks = nb;
-#ifdef GBP_BUILD_ABLATIONS
-  static const int env_spread = std::getenv("GBP_PERSIST_SPREAD") ? std::atoi(std::getenv("GBP_PERSIST_SPREAD")) : 0;
-  if (env_spread) spread = env_spread;      // placement study: the caller keeps nb within what the chosen placement can hold
-  static const int env_abl = std::getenv("GBP_PERSIST_ABL") ? std::atoi(std::getenv("GBP_PERSIST_ABL")) : 0;
-  if (env_abl) {
-    A.spread = 1;
-    if (env_abl == 256) { hipLaunchKernelGGL((k_persist<256, true>), dim3(nb), dim3(256), 0, s, A); return hipGetLastError(); }
-    if (env_abl == 64) { hipLaunchKernelGGL((k_persist<64, true>), dim3(nb), dim3(256), 0, s, A); return hipGetLastError(); }
-    if (env_abl == 768) { hipLaunchKernelGGL((k_persist<768, true>), dim3(nb), dim3(256), 0, s, A); return hipGetLastError(); }
-  }
+#ifdef GBP_BUILD_EXPERIMENTS
+  spread = lab_persist_spread(spread);      // placement studies / the forced time-out of tests/test_gpu_experiments.py (GBP_PERSIST_SPREAD)
 #endif
+  A.n_work_blocks = nb;
   A.spread = (uint32_t)spread;
   const uint32_t grid = spread > 1 ? nb * (uint32_t)spread : spread < -1 ? ((nb + 7) / 8) * (uint32_t)(-spread) * 8 : nb;
   if (cooperative) {
     void* args[] = {&A};
-    return hipLaunchCooperativeKernel(A.ev.on ? reinterpret_cast<const void*>(k_persist<0, true>) : reinterpret_cast<const void*>(k_persist<0, false>),
+    return hipLaunchCooperativeKernel(A.ev.on ? reinterpret_cast<const void*>(k_persist<true>) : reinterpret_cast<const void*>(k_persist<false>),
                                       dim3(grid), dim3(256), args, 0, s);
   }
-  if (A.ev.on) hipLaunchKernelGGL((k_persist<0, true>), dim3(grid), dim3(256), 0, s, A);
-  else hipLaunchKernelGGL((k_persist<0, false>), dim3(grid), dim3(256), 0, s, A);
+  if (A.ev.on) hipLaunchKernelGGL((k_persist<true>), dim3(grid), dim3(256), 0, s, A);
+  else hipLaunchKernelGGL((k_persist<false>), dim3(grid), dim3(256), 0, s, A);
   return hipGetLastError();
 }
 void launch_weaken(float4* prior, const float* scaling, uint32_t* flag, uint32_t n, int rec4, hipStream_t s) {
@@ -2566,5 +1817,12 @@ void launch_eval(const uint32_t* row_cam, const uint32_t* lmk_idx, const float4*
   hipLaunchKernelGGL(k_eval, dim3(eval_blocks(n_tiles)), dim3(256), 0, s, row_cam, lmk_idx, lmsg, fac, cam_mu, lmk_mu, K9_dev,
                      num_undamped_iters, partials, health2, health2_out, n_tiles);
 }
+
+#ifdef GBP_BUILD_TEST_HOOKS
+#include "hooks/gbp_debug_math.hip"          // k_debug_math: the device math layer on caller-supplied vectors (tests only)
+#endif
+#ifdef GBP_BUILD_EXPERIMENTS
+#include "experiments/gbp_lab_kernels.hip"   // mapping experiments and timing ablations (profiles/ only)
+#endif
 
 }  // namespace gbp

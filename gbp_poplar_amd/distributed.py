@@ -42,24 +42,10 @@ def landmark_partition(lmk_id, n_lmks, world):
     return np.asarray(bounds, dtype=np.uint32)
 
 
-def default_chunks(world):
-    """Pieces of the pipelined camera exchange (override: GBP_EXCHANGE_CHUNKS)."""
-    import os
-    env = os.environ.get("GBP_EXCHANGE_CHUNKS")
-    if env:
-        return int(env)
-    # Measured on one GPU with a 1-rank RCCL group (bench.py --force-sharded --exchange-chunks K): splitting the
-    # sweep into K same-stream pieces costs 25-35 us per extra piece (piece drain/ramp + the partial-sum kernel
-    # between pieces), more than an all-gather of this size is expected to cost, so the default is ONE piece;
-    # the pipelined path stays available for experiments on real multi-GPU nodes.
-    return 1
-
-
 class ShardedGbp:
     """The Poplar program list over `world` ranks.  Same verbs as GbpEngine / the oracle."""
 
-    def __init__(self, engine, n_cams, rank, world, dist=None, device="cpu", always_collective=False, use_graph=False,
-                 chunks=None):
+    def __init__(self, engine, n_cams, rank, world, dist=None, device="cpu", always_collective=False, use_graph=False):
         import torch
         self.torch = torch
         self.e = engine
@@ -80,21 +66,6 @@ class ShardedGbp:
             engine.set_stream(self.stream.cuda_stream)
             torch.cuda.synchronize()       # the zero-fills above ran on the default stream
         engine.set_exchange_buffers(self.send.data_ptr(), self.recv.data_ptr())
-        # Pipelined exchange: the camera partials are exchanged in `chunks` camera ranges; range i is all-gathered
-        # while the sweep of range i+1 runs, so only the last range's transfer (and the landmark half of the belief
-        # update, which overlaps it) is exposed.  The all-gather volume grows with world^2 under weak scaling
-        # (world x 1000 cameras x 176 B per rank), hence more pieces for more ranks.
-        if chunks is None:
-            chunks = default_chunks(self.world)
-        self.chunks = max(1, min(int(chunks), 8, self.C))
-        if self.chunks > 1 and not hasattr(engine, "iterate_begin_chunk"):
-            self.chunks = 1
-        if self.chunks > 1:
-            engine.set_exchange_chunks(self.chunks)
-        st = [self.C * i // self.chunks for i in range(self.chunks + 1)]
-        self.send_views = [self.send[st[i] * CAM_REC:st[i + 1] * CAM_REC] for i in range(self.chunks)]
-        self.recv_views = [self.recv[self.world * st[i] * CAM_REC:self.world * st[i + 1] * CAM_REC]
-                           for i in range(self.chunks)]
 
     def _on_stream(self):
         import contextlib
@@ -103,10 +74,9 @@ class ShardedGbp:
     def _exchange(self):
         with self._on_stream():
             if self.dist is None or (self.world == 1 and not self.always_collective):
-                self.recv.copy_(self.send)           # world == 1: the chunked layout equals the plain one
+                self.recv.copy_(self.send)
             else:
-                for rv, sv in zip(self.recv_views, self.send_views):
-                    self.dist.all_gather_into_tensor(rv, sv)
+                self.dist.all_gather_into_tensor(self.recv, self.send)
 
     def upload(self, state):
         self.e.upload(state)
@@ -120,21 +90,14 @@ class ShardedGbp:
 
     def _one_iteration(self, overlap):
         if overlap:
-            # Each collective runs on RCCL's stream, ordered after the piece that filled its slice of `send`; the
-            # next piece of the sweep — and finally the rank-local landmark half of the belief update — fill the
-            # GPU meanwhile; the camera combine waits for all of them.
-            works = []
-            for i in range(self.chunks):
-                if self.chunks > 1:
-                    self.e.iterate_begin_chunk(i)       # part of the sweep + partials of camera range i -> send
-                else:
-                    self.e.iterate_begin()
-                with self._on_stream():
-                    works.append(self.dist.all_gather_into_tensor(self.recv_views[i], self.send_views[i], async_op=True))
+            # The collective runs on RCCL's stream, ordered after the sweep that filled `send`; the rank-local landmark half of
+            # the belief update fills the GPU meanwhile; the camera combine waits for it.
+            self.e.iterate_begin()
+            with self._on_stream():
+                work = self.dist.all_gather_into_tensor(self.recv, self.send, async_op=True)
             self.e.iterate_local()
             with self._on_stream():
-                for w in works:
-                    w.wait()
+                work.wait()
         else:
             self.e.iterate_begin()                      # sweep + local camera partials -> send
             self._exchange()

@@ -146,12 +146,6 @@ class GbpEngine:
     def iterate_begin(self):
         self._chk(self.lib.gbp_iterate_begin(self.h), "gbp_iterate_begin")
 
-    def set_exchange_chunks(self, n):
-        self._chk(self.lib.gbp_set_exchange_chunks(self.h, int(n)), "gbp_set_exchange_chunks")
-
-    def iterate_begin_chunk(self, chunk):
-        self._chk(self.lib.gbp_iterate_begin_chunk(self.h, int(chunk)), "gbp_iterate_begin_chunk")
-
     def iterate_local(self):
         self._chk(self.lib.gbp_iterate_local(self.h), "gbp_iterate_local")
 

@@ -184,10 +184,50 @@ def eval_host(cam_id, lmk_id, n_cams, n_lmks, K9, active, meas, cbe, cbl, lbe, l
     return sn.value, sh.value, na.value
 
 
-def tile_order_local(tile_class, window=96):
-    """perm[wave slot] = tile of the local XCD-aware sweep order (gbp_params.tile_order = 3) for tiles of the given classes 0..7."""
+# ---- test hooks (include/gbp_mi355x_debug.h; libgbp_mi355x_test.so): the device order without a device ----
+
+def tile_order_local(tile_class, window=96, n_classes=8):
+    """perm[wave slot] = tile of the local XCD-aware sweep order (gbp_params.tile_order = 3) for tiles of the given classes."""
     cls = np.ascontiguousarray(tile_class, np.uint8)
     perm = np.zeros(cls.size, np.uint32)
-    _chk(load().gbp_tile_order_local(cls.ctypes.data_as(C.POINTER(C.c_uint8)), cls.size, int(window), cabi.ptr(perm, cabi.c_u32p)),
-         "gbp_tile_order_local")
+    _chk(load(hooks=True).gbp_debug_tile_order_local(cls.ctypes.data_as(C.POINTER(C.c_uint8)), cls.size, int(window), int(n_classes),
+                                                     cabi.ptr(perm, cabi.c_u32p)), "gbp_debug_tile_order_local")
     return perm
+
+
+LAYOUT_DIMS = ("C", "L", "E", "lmk_begin", "lmk_end", "L_loc", "E_loc", "n_rows", "n_tiles", "Ep", "row_window")
+LAYOUT_ARRAYS = ("pos_edge", "pos_cam", "pos_lmk_loc", "pos_lpos", "cam_row_ptr", "row_slot", "row_cam", "lmk_ptr", "lmk_fpos",
+                 "lmk_ix", "tile_perm")
+
+
+def layout_options(**kw):
+    """The construction knobs of the device order; defaults = the product's, keywords override (gbp_layout_options)."""
+    o = cabi.GbpLayoutOptions()
+    load(hooks=True).gbp_debug_layout_default_options(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, int(v))
+    return o
+
+
+def layout_build(cam_id, lmk_id, n_cams, n_lmks, tile_order=0, shard=None, options=None):
+    """What gbp_create builds before it touches the GPU (csrc/gbp_layout.cpp), as a dict of numpy arrays + dims.  No device needed."""
+    lib = load(hooks=True)
+    keep = []
+    p = cabi.make_problem(cam_id, lmk_id, n_cams, n_lmks, np.zeros(9, np.float32), keep)
+    sh = cabi.GbpShard(int(shard[0]), int(shard[1]), int(shard[2]), int(shard[3])) if shard is not None else None
+    h = C.c_void_p()
+    rc = lib.gbp_debug_layout_build(C.byref(p), int(tile_order), C.byref(sh) if sh is not None else None,
+                                    C.byref(options) if options is not None else None, C.byref(h))
+    if rc != 0:
+        raise RuntimeError("gbp_debug_layout_build: %s (status %d)" % (lib.gbp_last_error(None).decode(), rc))
+    try:
+        dims = np.zeros(len(LAYOUT_DIMS), np.uint32)
+        _chk(lib.gbp_debug_layout_dims(h, cabi.ptr(dims, cabi.c_u32p)), "gbp_debug_layout_dims")
+        out = {k: int(v) for k, v in zip(LAYOUT_DIMS, dims)}
+        for i, name in enumerate(LAYOUT_ARRAYS):
+            data, n = cabi.c_u32p(), C.c_size_t()
+            _chk(lib.gbp_debug_layout_array(h, i, C.byref(data), C.byref(n)), "gbp_debug_layout_array")
+            out[name] = np.ctypeslib.as_array(data, shape=(n.value,)).copy() if n.value else np.zeros(0, np.uint32)
+    finally:
+        lib.gbp_debug_layout_free(h)
+    return out

@@ -22,13 +22,24 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: GBP_API marks what it exports (nm -D shows these functions and nothing else). */
+#if defined(__GNUC__) || defined(__clang__)
+#define GBP_API __attribute__((visibility("default")))
+#else
+#define GBP_API
+#endif
+
 /* 2: gbp_timing_out gained exchange_ms, gbp_status gained GBP_ERR_COMM, the gbp_debug_* test hooks moved to
  *    gbp_mi355x_debug.h / libgbp_mi355x_test.so; gbp_params.persistent, gbp_iterate_eval.
  * 3: gbp_iterate_eval_each.
  * 4: gbp_params.persist_coop (was reserved[1]); a barrier time-out of the persistent kernel is recovered inside the library
  *    (state restored, burst replayed on the two-kernel path, GBP_OK + a warning in gbp_last_error) instead of GBP_ERR_HIP.
+ * 5: the library exports exactly the gbp_* functions declared here (hidden visibility for everything else); the pipelined
+ *    exchange (gbp_set_exchange_chunks / gbp_iterate_begin_chunk: measured slower than the plain one in every configuration) is
+ *    gone, gbp_tile_order_local moved to the test-hooks header; gbp_iterate_eval_each keeps the metric on the device on graphs
+ *    of any size.
  * Callers compare gbp_abi_version() with the header they were built against. */
-#define GBP_ABI_VERSION 4
+#define GBP_ABI_VERSION 5
 
 typedef enum {
   GBP_OK = 0,
@@ -195,66 +206,58 @@ typedef struct {
 } gbp_timing_out;
 
 /* ---- life cycle: graph build + Engine ctor/load (ba.cpp:659-937) -------------------------- */
-int  gbp_abi_version(void);
-void gbp_default_params(gbp_params* p);
-int  gbp_create(const gbp_problem* problem, const gbp_params* params /*NULL=defaults*/,
+GBP_API int  gbp_abi_version(void);
+GBP_API void gbp_default_params(gbp_params* p);
+GBP_API int  gbp_create(const gbp_problem* problem, const gbp_params* params /*NULL=defaults*/,
                 const gbp_shard* shard /*NULL=single GPU*/, gbp_ctx** out);
-void gbp_destroy(gbp_ctx* ctx);
-const char* gbp_last_error(const gbp_ctx* ctx /*NULL = last create error*/);
+GBP_API void gbp_destroy(gbp_ctx* ctx);
+GBP_API const char* gbp_last_error(const gbp_ctx* ctx /*NULL = last create error*/);
 
 /* ---- the program list ------------------------------------------------------------------- */
-int gbp_upload(gbp_ctx* ctx, const gbp_state_in* in);          /* WRITE_PROG      ba.cpp:868-886  */
-int gbp_linearise(gbp_ctx* ctx);                               /* LINEARISE_PROG  ba.cpp:890-893  */
-int gbp_iterate(gbp_ctx* ctx, int n_iters);                    /* GBP_PROG x n    ba.cpp:895-905  */
-int gbp_prepare(gbp_ctx* ctx);                                 /* optional: pay the one-off costs of gbp_iterate(n >= graph_unroll)
+GBP_API int gbp_upload(gbp_ctx* ctx, const gbp_state_in* in);          /* WRITE_PROG      ba.cpp:868-886  */
+GBP_API int gbp_linearise(gbp_ctx* ctx);                               /* LINEARISE_PROG  ba.cpp:890-893  */
+GBP_API int gbp_iterate(gbp_ctx* ctx, int n_iters);                    /* GBP_PROG x n    ba.cpp:895-905  */
+GBP_API int gbp_prepare(gbp_ctx* ctx);                                 /* optional: pay the one-off costs of gbp_iterate(n >= graph_unroll)
                                                                   now (hipGraph capture + instantiation + upload; runs nothing) —
                                                                   what Engine::load does for a Poplar program, ba.cpp:936-937 */
-int gbp_weaken_priors(gbp_ctx* ctx);                           /* WEAKEN_PRIORS   ba.cpp:863-865  */
-int gbp_read(gbp_ctx* ctx, gbp_state_out* out);                /* READ_PROG       ba.cpp:908-916  */
-int gbp_read_priors(gbp_ctx* ctx, gbp_priors_out* out);        /* READ_PRIORS     slam.cpp:913-917 */
-int gbp_new_keyframe(gbp_ctx* ctx, const gbp_kf_update* upd);  /* NEW_KEYFRAME    slam.cpp:919-928 */
-int gbp_eval(gbp_ctx* ctx, gbp_eval_out* out);                 /* util.cpp:74-144 on device (local shard) */
+GBP_API int gbp_weaken_priors(gbp_ctx* ctx);                           /* WEAKEN_PRIORS   ba.cpp:863-865  */
+GBP_API int gbp_read(gbp_ctx* ctx, gbp_state_out* out);                /* READ_PROG       ba.cpp:908-916  */
+GBP_API int gbp_read_priors(gbp_ctx* ctx, gbp_priors_out* out);        /* READ_PRIORS     slam.cpp:913-917 */
+GBP_API int gbp_new_keyframe(gbp_ctx* ctx, const gbp_kf_update* upd);  /* NEW_KEYFRAME    slam.cpp:919-928 */
+GBP_API int gbp_eval(gbp_ctx* ctx, gbp_eval_out* out);                 /* util.cpp:74-144 on device (local shard) */
 /* gbp_eval in two halves: begin queues the metric of the CURRENT beliefs, end waits for the oldest queued one.  Up to two
  * may be in flight, so the loop of ba.cpp:1001-1028 can queue iteration i+1 before it prints the metric of iteration i. */
-int gbp_eval_begin(gbp_ctx* ctx);
-int gbp_eval_end(gbp_ctx* ctx, gbp_eval_out* out);
+GBP_API int gbp_eval_begin(gbp_ctx* ctx);
+GBP_API int gbp_eval_end(gbp_ctx* ctx, gbp_eval_out* out);
 /* gbp_iterate(n) + gbp_eval_begin() in ONE call (collect with gbp_eval_end): the loop of ba.cpp:1001-1028 prints the metric
  * after every iteration; on a graph that runs in the persistent kernel the metric then rides in the same launch (identical
  * results), elsewhere it is exactly the two calls. */
-int gbp_iterate_eval(gbp_ctx* ctx, int n_iters);
+GBP_API int gbp_iterate_eval(gbp_ctx* ctx, int n_iters);
 /* n iterations with the metric after EVERY one (what the loops of ba.cpp:1001-1028 and slam.cpp print), blocking: out[k] is
  * what gbp_iterate(ctx, 1) followed by gbp_eval would have returned for the k-th of them.  A burst between two host events
  * (prior weakening, a new keyframe) is ONE launch on a graph that runs in the persistent kernel — the metric of iteration k
  * is computed inside the sweep phase of iteration k + 1 — and the plain loop elsewhere.  No evaluation may be in flight. */
-int gbp_iterate_eval_each(gbp_ctx* ctx, int n_iters, gbp_eval_out* out /* [n_iters] */);
-int gbp_sync(gbp_ctx* ctx);                                    /* wait for queued device work     */
-int gbp_timing(gbp_ctx* ctx, gbp_timing_out* out, int reset);  /* ba.cpp:980,1056-1058            */
+GBP_API int gbp_iterate_eval_each(gbp_ctx* ctx, int n_iters, gbp_eval_out* out /* [n_iters] */);
+GBP_API int gbp_sync(gbp_ctx* ctx);                                    /* wait for queued device work     */
+GBP_API int gbp_timing(gbp_ctx* ctx, gbp_timing_out* out, int reset);  /* ba.cpp:980,1056-1058            */
 
 /* ---- multi-GPU split-phase iteration (sharded ctx; exchange done by the caller, e.g.
  *      torch.distributed all_gather over RCCL).  gbp_iterate == begin + (local copy) + end
  *      when world == 1. -------------------------------------------------------------------- */
-int gbp_set_stream(gbp_ctx* ctx, void* hip_stream /* hipStream_t; NULL = ctx-owned stream */);
-/* send_dev: [C*GBP_CAM_REC] fp32 this rank's camera partial sums; recv_dev: [world][C*GBP_CAM_REC]
+GBP_API int gbp_set_stream(gbp_ctx* ctx, void* hip_stream /* hipStream_t; NULL = ctx-owned stream */);
+/* send_dev: [C*GBP_CAM_REC] fp32 this rank's camera partial sums; recv_dev: [world][C][GBP_CAM_REC]
  * (camera record = 44 floats: eta 6, pad 2, Lambda 36).  Caller-owned device memory (e.g. torch
  * tensors).  Must be set before begin/end on a world>1 ctx. */
 #define GBP_CAM_REC 44
-int gbp_set_exchange_buffers(gbp_ctx* ctx, void* send_dev, void* recv_dev);
-int gbp_iterate_begin(gbp_ctx* ctx);   /* prep + messages + local camera partial -> send_dev     */
-/* Pipelined exchange (optional).  gbp_set_exchange_chunks(n) splits the cameras into n ranges [i*C/n,(i+1)*C/n)
- * (same on every rank) and changes the layout of recv_dev to: for range i, [world][n_i][GBP_CAM_REC] floats
- * behind world * start_i * GBP_CAM_REC floats (send_dev stays [C][GBP_CAM_REC]; n = 1 is the plain layout).
- * gbp_iterate_begin_chunk(i), i = 0..n-1 in order, sweeps the part of the (camera-major) device order that
- * completes range i and writes that range's partial sums, so the caller can all-gather range i while piece
- * i+1 runs.  The n calls together equal one gbp_iterate_begin. */
-int gbp_set_exchange_chunks(gbp_ctx* ctx, int n_chunks /* 1..8 */);
-int gbp_iterate_begin_chunk(gbp_ctx* ctx, int chunk);
-int gbp_iterate_local(gbp_ctx* ctx);   /* optional: landmark beliefs now (rank-local), to overlap with the exchange */
-int gbp_iterate_end(gbp_ctx* ctx);     /* camera beliefs = prior + sum_r recv_dev[r]; landmark beliefs unless done */
+GBP_API int gbp_set_exchange_buffers(gbp_ctx* ctx, void* send_dev, void* recv_dev);
+GBP_API int gbp_iterate_begin(gbp_ctx* ctx);   /* prep + messages + local camera partial -> send_dev     */
+GBP_API int gbp_iterate_local(gbp_ctx* ctx);   /* optional: landmark beliefs now (rank-local), to overlap with the exchange */
+GBP_API int gbp_iterate_end(gbp_ctx* ctx);     /* camera beliefs = prior + sum_r recv_dev[r]; landmark beliefs unless done */
 /* Re-derive beliefs after an exchange outside an iteration (LINEARISE / NEW_KEYFRAME on world>1):
  * gbp_refresh_begin computes the local camera partials into send_dev, gbp_refresh_end combines. */
-int gbp_refresh_begin(gbp_ctx* ctx);
-int gbp_refresh_end(gbp_ctx* ctx);
-int gbp_linearise_factors(gbp_ctx* ctx);  /* the factor half of LINEARISE_PROG (after a refresh) */
+GBP_API int gbp_refresh_begin(gbp_ctx* ctx);
+GBP_API int gbp_refresh_end(gbp_ctx* ctx);
+GBP_API int gbp_linearise_factors(gbp_ctx* ctx);  /* the factor half of LINEARISE_PROG (after a refresh) */
 
 /* ---- multi-GPU from the C++ host: the exchange owned by the library ---------------------------------------------------
  * Replaces `--ipus N` (ba.cpp:414-417,617-649) without any Python: one process per GPU, each with a sharded ctx
@@ -274,38 +277,38 @@ int gbp_linearise_factors(gbp_ctx* ctx);  /* the factor half of LINEARISE_PROG (
  * queue costs more per dispatch than a small all-gather gives back).  Environment GBP_COMM_SINGLE_STREAM=0|1, read by
  * gbp_comm_init*, overrides the rule (measurements, tests). */
 #define GBP_COMM_ID_BYTES 128
-int gbp_device_count(void);                                    /* visible GPUs (initialises the HIP runtime)      */
-int gbp_set_device(int device);                                /* the GPU later gbp_create calls of this process use */
+GBP_API int gbp_device_count(void);                                    /* visible GPUs (initialises the HIP runtime)      */
+GBP_API int gbp_set_device(int device);                                /* the GPU later gbp_create calls of this process use */
 /* contiguous landmark ranges balanced by factor count: bounds[world + 1], shard r = [bounds[r], bounds[r+1]) */
-int gbp_landmark_partition(const gbp_problem* problem, int world, uint32_t* bounds);
-size_t gbp_comm_region_bytes(uint32_t n_cams, int world);
-int gbp_comm_region_init(void* region, size_t bytes, uint32_t n_cams, int world);
-void gbp_comm_region_abort(void* region);                      /* supervisor: a rank died, fail the waiting ones */
+GBP_API int gbp_landmark_partition(const gbp_problem* problem, int world, uint32_t* bounds);
+GBP_API size_t gbp_comm_region_bytes(uint32_t n_cams, int world);
+GBP_API int gbp_comm_region_init(void* region, size_t bytes, uint32_t n_cams, int world);
+GBP_API void gbp_comm_region_abort(void* region);                      /* supervisor: a rank died, fail the waiting ones */
 /* the region's cross-process protocol alone (gathers + barriers, no device): every rank of `world` calls it; test hook */
-int gbp_comm_region_selftest(void* region, int rank, int world, int rounds);
-int gbp_comm_init(gbp_ctx* ctx, void* region, int transport);
-int gbp_comm_unique_id(void* id128);
-int gbp_comm_init_rccl(gbp_ctx* ctx, const void* id128);
-const char* gbp_comm_transport(const gbp_ctx* ctx);            /* "rccl", "host-staged" or "none" */
-int gbp_comm_barrier(gbp_ctx* ctx);
+GBP_API int gbp_comm_region_selftest(void* region, int rank, int world, int rounds);
+GBP_API int gbp_comm_init(gbp_ctx* ctx, void* region, int transport);
+GBP_API int gbp_comm_unique_id(void* id128);
+GBP_API int gbp_comm_init_rccl(gbp_ctx* ctx, const void* id128);
+GBP_API const char* gbp_comm_transport(const gbp_ctx* ctx);            /* "rccl", "host-staged" or "none" */
+GBP_API int gbp_comm_barrier(gbp_ctx* ctx);
 /* What a first multi-GPU run puts on record next to its numbers (bench.py's preflight block): gbp_comm_describe writes one
  * JSON object (rank, world, device, PCI bus id, transport, the collective library's resolved path and version, schedule);
  * gbp_comm_probe times `reps` all-gathers of the camera partial buffers back to back (collective); gbp_comm_set_schedule
  * switches between the one-stream and the two-stream form of the sharded iteration (identical results) so that a launcher can
  * MEASURE both and keep the faster one instead of trusting the ">= 4 ranks" rule (ba.cpp:617-649 has no such choice to make:
  * Poplar compiles the exchange into the program). */
-int gbp_comm_describe(gbp_ctx* ctx, char* json_buf, size_t cap);
-int gbp_comm_set_schedule(gbp_ctx* ctx, int two_streams);
-int gbp_comm_probe(gbp_ctx* ctx, int reps, double* avg_us);
-int gbp_graph_state(const gbp_ctx* ctx);                       /* 2 = bursts run inside the persistent kernel (small graph), 1 = gbp_iterate replays a captured hipGraph, 0 = not captured (yet), -1 = capture failed: direct launches */
-int gbp_eval_global(gbp_ctx* ctx, gbp_eval_out* out);          /* gbp_eval summed over all shards */
+GBP_API int gbp_comm_describe(gbp_ctx* ctx, char* json_buf, size_t cap);
+GBP_API int gbp_comm_set_schedule(gbp_ctx* ctx, int two_streams);
+GBP_API int gbp_comm_probe(gbp_ctx* ctx, int reps, double* avg_us);
+GBP_API int gbp_graph_state(const gbp_ctx* ctx);                       /* 2 = bursts run inside the persistent kernel (small graph), 1 = gbp_iterate replays a captured hipGraph, 0 = not captured (yet), -1 = capture failed: direct launches */
+GBP_API int gbp_eval_global(gbp_ctx* ctx, gbp_eval_out* out);          /* gbp_eval summed over all shards */
 
 /* ---- measurement ---------------------------------------------------------------------------- */
 /* per_stage_events != 0: gbp_iterate launches kernels directly with a hipEvent pair around the
  * sweep and the belief kernels of every iteration (feeds gbp_timing.sweep_ms / belief_ms); in the
  * split-phase path gbp_iterate_begin brackets its sweep launch the same way (sweep_ms and iterations
  * only; the pairs are read by the next gbp_timing call). */
-int gbp_set_profiling(gbp_ctx* ctx, int per_stage_events);
+GBP_API int gbp_set_profiling(gbp_ctx* ctx, int per_stage_events);
 
 /* ---- host-side helpers of the path's callers (pure CPU, no device needed) ---------------- */
 /* BALProblem::LoadFile (dataio.cpp:17-57).  Two-call pattern: pass NULL arrays to get sizes. */
@@ -318,9 +321,9 @@ typedef struct {
   double*   cameras;       /* [6C] */
   double*   points;        /* [3L] */
 } gbp_bal;
-int gbp_bal_read_header(const char* path, gbp_bal* hdr);
-int gbp_bal_read(const char* path, gbp_bal* bal);
-int gbp_bal_write(const char* path, const gbp_bal* bal);
+GBP_API int gbp_bal_read_header(const char* path, gbp_bal* hdr);
+GBP_API int gbp_bal_read(const char* path, gbp_bal* bal);
+GBP_API int gbp_bal_write(const char* path, const gbp_bal* bal);
 /* Import of a standard "Bundle Adjustment in the Large" text file (C L E; E x "cam point x y"; 9 values per
  * camera: Rodrigues R, t, f, k1, k2; 3 per point; camera looks down -z, image origin at the centre, y up) into
  * the reference's conventions (sequences/README.md:5-16: one shared pin-hole K, cameras [t_cw, w_cw] looking
@@ -328,19 +331,19 @@ int gbp_bal_write(const char* path, const gbp_bal* bal);
  * (fx = fy = mean f, cx = cy = 0), edges sorted by (camera, landmark) as util.cpp:95-99 / dataio.cpp:483-486
  * assume.  Same two-call pattern as gbp_bal_read; the result can be written with gbp_bal_write and fed to
  * ./ba or ./slam.  Not in the reference. */
-int gbp_bal_import_standard_header(const char* path, gbp_bal* hdr);
-int gbp_bal_import_standard(const char* path, gbp_bal* bal);
+GBP_API int gbp_bal_import_standard_header(const char* path, gbp_bal* hdr);
+GBP_API int gbp_bal_import_standard(const char* path, gbp_bal* bal);
 
 /* set_prior_lambda (dataio.cpp:67-117 + util.cpp:48-72), O(E).  cam_file/lmk_file are the FILE
  * values cast to float (the linearisation point of the prior strength), *_mean the (possibly
  * noised) prior means. */
-int gbp_set_prior_lambda(const gbp_problem* problem, float reproj_meas_var,
+GBP_API int gbp_set_prior_lambda(const gbp_problem* problem, float reproj_meas_var,
                          const float* cam_file /*[6C]*/, const float* lmk_file /*[3L]*/,
                          const float* cam_mean /*[6C]*/, const float* lmk_mean /*[3L]*/,
                          float* cam_priors_eta, float* cam_priors_lambda,
                          float* lmk_priors_eta, float* lmk_priors_lambda);
 /* Prior-weakening scale factors (ba.cpp:561-572). */
-int gbp_prior_scalings(uint32_t n_cams, uint32_t n_lmks, const float* cam_priors_lambda,
+GBP_API int gbp_prior_scalings(uint32_t n_cams, uint32_t n_lmks, const float* cam_priors_lambda,
                        float steps, float prior_std_weaker_factor, float first_cam_prior_std,
                        float* cam_scaling, float* lmk_scaling);
 /* Initialisation options of ba.cpp:536-548.  gbp_init_add_noise = add_cam_trans_noise (--tn, metres), add_cam_rot_noise
@@ -348,30 +351,25 @@ int gbp_prior_scalings(uint32_t n_cams, uint32_t n_lmks, const float* cam_priors
  * MEANS in place; cameras 0 and 1 stay exact (dataio.h:114-119).  The reference seeds from the clock; here the seed is
  * explicit (`--seed`), zero stds draw nothing.  gbp_init_av_depth = av_depth_init (--avdepth_on,
  * dataio.cpp:417-453): every landmark is placed one unit in front of the lowest-indexed camera observing it. */
-int gbp_init_add_noise(uint32_t n_cams, uint32_t n_lmks, float trans_std, float rot_std_deg, float lmk_std,
+GBP_API int gbp_init_add_noise(uint32_t n_cams, uint32_t n_lmks, float trans_std, float rot_std_deg, float lmk_std,
                        uint64_t seed, float* cam_mean /*[6C] in/out*/, float* lmk_mean /*[3L] in/out*/);
-int gbp_init_av_depth(const gbp_problem* problem, const float* cam_mean /*[6C]*/, float* lmk_mean /*[3L] out*/);
-/* The local XCD-aware execution order of the sweep (gbp_params.tile_order = 3), as a pure function of the tiles' landmark
- * classes (0..7): perm[wave slot] = tile.  What gbp_create builds internally; exported so that the construction — a
- * bijection that keeps every tile within `window` + 32 slots of its sequential place — can be tested without a device.  No reference counterpart
- * (Poplar places vertices on tiles explicitly, ba.cpp:243-366). */
-int gbp_tile_order_local(const uint8_t* tile_class /*[n_tiles]*/, uint32_t n_tiles, uint32_t window, uint32_t* perm /*[n_tiles]*/);
+GBP_API int gbp_init_av_depth(const gbp_problem* problem, const float* cam_mean /*[6C]*/, float* lmk_mean /*[3L] out*/);
 /* SLAM flag bookkeeping (dataio.cpp:455-475, 477-508).  update returns n_new_lmks via out. */
-int gbp_slam_create_flags(const gbp_problem* problem, uint32_t steps, uint32_t* active_flag,
+GBP_API int gbp_slam_create_flags(const gbp_problem* problem, uint32_t steps, uint32_t* active_flag,
                           uint32_t* cam_weaken_flag, uint32_t* lmk_weaken_flag,
                           uint32_t* lmk_active_flag);
-int gbp_slam_update_flags(const gbp_problem* problem, uint32_t steps, uint32_t data_counter,
+GBP_API int gbp_slam_update_flags(const gbp_problem* problem, uint32_t steps, uint32_t data_counter,
                           uint32_t* active_flag, uint32_t* lmk_weaken_flag,
                           uint32_t* cam_weaken_flag, uint32_t* lmk_active_flag,
                           int32_t* n_new_lmks);
 /* initialise_new_kf (util.cpp:183-223): prior eta of camera data_counter+1 from the belief mean of
  * camera data_counter.  The new-landmark branch is dead in the reference (out-of-bounds index,
  * util.cpp:215) and is not reproduced. */
-int gbp_slam_initialise_new_kf(uint32_t data_counter, const float* cam_beliefs_eta,
+GBP_API int gbp_slam_initialise_new_kf(uint32_t data_counter, const float* cam_beliefs_eta,
                                const float* cam_beliefs_lambda, const float* cam_priors_lambda,
                                float* cam_priors_eta);
 /* Host metric (util.cpp:74-144) on read-back beliefs; same arithmetic as gbp_eval. */
-int gbp_eval_host(const gbp_problem* problem, const uint32_t* active_flag, const float* measurements,
+GBP_API int gbp_eval_host(const gbp_problem* problem, const uint32_t* active_flag, const float* measurements,
                   const float* cam_beliefs_eta, const float* cam_beliefs_lambda,
                   const float* lmk_beliefs_eta, const float* lmk_beliefs_lambda,
                   double* sum_norm, double* sum_half_sq, uint64_t* n_active);
@@ -379,12 +377,12 @@ int gbp_eval_host(const gbp_problem* problem, const uint32_t* active_flag, const
 /* The solution: belief means mu = Lambda^-1 eta of every camera ([6C]: t_cw, axis-angle) and landmark ([3L]) from
  * read-back beliefs, same solve as the metric (util.cpp:103-108).  With gbp_bal_write this gives `--out_file`: the
  * refined problem in the input's own format (the reference only prints metrics and keeps the result on the device). */
-int gbp_belief_means(uint32_t n_cams, uint32_t n_lmks, const float* cam_beliefs_eta, const float* cam_beliefs_lambda,
+GBP_API int gbp_belief_means(uint32_t n_cams, uint32_t n_lmks, const float* cam_beliefs_eta, const float* cam_beliefs_lambda,
                      const float* lmk_beliefs_eta, const float* lmk_beliefs_lambda, double* cameras, double* points);
 
 /* Synthetic BAL generator (SURVEY 8d spec; the reference has none).  Fills a caller-allocated
  * gbp_bal with n_edges = n_lmks * obs_per_lmk, edges sorted by (camera, landmark). */
-int gbp_synth_generate(uint32_t n_cams, uint32_t n_lmks, uint32_t obs_per_lmk, uint64_t seed,
+GBP_API int gbp_synth_generate(uint32_t n_cams, uint32_t n_lmks, uint32_t obs_per_lmk, uint64_t seed,
                        gbp_bal* out, double* gt_cameras /*[6C] or NULL*/, double* gt_points /*[3L] or NULL*/);
 
 #ifdef __cplusplus

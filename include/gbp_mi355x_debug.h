@@ -16,13 +16,13 @@ extern "C" {
  *   what 1: a = cam message eta [6E],        b = cam message Lambda [36E] (lower triangle as stored; upper 0)
  *   what 2: a = lmk message eta [3E],        b = lmk message Lambda [9E]
  *   what 3: a = mu [9E],                     b = dmu [E]                                          */
-int gbp_debug_get(gbp_ctx* ctx, int what, float* a, float* b);
+GBP_API int gbp_debug_get(gbp_ctx* ctx, int what, float* a, float* b);
 /* Timing experiment: average us per launch of an ablated sweep kernel (1 = no landmark-message
  * gather/scatter, 2 = no landmark-belief gather, 4 = no arithmetic, 8 = streaming landmark messages;
- * bits combine).  Leaves garbage in the ctx. */
-int gbp_debug_time_sweep(gbp_ctx* ctx, int ablation, int reps, double* avg_us);
+ * bits combine; ablations other than 0 and 100-102 exist in the experiments build only).  Leaves garbage in the ctx. */
+GBP_API int gbp_debug_time_sweep(gbp_ctx* ctx, int ablation, int reps, double* avg_us);
 /* Overwrite the factor potentials from reference-layout arrays (inverse of what 0). Test hook. */
-int gbp_debug_set_factor_potentials(gbp_ctx* ctx, const float* eta9E, const float* lambda81E);
+GBP_API int gbp_debug_set_factor_potentials(gbp_ctx* ctx, const float* eta9E, const float* lambda81E);
 
 /* The device math layer on caller-supplied vectors, one GPU lane per vector (no ctx): lets a test compare the HIP
  * routines directly with outputs of the reference's own matlib.cpp / bafuncs.cpp.  in/out are [n][width] fp32:
@@ -35,9 +35,47 @@ int gbp_debug_set_factor_potentials(gbp_ctx* ctx, const float* eta9E, const floa
  *        element, reference order): 36 -> 36, bit-identical to op 1; exists to be measured against it
  *   op 10 div_shared: x9 m1 -> 9 quotients x[i] / m — the shared-reciprocal division of gbp_device_math.hpp, which must equal
  *        the IEEE fp32 division bit for bit (tests/test_gpu_device_math.py)                                             */
-int gbp_debug_math(int op, const float* in, float* out, int n);
+GBP_API int gbp_debug_math(int op, const float* in, float* out, int n);
 /* same, then `reps` back-to-back launches timed with hipEvents: average microseconds per launch */
-int gbp_debug_math_timed(int op, const float* in, float* out, int n, int reps, double* avg_us);
+GBP_API int gbp_debug_math_timed(int op, const float* in, float* out, int n, int reps, double* avg_us);
+
+/* ---- the device order without a device ---------------------------------------------------------------------------------
+ * gbp_create first builds the DEVICE ORDER of the graph — which factor sits at which device position, where a camera's rows
+ * and a landmark's message records are, in which order the sweep's wavefronts take the tiles — as pure host code
+ * (csrc/gbp_layout.cpp; replaces the vertex-to-tile mapping of ba.cpp:243-366).  These hooks hand that construction out so that
+ * CPU property tests (tests/test_layout.py; tests/sanitize/ under ASan + UBSan) can check it on any graph: no HIP call is made.
+ * gbp_layout_options: the construction's knobs; the defaults ARE the product (gbp_debug_layout_default_options). */
+typedef struct {
+  uint32_t row_placement;      /* 1; 0 = rows always in camera-major order                                                     */
+  uint32_t row_window;         /* 32: cameras whose rows are placed together                                                   */
+  uint32_t row_place_max_deg;  /* 512: rows are placed by landmark class where a camera has fewer factors than this on average  */
+  uint32_t row_key_lane;       /* 0: the factor of a row whose landmark classes the row                                        */
+  uint32_t classes;            /* 8: landmark classes of rows and tiles                                                        */
+  uint32_t tile_window;        /* 96: look-ahead of the local tile permutation, in tiles                                        */
+  uint32_t tile_min_tiles;     /* 2048: tile_order 0 permutes tiles (and places rows) only on graphs of at least this many      */
+  uint32_t tile_identity;      /* 0; 1 = every tile in class 0                                                                 */
+} gbp_layout_options;
+typedef struct gbp_layout gbp_layout;
+GBP_API void gbp_debug_layout_default_options(gbp_layout_options* opt);
+/* the options LATER gbp_create calls of this process build their device order with (NULL = the defaults again); measurements */
+GBP_API int gbp_debug_layout_options(const gbp_layout_options* opt);
+/* the cache policy of the sweep's message streams (SweepArgs.policy bits: 1 = camera messages loaded cached, 2 / 4 = landmark
+ * messages loaded / stored non-temporal) later gbp_create calls use instead of the choice by graph shape; -1 = by shape */
+GBP_API int gbp_debug_force_sweep_policy(int policy);
+GBP_API int gbp_debug_layout_build(const gbp_problem* problem, int tile_order, const gbp_shard* shard /*NULL = whole graph*/,
+                           const gbp_layout_options* opt /*NULL = the process's current options*/, gbp_layout** out);
+/* dims[11] = C, L, E, lmk_begin, lmk_end, L_loc, E_loc, n_rows, n_tiles, Ep, row_window */
+GBP_API int gbp_debug_layout_dims(const gbp_layout* lay, uint32_t* dims);
+/* which: 0 pos_edge [Ep] (~0 = pad), 1 pos_cam [Ep], 2 pos_lmk_loc [Ep], 3 pos_lpos [Ep], 4 cam_row_ptr [C+1], 5 row_slot
+ * [n_rows] or empty, 6 row_cam [Ep/16], 7 lmk_ptr [L_loc+1], 8 lmk_fpos [E_loc], 9 lmk_ix [L_loc][16], 10 tile_perm [n_tiles] or
+ * empty.  The pointer stays valid until gbp_debug_layout_free. */
+GBP_API int gbp_debug_layout_array(const gbp_layout* lay, int which, const uint32_t** data, size_t* n);
+GBP_API void gbp_debug_layout_free(gbp_layout* lay);
+/* The local XCD-aware execution order of the sweep (gbp_params.tile_order = 3) as a pure function of the tiles' landmark
+ * classes (0 .. n_classes - 1): perm[wave slot] = tile — a bijection that keeps every tile within `window` + 32 slots of its
+ * sequential place. */
+GBP_API int gbp_debug_tile_order_local(const uint8_t* tile_class /*[n_tiles]*/, uint32_t n_tiles, uint32_t window, uint32_t n_classes,
+                               uint32_t* perm /*[n_tiles]*/);
 
 #ifdef __cplusplus
 }

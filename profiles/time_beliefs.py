@@ -15,9 +15,7 @@ eng = GbpEngine(bal["cam_id"], bal["lmk_id"], cams, lmks, K, hooks=True)
 eng.upload(state)
 eng.linearise()
 eng.iterate(12)
-for abl, name in ((100, "k_beliefs"), (101, "camera part"), (102, "landmark part"),
-                  (103, "landmark part, records read in landmark-major order (streaming gather; experiments build)"),
-                  (104, "landmark part, random records WITHOUT the index-record load (experiments build)")):
+for abl, name in ((100, "k_beliefs"), (101, "camera part"), (102, "landmark part")):
     us = C.c_double()
     rc = eng.lib.gbp_debug_time_sweep(eng.h, abl, 50, C.byref(us))
     print("%-14s %8.2f us  rc=%d" % (name, us.value, rc))

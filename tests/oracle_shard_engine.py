@@ -23,8 +23,7 @@ class OracleShardEngine(orc.Oracle):
         self._chk(lib.orc_set_shard(self.h, rank, world, lb, le), "set_shard")
         self.shard = shard
         self.send = self.recv = None
-        self.world, self.chunks = world, 1
-        self._flat = None
+        self.world = world
 
     def set_stream(self, s):
         pass
@@ -32,28 +31,8 @@ class OracleShardEngine(orc.Oracle):
     def set_exchange_buffers(self, send_ptr, recv_ptr):
         self.send, self.recv = C.c_void_p(send_ptr), C.c_void_p(recv_ptr)
 
-    # ---- pipelined exchange: the oracle computes all partials in piece 0; the chunked receive layout
-    #      ([chunk][world][n_i][44]) is re-flattened to the oracle's [world][C][44] before combining ----
-    def set_exchange_chunks(self, n):
-        self.chunks = int(n)
-
-    def iterate_begin_chunk(self, chunk):
-        if chunk == 0:
-            self.iterate_begin()
-
     def _recv_ptr(self):
-        if self.chunks == 1:
-            return self.recv
-        n = self.world * self.C * 44
-        raw = np.ctypeslib.as_array((C.c_float * n).from_address(self.recv.value))
-        flat = np.empty((self.world, self.C, 44), np.float32)
-        st = [self.C * i // self.chunks for i in range(self.chunks + 1)]
-        for i in range(self.chunks):
-            n_i = st[i + 1] - st[i]
-            blk = raw[self.world * st[i] * 44:self.world * st[i + 1] * 44].reshape(self.world, n_i, 44)
-            flat[:, st[i]:st[i + 1], :] = blk
-        self._flat = np.ascontiguousarray(flat)
-        return C.c_void_p(self._flat.ctypes.data)
+        return self.recv
 
     def iterate_begin(self):
         self._chk(self.lib.orc_iterate_begin(self.h, self.send), "iterate_begin")

@@ -1,5 +1,6 @@
 // AddressSanitizer / UBSan harness for the CPU-side code (GPU ASan is not available on this pool):
-//   * the host helpers exported through the C-ABI (gbp_poplar_amd/csrc/gbp_host.cpp), and
+//   * the host helpers exported through the C-ABI (gbp_poplar_amd/csrc/gbp_host.cpp),
+//   * the device-order builder gbp_create runs before it touches the GPU (gbp_poplar_amd/csrc/gbp_layout.cpp; layout_sanitize.cpp), and
 //   * the oracle (oracle/oracle_gbp.c, oracle_math.c — test infrastructure whose answers the GPU is judged by).
 // Built and run by tests/test_host_sanitizers.py:
 //   g++ -fsanitize=address,undefined -fno-sanitize-recover=all gbp_host.cpp oracle_*.c host_sanitize_main.cpp
@@ -29,8 +30,11 @@ struct Bal {
   }
 };
 
+int layout_sanitize();   // layout_sanitize.cpp: the device-order builder of gbp_create (gbp_layout.cpp)
+
 int main(int argc, char** argv) {
   const std::string dir = argc > 1 ? argv[1] : "/tmp";
+  REQUIRE(layout_sanitize() == 0);
   // ---- synthetic graph -> file -> loader round trip ----
   Bal s;
   s.b.n_cams = 6; s.b.n_lmks = 50; s.b.n_edges = 50 * 4;

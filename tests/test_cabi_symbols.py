@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_functions(header="gbp_mi355x.h"):
     src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    names = re.findall(r"^\s*(?:const\s+char\s*\*|int|void|size_t)\s+(gbp_\w+)\s*\(", src, flags=re.M)
+    names = re.findall(r"^\s*(?:GBP_API\s+)?(?:const\s+char\s*\*|int|void|size_t)\s+(gbp_\w+)\s*\(", src, flags=re.M)
     return sorted(set(names))
 
 
@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "libgbp_mi355x.so does not export %s" % n
     assert sorted(_lib.symbols()) == names, set(names) ^ set(_lib.symbols())
-    assert lib.gbp_abi_version() == _cabi.GBP_ABI_VERSION == 4
+    assert lib.gbp_abi_version() == _cabi.GBP_ABI_VERSION == 5
 
 
 def _exported(path):
@@ -52,11 +52,20 @@ def test_product_library_exports_no_test_hooks():
     assert exported_api == set(declared_functions()), exported_api ^ set(declared_functions())
 
 
+def test_libraries_export_the_c_abi_and_nothing_else():
+    """-fvisibility=hidden + csrc/gbp_exports.map: `nm -D` of the product shows the functions include/gbp_mi355x.h declares and
+    nothing else — no C++ symbol of the library's own (_ZN3gbp...), no kernel stub, no weak libstdc++ instantiation; the
+    test-hooks build adds exactly the functions of include/gbp_mi355x_debug.h."""
+    from gbp_poplar_amd import _lib
+    assert _exported(_lib.LIB_PATH) == set(declared_functions())
+    assert _exported(_lib.TEST_LIB_PATH) == set(declared_functions()) | set(declared_functions("gbp_mi355x_debug.h"))
+
+
 def test_test_hooks_library_exports_the_debug_header():
     from gbp_poplar_amd import _lib
     lib = _lib.load(hooks=True)
     names = declared_functions("gbp_mi355x_debug.h")
-    assert names == sorted(_lib.debug_symbols()) and len(names) == 5
+    assert names == sorted(_lib.debug_symbols()) and len(names) == 13
     for n in names + declared_functions():
         assert hasattr(lib, n), "libgbp_mi355x_test.so does not export %s" % n
 

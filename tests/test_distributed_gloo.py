@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def _worker(rank, world, port, out_dir, chunks=1, slam=False):
+def _worker(rank, world, port, out_dir, slam=False):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -28,12 +28,7 @@ def _worker(rank, world, port, out_dir, chunks=1, slam=False):
     bounds = landmark_partition(bal["lmk_id"], bal["n_lmks"], world)
     eng = OracleShardEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K,
                             (rank, world, int(bounds[rank]), int(bounds[rank + 1])))
-    run = ShardedGbp(eng, bal["n_cams"], rank, world, dist=dist, device="cpu", chunks=chunks)
-    if chunks > 1:                      # CPU tensors have no stream: drive the pipelined path explicitly
-        run._one_iteration.__func__     # (attribute exists)
-        orig = run._one_iteration
-        run.iterate = lambda n=1: [orig(True) for _ in range(int(n))]
-        run._on_stream = __import__("contextlib").nullcontext
+    run = ShardedGbp(eng, bal["n_cams"], rank, world, dist=dist, device="cpu")
     if slam:
         traj = driver.run_slam(run, hostlib, bal, state, extra, opts, iters_between_kfs=6, max_iters=40, eval_every=1)
     else:
@@ -44,15 +39,14 @@ def _worker(rank, world, port, out_dir, chunks=1, slam=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("chunks", [1, 3])
-def test_two_rank_gloo_matches_two_shard_oracle(chunks):
+def test_two_rank_gloo_matches_two_shard_oracle():
     import torch.multiprocessing as mp
     from gbp_poplar_amd import driver, hostlib
     from oracle import oracle as orc
     world = 2
     port = 29500 + (os.getpid() % 2000)
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(world, port + chunks, d, chunks), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, port + 1, d), nprocs=world, join=True)
         res = [np.load(os.path.join(d, "rank%d.npz" % r)) for r in range(world)]
         res = [{k: x[k] for k in x.files} for x in res]
     bal = hostlib.synth_generate(14, 260, 5, 5)
@@ -91,7 +85,7 @@ def test_two_rank_gloo_slam_matches_two_shard_oracle():
     world = 2
     port = 31500 + (os.getpid() % 2000)
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(world, port, d, 1, True), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, port, d, True), nprocs=world, join=True)
         res = [np.load(os.path.join(d, "rank%d.npz" % r)) for r in range(world)]
         res = [{k: x[k] for k in x.files} for x in res]
     bal = hostlib.synth_generate(14, 260, 5, 5)

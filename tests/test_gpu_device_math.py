@@ -19,10 +19,10 @@ pytestmark = pytest.mark.gpu
 G = np.load(os.path.join(os.path.dirname(__file__), "golden", "math_vectors.npz"))
 
 
-def _run(op, inp, out_w):
+def _run(op, inp, out_w, hooks=True):
     from gbp_poplar_amd import _cabi as cabi
     from gbp_poplar_amd._lib import load
-    lib = load(hooks=True)      # gbp_debug_math lives in the test-hooks build of the same sources
+    lib = load(hooks=hooks)     # gbp_debug_math lives in the test-hooks build of the same sources
     inp = np.ascontiguousarray(inp, np.float32)
     n = inp.shape[0]
     out = np.zeros((n, out_w), np.float32)
@@ -112,17 +112,23 @@ def test_hfunc_and_jac_vs_reference():
     assert np.all(jk[:, 1] == 0) and np.all(jk[:, 6] == 0)                                       # structural zeros
 
 
+def _exp_lib_present():
+    from gbp_poplar_amd import _lib
+    return os.path.exists(_lib.EXP_LIB_PATH)
+
+
+@pytest.mark.skipif(not _exp_lib_present(), reason="experiments build absent (python -m gbp_poplar_amd.build --experiments)")
 def test_subwave_mapping_of_inv6x6_is_bit_identical():
-    """op 9: the north star's sub-wave mapping (16 lanes per matrix, operands in LDS, lane = output element) built
-    for the dominant routine: bit-identical to the reference's inv6x6 (golden) and to the lane-per-matrix routine on
-    5 000 fresh SPD matrices with ragged tails (n not a multiple of 4, 16 or 64)."""
-    out = _run(9, G["inv6_in"].reshape(-1, 36), 36)
+    """op 9 (experiments build, csrc/experiments/): the north star's sub-wave mapping (16 lanes per matrix, operands in LDS, lane =
+    output element) built for the dominant routine: bit-identical to the reference's inv6x6 (golden) and to the lane-per-matrix
+    routine on 5 000 fresh SPD matrices with ragged tails (n not a multiple of 4, 16 or 64)."""
+    out = _run(9, G["inv6_in"].reshape(-1, 36), 36, hooks="exp")
     assert np.array_equal(out, G["inv6_out"].reshape(-1, 36))
     rng = np.random.default_rng(5)
     for n in (1, 3, 17, 4999):
         a = rng.standard_normal((n, 6, 6))
         m = (a @ a.transpose(0, 2, 1) + 0.5 * np.eye(6)).astype(np.float32).reshape(n, 36)
-        assert np.array_equal(_run(9, m, 36), _run(1, m, 36)), n
+        assert np.array_equal(_run(9, m, 36, hooks="exp"), _run(1, m, 36)), n
 
 
 def test_shared_reciprocal_division_is_the_ieee_division():

@@ -71,6 +71,11 @@ def flow(e):
     steps = {"plain": lambda: e.iterate(20),                                        # mode 0: a plain burst
              "eval": lambda: (e.iterate_eval(15), out.append(e.eval_end())),        # mode 1: burst + metric in one launch
              "each": lambda: out.extend(e.iterate_eval_each(12))}                   # mode 2: the metric after every iteration (blocking)
+    if %(first)r == "read":                         # the burst that times out, then READ_PROG with nothing in between: the replay
+        e.iterate(20)                               # queued by the recovery must have completed when gbp_read copies the beliefs
+        st = e.read()
+        out.extend(e.iterate_eval_each(13))
+        return out, st
     order = {"plain": ("plain", "eval", "each"), "eval": ("eval", "each", "plain"), "each": ("each", "plain", "eval")}[%(first)r]
     for k in order:                                 # the FIRST of them is the launch that times out / is refused
         steps[k]()
@@ -96,14 +101,15 @@ print('RECOVERED %%.1f s graph_state_after_upload %%d :: %%s' %% (dt, eng.graph_
 
 
 @pytest.mark.skipif(not _exp_lib_present(), reason="experiments build absent (python -m gbp_poplar_amd.build --experiments)")
-@pytest.mark.parametrize("coop,first", [(0, "plain"), (0, "eval"), (0, "each"), (1, "plain")])
+@pytest.mark.parametrize("coop,first", [(0, "plain"), (0, "eval"), (0, "each"), (1, "plain"), (0, "read")])
 def test_persistent_kernel_time_out_is_recovered(coop, first):
     """A k_persist launch whose workgroups can NOT all be resident (forced: every 8th dispatch slot = one XCD = 32 CUs for the
     52 workgroups of fr1xyz; experiments build) must not hang and must not lose the run:
       * plain launch (persist_coop = 0, the default): the barrier gives up after 1.5 s, later launches return at once, the library restores
         the snapshot taken before the failed launch and replays the bursts on the two-kernel path;
       * cooperative launch (persist_coop = 1): the runtime refuses the grid before anything runs, same fallback.
-    The launch that fails is a plain burst, a burst with the metric at its end, or an every-iteration burst (`first`).
+    The launch that fails is a plain burst, a burst with the metric at its end, or an every-iteration burst (`first`); "read": a
+    plain burst followed by gbp_read with no synchronisation of the caller's in between.
     Either way: rc 0 everywhere, every belief / damping / counter and every metric equal to the two-kernel path's, a warning in
     gbp_last_error, and the persistent path back after the next gbp_upload."""
     import subprocess

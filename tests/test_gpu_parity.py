@@ -733,14 +733,13 @@ class _FakeDist:
             m.stream.synchronize()
         for dst in self.members:
             for r, src in enumerate(self.members):
-                for i in range(dst.chunks):          # chunk i of the receive buffer is [world][n_i * 44]
-                    n_i = src.send_views[i].numel()
-                    dst.recv_views[i][r * n_i:(r + 1) * n_i].copy_(src.send_views[i])
+                n = src.send.numel()                 # the receive buffer is [world][C * 44]
+                dst.recv[r * n:(r + 1) * n].copy_(src.send)
         torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("world,chunks", [(2, 1), (3, 1), (2, 2), (3, 4)])
-def test_sharded_kernels_on_one_gpu_match_sharded_oracle(world, chunks, oracle_mod):
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_kernels_on_one_gpu_match_sharded_oracle(world, oracle_mod):
     """`world` landmark-shard contexts on the same GPU, exchange done by device copies: the sharded C-ABI path
     (gbp_iterate_begin/_end, refresh, linearise_factors, weaken on a sharded ctx, torch-owned buffers and
     stream) against the oracle in `world`-shard device order, bit for bit, through relinearisations."""
@@ -757,7 +756,7 @@ def test_sharded_kernels_on_one_gpu_match_sharded_oracle(world, chunks, oracle_m
     for r in range(world):
         eng = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K,
                         shard=(r, world, int(bounds[r]), int(bounds[r + 1])))
-        sh = ShardedGbp(eng, bal["n_cams"], r, world, dist=None, device="cuda", chunks=chunks)
+        sh = ShardedGbp(eng, bal["n_cams"], r, world, dist=None, device="cuda")
         sh._exchange = lambda: None          # the exchange is performed for all shards at once below
         fake.members.append(sh)
         shards.append(sh)
@@ -778,11 +777,7 @@ def test_sharded_kernels_on_one_gpu_match_sharded_oracle(world, chunks, oracle_m
             if (it + 1) % 2 == 0 and it < 10:
                 all_do("weaken_priors")
                 orc.weaken_priors()
-            if chunks > 1 and it % 3:                # pipelined pieces of the sweep (camera ranges) ...
-                for i in range(chunks):
-                    all_do("iterate_begin_chunk", i)
-            else:                                    # ... or the sweep in one piece: same result
-                all_do("iterate_begin")
+            all_do("iterate_begin")
             if it % 2:
                 all_do("iterate_local")          # landmark half first (what overlaps the all-gather on N GPUs)
             fake.gather_all()
@@ -812,14 +807,12 @@ def test_sharded_kernels_on_one_gpu_match_sharded_oracle(world, chunks, oracle_m
     assert abs(tot["sum_norm"] - eo["sum_norm"]) <= 1e-5 * eo["sum_norm"]
 
 
-@pytest.mark.parametrize("chunks", [1, 3])
-def test_row_placement_is_unobservable(chunks):
+def test_row_placement_is_unobservable():
     """Graphs of many small cameras (fewer than 512 factors per camera, >= 2 048 tiles: BASELINE config 5's shape) get their
-    16-factor rows laid out by landmark octile inside windows of 32 cameras (gbp_capi.cpp, row placement).  A row stays whole
+    16-factor rows laid out by landmark class inside windows of 32 cameras (gbp_layout.cpp, row placement).  A row stays whole
     and a camera's rows are added in the camera's own order, so nothing may change: the default engine against tile_order = 1
     (camera-major rows, sequential tiles) on a 4 096-camera x 40 000-landmark x 400 000-factor graph, bit for bit through the
-    start of a BA run; and the same through the sharded C-ABI path of a 1-shard ctx with the sweep issued in `chunks` pieces
-    (camera ranges that do NOT end on window boundaries: a piece sweeps to the end of the window its range ends in)."""
+    start of a BA run; and the same through the sharded C-ABI path of a 1-shard ctx."""
     from gbp_poplar_amd import _cabi, driver, hostlib
     from gbp_poplar_amd.distributed import ShardedGbp
     from gbp_poplar_amd.engine import GbpEngine
@@ -828,7 +821,7 @@ def test_row_placement_is_unobservable(chunks):
     K, state, _ = driver.build_inputs(bal, opts, hostlib)
     ref = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K, params=_cabi.GbpParams.defaults(tile_order=1))
     eng = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K, shard=(0, 1, 0, bal["n_lmks"]))
-    sh = ShardedGbp(eng, bal["n_cams"], 0, 1, dist=None, device="cuda", chunks=chunks)
+    sh = ShardedGbp(eng, bal["n_cams"], 0, 1, dist=None, device="cuda")
     fake = _FakeDist()
     fake.members.append(sh)
     sh._exchange = lambda: None
@@ -841,11 +834,7 @@ def test_row_placement_is_unobservable(chunks):
             ref.weaken_priors()
             eng.weaken_priors()
         ref.iterate(1)
-        if chunks > 1:
-            for i in range(chunks):
-                eng.iterate_begin_chunk(i)
-        else:
-            eng.iterate_begin()
+        eng.iterate_begin()
         fake.gather_all()
         eng.iterate_end()
     a, b = ref.read(), sh.read()
@@ -1604,8 +1593,7 @@ def test_empty_landmark_shard(oracle_mod):
     assert shards[1].e.eval()["n_active"] == 0
 
 
-@pytest.mark.parametrize("chunks", [1, 3])
-def test_rccl_single_rank_group_overlap_path(chunks):
+def test_rccl_single_rank_group_overlap_path():
     """The exact code path of an N-GPU run (RCCL all_gather_into_tensor with async_op, landmark half overlapped,
     stream-ordered camera combine) on a 1-rank RCCL group: must equal the plain single-GPU engine bit for bit."""
     import os
@@ -1624,7 +1612,7 @@ def test_rccl_single_rank_group_overlap_path(chunks):
         K, state, _ = driver.build_inputs(bal, opts, hostlib)
         plain = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K)
         eng = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K, shard=(0, 1, 0, bal["n_lmks"]))
-        sh = ShardedGbp(eng, bal["n_cams"], 0, 1, dist=dist, device="cuda", always_collective=True, chunks=chunks)
+        sh = ShardedGbp(eng, bal["n_cams"], 0, 1, dist=dist, device="cuda", always_collective=True)
         ta = driver.run_ba(plain, state, opts, n_iters=30, eval_every=10)
         tb = driver.run_ba(sh, state, opts, n_iters=30, eval_every=10)
         assert ta == tb
@@ -1804,6 +1792,49 @@ def test_iterations_captured_into_a_callers_graph_use_the_two_kernel_path(oracle
         assert np.array_equal(g[k], o[k], equal_nan=True), k
     eng.iterate(5)                                     # and the ctx is back on its own stream and path afterwards
     ref.iterate(5)
+    g, o = eng.read(), ref.read()
+    for k in g:
+        assert np.array_equal(g[k], o[k], equal_nan=True), k
+
+
+def test_capture_begun_with_bursts_in_flight_is_refused_not_broken(oracle_mod):
+    """a caller who begins capturing their stream while k_persist bursts of the ctx are still unvalidated must get
+    GBP_ERR_STATE ("gbp_sync before beginning a stream capture") from the next call — the library never synchronises a capturing
+    stream, so the caller's capture stays valid, and after gbp_sync the same sequence works."""
+    import torch
+    from gbp_poplar_amd import driver, hostlib
+    from gbp_poplar_amd.engine import GbpEngine, GbpError
+    bal = _bal("fr2robot2")
+    K, state, _ = driver.build_inputs(bal, driver.Options(), hostlib)
+    eng = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K)
+    ref = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K)
+    stream = torch.cuda.Stream()
+    for e in (eng, ref):
+        e.upload(state)
+        e.linearise()
+    eng.set_stream(stream.cuda_stream)
+    assert eng.graph_state() == 2
+    eng.iterate(6)                                     # a k_persist burst on the caller's stream, not yet validated
+    ref.iterate(6)
+    graph = torch.cuda.CUDAGraph()
+    x = torch.zeros(8, device="cuda")
+    with torch.cuda.graph(graph, stream=stream):
+        x += 1                                         # (something of the caller's own in the capture)
+        with pytest.raises(GbpError, match="gbp_sync before beginning a stream capture"):
+            eng.iterate(1)
+        with pytest.raises(GbpError, match="gbp_sync before beginning a stream capture"):
+            eng.weaken_priors()
+    graph.replay()                                     # the capture ended cleanly (an invalidated one raises at its end)
+    stream.synchronize()
+    assert float(x.sum()) == 8.0
+    eng.sync()
+    graph2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph2, stream=stream):
+        eng.iterate(2)
+    graph2.replay()
+    stream.synchronize()
+    eng.set_stream(0)
+    ref.iterate(2)
     g, o = eng.read(), ref.read()
     for k in g:
         assert np.array_equal(g[k], o[k], equal_nan=True), k

@@ -1,4 +1,4 @@
-"""AddressSanitizer + UBSan over the CPU-side C/C++ (host helpers of the C-ABI and the oracle).  GPU sanitizers are
+"""AddressSanitizer + UBSan over the CPU-side C/C++ (host helpers of the C-ABI, the device-order builder of gbp_create and the oracle).  GPU sanitizers are
 not available on this pool, so this is the memory-safety gate of everything that runs on the host; the harness is
 tests/sanitize/host_sanitize_main.cpp."""
 import os
@@ -24,6 +24,7 @@ def test_host_code_and_oracle_under_asan_ubsan(tmp_path):
     # harness only exercises the parts that need no device (region layout, abort flag)
     subprocess.check_call(["g++", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
                            os.path.join(ROOT, "gbp_poplar_amd/csrc/gbp_host.cpp"), os.path.join(ROOT, "gbp_poplar_amd/csrc/gbp_comm.cpp"),
+                           os.path.join(ROOT, "gbp_poplar_amd/csrc/gbp_layout.cpp"), os.path.join(ROOT, "tests/sanitize/layout_sanitize.cpp"),
                            os.path.join(ROOT, "tests/sanitize/comm_glue.cpp"),
                            os.path.join(ROOT, "tests/sanitize/host_sanitize_main.cpp")] + objs + san
                           + ["-L/opt/rocm/lib", "-lamdhip64", "-ldl", "-lm", "-Wl,-rpath,/opt/rocm/lib", "-o", exe], cwd=ROOT)
