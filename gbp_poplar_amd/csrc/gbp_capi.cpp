@@ -97,6 +97,14 @@ struct gbp_ctx {
   hipGraphExec_t graph_exec = nullptr;
   int graph_iters = 0;
   bool graph_failed = false;           // a capture / instantiation failed once: direct launches from then on
+  // the same for iterations that carry the metric (k_sweep<EV> + k_beliefs<EV>: gbp_iterate_eval_each beyond k_persist)
+  hipGraph_t graph_ev = nullptr;
+  hipGraphExec_t graph_exec_ev = nullptr;
+  DevBuf ev_cam, ev_lmk, ev_part, ev_ctl;   // metric records of the belief owners, ring of per-tile partial sums, counter + health words
+  uint32_t ev_depth = 0;               // slots of the ring = iterations per piece of a burst
+  void* ev_host = nullptr;             // pinned + device-mapped: one gbp_eval_out per iteration of a burst (k_eval_fold)
+  size_t ev_host_cap = 0;
+  void* ev_host_dev = nullptr;
   bool sharded_graph = false;          // gbp_params.graph_unroll > 0 was asked for explicitly (see iterate_sharded)
   bool uploaded = false, beliefs_valid = false;
   bool lmk_half_done = false;          // gbp_iterate_local already refreshed the landmark beliefs of this iteration
@@ -180,12 +188,15 @@ SweepArgs sweep_args(gbp_ctx* c) {
   a.variant = c->prm.reserved[0];      // read by the experiments build only
   a.tile_perm = c->use_tile_perm ? P<uint32_t>(c->tile_perm) : nullptr;
   a.policy = c->sweep_policy;
+  a.ev = EvalRide{};
   return a;
 }
 
 void drop_graph(gbp_ctx* c) {
   if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
   if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
+  if (c->graph_exec_ev) { (void)hipGraphExecDestroy(c->graph_exec_ev); c->graph_exec_ev = nullptr; }
+  if (c->graph_ev) { (void)hipGraphDestroy(c->graph_ev); c->graph_ev = nullptr; }
   c->graph_iters = 0;
 }
 
@@ -223,11 +234,24 @@ int refresh_beliefs_from_partials(gbp_ctx* c, bool roll, bool do_lmk = true) {
   return GBP_OK;
 }
 
-void enqueue_iteration(gbp_ctx* c, const SweepArgs& a) {
-  launch_sweep(a, c->n_tiles, c->hoist, c->stream);
+// the riding metric's view of the ctx (gbp_kernels.h: EvalRide); valid once ev_alloc has run
+EvalRide eval_ride(gbp_ctx* c) {
+  EvalRide e{};
+  e.cam_rec = P<float4>(c->ev_cam); e.lmk_mean = P<float4>(c->ev_lmk); e.part = P<EvalRec>(c->ev_part);
+  e.counter = P<unsigned>(c->ev_ctl);
+  e.health = reinterpret_cast<unsigned long long*>(static_cast<char*>(c->ev_ctl.p) + 8);
+  e.slot_health = reinterpret_cast<unsigned long long*>(static_cast<char*>(c->ev_ctl.p) + 64);
+  e.n_tiles = c->n_tiles; e.num_undamped = c->prm.num_undamped_iters;
+  return e;
+}
+
+// one iteration: k_sweep + k_beliefs; ev: the instantiations that carry the metric (a.ev filled in by the caller)
+void enqueue_iteration(gbp_ctx* c, const SweepArgs& a, bool ev = false) {
+  launch_sweep(a, c->n_tiles, c->hoist, c->stream, ev);
   BeliefArgs b = belief_args(c);
   b.roll = 1;
-  launch_beliefs(b, true, true, c->stream);
+  if (ev) b.ev = a.ev;
+  launch_beliefs(b, true, true, c->stream, ev);
 }
 
 // local camera partials only (before an exchange / before a prior-only refresh)
@@ -374,6 +398,7 @@ void gbp_destroy(gbp_ctx* c) {
   for (auto& v : {&c->spans, &c->span_pool})
     for (auto& sp : *v) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
   if (c->eval_host) (void)hipHostFree(c->eval_host);
+  if (c->ev_host) (void)hipHostFree(c->ev_host);
   if (c->series_host) (void)hipHostFree(c->series_host);
   if (c->pstatus_host) (void)hipHostFree(c->pstatus_host);
   for (hipEvent_t e : c->eval_ev) if (e) (void)hipEventDestroy(e);
@@ -546,6 +571,9 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
     }
     if (rc != GBP_OK) return rc;
   }
+  // (the zero-fills of dev_alloc ran on the NULL stream, which the ctx's non-blocking stream does not order against)
+  CK(hipDeviceSynchronize(), "hipDeviceSynchronize");
+  if (rc != GBP_OK) return rc;
   owner.p = nullptr;
   *out = c;
   return GBP_OK;
@@ -879,14 +907,16 @@ int gbp_iterate_end(gbp_ctx* c) {
 // Capture `graph_unroll` single-GPU iterations once (nothing is executed by a capture).  Any failure leaves the stream
 // out of capture mode, drops the partial graph and falls back to direct launches for the life of the ctx (results are
 // identical either way).
-static bool ensure_graph(gbp_ctx* c, const SweepArgs& a) {
-  if (c->graph_exec) return true;
+static bool ensure_graph(gbp_ctx* c, const SweepArgs& a, bool ev = false) {
+  hipGraph_t& g = ev ? c->graph_ev : c->graph;
+  hipGraphExec_t& x = ev ? c->graph_exec_ev : c->graph_exec;
+  if (x) return true;
   if (c->graph_failed || c->prm.graph_unroll <= 0 || c->stream != c->own_stream) return false;
   hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
   if (e == hipSuccess) {
-    for (int i = 0; i < c->prm.graph_unroll; ++i) enqueue_iteration(c, a);
-    e = hipStreamEndCapture(c->stream, &c->graph);          // also ends a capture that was invalidated on the way
-    if (e == hipSuccess) e = hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0);
+    for (int i = 0; i < c->prm.graph_unroll; ++i) enqueue_iteration(c, a, ev);
+    e = hipStreamEndCapture(c->stream, &g);          // also ends a capture that was invalidated on the way
+    if (e == hipSuccess) e = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
   }
   if (e != hipSuccess) {
     (void)hipGetLastError();
@@ -911,17 +941,19 @@ int gbp_prepare(gbp_ctx* c) {
 }
 
 // GBP_PROG x n on the two-kernel path: replay of a captured hipGraph of `graph_unroll` iterations, remainder launched directly.
-static int iterate_plain(gbp_ctx* c, const SweepArgs& a, int n) {
+// (ev: the iterations carry the metric — a.ev set, see eval_each_ride; their launches depend on the iteration only through a
+// counter in device memory, so they replay from a graph of their own)
+static int iterate_plain(gbp_ctx* c, const SweepArgs& a, int n, bool ev = false) {
   int left = n;
   bool use_graph = (c->stream == c->own_stream) && c->prm.graph_unroll > 0 && n >= c->prm.graph_unroll && !c->graph_failed;
-  if (use_graph && !c->graph_exec) use_graph = ensure_graph(c, a);
+  if (use_graph && !(ev ? c->graph_exec_ev : c->graph_exec)) use_graph = ensure_graph(c, a, ev);
   if (use_graph) {
     while (left >= c->graph_iters) {
-      HIPCHK(c, hipGraphLaunch(c->graph_exec, c->stream));
+      HIPCHK(c, hipGraphLaunch(ev ? c->graph_exec_ev : c->graph_exec, c->stream));
       left -= c->graph_iters;
     }
   }
-  for (; left > 0; --left) enqueue_iteration(c, a);
+  for (; left > 0; --left) enqueue_iteration(c, a, ev);
   HIPCHK(c, hipGetLastError());
   return GBP_OK;
 }
@@ -1296,7 +1328,7 @@ static int eval_begin_impl(gbp_ctx* c) {
 // part[0] = the two health counters; then one record per workgroup of k_eval (per_wave = false: nb of them), or one per tile
 // wave of k_persist (per_wave = true: n_tiles of them) — the four waves of a workgroup added as k_eval's block reduction adds
 // them, ((w0 + w1) + w2) + w3, then the workgroups in order: the same fp64 additions in the same order either way.
-static int sum_eval(gbp_ctx* c, const DeviceEval* part, uint32_t nb, gbp_eval_out* o, bool per_wave = false) {
+static int sum_eval(gbp_ctx* c, const DeviceEval* part, uint32_t nb, gbp_eval_out* o, bool per_wave) {
   std::memset(o, 0, sizeof(*o));
   if (per_wave) {
     for (uint32_t b = 0; b < nb; ++b) {
@@ -1391,6 +1423,58 @@ static int iterate_eval_impl(gbp_ctx* c, int n) {
   return eval_begin_impl(c);
 }
 
+// gbp_iterate_eval_each on a graph that does not run in k_persist: the metric of iteration k rides in the sweep of iteration
+// k + 1 (k_sweep<EV>, k_beliefs<EV>: EvalRide in gbp_kernels.h), the iterations replay from a hipGraph like gbp_iterate's, the
+// host is not involved until the burst has ended: per piece of at most ev_depth iterations (the ring of per-tile records) one
+// k_eval_ride for the piece's last iteration and one k_eval_fold, which reduces every slot to one 56-byte result in host-mapped
+// memory.  Bit-identical to gbp_iterate(1) + gbp_eval per iteration (same operations, same order of the sums).
+static int ev_alloc(gbp_ctx* c) {
+  if (c->ev_depth) return GBP_OK;
+  const size_t slot_bytes = (size_t)c->n_tiles * sizeof(EvalRec);
+  const uint32_t depth = (uint32_t)std::min<size_t>(256, std::max<size_t>(2, ((size_t)128 << 20) / slot_bytes));      // <= 128 MB of ring
+  if (int rc = dev_alloc(c, c->ev_cam, (size_t)c->C * 3 * 16)) return rc;
+  if (int rc = dev_alloc(c, c->ev_lmk, (size_t)c->L_loc * 16)) return rc;
+  if (int rc = dev_alloc(c, c->ev_part, slot_bytes * depth)) return rc;
+  if (int rc = dev_alloc(c, c->ev_ctl, 64 + (size_t)depth * 16)) return rc;
+  // dev_alloc zero-fills on the NULL stream, which the ctx's non-blocking stream does not order against — and hipMemset of device
+  // memory may return before the fill has run: without this wait the fill raced the first burst's records (seen: a first metric
+  // over 3 062 of 200 000 factors)
+  HIPCHK(c, hipDeviceSynchronize());
+  c->ev_depth = depth;
+  return GBP_OK;
+}
+static int eval_each_ride(gbp_ctx* c, int n, gbp_eval_out* out) {
+  if (int rc = settle(c)) return rc;
+  if (int rc = ev_alloc(c)) return rc;
+  if ((size_t)n > c->ev_host_cap) {       // one 56-byte result per iteration of the burst, host-mapped
+    if (c->ev_host) { (void)hipHostFree(c->ev_host); c->ev_host = nullptr; c->ev_host_cap = 0; }
+    const size_t cap = std::max<size_t>(1024, (size_t)n);
+    HIPCHK(c, hipHostMalloc(&c->ev_host, sizeof(gbp_eval_out) * cap, hipHostMallocMapped));
+    HIPCHK(c, hipHostGetDevicePointer(&c->ev_host_dev, c->ev_host, 0));
+    c->ev_host_cap = cap;
+  }
+  static_assert(sizeof(gbp_eval_out) == 56, "k_eval_fold writes gbp_eval_out records");
+  SweepArgs a = sweep_args(c);
+  a.ev = eval_ride(c);
+  gbp_ctx::Span sp{};
+  if (int rc = span_begin(c, sp)) return rc;
+  for (int done = 0; done < n;) {         // pieces of at most ev_depth iterations, queued behind each other: no host wait in between
+    const int m = std::min(n - done, (int)c->ev_depth);
+    HIPCHK(c, hipMemsetAsync(c->ev_ctl.p, 0, 64, c->stream));      // iteration counter and health words of this piece
+    if (int rc = iterate_plain(c, a, m, true)) { c->span_pool.push_back(sp); return rc; }
+    launch_eval_ride(a.ev, P<uint32_t>(c->row_cam), P<uint32_t>(c->lmk_idx), P<float4>(c->lmsg), P<float4>(c->fac), P<float>(c->dK), c->stream);
+    launch_eval_fold(a.ev, (uint32_t)m, static_cast<gbp_eval_out*>(c->ev_host_dev) + done, c->stream);
+    HIPCHK(c, hipGetLastError());
+    done += m;
+  }
+  if (int rc = span_end(c, sp)) return rc;
+  c->timed_iters += (uint64_t)n;
+  c->beliefs_valid = true;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::memcpy(out, c->ev_host, sizeof(gbp_eval_out) * (size_t)n);
+  return GBP_OK;
+}
+
 // n iterations with the metric after EVERY one of them (the reference's default loop, ba.cpp:1009-1028 / slam.cpp), blocking:
 // out[k] = what gbp_iterate(1) + gbp_eval_global() would have returned for the k-th of them.  On a graph that runs in
 // k_persist a burst is ONE launch: the metric of iteration k rides in the sweep phase of iteration k + 1 (both only read the
@@ -1442,6 +1526,8 @@ static int iterate_eval_each_impl(gbp_ctx* c, int n, gbp_eval_out* out) {
       done += m;
     }
   }
+  if (done < n && !c->comm && c->world == 1 && c->hoist && !c->profile_stages && !stream_is_capturing(c))
+    return eval_each_ride(c, n - done, out + done);
   int collected = done;
   for (int k = done; k < n; ++k) {
     if (int rc = iterate_impl(c, 1)) return rc;
@@ -1668,6 +1754,7 @@ static int comm_attach(gbp_ctx* c, gbp::Comm* comm) {
   if (!c->xsend.p) rc = dev_alloc(c, c->xsend, (size_t)c->C * kCamRec * 4);
   if (rc == GBP_OK && !c->xrecv.p) rc = dev_alloc(c, c->xrecv, (size_t)c->world * c->C * kCamRec * 4);
   if (rc != GBP_OK) return rc;
+  HIPCHK(c, hipDeviceSynchronize());      // (dev_alloc's zero-fill runs on the NULL stream)
   c->send_dev = c->xsend.p; c->recv_dev = c->xrecv.p;
   if (!c->comm_stream && !c->comm_single_stream) {
     // highest priority: the all-gather is issued while the landmark half of k_beliefs fills the GPU; it must not queue
@@ -1789,7 +1876,7 @@ int gbp_comm_probe(gbp_ctx* c, int reps, double* avg_us) {
   return GBP_OK;
 }
 
-int gbp_graph_state(const gbp_ctx* c) { return !c ? 0 : (c->persist_ok ? 2 : (c->graph_exec ? 1 : (c->graph_failed ? -1 : 0))); }
+int gbp_graph_state(const gbp_ctx* c) { return !c ? 0 : (c->persist_ok ? 2 : ((c->graph_exec || c->graph_exec_ev) ? 1 : (c->graph_failed ? -1 : 0))); }
 
 const char* gbp_comm_transport(const gbp_ctx* c) { return (c && c->comm) ? c->comm->name() : "none"; }
 

@@ -51,6 +51,37 @@ struct Hyper {  // gbp_codelets.cpp:11-16
   int relin_mode;
 };
 
+// The metric riding in the two-kernel path (gbp_iterate_eval_each on graphs that do not run in k_persist): eval_reprojection_error
+// (util.cpp:74-144) + the counters of ba.cpp:1011-1020 after EVERY iteration without a launch of their own and without the host.
+//   k_beliefs<EV> of iteration k   also computes what k_means computes — the fp64 pivoted means of its new beliefs — and leaves
+//                                  them as METRIC RECORDS: per camera the rotation and translation the residuals need (the rotation
+//                                  evaluated once per camera instead of once per factor: same operations, same bits), per landmark
+//                                  its mean; it counts the non-finite / non-PD beliefs and advances the iteration counter;
+//   k_sweep<EV> of iteration k+1   holds every factor's state as sweep k left it and its measurement in registers anyway: two
+//                                  L2-resident gathers more give the residual; one partial-sum record per wave goes to slot k of a
+//                                  device ring (index = TILE, not wave slot: the order of the sums is a property of the graph);
+//   k_eval_fold, once per burst    reduces the per-tile records of every slot in the order of every other metric (the lane tree of
+//                                  a wave, ((w0 + w1) + w2) + w3 for the four tiles of a 256-factor block, blocks j, j + 1024,
+//                                  j + 2048 ... serially = the <= 1 024 block sums k_eval produces, then those serially as the
+//                                  host adds them) and writes ONE result per iteration to host-mapped memory.
+// The slot comes from a counter in DEVICE memory, so the launches of a burst are the same for every iteration and replay from a
+// hipGraph.  The metric of a piece's last iteration, which no sweep follows, comes from k_eval_ride (the same records from the same
+// metric records, one wave per tile); nothing of a burst waits for the host.
+struct EvalRec {           // partial sums of one tile (one wavefront of the sweep)
+  double sum_norm, sum_half_sq;
+  uint32_t n_active, n_relin, n_robust, pad;
+};
+struct EvalRide {
+  float4* cam_rec;             // [C][3]   (R0 R1 R2 t0) (R3 R4 R5 t1) (R6 R7 R8 t2): eigenso3exp of the camera's metric mean + its translation
+  float4* lmk_mean;            // [L]      metric mean of the landmark (x y z 0)
+  EvalRec* part;               // [depth][n_tiles] ring of per-tile partial sums
+  unsigned long long* health;  // [2] non-finite means / non-PD beliefs counted by the CURRENT belief update (the next sweep collects and zeroes them)
+  unsigned long long* slot_health;  // [depth][2] what the sweep collected for each slot
+  unsigned* counter;           // iterations of this burst completed so far (advanced by k_beliefs<EV>); sweep k + 1 fills slot counter - 1
+  uint32_t n_tiles;
+  int num_undamped;
+};
+
 struct SweepArgs {
   const uint32_t* row_cam;   // [Ep/16] camera of each 16-lane row
   const uint32_t* lmk_idx;   // [Ep]    landmark (local index) of each factor
@@ -71,6 +102,7 @@ struct SweepArgs {
                              // workgroups are dealt round-robin over the 8 XCDs, the table hands every XCD the tiles of one landmark
                              // class so that its private L2 holds that slice of the gathered landmark tables
   uint32_t policy;           // kPol* bits: cache policy of the two message streams, chosen per graph shape (gbp_capi.cpp: sweep_policy)
+  EvalRide ev;               // k_sweep<EV> only
 };
 // SweepArgs.policy.  The potentials (read once per sweep) and every tile STORE of the camera messages carry the non-temporal
 // hint on every graph; what varies with the shape is how the two message streams, which a tile reads and rewrites in place, are
@@ -98,6 +130,7 @@ struct BeliefArgs {
   int partial_only;          // camera part writes cam_local only (multi-GPU: before the exchange)
   int hoist;                 // compute per-variable means + dmu^2 pieces
   int roll;                  // end of an iteration: "means used by the last sweep" := current means, then recompute
+  EvalRide ev;               // k_beliefs<EV> only
 };
 
 // k_persist: n GBP iterations in ONE launch for graphs small enough that every workgroup is resident at once
@@ -148,9 +181,13 @@ struct DeviceEval {  // per-block partials, summed on the host in block order
   unsigned long long n_active, n_relin, n_robust, pad;
 };
 
-void launch_sweep(const SweepArgs& a, uint32_t n_tiles, bool hoist, hipStream_t s);
+void launch_sweep(const SweepArgs& a, uint32_t n_tiles, bool hoist, hipStream_t s, bool ev = false);
 void launch_linearise(const SweepArgs& a, uint32_t n_tiles, hipStream_t s);
-void launch_beliefs(BeliefArgs b, bool do_cam, bool do_lmk, hipStream_t s);
+void launch_beliefs(BeliefArgs b, bool do_cam, bool do_lmk, hipStream_t s, bool ev = false);
+// per-tile records of ring slots [0, n_slots) -> out[slot]: one gbp_eval_out-shaped result per slot (may be mapped host memory)
+void launch_eval_fold(const EvalRide& ev, uint32_t n_slots, void* out, hipStream_t s);
+// the riding metric of the CURRENT beliefs (a piece's last iteration: no sweep follows) into ring slot counter - 1
+void launch_eval_ride(const EvalRide& ev, const uint32_t* row_cam, const uint32_t* lmk_idx, const float4* lmsg, const float4* fac, const float* K9_dev, hipStream_t s);
 // workgroups of a k_persist launch for a graph; with_metric: + one wave per camera for the metric roles where the placement allows
 uint32_t persist_blocks(uint32_t n_tiles, uint32_t n_cams, uint32_t n_lmks, bool with_metric);
 int persist_max_resident_blocks();                                            // how many of them this GPU keeps resident at once

@@ -431,6 +431,182 @@ GBP_DEV void factor_update(float (&fac)[56], const float (&cm)[28], float (&mu)[
 }  // namespace
 
 // =================================================================================================
+// Metric: util.cpp:74-144.  Variable means by an fp64 partial-pivot solve of the fp32 belief
+// (stands in for Eigen's general inverse), residuals in fp32, sums in fp64.
+// =================================================================================================
+// Every loop has compile-time bounds and every row swap is a select, so the 6 x 7 fp64 tableau lives in registers
+// (no scratch: this kernel sits on the critical path of the per-iteration metric of small graphs).
+template <int N>
+GBP_DEV void solve_pivot(const float* A, int lda, const float* b, float* x) {
+  double M[N][N + 1];
+  GBP_UNROLL
+  for (int i = 0; i < N; ++i) {
+    GBP_UNROLL
+    for (int j = 0; j < N; ++j) M[i][j] = A[i * lda + j];
+    M[i][N] = b[i];
+  }
+  GBP_UNROLL
+  for (int k = 0; k < N; ++k) {
+    int piv = k;
+    double best = fabs(M[k][k]);
+    GBP_UNROLL
+    for (int i = k + 1; i < N; ++i)
+      if (fabs(M[i][k]) > best) { best = fabs(M[i][k]); piv = i; }
+    GBP_UNROLL
+    for (int i = k + 1; i < N; ++i) {      // swap rows k and piv (at most one i matches)
+      const bool sw = piv == i;
+      GBP_UNROLL
+      for (int j = 0; j <= N; ++j) {
+        const double t = M[k][j];
+        M[k][j] = sw ? M[i][j] : t;
+        M[i][j] = sw ? t : M[i][j];
+      }
+    }
+    GBP_UNROLL
+    for (int i = k + 1; i < N; ++i) {
+      const double f = M[i][k] / M[k][k];
+      GBP_UNROLL
+      for (int j = k; j <= N; ++j) M[i][j] -= f * M[k][j];
+    }
+  }
+  GBP_UNROLL
+  for (int i = N - 1; i >= 0; --i) {
+    double s = M[i][N];
+    GBP_UNROLL
+    for (int j = i + 1; j < N; ++j) s -= M[i][j] * (double)x[j];
+    x[i] = (float)(s / M[i][i]);
+  }
+}
+
+// health check (SURVEY App. C-2): a belief Lambda is usable by inv6x6 / inv3x3 only while the un-pivoted
+// LDL^T pivots of its lower triangle (matlib.cpp:193-206) stay positive; a non-PD landmark belief is the
+// early-warning sign of the blow-ups seen on fr1xyz.
+template <int N>
+GBP_DEV bool ldl_pivots_positive(const float* A, int lda) {
+  double L[N][N], D[N];
+  bool ok = true;
+  GBP_UNROLL
+  for (int j = 0; j < N; ++j) {
+    double d = A[j * lda + j];
+    GBP_UNROLL
+    for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k] * D[k];
+    D[j] = d;
+    if (!(d > 0.0)) ok = false;
+    GBP_UNROLL
+    for (int i = j + 1; i < N; ++i) {
+      double v = A[i * lda + j];
+      GBP_UNROLL
+      for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k] * D[k];
+      L[i][j] = v / d;
+    }
+  }
+  return ok;
+}
+
+// One factor's share of the metric (util.cpp:95-129): reprojection residual of the belief means, in two steps — the rotation
+// of the camera's mean (eigenso3exp, util.cpp:20-32: a function of the camera alone), then the residual of one factor.  k_eval and
+// the metric phase of k_persist evaluate both per factor (eval_factor), the metric that rides in the two-kernel path evaluates
+// the first once per camera (k_beliefs<EV>) and the second per factor (k_sweep<EV>): the same operations on the same operands.
+GBP_DEV void eval_cam_rot(const float (&cm)[6], float (&R)[9]) {
+  // eigenso3exp, util.cpp:20-32 (single expression)
+  const float th = sqrtf(cm[3] * cm[3] + cm[4] * cm[4] + cm[5] * cm[5]);
+  GBP_UNROLL
+  for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.f : 0.f;
+  if (!(th < 1e-6)) {
+    const float W[9] = {0.f, -cm[5], cm[4], cm[5], 0.f, -cm[3], -cm[4], cm[3], 0.f};
+    const float sa = sinf(th) / th, sb = (1 - cosf(th)) / (th * th);
+    GBP_UNROLL
+    for (int r = 0; r < 3; ++r) {
+      GBP_UNROLL
+      for (int c = 0; c < 3; ++c) {
+        float ww = 0.f;
+        GBP_UNROLL
+        for (int k = 0; k < 3; ++k) ww += W[r * 3 + k] * W[k * 3 + c];
+        R[r * 3 + c] = R[r * 3 + c] + (sa * W[r * 3 + c] + sb * ww);
+      }
+    }
+  }
+}
+template <class KF>     // Kd[i]: the pin-hole matrix from a device pointer (k_eval) or from the kernel arguments
+GBP_DEV void eval_residual(const float (&R)[9], const float (&t)[3], const float (&lmu)[3], float z0, float z1, KF&& Kd, double& s_norm, double& s_half) {
+  float pcf[3], pr[2];
+  GBP_UNROLL
+  for (int i = 0; i < 3; ++i) pcf[i] = (R[i * 3] * lmu[0] + R[i * 3 + 1] * lmu[1]) + R[i * 3 + 2] * lmu[2];
+  GBP_UNROLL
+  for (int i = 0; i < 3; ++i) pcf[i] += t[i];
+  GBP_UNROLL
+  for (int i = 0; i < 2; ++i) pr[i] = ((Kd[i * 3] * pcf[0] + Kd[i * 3 + 1] * pcf[1]) + Kd[i * 3 + 2] * pcf[2]) / pcf[2];
+  const float r0 = z0 - pr[0], r1 = z1 - pr[1];
+  s_norm += (double)sqrtf(r0 * r0 + r1 * r1);
+  s_half += (double)(float)(0.5 * (double)(r0 * r0 + r1 * r1));
+}
+GBP_DEV void eval_factor(const float (&cm)[6], const float (&lmu)[3], float z0, float z1, const float* Kd, double& s_norm, double& s_half) {
+  float R[9];
+  eval_cam_rot(cm, R);
+  const float t[3] = {cm[0], cm[1], cm[2]};
+  eval_residual(R, t, lmu, z0, z1, Kd, s_norm, s_half);
+}
+// THE ORDER OF THE METRIC'S SUMS (every path produces exactly these fp64 additions):
+//   w_t  = the 64 lane values of tile t (0 + the factor's term) reduced by the shuffle tree below;
+//   B_b  = ((w_4b + w_4b+1) + w_4b+2) + w_4b+3      the 256 factor positions of sweep workgroup b;
+//   S_j  = B_j + B_j+N + B_j+2N + ...  (serially, from 0)   N = eval_blocks(n_tiles) <= 1 024 block sums travel to the host;
+//   sum  = S_0 + S_1 + ... (serially, on the host: sum_eval in gbp_capi.cpp).
+// (lane 0 ends with the sum; what the other lanes end with is not used.  The tree is s += shfl_down(s, off) for off = 32, 16, 8,
+// 4, 2, 1; from 8 on the lanes that still matter read inside their own DPP row: a row shift — two v_mov_b32_dpp per double — instead
+// of two ds_bpermute round trips through the LDS crossbar per double and step.  Same operands, same additions.)
+GBP_DEV double row_shl_f64(double v, const int ctrl_row_shl) {
+  const long long b = __double_as_longlong(v);
+  int lo = (int)(unsigned)b, hi = (int)(unsigned)((unsigned long long)b >> 32);
+  switch (ctrl_row_shl) {      // (the DPP control is an immediate)
+    case 8: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x108, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x108, 0xF, 0xF, false); break;
+    case 4: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x104, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x104, 0xF, 0xF, false); break;
+    case 2: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x102, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x102, 0xF, 0xF, false); break;
+    default: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x101, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x101, 0xF, 0xF, false); break;
+  }
+  return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+GBP_DEV void eval_wave_tree(double& s_norm, double& s_half) {
+  s_norm += __shfl_down(s_norm, 32); s_half += __shfl_down(s_half, 32);
+  s_norm += __shfl_down(s_norm, 16); s_half += __shfl_down(s_half, 16);
+  s_norm += row_shl_f64(s_norm, 8); s_half += row_shl_f64(s_half, 8);
+  s_norm += row_shl_f64(s_norm, 4); s_half += row_shl_f64(s_half, 4);
+  s_norm += row_shl_f64(s_norm, 2); s_half += row_shl_f64(s_half, 2);
+  s_norm += row_shl_f64(s_norm, 1); s_half += row_shl_f64(s_half, 1);
+}
+
+// One tile's share of the riding metric (EvalRide in gbp_kernels.h): the residual of every factor from its state word, its
+// measurement and the metric records of its camera (q0..q2) and landmark (lq); the wave's partial sums go to slot counter - 1 of
+// the ring, at index TILE.  Every lane computes (no branch for the callers' loads to sink into); the launch is the same for every
+// iteration of a burst, the first included: the slot comes from a counter in device memory, and while that is 0 there is nothing
+// to store.  Wave slot 0 also collects what the belief update counted and zeroes the counters for the next one.
+// `done` = *ev.counter, read by the caller BEFORE its first store: behind stores the load would be a vector load, and waiting for
+// it would wait for every store the wave has in flight (vmcnt counts both, in order: +1.5 us at the end of every sweep wave).
+template <class KF>
+GBP_DEV void ride_metric(const EvalRide& ev, uint32_t done, uint32_t ws, uint32_t tile, uint32_t lane, int packed, float z0, float z1,
+                         const float4 q0, const float4 q1, const float4 q2, const float4 lq, KF&& K) {
+  const uint32_t flags = (uint32_t)packed & 7u;
+  const bool pad = (flags & kFlagPad) != 0, counts = !pad && (flags & kFlagActive) != 0;
+  const float R[9] = {q0.x, q0.y, q0.z, q1.x, q1.y, q1.z, q2.x, q2.y, q2.z}, t[3] = {q0.w, q1.w, q2.w}, lmu[3] = {lq.x, lq.y, lq.z};
+  double r_norm = 0, r_half = 0;
+  eval_residual(R, t, lmu, z0, z1, K, r_norm, r_half);
+  double s_norm = counts ? r_norm : 0.0, s_half = counts ? r_half : 0.0;
+  eval_wave_tree(s_norm, s_half);
+  const uint32_t n_act = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(counts));
+  const uint32_t n_rel = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(!pad && (packed >> 3) == -ev.num_undamped));
+  const uint32_t n_rob = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(!pad && (flags & kFlagRobust) != 0));
+  if (done != 0u && lane == 0) {
+    const uint32_t slot = done - 1u;
+    EvalRec r;
+    r.sum_norm = s_norm; r.sum_half_sq = s_half; r.n_active = n_act; r.n_relin = n_rel; r.n_robust = n_rob; r.pad = 0;
+    ev.part[(size_t)slot * ev.n_tiles + tile] = r;
+    if (ws == 0u) {
+      ev.slot_health[2 * (size_t)slot] = ev.health[0]; ev.slot_health[2 * (size_t)slot + 1] = ev.health[1];
+      ev.health[0] = 0ull; ev.health[1] = 0ull;
+    }
+  }
+}
+
+// =================================================================================================
 // k_sweep: one lane = one factor.
 // =================================================================================================
 // HOIST = true: the belief means are per-VARIABLE quantities (inf2mean of the camera / landmark belief,
@@ -443,12 +619,14 @@ GBP_DEV void factor_update(float (&fac)[56], const float (&cm)[28], float (&mu)[
 constexpr int kWpb = 4;      // wavefronts per workgroup of the sweep (the waves of a workgroup share nothing)
 // POL: cache policy of the two message streams (SweepArgs.policy, chosen per graph shape by gbp_capi.cpp; a template parameter,
 // not a branch on the flag: with both load sequences behind a branch the non-temporal path lost 1.2 %)
-template <bool HOIST, uint32_t POL = 0>
+// EV: the metric of the PREVIOUS iteration rides in this sweep (EvalRide in gbp_kernels.h)
+template <bool HOIST, uint32_t POL = 0, bool EV = false>
 GBP_DEV void sweep_tile(const SweepArgs& a, const uint32_t wslot) {
   // (the slot is wave-uniform: as an SGPR it turns the permutation look-up into one scalar load)
   const uint32_t ws = (uint32_t)__builtin_amdgcn_readfirstlane((int)wslot);
   const uint32_t tile = a.tile_perm ? a.tile_perm[ws] : ws;
   const uint32_t lane = threadIdx.x & 63, p = tile * 64 + lane;
+  const uint32_t ev_done = EV ? (uint32_t)__builtin_amdgcn_readfirstlane((int)*a.ev.counter) : 0u;     // (a scalar load, up here)
 
   const uint32_t cam_i = a.row_cam[p >> 4];
   const uint32_t lmk_i = __builtin_nontemporal_load(a.lmk_idx + p);
@@ -492,6 +670,20 @@ GBP_DEV void sweep_tile(const SweepArgs& a, const uint32_t wslot) {
   }
   load_rec<kCamRec4>(a.camb + (size_t)cam_i * kCamRec4, cb);
   load_rec<kLmkRec4>(a.lmkb + (size_t)lmk_i * kLmkRec4, lb);
+  // EV: the camera's metric record (one address per 16-lane row) and the landmark's metric mean (a 16-byte gather from a table
+  // 1/4 the size of the beliefs') go out WITH the belief gathers — unconditionally: pads index 0 — and wait in a wave-private
+  // LDS area for the end of the tile, where the registers are free: 16 more live registers in this prologue (50 loads in
+  // flight, 236 of 256 VGPRs) made the compiler issue the belief gathers BEHIND the metric — two dependent round trips per
+  // wave, +8 us per sweep (the ISA showed it, profiles/r05_default_loop.md).
+  __shared__ float4 ev_stage[EV ? kWpb : 1][EV ? 64 * 4 : 1];
+  float4 evq0, evq1, evq2, evq3;
+  if (EV) {
+    evq0 = a.ev.cam_rec[(size_t)cam_i * 3]; evq1 = a.ev.cam_rec[(size_t)cam_i * 3 + 1]; evq2 = a.ev.cam_rec[(size_t)cam_i * 3 + 2];
+    evq3 = a.ev.lmk_mean[lmk_i];
+    // (a compiler barrier: without it the belief gathers above — used only by active lanes — are sunk into that branch, behind
+    // the wait for the metric records)
+    asm volatile("" ::: "memory");
+  }
   // per-factor scalar state rides in the pad slots of the landmark-message record (read and rewritten
   // every sweep anyway): [3] damping, [13] (damping_count << 3) | flags, [14] measurement variance
   float damping = lm[3];
@@ -504,6 +696,13 @@ GBP_DEV void sweep_tile(const SweepArgs& a, const uint32_t wslot) {
   float K[9];
   GBP_UNROLL
   for (int i = 0; i < 9; ++i) K[i] = a.K[i];
+
+  const int ev_packed = packed;      // EV: the factor's state word as the sweep of the evaluated iteration left it
+  const float ev_z0 = fac[54], ev_z1 = fac[55];
+  if (EV) {
+    float4* park = ev_stage[threadIdx.x >> 6];
+    park[lane] = evq0; park[64 + lane] = evq1; park[128 + lane] = evq2; park[192 + lane] = evq3;
+  }
 
   float oc_eta[6], oc_lam[36], ol[16];
   bool relin;
@@ -577,11 +776,17 @@ GBP_DEV void sweep_tile(const SweepArgs& a, const uint32_t wslot) {
     if (!HOIST) store_tile<kMuG>(a.mu, tile, lane, mu);
     if (relin) store_tile<kFacG>(a.fac, tile, lane, fac);
   }
+  if (EV) {
+    // The metric of the iteration that has just ended (EvalRide in gbp_kernels.h), behind this tile's own work: the factor's
+    // state word as ITS sweep left it, the measurement, the metric records parked above.
+    const float4* park = ev_stage[threadIdx.x >> 6];
+    ride_metric(a.ev, ev_done, ws, tile, lane, ev_packed, ev_z0, ev_z1, park[lane], park[64 + lane], park[128 + lane], park[192 + lane], K);
+  }
 }
 
-template <bool HOIST, uint32_t POL = 0>
+template <bool HOIST, uint32_t POL = 0, bool EV = false>
 __global__ __launch_bounds__(64 * kWpb) void k_sweep(const SweepArgs a) {
-  sweep_tile<HOIST, POL>(a, blockIdx.x * kWpb + (threadIdx.x >> 6));
+  sweep_tile<HOIST, POL, EV>(a, blockIdx.x * kWpb + (threadIdx.x >> 6));
 }
 
 // =================================================================================================
@@ -643,8 +848,12 @@ GBP_DEV void cam_mean(REC&& cb, float (&x0c)[6]) {
   solve6_lower([&](int i, int j) { return cb[8 + i * 6 + j]; }, [&](int k) { return cb[k]; }, x0c);
 }
 
-__global__ __launch_bounds__(256) void k_beliefs(const BeliefArgs b) {
+// EV: the belief owners also leave the METRIC RECORDS of the new beliefs (EvalRide in gbp_kernels.h): what k_means computes.
+template <bool EV>
+GBP_DEV void beliefs_body(const BeliefArgs& b) {
   __shared__ float sh[4][48];
+  __shared__ float lrec[EV ? 64 : 1][13];      // EV: the beliefs of the workgroup's 64 landmarks (eta 3, Lambda 9; 13: bank spread)
+  if (EV && blockIdx.x == 0 && threadIdx.x == 0) *b.ev.counter = *b.ev.counter + 1u;     // one more iteration of the burst done (read by the NEXT sweep)
   if (blockIdx.x < b.cam_blocks) {
     const uint32_t w = threadIdx.x >> 6, j = threadIdx.x & 63;
     const uint32_t c = blockIdx.x * 4 + w;
@@ -741,6 +950,33 @@ __global__ __launch_bounds__(256) void k_beliefs(const BeliefArgs b) {
         cam_lin_pack(cl, q);
         GBP_UNROLL
         for (int g = 0; g < kCamLin4; ++g) b.cam_lin[(size_t)cj * kCamLin4 + g] = q[g];
+      }
+    }
+    if (EV && (w == 1 || w == 2) && j < 4) {
+      // The metric's share of a camera, on the workgroup's OTHER waves (three long serial chains on one lane would set the
+      // length of the whole kernel): wave 1 solves the fp64 pivoted means of the four cameras (util.cpp:103-105 stand-in, as
+      // k_means) and leaves rotation + translation for the residuals, wave 2 checks the LDL^T pivots.  Both read the belief
+      // (eta at sh[.][0..5], Lambda at sh[.][8..43]); wave 0 writes sh[.][6] only.  The 6 x 7 fp64 tableau takes the kernel from
+      // 68 to 96 VGPRs = from 7 to 5 waves per SIMD, which costs the landmark part 1.5 us; measured and worse: the occupancy
+      // pinned at 7 (the tableau spills: 20.1 us against 18.3), the tableau in LDS (21.4 - 25.1 us: the camera chain then sets the
+      // kernel's length) — profiles/r05_default_loop.md.
+      const uint32_t cj = blockIdx.x * 4 + j;
+      if (cj < b.n_cams) {
+        if (w == 1) {
+          float xm[6], R[9];
+          solve_pivot<6>(sh[j] + 8, 6, sh[j], xm);
+          bool finite = true;
+          GBP_UNROLL
+          for (int i = 0; i < 6; ++i) finite &= (xm[i] - xm[i] == 0.f);
+          if (!finite) atomicAdd(&b.ev.health[0], 1ull);
+          eval_cam_rot(xm, R);
+          float4* rec = b.ev.cam_rec + (size_t)cj * 3;
+          rec[0] = make_float4(R[0], R[1], R[2], xm[0]);
+          rec[1] = make_float4(R[3], R[4], R[5], xm[1]);
+          rec[2] = make_float4(R[6], R[7], R[8], xm[2]);
+        } else if (!ldl_pivots_positive<6>(sh[j] + 8, 6)) {
+          atomicAdd(&b.ev.health[1], 1ull);
+        }
       }
     }
     __syncthreads();
@@ -845,6 +1081,33 @@ __global__ __launch_bounds__(256) void k_beliefs(const BeliefArgs b) {
       u[1] = (used.y - x0l[1]) * (used.y - x0l[1]);
       u[2] = (used.z - x0l[2]) * (used.z - x0l[2]);
       mu[0] = make_float4(x0l[0], x0l[1], x0l[2], 0.f);
+      if (EV) {   // the belief (eta 3, Lambda 9) for the metric below
+        GBP_UNROLL
+        for (int i = 0; i < 3; ++i) lrec[threadIdx.x >> 2][i] = rec[i];
+        GBP_UNROLL
+        for (int i = 0; i < 9; ++i) lrec[threadIdx.x >> 2][3 + i] = rec[4 + i];
+      }
+    }
+    if (EV) {
+      // The landmarks' metric means (what k_means computes: fp64 pivoted solve, LDL^T pivots) — long fp64 chains that one lane
+      // in four would run at a quarter of the wave's width in each of the four waves: the 64 landmarks of the workgroup meet in
+      // LDS and ONE wave solves them, all lanes busy (k_beliefs<EV> 18.6 -> measured in profiles/r05_default_loop.md).
+      __syncthreads();
+      if (threadIdx.x < 64) {
+        const uint32_t le = lb * 64 + threadIdx.x;
+        if (le < b.n_lmks) {
+          float r12[12], x[3];
+          GBP_UNROLL
+          for (int i = 0; i < 12; ++i) r12[i] = lrec[threadIdx.x][i];
+          solve_pivot<3>(r12 + 3, 3, r12, x);
+          bool finite = true;
+          GBP_UNROLL
+          for (int i = 0; i < 3; ++i) finite &= (x[i] - x[i] == 0.f);
+          b.ev.lmk_mean[le] = make_float4(x[0], x[1], x[2], 0.f);
+          if (!finite) atomicAdd(&b.ev.health[0], 1ull);
+          if (!ldl_pivots_positive<3>(r12 + 3, 3)) atomicAdd(&b.ev.health[1], 1ull);
+        }
+      }
     }
     const float u0 = __shfl(u[0], 0, 4), u1 = __shfl(u[1], 0, 4), u2 = __shfl(u[2], 0, 4);
     if (q == 0) acc.w = u0;                       // record slot 3
@@ -852,134 +1115,8 @@ __global__ __launch_bounds__(256) void k_beliefs(const BeliefArgs b) {
   }
   if (live) b.lmkb[(size_t)l * 4 + q] = acc;
 }
-
-// =================================================================================================
-// Metric: util.cpp:74-144.  Variable means by an fp64 partial-pivot solve of the fp32 belief
-// (stands in for Eigen's general inverse), residuals in fp32, sums in fp64.
-// =================================================================================================
-// Every loop has compile-time bounds and every row swap is a select, so the 6 x 7 fp64 tableau lives in registers
-// (no scratch: this kernel sits on the critical path of the per-iteration metric of small graphs).
-template <int N>
-GBP_DEV void solve_pivot(const float* A, int lda, const float* b, float* x) {
-  double M[N][N + 1];
-  GBP_UNROLL
-  for (int i = 0; i < N; ++i) {
-    GBP_UNROLL
-    for (int j = 0; j < N; ++j) M[i][j] = A[i * lda + j];
-    M[i][N] = b[i];
-  }
-  GBP_UNROLL
-  for (int k = 0; k < N; ++k) {
-    int piv = k;
-    double best = fabs(M[k][k]);
-    GBP_UNROLL
-    for (int i = k + 1; i < N; ++i)
-      if (fabs(M[i][k]) > best) { best = fabs(M[i][k]); piv = i; }
-    GBP_UNROLL
-    for (int i = k + 1; i < N; ++i) {      // swap rows k and piv (at most one i matches)
-      const bool sw = piv == i;
-      GBP_UNROLL
-      for (int j = 0; j <= N; ++j) {
-        const double t = M[k][j];
-        M[k][j] = sw ? M[i][j] : t;
-        M[i][j] = sw ? t : M[i][j];
-      }
-    }
-    GBP_UNROLL
-    for (int i = k + 1; i < N; ++i) {
-      const double f = M[i][k] / M[k][k];
-      GBP_UNROLL
-      for (int j = k; j <= N; ++j) M[i][j] -= f * M[k][j];
-    }
-  }
-  GBP_UNROLL
-  for (int i = N - 1; i >= 0; --i) {
-    double s = M[i][N];
-    GBP_UNROLL
-    for (int j = i + 1; j < N; ++j) s -= M[i][j] * (double)x[j];
-    x[i] = (float)(s / M[i][i]);
-  }
-}
-
-// health check (SURVEY App. C-2): a belief Lambda is usable by inv6x6 / inv3x3 only while the un-pivoted
-// LDL^T pivots of its lower triangle (matlib.cpp:193-206) stay positive; a non-PD landmark belief is the
-// early-warning sign of the blow-ups seen on fr1xyz.
-template <int N>
-GBP_DEV bool ldl_pivots_positive(const float* A, int lda) {
-  double L[N][N], D[N];
-  bool ok = true;
-  GBP_UNROLL
-  for (int j = 0; j < N; ++j) {
-    double d = A[j * lda + j];
-    GBP_UNROLL
-    for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k] * D[k];
-    D[j] = d;
-    if (!(d > 0.0)) ok = false;
-    GBP_UNROLL
-    for (int i = j + 1; i < N; ++i) {
-      double v = A[i * lda + j];
-      GBP_UNROLL
-      for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k] * D[k];
-      L[i][j] = v / d;
-    }
-  }
-  return ok;
-}
-
-// One factor's share of the metric (util.cpp:95-129): reprojection residual of the belief means.  Shared by k_eval and
-// by the metric phase of k_persist, so that both evaluate it with the same operations in the same order.
-GBP_DEV void eval_factor(const float (&cm)[6], const float (&lmu)[3], float z0, float z1, const float* Kd, double& s_norm, double& s_half) {
-  // eigenso3exp, util.cpp:20-32 (single expression)
-  const float th = sqrtf(cm[3] * cm[3] + cm[4] * cm[4] + cm[5] * cm[5]);
-  float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-  if (!(th < 1e-6)) {
-    const float W[9] = {0.f, -cm[5], cm[4], cm[5], 0.f, -cm[3], -cm[4], cm[3], 0.f};
-    const float sa = sinf(th) / th, sb = (1 - cosf(th)) / (th * th);
-    for (int r = 0; r < 3; ++r)
-      for (int c = 0; c < 3; ++c) {
-        float ww = 0.f;
-        for (int k = 0; k < 3; ++k) ww += W[r * 3 + k] * W[k * 3 + c];
-        R[r * 3 + c] = R[r * 3 + c] + (sa * W[r * 3 + c] + sb * ww);
-      }
-  }
-  float pcf[3], pr[2];
-  for (int i = 0; i < 3; ++i) pcf[i] = (R[i * 3] * lmu[0] + R[i * 3 + 1] * lmu[1]) + R[i * 3 + 2] * lmu[2];
-  for (int i = 0; i < 3; ++i) pcf[i] += cm[i];
-  for (int i = 0; i < 2; ++i) pr[i] = ((Kd[i * 3] * pcf[0] + Kd[i * 3 + 1] * pcf[1]) + Kd[i * 3 + 2] * pcf[2]) / pcf[2];
-  const float r0 = z0 - pr[0], r1 = z1 - pr[1];
-  s_norm += (double)sqrtf(r0 * r0 + r1 * r1);
-  s_half += (double)(float)(0.5 * (double)(r0 * r0 + r1 * r1));
-}
-// block reduction of the metric partials in a fixed order (deterministic): lane tree via shuffles, then thread 0 adds the 4
-// wave sums; all 256 threads of the workgroup call it
-GBP_DEV void eval_block_reduce(double s_norm, double s_half, unsigned long long n_act, unsigned long long n_rel, unsigned long long n_rob,
-                               DeviceEval* out) {
-  __shared__ double sh_d[2][4];
-  __shared__ unsigned long long sh_u[3][4];
-  for (int off = 32; off > 0; off >>= 1) {
-    s_norm += __shfl_down(s_norm, off);
-    s_half += __shfl_down(s_half, off);
-    n_act += __shfl_down(n_act, off);
-    n_rel += __shfl_down(n_rel, off);
-    n_rob += __shfl_down(n_rob, off);
-  }
-  const uint32_t w = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) {
-    sh_d[0][w] = s_norm; sh_d[1][w] = s_half;
-    sh_u[0][w] = n_act; sh_u[1][w] = n_rel; sh_u[2][w] = n_rob;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    DeviceEval o;
-    o.sum_norm = ((sh_d[0][0] + sh_d[0][1]) + sh_d[0][2]) + sh_d[0][3];
-    o.sum_half_sq = ((sh_d[1][0] + sh_d[1][1]) + sh_d[1][2]) + sh_d[1][3];
-    o.n_active = sh_u[0][0] + sh_u[0][1] + sh_u[0][2] + sh_u[0][3];
-    o.n_relin = sh_u[1][0] + sh_u[1][1] + sh_u[1][2] + sh_u[1][3];
-    o.n_robust = sh_u[2][0] + sh_u[2][1] + sh_u[2][2] + sh_u[2][3];
-    o.pad = 0;
-    *out = o;
-  }
-}
+__global__ __launch_bounds__(256) void k_beliefs(const BeliefArgs b) { beliefs_body<false>(b); }
+__global__ __launch_bounds__(256) void k_beliefs_ev(const BeliefArgs b) { beliefs_body<true>(b); }
 
 // =================================================================================================
 // k_persist: n iterations of {k_sweep; k_beliefs} in ONE launch, for graphs whose workgroups are all resident at once.
@@ -1240,7 +1377,7 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
       }
     }
     DeviceEval* slots = A.ev.slots + (size_t)(A.ev.each ? k : 0u) * A.ev.stride;
-    if (has_tile) {     // the lane tree of eval_block_reduce, then one record per wave
+    if (has_tile) {     // the lane tree of eval_wave_tree, then one record per wave
       for (int off = 32; off > 0; off >>= 1) {
         s_norm += __shfl_down(s_norm, off);
         s_half += __shfl_down(s_half, off);
@@ -1647,28 +1784,110 @@ __global__ __launch_bounds__(256) void k_eval(const uint32_t* __restrict__ row_c
                                               int num_undamped, DeviceEval* partials, const unsigned long long* health,
                                               unsigned long long* health_out, uint32_t n_tiles) {
   if (blockIdx.x == 0 && threadIdx.x == 0) { health_out[0] = health[0]; health_out[1] = health[1]; }   // k_means has finished (stream order)
-  double s_norm = 0, s_half = 0;
-  unsigned long long n_act = 0, n_rel = 0, n_rob = 0;
-  const uint32_t total = n_tiles * 64;
-  for (uint32_t p = blockIdx.x * 256 + threadIdx.x; p < total; p += gridDim.x * 256) {
+  // block j produces S_j (see "THE ORDER OF THE METRIC'S SUMS"): one 256-factor block of the sweep at a time, wave w = tile 4b + w
+  __shared__ double sh_d[2][4];
+  __shared__ unsigned sh_u[3][4];
+  const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  DeviceEval o;
+  o.sum_norm = 0; o.sum_half_sq = 0; o.n_active = 0; o.n_relin = 0; o.n_robust = 0; o.pad = 0;
+  for (uint32_t b = blockIdx.x; b < n_tiles / 4; b += gridDim.x) {
+    const uint32_t tile = b * 4 + w, p = tile * 64 + lane;
     const int packed = __float_as_int(lmsg[(size_t)p * 4 + 3].y);
     const uint32_t flags = (uint32_t)packed & 7u;
-    if (flags & kFlagPad) continue;
-    if (flags & kFlagRobust) ++n_rob;
-    if ((packed >> 3) == -num_undamped) ++n_rel;
-    if (!(flags & kFlagActive)) continue;
-    const uint32_t cam_i = row_cam[p >> 4], lmk_i = lmk_idx[p];
-    const uint32_t tile = p >> 6, lane = p & 63;
-    const float4 zg = fac[((size_t)tile * kFacG + 13) * 64 + lane];  // floats 52..55: z = .z, .w
-    float cm[6], lmu[3];
-    for (int i = 0; i < 6; ++i) cm[i] = cam_mu[(size_t)cam_i * 6 + i];
-    for (int i = 0; i < 3; ++i) lmu[i] = lmk_mu[(size_t)lmk_i * 3 + i];
-    eval_factor(cm, lmu, zg.z, zg.w, Kd, s_norm, s_half);
-    ++n_act;
+    const bool pad = (flags & kFlagPad) != 0, active = !pad && (flags & kFlagActive) != 0;
+    double s_norm = 0, s_half = 0;
+    if (active) {
+      const uint32_t cam_i = row_cam[p >> 4], lmk_i = lmk_idx[p];
+      const float4 zg = fac[((size_t)tile * kFacG + 13) * 64 + lane];  // floats 52..55: z = .z, .w
+      float cm[6], lmu[3];
+      for (int i = 0; i < 6; ++i) cm[i] = cam_mu[(size_t)cam_i * 6 + i];
+      for (int i = 0; i < 3; ++i) lmu[i] = lmk_mu[(size_t)lmk_i * 3 + i];
+      eval_factor(cm, lmu, zg.z, zg.w, Kd, s_norm, s_half);
+    }
+    eval_wave_tree(s_norm, s_half);
+    const unsigned n_act = (unsigned)__popcll(__builtin_amdgcn_ballot_w64(active));
+    const unsigned n_rel = (unsigned)__popcll(__builtin_amdgcn_ballot_w64(!pad && (packed >> 3) == -num_undamped));
+    const unsigned n_rob = (unsigned)__popcll(__builtin_amdgcn_ballot_w64(!pad && (flags & kFlagRobust) != 0));
+    if (lane == 0) { sh_d[0][w] = s_norm; sh_d[1][w] = s_half; sh_u[0][w] = n_act; sh_u[1][w] = n_rel; sh_u[2][w] = n_rob; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      o.sum_norm += ((sh_d[0][0] + sh_d[0][1]) + sh_d[0][2]) + sh_d[0][3];
+      o.sum_half_sq += ((sh_d[1][0] + sh_d[1][1]) + sh_d[1][2]) + sh_d[1][3];
+      o.n_active += sh_u[0][0] + sh_u[0][1] + sh_u[0][2] + sh_u[0][3];
+      o.n_relin += sh_u[1][0] + sh_u[1][1] + sh_u[1][2] + sh_u[1][3];
+      o.n_robust += sh_u[2][0] + sh_u[2][1] + sh_u[2][2] + sh_u[2][3];
+    }
+    __syncthreads();
   }
-  eval_block_reduce(s_norm, s_half, n_act, n_rel, n_rob, partials + blockIdx.x);
+  if (threadIdx.x == 0) partials[blockIdx.x] = o;
 }
 
+// The riding metric of a piece's LAST iteration, which no sweep follows: the same per-tile records from the same metric records
+// (one wave per tile, ride_metric), into slot counter - 1.
+__global__ __launch_bounds__(256) void k_eval_ride(const EvalRide ev, const uint32_t* __restrict__ row_cam, const uint32_t* __restrict__ lmk_idx,
+                                                   const float4* __restrict__ lmsg, const float4* __restrict__ fac, const float* __restrict__ Kd) {
+  const uint32_t ws = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, p = ws * 64 + lane;
+  const uint32_t cam_i = row_cam[p >> 4], lmk_i = lmk_idx[p];
+  const int packed = __float_as_int(lmsg[(size_t)p * 4 + 3].y);
+  const float4 zg = fac[((size_t)ws * kFacG + 13) * 64 + lane];  // floats 52..55: z = .z, .w
+  const float4 q0 = ev.cam_rec[(size_t)cam_i * 3], q1 = ev.cam_rec[(size_t)cam_i * 3 + 1], q2 = ev.cam_rec[(size_t)cam_i * 3 + 2];
+  const float4 lq = ev.lmk_mean[lmk_i];
+  ride_metric(ev, (uint32_t)__builtin_amdgcn_readfirstlane((int)*ev.counter), ws, ws, lane, packed, zg.z, zg.w, q0, q1, q2, lq, Kd);
+}
+
+// The per-tile records k_sweep<EV> left in ring slot blockIdx.x reduced to ONE result, in the order of every other metric (see
+// "THE ORDER OF THE METRIC'S SUMS"): thread j forms the block sum S_j k_eval would have produced, thread 0 then adds S_0, S_1, ...
+// serially — what the host does with k_eval's block sums, done here so that 56 bytes per iteration cross PCIe instead of 49 KB.
+struct EvalSum {       // == gbp_eval_out (include/gbp_mi355x.h)
+  double sum_norm, sum_half_sq;
+  unsigned long long n_active, n_relin, n_robust, n_nonfinite, n_nonpd;
+};
+__global__ __launch_bounds__(1024) void k_eval_fold(const EvalRide ev, EvalSum* out, uint32_t n_sums) {
+  __shared__ double sh_d[2][1024];
+  __shared__ unsigned sh_u[3][1024];
+  const uint32_t j = threadIdx.x, slot = blockIdx.x, nb = ev.n_tiles / 4;
+  const EvalRec* part = ev.part + (size_t)slot * ev.n_tiles;
+  double s_norm = 0, s_half = 0;
+  unsigned n_act = 0, n_rel = 0, n_rob = 0;
+  if (j < n_sums) {
+    for (uint32_t b0 = j; b0 < nb; b0 += 4 * n_sums) {      // four blocks' records in flight at once (clamped, unconditional), added in order
+      EvalRec w[4][4];
+      GBP_UNROLL
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t b = b0 + (uint32_t)u * n_sums < nb ? b0 + (uint32_t)u * n_sums : b0;
+        GBP_UNROLL
+        for (int k = 0; k < 4; ++k) w[u][k] = part[4 * (size_t)b + k];
+      }
+      GBP_UNROLL
+      for (int u = 0; u < 4; ++u) {
+        if (b0 + (uint32_t)u * n_sums >= nb) break;
+        s_norm += ((w[u][0].sum_norm + w[u][1].sum_norm) + w[u][2].sum_norm) + w[u][3].sum_norm;
+        s_half += ((w[u][0].sum_half_sq + w[u][1].sum_half_sq) + w[u][2].sum_half_sq) + w[u][3].sum_half_sq;
+        n_act += w[u][0].n_active + w[u][1].n_active + w[u][2].n_active + w[u][3].n_active;
+        n_rel += w[u][0].n_relin + w[u][1].n_relin + w[u][2].n_relin + w[u][3].n_relin;
+        n_rob += w[u][0].n_robust + w[u][1].n_robust + w[u][2].n_robust + w[u][3].n_robust;
+      }
+    }
+  }
+  sh_d[0][j] = s_norm; sh_d[1][j] = s_half; sh_u[0][j] = n_act; sh_u[1][j] = n_rel; sh_u[2][j] = n_rob;
+  __syncthreads();
+  if (j == 0) {
+    EvalSum o;
+    o.sum_norm = 0; o.sum_half_sq = 0; o.n_active = 0; o.n_relin = 0; o.n_robust = 0;
+    for (uint32_t k0 = 0; k0 < n_sums; k0 += 16) {      // sixteen LDS reads in flight, added in order (entries >= n_sums hold zeros)
+      double a[16], h[16];
+      GBP_UNROLL
+      for (int u = 0; u < 16; ++u) { a[u] = sh_d[0][k0 + u]; h[u] = sh_d[1][k0 + u]; }
+      GBP_UNROLL
+      for (int u = 0; u < 16; ++u)
+        if (k0 + (uint32_t)u < n_sums) { o.sum_norm += a[u]; o.sum_half_sq += h[u]; }
+      GBP_UNROLL
+      for (int u = 0; u < 16; ++u) { o.n_active += sh_u[0][k0 + u]; o.n_relin += sh_u[1][k0 + u]; o.n_robust += sh_u[2][k0 + u]; }
+    }
+    o.n_nonfinite = ev.slot_health[2 * (size_t)slot]; o.n_nonpd = ev.slot_health[2 * (size_t)slot + 1];
+    out[slot] = o;
+  }
+}
 
 // =================================================================================================
 // launchers
@@ -1678,8 +1897,13 @@ static inline uint32_t blocks_for(uint64_t threads) { return (uint32_t)((threads
 #ifdef GBP_BUILD_EXPERIMENTS
 bool lab_launch_sweep(const SweepArgs& a, uint32_t n_tiles, bool hoist, hipStream_t s);   // experiments/gbp_lab_kernels.hip
 #endif
-void launch_sweep(const SweepArgs& a, uint32_t n_tiles, bool hoist, hipStream_t s) {
+void launch_sweep(const SweepArgs& a, uint32_t n_tiles, bool hoist, hipStream_t s, bool ev) {
   const dim3 g(n_tiles / kWpb), b(64 * kWpb);
+  if (ev && hoist) {        // the metric rides along (gbp_iterate_eval_each beyond k_persist): the policies sweep_policy_for() chooses
+    if (a.policy == kPolCmsgLoadCached) hipLaunchKernelGGL((k_sweep<true, kPolCmsgLoadCached, true>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((k_sweep<true, 0, true>), g, b, 0, s, a);
+    return;
+  }
 #ifdef GBP_BUILD_EXPERIMENTS
   if (lab_launch_sweep(a, n_tiles, hoist, s)) return;     // a mapping experiment / an ablated sweep was asked for (SweepArgs.variant)
 #endif
@@ -1693,12 +1917,20 @@ void launch_sweep(const SweepArgs& a, uint32_t n_tiles, bool hoist, hipStream_t 
 void launch_linearise(const SweepArgs& a, uint32_t n_tiles, hipStream_t s) {
   hipLaunchKernelGGL(k_linearise, dim3(n_tiles / 4), dim3(256), 0, s, a);
 }
-void launch_beliefs(BeliefArgs b, bool do_cam, bool do_lmk, hipStream_t s) {
+void launch_beliefs(BeliefArgs b, bool do_cam, bool do_lmk, hipStream_t s, bool ev) {
   b.cam_blocks = do_cam ? (b.n_cams + 3) / 4 : 0;
   const uint32_t lmk_blocks = do_lmk ? blocks_for((uint64_t)b.n_lmks * 4) : 0;
   b.lmk_blocks = lmk_blocks;
   if (b.cam_blocks + lmk_blocks == 0) return;
-  hipLaunchKernelGGL(k_beliefs, dim3(b.cam_blocks + lmk_blocks), dim3(256), 0, s, b);
+  if (ev) hipLaunchKernelGGL(k_beliefs_ev, dim3(b.cam_blocks + lmk_blocks), dim3(256), 0, s, b);
+  else hipLaunchKernelGGL(k_beliefs, dim3(b.cam_blocks + lmk_blocks), dim3(256), 0, s, b);
+}
+void launch_eval_ride(const EvalRide& ev, const uint32_t* row_cam, const uint32_t* lmk_idx, const float4* lmsg, const float4* fac, const float* K9_dev, hipStream_t s) {
+  hipLaunchKernelGGL(k_eval_ride, dim3(ev.n_tiles / 4), dim3(256), 0, s, ev, row_cam, lmk_idx, lmsg, fac, K9_dev);
+}
+void launch_eval_fold(const EvalRide& ev, uint32_t n_slots, void* out, hipStream_t s) {
+  if (n_slots == 0) return;
+  hipLaunchKernelGGL(k_eval_fold, dim3(n_slots), dim3(1024), 0, s, ev, static_cast<EvalSum*>(out), eval_blocks(ev.n_tiles));
 }
 // The placement of k_persist without its work: the same grid, the same filler rule, three barriers.  gbp_create runs it
 // once: if the working workgroups of this graph are NOT all resident at once on this device (another partition mode, another

@@ -6,6 +6,6 @@ NAME=$1; shift
 REPO=$(cd $(dirname $0)/.. && pwd)
 mkdir -p $REPO/profiles/_bin/$NAME
 C=$REPO/gbp_poplar_amd/csrc
-hipcc -shared -o $REPO/profiles/_bin/$NAME/libgbp_mi355x.so -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wall -Wno-unused-function "$@" \
-  -x hip $C/gbp_kernels.hip $C/gbp_capi.cpp $C/gbp_comm.cpp $C/gbp_host.cpp -ldl
+hipcc -shared -o $REPO/profiles/_bin/$NAME/libgbp_mi355x.so -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden --offload-arch=gfx950 -Wall -Wno-unused-function "$@" \
+  -x hip $C/gbp_kernels.hip $C/gbp_capi.cpp $C/gbp_layout.cpp $C/gbp_comm.cpp $C/gbp_host.cpp -ldl -Wl,--version-script=$C/gbp_exports.map
 echo built profiles/_bin/$NAME
