@@ -220,8 +220,13 @@ inline bool exch(const gbp_ctx* c) { return c->world > 1 || c->comm != nullptr; 
 // camera beliefs from stored partials (single GPU: d_local; multi: recv_dev) + landmark beliefs re-summed.
 // roll = true at the end of an iteration (the sweep has consumed the current means), false for
 // prior-only refreshes (WEAKEN_PRIORS, NEW_KEYFRAME, LINEARISE).
-int refresh_beliefs_from_partials(gbp_ctx* c, bool roll, bool do_lmk = true) {
+int refresh_beliefs_from_partials(gbp_ctx* c, bool roll, bool do_lmk = true, bool weaken = false) {
   BeliefArgs b = belief_args(c);
+  if (weaken) {
+    b.weaken = 1;
+    b.cam_prior_rw = P<float>(c->camp); b.cam_scale = P<float>(c->cscale); b.cam_wflag = P<uint32_t>(c->cwf);
+    b.lmk_prior_rw = P<float4>(c->lmkp); b.lmk_scale = P<float>(c->lscale); b.lmk_wflag = P<uint32_t>(c->lwf);
+  }
   if (!exch(c)) {
     b.gathered = P<float>(c->local); b.world = 1;
   } else {
@@ -1165,10 +1170,7 @@ static int iterate_impl(gbp_ctx* c, int n) {
 int gbp_weaken_priors(gbp_ctx* c) {
   if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "gbp_weaken_priors: upload first");
   if (int rc = settle(c)) return rc;
-  launch_weaken(P<float4>(c->camp), P<float>(c->cscale), P<uint32_t>(c->cwf), c->C, kCamRec4, c->stream);
-  if (c->L_loc) launch_weaken(P<float4>(c->lmkp), P<float>(c->lscale), P<uint32_t>(c->lwf), c->L_loc, kLmkRec4, c->stream);
-  HIPCHK(c, hipGetLastError());
-  return refresh_beliefs_from_partials(c, false);
+  return refresh_beliefs_from_partials(c, false, true, /*weaken=*/true);      // ONE launch: the prior owners scale on their way into the sums
 }
 
 // READ_PROG (ba.cpp:908-916)

@@ -130,6 +130,11 @@ struct BeliefArgs {
   int partial_only;          // camera part writes cam_local only (multi-GPU: before the exchange)
   int hoist;                 // compute per-variable means + dmu^2 pieces
   int roll;                  // end of an iteration: "means used by the last sweep" := current means, then recompute
+  // WEAKEN_PRIORS (ba.cpp:863-865) = WeakenPriorVertex on every variable + this belief refresh, in ONE launch: weaken != 0 makes
+  // the owner of every prior element with flag in 1..5 scale it (written back through *_prior_rw) and count the flag down
+  int weaken;
+  float* cam_prior_rw; const float* cam_scale; uint32_t* cam_wflag;
+  float4* lmk_prior_rw; const float* lmk_scale; uint32_t* lmk_wflag;
   EvalRide ev;               // k_beliefs<EV> only
 };
 
@@ -199,7 +204,6 @@ void launch_copy_segments(const CopySegs& t, const unsigned* guard /* abort word
 // runs the placement + barriers of k_persist for this graph once (blocking); false = the workgroups are not co-resident here
 bool persist_probe(uint32_t n_tiles, uint32_t n_cams, uint32_t n_lmks, unsigned* sync, unsigned* status_dev, volatile unsigned* status_host,
                    bool cooperative, hipStream_t s);
-void launch_weaken(float4* prior, const float* scaling, uint32_t* flag, uint32_t n, int rec4, hipStream_t s);
 void launch_state_get(const float4* lmsg, float* damping, int* packed, uint32_t n, hipStream_t s);
 void launch_state_set(float4* lmsg, const int* new_count, const uint32_t* ctl, uint32_t n, hipStream_t s);
 void launch_means(const float4* camb, const float4* lmkb, float* cam_mu, float* lmk_mu, uint32_t n_cams,

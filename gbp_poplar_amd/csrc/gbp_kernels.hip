@@ -7,7 +7,7 @@
 //   k_beliefs      the rest of buildUpdateBeliefsProg (ba.cpp:104-139): camera rows + prior, landmark messages + prior
 //   k_persist      n iterations of the two above inside ONE launch (graphs whose workgroups are all resident at once)
 //   k_linearise    RelineariseFactorVertex (gbp_codelets.cpp:20-172)
-//   k_weaken       WeakenPriorVertex (gbp_codelets.cpp:176-197)
+//                  + WeakenPriorVertex (gbp_codelets.cpp:176-197) inside the refresh WEAKEN_PRIORS ends with
 //   k_means/k_eval eval_reprojection_error (util.cpp:74-144) + counters (ba.cpp:1011-1020)
 //
 // Mapping: one LANE per factor, 64 factors per wavefront, all blocks in VGPRs.
@@ -860,9 +860,18 @@ GBP_DEV void beliefs_body(const BeliefArgs& b) {
     const bool live = c < b.n_cams && j < (uint32_t)kCamRec;
     float bel = 0.f;
     if (live) {
+      // WeakenPriorVertex (gbp_codelets.cpp:176-197) rides in the belief refresh WEAKEN_PRIORS ends with (ba.cpp:863-865): the
+      // owner of a prior element scales it on its way into the sum and writes it back; lane 0 then counts the flag down (every
+      // lane of the record sits in this wave and has read the flag by then)
+      float prior = b.cam_prior[(size_t)c * kCamRec + j];
+      const uint32_t wf = b.weaken ? b.cam_wflag[c] : 0u;
+      if (wf >= 1u && wf <= 5u) {
+        prior *= b.cam_scale[c];
+        b.cam_prior_rw[(size_t)c * kCamRec + j] = prior;
+      }
       if (b.gathered) {
         const float* g = b.gathered + (size_t)c * kCamRec + j;      // exchange layout: [world][C][44]
-        float acc = b.cam_prior[(size_t)c * kCamRec + j];
+        float acc = prior;
         for (int r0 = 0; r0 < b.world; r0 += 8) {      // the partials of eight ranks in flight at once (clamped, unconditional), added in rank order
           float v[8];
           GBP_UNROLL
@@ -917,9 +926,10 @@ GBP_DEV void beliefs_body(const BeliefArgs& b) {
           }
         }
         b.cam_local[(size_t)c * kCamRec + j] = acc;
-        bel = b.cam_prior[(size_t)c * kCamRec + j] + acc;
+        bel = prior + acc;
       }
       sh[w][j] = bel;
+      if (j == 0 && wf >= 1u && wf <= 5u) b.cam_wflag[c] = wf - 1u;
     }
     if (b.partial_only) return;
     __syncthreads();
@@ -1005,6 +1015,15 @@ GBP_DEV void beliefs_body(const BeliefArgs& b) {
   if (live) {
     ix = reinterpret_cast<const uint4*>(b.lmk_ix)[(size_t)l * 4 + q];
     acc = b.lmk_prior[(size_t)l * 4 + q];
+    if (b.weaken) {        // WeakenPriorVertex on the landmark's prior (see the camera part): the quad's four lanes share a wave
+      const uint32_t wf = b.lmk_wflag[l];
+      if (wf >= 1u && wf <= 5u) {
+        const float sc = b.lmk_scale[l];
+        acc.x *= sc; acc.y *= sc; acc.z *= sc; acc.w *= sc;
+        b.lmk_prior_rw[(size_t)l * 4 + q] = acc;
+        if (q == 0) b.lmk_wflag[l] = wf - 1u;
+      }
+    }
     // the mean the last sweep used (roll: the current one becomes it) goes out with the first round of loads: fetched where it
     // is consumed — behind the gathers — it was a third dependent round trip of every wave
     if (b.hoist && q == 0) used_mu = b.lmk_mu[(size_t)l * 2 + (b.roll ? 0 : 1)];
@@ -1723,27 +1742,6 @@ __global__ __launch_bounds__(256) void k_state_set(float4* __restrict__ lmsg, co
   lmsg[(size_t)p * 4 + 3] = st;
 }
 
-// WeakenPriorVertex: one lane per float4 of a prior record; lane q == 0 updates the flag
-__global__ __launch_bounds__(256) void k_weaken(float4* prior, const float* __restrict__ scaling, uint32_t* flag, uint32_t n,
-                                                int rec4) {
-  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-  const uint32_t v = t / (uint32_t)rec4, q = t - v * (uint32_t)rec4;
-  if (v >= n) return;
-  const uint32_t f = flag[v];
-  if (f >= 1 && f <= 5) {
-    const float s = scaling[v];
-    float4 x = prior[(size_t)v * rec4 + q];
-    x.x *= s; x.y *= s; x.z *= s; x.w *= s;
-    prior[(size_t)v * rec4 + q] = x;
-  }
-}
-__global__ __launch_bounds__(256) void k_weaken_flags(uint32_t* flag, uint32_t n) {
-  const uint32_t v = blockIdx.x * 256 + threadIdx.x;
-  if (v >= n) return;
-  const uint32_t f = flag[v];
-  if (f >= 1 && f <= 5) flag[v] = f - 1;
-}
-
 __global__ __launch_bounds__(256) void k_means(const float* __restrict__ camb, const float* __restrict__ lmkb,
                                                float* __restrict__ cam_mu, float* __restrict__ lmk_mu, uint32_t n_cams,
                                                uint32_t n_lmks, unsigned long long* health, unsigned long long* health_next,
@@ -2027,10 +2025,6 @@ hipError_t launch_persist(PersistArgs A, bool cooperative, hipStream_t s) {
   if (A.ev.on) hipLaunchKernelGGL((k_persist<true>), dim3(grid), dim3(256), 0, s, A);
   else hipLaunchKernelGGL((k_persist<false>), dim3(grid), dim3(256), 0, s, A);
   return hipGetLastError();
-}
-void launch_weaken(float4* prior, const float* scaling, uint32_t* flag, uint32_t n, int rec4, hipStream_t s) {
-  hipLaunchKernelGGL(k_weaken, dim3(blocks_for((uint64_t)n * rec4)), dim3(256), 0, s, prior, scaling, flag, n, rec4);
-  hipLaunchKernelGGL(k_weaken_flags, dim3(blocks_for(n)), dim3(256), 0, s, flag, n);
 }
 void launch_state_get(const float4* lmsg, float* damping, int* packed, uint32_t n, hipStream_t s) {
   hipLaunchKernelGGL(k_state_get, dim3(blocks_for(n)), dim3(256), 0, s, lmsg, damping, packed, n);

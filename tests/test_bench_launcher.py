@@ -86,6 +86,92 @@ def test_bench_live_pmc_traffic():
     assert r["traffic_source"].startswith("live rocprofv3") and r["traffic"] > 0 and 0 < r["frac"] < 1.0, r
     assert {k["kernel"] for k in r["kernels"]} == {"k_sweep", "k_beliefs"}
     assert r["profiled_ms_per_step"] * 1e3 >= 0.9 * (r["avg_launch_us"] + r["belief_kernels_avg_us"])
+    assert abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-3            # achieved, peak and frac are one statement
+
+
+@pytest.mark.gpu
+def test_bench_line_describes_the_run_it_times():
+    """VERDICT r04 item 1, on a small graph (the driver's own `--steps 20 --warmup 5` shape of flags):
+      * the timed region is iterations 5..24 of the ./ba flow, the prior weakenings in front of 5, 7, 9 inside it and on record;
+      * `windows` {min, median, max} of five further windows and a `sustained` window of >= 1 s beside `value`;
+      * the flow trace: the timed engine's metric at the end of the timed region and of the profiled window lies on the
+        trajectory of a second engine running the reference's default loop; `configs.s1_default_loop` reports that loop;
+      * the PMC child replayed the same launches (its n_relin per profiled iteration == the trajectory's, same final metric);
+      * cpu_baseline: every belief and the per-factor state bit-exact against the oracle after the sample's iterations."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cams", "200", "--lmks", "20000", "--steps", "20", "--warmup", "5",
+                        "--profile-steps", "12", "--cpu-seconds", "4", "--sustained-seconds", "1", "--small-configs", "off"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+    tr = out["config"]["timed_region"]
+    assert tr == {"first_iteration": 5, "iterations": 20, "prior_weakenings_inside": [5, 7, 9], "is": tr["is"]}
+    assert out["config"]["iterations_run"] == 25 and out["steps"] == 20 and out["warmup"] == 5
+    w, su = out["windows"], out["sustained"]
+    assert w["n"] == 5 and 0 < w["min"] <= w["median"] <= w["max"] and w["iterations_each"] == 20
+    assert su["seconds"] >= 1.0 and su["iterations"] >= 20 and su["value"] > 0
+    ft = out["config"]["flow_trace"]
+    assert ft["timed_run_on_trajectory"] is True and ft["profiled_run_on_trajectory"] is True, ft
+    assert abs(ft["rmse_px_at_end_of_timed_region"] - out["config"]["reproj_rmse_px_final"]) < 1e-6
+    rep = out["roofline"]["replay"]
+    assert rep["child_replayed_the_same_launches"] is True, rep
+    assert len(rep["n_relin_per_iteration"]) == 12 and out["roofline"]["window"]["first_iteration"] == 25
+    cb = out["cpu_baseline"]
+    assert cb["beliefs_bit_exact_vs_oracle"] is True and cb["max_rel_deviation"] == 0.0, cb
+    assert cb["gpu_n_relin_same_iterations"] == cb["n_relin"] and cb["rmse_rel_diff"] < 1e-6
+    dl = out["configs"]["s1_default_loop"]
+    assert dl["iterations"] >= 37 and dl["iters_per_sec"] > 0 and dl["oracle_metric_same_iteration"]["rel_diff"] < 1e-6
+    assert dl["oracle_metric_same_iteration"]["gpu_n_relin"] == dl["oracle_metric_same_iteration"]["oracle_n_relin"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_with_real_ranks_sharing_one_gpu(world, oracle_mod):
+    """`bench.py --gpus N --share-gpu` runs the N > 1 code path with N REAL processes on the one GPU of the
+    box — self-launch through torch.distributed.run, per-rank shard build, rendezvous, preflight block, schedule choice, MAX-over-
+    ranks timing, rank-0 relay — with the launcher's group on gloo and the library's communicator on its host-staged transport
+    (RCCL refuses duplicate GPUs).  The line says so (all_ranks_on_distinct_gpus false), and the run is RIGHT: the final RMSE is
+    the N-shard oracle's after the same iterations of the same flow."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from gbp_poplar_amd import driver, hostlib
+    from gbp_poplar_amd.distributed import landmark_partition
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cams, lmks = 40, 1500                  # per rank
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--share-gpu", "--cams", str(cams), "--lmks", str(lmks),
+                        "--steps", "8", "--warmup", "4", "--profile-steps", "4", "--cpu-seconds", "0", "--pmc", "off", "--windows", "2",
+                        "--sustained-seconds", "0.2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    out = json.loads(lines[-1])
+    assert out["n_gpus"] == world and out["value"] > 0 and out["steps"] == 8 and out["scaling"] == "weak"
+    pre = out["config"]["preflight"]
+    assert pre["all_ranks_on_distinct_gpus"] is False and pre["ranks_share_gpus"] is True and pre["distinct_pci_bus_ids"] == 1
+    assert len(pre["ranks"]) == world and {r["rank"] for r in pre["ranks"]} == set(range(world))
+    assert all(r["transport"] == "host-staged" for r in pre["ranks"]) and pre["exchange_probe_us"] > 0
+    assert "host-staged" in out["config"]["exchange"] and out["config"]["comm_error"] is None
+    assert out["roofline"]["rank_step_ms_max"] >= out["roofline"]["rank_step_ms_min"] > 0
+    n_it = out["config"]["iterations_run"]
+    assert n_it == 4 + 50 + 8 and out["windows"]["n"] == 2 and out["sustained"]["iterations"] >= 8
+    # the N-shard oracle through the same flow: RMSE after the timed region
+    C, L = cams * world, lmks * world
+    bal = hostlib.synth_generate(C, L, 10, 20200303)
+    opts = driver.Options()
+    K, state, _ = driver.build_inputs(bal, opts, hostlib)
+    oracle_mod.set_trig_mode(1)
+    try:
+        orc = oracle_mod.Oracle(bal["cam_id"], bal["lmk_id"], C, L, K)
+        orc.set_sum_order(1, landmark_partition(bal["lmk_id"], L, world))
+        traj = driver.run_ba(orc, state, opts, n_iters=n_it, eval_every=n_it)
+        ev = orc.eval()
+    finally:
+        oracle_mod.set_trig_mode(0)
+    rmse = float(np.sqrt(2.0 * ev["sum_half_sq"] / ev["n_active"]))
+    assert abs(out["config"]["reproj_rmse_px_final"] - rmse) <= 2e-6 * rmse, (out["config"]["reproj_rmse_px_final"], rmse, traj[-1])
 
 
 @pytest.mark.gpu
@@ -114,6 +200,8 @@ def test_bench_sharded_line_is_complete_on_the_config5_shard_shape():
     assert sched["one_stream"] > 0 and sched["two_streams"] > 0
     assert pre["stream_mode_chosen"] == min(sched, key=sched.get)
     assert out["config"]["iterations_run"] == 5 + 50 + 20
+    assert out["config"]["timed_region"]["first_iteration"] == 55 and out["config"]["timed_region"]["prior_weakenings_inside"] == []
+    assert out["windows"]["n"] == 5 and out["sustained"]["seconds"] >= 1.5
 
 
 @pytest.mark.gpu
