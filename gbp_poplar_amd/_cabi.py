@@ -40,7 +40,7 @@ class GbpLayoutOptions(C.Structure):
     """include/gbp_mi355x_debug.h: knobs of the device-order construction (test-hooks build only)."""
     _fields_ = [("row_placement", C.c_uint32), ("row_window", C.c_uint32), ("row_place_max_deg", C.c_uint32),
                 ("row_key_lane", C.c_uint32), ("classes", C.c_uint32), ("tile_window", C.c_uint32),
-                ("tile_min_tiles", C.c_uint32), ("tile_identity", C.c_uint32)]
+                ("tile_min_tiles", C.c_uint32), ("tile_identity", C.c_uint32), ("row_sort_in_class", C.c_uint32)]
 
 
 class GbpShard(C.Structure):

@@ -1672,7 +1672,7 @@ static LayoutOptions to_options(const gbp_layout_options* o) {
   if (o) {
     r.row_placement = o->row_placement; r.row_window = o->row_window; r.row_place_max_deg = o->row_place_max_deg;
     r.row_key_lane = o->row_key_lane; r.classes = o->classes; r.tile_window = o->tile_window; r.tile_min_tiles = o->tile_min_tiles;
-    r.tile_identity = o->tile_identity;
+    r.tile_identity = o->tile_identity; r.row_sort_in_class = o->row_sort_in_class;
   }
   return r;
 }
@@ -1681,7 +1681,7 @@ void gbp_debug_layout_default_options(gbp_layout_options* o) {
   const LayoutOptions d;
   o->row_placement = d.row_placement; o->row_window = d.row_window; o->row_place_max_deg = d.row_place_max_deg;
   o->row_key_lane = d.row_key_lane; o->classes = d.classes; o->tile_window = d.tile_window; o->tile_min_tiles = d.tile_min_tiles;
-  o->tile_identity = d.tile_identity;
+  o->tile_identity = d.tile_identity; o->row_sort_in_class = d.row_sort_in_class;
 }
 int gbp_debug_layout_options(const gbp_layout_options* o) { g_layout_options = to_options(o); return GBP_OK; }
 int gbp_debug_force_sweep_policy(int policy) { g_force_sweep_policy = policy; return GBP_OK; }

@@ -1909,6 +1909,13 @@ void launch_sweep(const SweepArgs& a, uint32_t n_tiles, bool hoist, hipStream_t 
   switch (a.policy) {      // the instantiations gbp_capi.cpp's sweep_policy() can choose
     case kPolCmsgLoadCached: hipLaunchKernelGGL((k_sweep<true, kPolCmsgLoadCached>), g, b, 0, s, a); break;
     case kPolLmsgLoadNt | kPolLmsgStoreNt: hipLaunchKernelGGL((k_sweep<true, kPolLmsgLoadNt | kPolLmsgStoreNt>), g, b, 0, s, a); break;
+#ifdef GBP_BUILD_TEST_HOOKS      // the other combinations, for measurements (gbp_debug_force_sweep_policy)
+    case 2: hipLaunchKernelGGL((k_sweep<true, 2>), g, b, 0, s, a); break;
+    case 3: hipLaunchKernelGGL((k_sweep<true, 3>), g, b, 0, s, a); break;
+    case 4: hipLaunchKernelGGL((k_sweep<true, 4>), g, b, 0, s, a); break;
+    case 5: hipLaunchKernelGGL((k_sweep<true, 5>), g, b, 0, s, a); break;
+    case 7: hipLaunchKernelGGL((k_sweep<true, 7>), g, b, 0, s, a); break;
+#endif
     default: hipLaunchKernelGGL((k_sweep<true, 0>), g, b, 0, s, a); break;
   }
 }

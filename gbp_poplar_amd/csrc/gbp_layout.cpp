@@ -40,6 +40,7 @@ inline uint32_t lmk_class(uint32_t l_loc, uint32_t L_loc, uint32_t classes) {
 void place_rows(const gbp_problem* pr, const LayoutOptions& opt, Layout& y) {
   const uint32_t C = y.C, W = opt.row_window, K = opt.classes;
   std::vector<uint8_t> key(y.n_rows, 0);
+  std::vector<uint32_t> key_lmk(opt.row_sort_in_class ? y.n_rows : 0, 0);
   {
     std::vector<uint32_t> cfill(C, 0);
     for (uint32_t e = 0; e < y.E; ++e) {
@@ -47,14 +48,23 @@ void place_rows(const gbp_problem* pr, const LayoutOptions& opt, Layout& y) {
       if (l < y.lmk_begin || l >= y.lmk_end) continue;
       const uint32_t i = cfill[cam]++;
       // the row's first factor always sets a key; the key lane (a short last row may not have one) overrides it
-      if (i % kLayoutRow == opt.row_key_lane || i % kLayoutRow == 0)
+      if (i % kLayoutRow == opt.row_key_lane || i % kLayoutRow == 0) {
         key[y.cam_row_ptr[cam] + i / kLayoutRow] = (uint8_t)lmk_class(l - y.lmk_begin, y.L_loc, K);
+        if (opt.row_sort_in_class) key_lmk[y.cam_row_ptr[cam] + i / kLayoutRow] = l - y.lmk_begin;
+      }
     }
   }
   y.row_slot.assign(y.n_rows, 0);
-  std::vector<uint32_t> cnt(K + 1);
+  std::vector<uint32_t> cnt(K + 1), order;
   for (uint32_t c0 = 0; c0 < C; c0 += W) {
     const uint32_t c1 = std::min<uint32_t>(C, c0 + W), R0 = y.cam_row_ptr[c0], R1 = y.cam_row_ptr[c1];
+    if (opt.row_sort_in_class) {        // (measurement option) by class, then by key landmark, then camera-major
+      order.resize(R1 - R0);
+      for (uint32_t r = R0; r < R1; ++r) order[r - R0] = r;
+      std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return key[a] != key[b] ? key[a] < key[b] : key_lmk[a] < key_lmk[b]; });
+      for (uint32_t i = 0; i < R1 - R0; ++i) y.row_slot[order[i]] = R0 + i;
+      continue;
+    }
     std::fill(cnt.begin(), cnt.end(), 0u);
     for (uint32_t r = R0; r < R1; ++r) cnt[key[r] + 1]++;
     for (uint32_t k = 0; k < K; ++k) cnt[k + 1] += cnt[k];

@@ -28,11 +28,13 @@ struct LayoutOptions {
   uint32_t row_placement = 1;        // 0: rows always in camera-major order
   uint32_t row_window = 32;          // cameras whose rows are placed together (16 .. 48 measured equal, 64 .. 256 worse: profiles/HISTORY.md)
   uint32_t row_place_max_deg = 512;  // rows are placed by landmark class where a camera has fewer factors than this on average
-  uint32_t row_key_lane = 0;         // the factor of a row whose landmark classes the row (0 = first, 8 = middle)
+  uint32_t row_key_lane = 8;         // the factor of a row whose landmark classes the row: the middle one (a short last row: its first).
+                                     // Config-5 shard shape: 153.3 -> 150.8 us per iteration, 835 -> 822 MB per sweep against lane 0 (4, 12: between)
   uint32_t classes = 8;              // landmark classes of rows and tiles (8 = one per XCD; multiples of 8 give finer runs inside an XCD's share)
   uint32_t tile_window = 96;         // look-ahead of the local tile permutation, in tiles (32 / 48 / 192 measured: no difference)
   uint32_t tile_min_tiles = 2048;    // tile_order 0 permutes (and places rows) only on graphs of at least this many tiles
   uint32_t tile_identity = 0;        // 1: every tile in class 0 (what does the look-up itself cost?)
+  uint32_t row_sort_in_class = 0;    // 1: the rows of a class (inside a window) ordered by their key landmark instead of camera-major
 };
 
 struct Layout {

@@ -49,11 +49,12 @@ typedef struct {
   uint32_t row_placement;      /* 1; 0 = rows always in camera-major order                                                     */
   uint32_t row_window;         /* 32: cameras whose rows are placed together                                                   */
   uint32_t row_place_max_deg;  /* 512: rows are placed by landmark class where a camera has fewer factors than this on average  */
-  uint32_t row_key_lane;       /* 0: the factor of a row whose landmark classes the row                                        */
+  uint32_t row_key_lane;       /* 8: the factor of a row whose landmark classes the row (the middle one)                       */
   uint32_t classes;            /* 8: landmark classes of rows and tiles                                                        */
   uint32_t tile_window;        /* 96: look-ahead of the local tile permutation, in tiles                                        */
   uint32_t tile_min_tiles;     /* 2048: tile_order 0 permutes tiles (and places rows) only on graphs of at least this many      */
   uint32_t tile_identity;      /* 0; 1 = every tile in class 0                                                                 */
+  uint32_t row_sort_in_class;  /* 0; 1 = the rows of a class (inside a window) ordered by their key landmark (measurement)      */
 } gbp_layout_options;
 typedef struct gbp_layout gbp_layout;
 GBP_API void gbp_debug_layout_default_options(gbp_layout_options* opt);

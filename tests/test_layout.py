@@ -69,7 +69,7 @@ def check_layout(cam_id, lmk_id, C, L, y, shard=None, opt=None, tile_order=0):
     if y["row_slot"].size:
         W, K = y["row_window"], (opt.classes if opt is not None else 8)
         assert W > 0
-        key_lane = opt.row_key_lane if opt is not None else 0
+        key_lane = opt.row_key_lane if opt is not None else 8
         first = np.full(y["n_rows"], -1, np.int64)
         r_of = y["cam_row_ptr"][cam_of] + i_in_cam // 16
         for lane in sorted({0, key_lane}):                                      # the key lane overrides the first factor where the row has one
@@ -81,7 +81,11 @@ def check_layout(cam_id, lmk_id, C, L, y, shard=None, opt=None, tile_order=0):
             R0, R1 = y["cam_row_ptr"][c0], y["cam_row_ptr"][c1]
             sl = y["row_slot"][R0:R1].astype(np.int64)
             assert np.array_equal(np.sort(sl), np.arange(R0, R1))
-            assert np.array_equal(np.argsort(sl), np.argsort(cls[R0:R1], kind="stable"))   # device order = stable sort by class
+            if opt is not None and opt.row_sort_in_class:      # (measurement option: by class, then by the key landmark, then camera-major)
+                want = np.argsort(cls[R0:R1] * (hi - lo + 1) + first[R0:R1], kind="stable")
+            else:
+                want = np.argsort(cls[R0:R1], kind="stable")
+            assert np.array_equal(np.argsort(sl), want)                 # device order = stable sort by class
     else:
         assert y["row_window"] == 0
     # execution order of the tiles: a bijection; the local order keeps every tile near its sequential place
@@ -115,7 +119,7 @@ def test_random_graphs(seed, tile_order):
     C, L = int(rng.integers(1, 40)), int(rng.integers(1, 300))
     E = int(rng.integers(1, 4000))
     cam, lmk = random_graph(rng, C, L, E, sort=seed % 2 == 0, dup=seed % 3 == 0)
-    for kw in ({}, SMALL, dict(SMALL, classes=16, row_key_lane=8, tile_window=7)):
+    for kw in ({}, SMALL, dict(SMALL, classes=16, row_key_lane=3, tile_window=7), dict(SMALL, row_sort_in_class=1, row_key_lane=0)):
         opt = hostlib.layout_options(**kw)
         y = hostlib.layout_build(cam, lmk, C, L, tile_order=tile_order, options=opt)
         check_layout(cam, lmk, C, L, y, opt=opt, tile_order=tile_order)
