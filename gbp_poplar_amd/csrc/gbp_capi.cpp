@@ -132,6 +132,9 @@ struct gbp_ctx {
   // word is set), later launches of the ctx return at once, and the host — at the next point where it synchronises anyway —
   // restores the snapshot and replays the logged launches from the first failed one on.
   struct Burst { unsigned seq; int n; int mode; int area; };   // mode 0 = gbp_iterate, 1 = gbp_iterate_eval (metric in eval area `area`), 2 = eval_each (blocking)
+  DevBuf pflow;                        // tagged shadows of k_persist_flow (PersistFlow), one allocation
+  PersistFlow flow{};                  // flow.lmsg == NULL: bursts without the metric run in k_persist<false> (barriers)
+  bool persist_flow = true;            // gbp_debug_set_persist_flow / GBP_PERSIST_FLOW=0: keep the barrier kernel (A/B measurements)
   std::vector<Burst> persist_log;      // launched, completion not yet validated
   unsigned persist_seq = 0;
   DevBuf psnap;                        // snapshot arena
@@ -568,6 +571,23 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
               ++i;
             }
             c->snap_save.n = c->snap_restore.n = i;
+          } else {
+            g_create_error = c->err;
+          }
+        }
+        if (rc == GBP_OK && c->persist_ok) {
+          // tagged shadows of the arrays that cross waves inside a launch (k_persist_flow): two halves each
+          const size_t Ep = (size_t)c->n_tiles * 64, C_ = c->C, L_ = c->L_loc;
+          const size_t n4[7] = {2 * Ep * 4, 2 * (Ep / 16) * kFlowRow4, 2 * C_ * kFlowCam4, 2 * C_ * 2, 2 * C_ * kFlowClin4, 2 * L_ * kFlowLmk4, 2 * L_};
+          size_t total = 0;
+          for (size_t n : n4) total += n;
+          rc = dev_alloc(c, c->pflow, total * 16);
+          if (rc == GBP_OK) {
+            float4* q = static_cast<float4*>(c->pflow.p);
+            float4** dst[7] = {&c->flow.lmsg, &c->flow.rowp, &c->flow.camb, &c->flow.cmu, &c->flow.clin, &c->flow.lmkb, &c->flow.lmu};
+            for (int i = 0; i < 7; ++i) { *dst[i] = q; q += n4[i]; }
+            const char* pf = prm ? nullptr : std::getenv("GBP_PERSIST_FLOW");
+            if (pf && std::atoi(pf) == 0) c->persist_flow = false;
           } else {
             g_create_error = c->err;
           }
@@ -1048,6 +1068,11 @@ static int launch_persist_burst(gbp_ctx* c, const SweepArgs& a, int n, const Per
   A.epoch_base = c->persist_epoch_base;
   A.seq = c->persist_seq + 1;
   if (ev) A.ev = *ev;
+  const bool flow = !ev && c->persist_flow && c->flow.lmsg != nullptr;      // no metric in the launch: hand-offs through tagged records
+  if (flow) {
+    A.f = c->flow;
+    A.f.tag0 = (A.seq & 0x7ffffu) << 13;      // + iteration (<= kPersistChunk) + 1: never the tag of a record an earlier launch left behind
+  }
   {
     // Two k_persist launches must never compete for CUs (each spins at its barriers until ALL its workgroups are resident).
     // Across processes that is the cooperative launch's guarantee; inside a process a launch from another ctx or stream than
@@ -1077,7 +1102,7 @@ static int launch_persist_burst(gbp_ctx* c, const SweepArgs& a, int n, const Per
     g_persist_last_stream[dev & 15] = c->stream;
   }
   const unsigned nb = persist_blocks(c->n_tiles, c->C, c->L_loc, ev != nullptr && ev->each != 0);      // the grid launch_persist used
-  c->persist_epoch_base += nb * (unsigned)(2 * n - 1 + (ev ? 1 : 0));      // n <= kPersistChunk; the counter wraps, grid_sync compares wrap-safe
+  if (!flow) c->persist_epoch_base += nb * (unsigned)(2 * n - 1 + (ev ? 1 : 0));      // n <= kPersistChunk; the counter wraps, grid_sync compares wrap-safe
   c->persist_seq += 1;
   c->persist_log.push_back(gbp_ctx::Burst{c->persist_seq, n, mode, area});
   c->persist_launches += 1;
@@ -1685,6 +1710,11 @@ void gbp_debug_layout_default_options(gbp_layout_options* o) {
 }
 int gbp_debug_layout_options(const gbp_layout_options* o) { g_layout_options = to_options(o); return GBP_OK; }
 int gbp_debug_force_sweep_policy(int policy) { g_force_sweep_policy = policy; return GBP_OK; }
+int gbp_debug_persist_flow(gbp_ctx* c, int on) {
+  if (!c) return GBP_ERR_INVALID;
+  c->persist_flow = on != 0;
+  return GBP_OK;
+}
 int gbp_debug_layout_build(const gbp_problem* pr, int tile_order, const gbp_shard* sh, const gbp_layout_options* o, gbp_layout** out) {
   if (!out) return GBP_ERR_INVALID;
   return guarded(nullptr, "gbp_debug_layout_build", [&] {

@@ -156,10 +156,32 @@ struct PersistEval {
   unsigned long long* health_each;     // [2][2] each == 1: the counters of iteration k in pair k & 1 (all zero on entry and on exit)
   unsigned long long* health_next;     // zeroed for the next evaluation
 };
+// k_persist_flow: the same launch without device-wide barriers.  Every array that crosses waves inside the launch has a TAGGED
+// shadow: 16-byte records of three payload floats and the number of the iteration that produced them (a 16-byte aligned store of
+// one lane is not torn), two halves alternating by the parity of the iteration.  A consumer re-loads its records until all of them
+// carry the iteration it waits for; what an iteration waits for is exactly what it reads (profiles/exp_dataflow.hip: 6.9 -> 4.7 us
+// per hand-off at 51 workgroups).  The shadows live only inside a launch: its prologue publishes the beliefs it starts from, its
+// last iteration writes the ordinary arrays.
+constexpr uint32_t kFlowRow4 = 15;    // float4 per 16-lane row: lane q of the row's last quad stores 4 (q = 3: 3) of them
+constexpr uint32_t kFlowCam4 = 10;    // camera belief: eta 6, S, lower triangle of Lambda 21 (+ 2 unused slots)
+constexpr uint32_t kFlowClin4 = 7;    // CAM_LIN: 20 floats
+constexpr uint32_t kFlowLmk4 = 5;     // landmark belief: eta 3, Lambda 9, the three squared mean changes
+struct PersistFlow {
+  float4* lmsg;    // [2][Ep][4]         eta | Lambda rows 0, 1, 2 of the factor -> landmark message
+  float4* rowp;    // [2][Ep / 16][15]   row sums of the factor -> camera messages
+  float4* camb;    // [2][C][10]
+  float4* cmu;     // [2][C][2]          hoisted camera mean
+  float4* clin;    // [2][C][7]
+  float4* lmkb;    // [2][L][5]
+  float4* lmu;     // [2][L][1]          hoisted landmark mean
+  unsigned tag0;   // tags of this launch: tag0 (what the prologue publishes), tag0 + 1 + it (what iteration it produces)
+};
+
 struct PersistArgs {
   SweepArgs s;
   BeliefArgs b;
   PersistEval ev;
+  PersistFlow f;           // f.lmsg != NULL and no metric in the launch: k_persist_flow
   unsigned epoch_base;     // arrivals the barrier counter has already seen (launches of one ctx keep counting: no memset per launch)
   uint32_t n_tiles;        // sweep tiles = waves with a phase-A role
   uint32_t n_lmk_groups;   // ceil(L / 16): waves [C, C + n_lmk_groups) own 16 landmarks each in phase B

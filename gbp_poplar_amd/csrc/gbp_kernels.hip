@@ -1713,6 +1713,491 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
   }
 }
 
+// =================================================================================================
+// k_persist_flow: k_persist without device-wide barriers (PersistFlow in gbp_kernels.h).  Same roles, same per-lane arithmetic in
+// the same order — bit-identical results — but every hand-off is a dependency on DATA: a consumer re-loads the tagged records it
+// needs until they carry the iteration it waits for.  Why the two halves suffice: a tile wave overwrites its records of iteration
+// it when it produces those of it + 2, for which it needed the beliefs of it + 1 of ALL of its variables, whose owners produced them
+// after reading the tile's records of it + 1 — after those of it; and the other way round.  Launches without the metric only.
+// A wait is bounded like k_persist's barriers (1.5 s, abort word, *status): the wave then returns and the host restores the
+// snapshot and replays on the two-kernel path.
+// =================================================================================================
+GBP_DEV bool flow_give_up(unsigned spin, unsigned long long& t0, unsigned* sync, unsigned* status, unsigned seq) {
+  if ((spin & 255u) != 255u) return false;
+  const unsigned long long now = wall_clock64();
+  if (t0 == 0) t0 = now;
+  if (now - t0 > kBarrierTimeoutTicks || __hip_atomic_load(sync + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+    if (__hip_atomic_exchange(sync + 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) *status = seq;
+    return true;
+  }
+  return false;
+}
+// `attempt()` issues a round of loads and says per lane whether everything it needs has arrived; true once every lane says so
+// (a waiting wave re-loads through the fabric — sc1 loads miss the L2 by design: between two rounds it sleeps, and where a round is
+// many records per lane it first polls ONE of them, `probe`, the one its producer writes last; 200 waves re-loading 30 records per
+// lane flat out were 5 TB/s of polling and made fr1xyz 2 us per iteration SLOWER than the barriers)
+template <class Attempt>
+GBP_DEV bool flow_wait(Attempt&& attempt, unsigned* sync, unsigned* status, unsigned seq) {
+  unsigned long long t0 = 0;
+  for (unsigned spin = 0;; ++spin) {
+    asm volatile("" ::: "memory");      // the loads are re-issued every time round
+    if (__all(attempt())) return true;
+    if (flow_give_up(spin, t0, sync, status, seq)) return false;
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
+GBP_DEV float4 flow_rec(float x, float y, float z, unsigned tag) { return make_float4(x, y, z, __uint_as_float(tag)); }
+GBP_DEV bool flow_is(const float4 v, unsigned tag) { return __float_as_uint(v.w) == tag; }
+GBP_DEV float flow_pick(const float4 v, uint32_t c) { return c == 0u ? v.x : c == 1u ? v.y : v.z; }
+// payload slot k (0 .. 29) of the tagged camera belief -> float of the 44-float CAMB record (eta 0..5, S, lower triangle row-wise)
+GBP_DEV uint32_t flow_camb_src(uint32_t k) {
+  if (k < 7u) return k;
+  if (k >= 28u) return 0u;
+  const uint32_t t = k - 7u;
+  uint32_t i = 0;
+  while ((i + 1u) * (i + 2u) / 2u <= t) ++i;
+  return 8u + i * 6u + (t - i * (i + 1u) / 2u);
+}
+
+__global__ __launch_bounds__(256) void k_persist_flow(const PersistArgs A) {
+  const SweepArgs& a = A.s;
+  const BeliefArgs& b = A.b;
+  const PersistFlow& F = A.f;
+  const uint32_t wib = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (__hip_atomic_load(A.sync + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;      // (see k_persist)
+  uint32_t bid = blockIdx.x, nblk = gridDim.x;
+  if ((int)A.spread > 1) {
+    if (blockIdx.x % A.spread) return;
+    bid = blockIdx.x / A.spread; nblk = gridDim.x / A.spread;
+  } else if ((int)A.spread < -1) {
+    const uint32_t sp = (uint32_t)(-(int)A.spread), slot = blockIdx.x >> 3;
+    if (slot % sp) return;
+    bid = (slot / sp) * 8 + (blockIdx.x & 7u); nblk = A.n_work_blocks;
+    if (bid >= nblk) return;
+  }
+  const uint32_t w = bid * 4 + wib;
+  __shared__ float4 lm_stage[4][64 * 4];
+  __shared__ float sh[4][48];
+  float4* stage = lm_stage[wib];
+  const XwBuf S_lmsg(F.lmsg), S_rowp(F.rowp), S_camb(F.camb), S_cmu(F.cmu), S_clin(F.clin), S_lmkb(F.lmkb), S_lmu(F.lmu);
+  const uint32_t nC = b.n_cams, nL = b.n_lmks, Ep = A.n_tiles * 64u, n_rows = A.n_tiles * 4u;
+
+  // ---- phase-A role: sweep tile w; the factor's potential and both of its messages stay in registers ----
+  const bool has_tile = w < A.n_tiles;
+  const uint32_t tile = has_tile ? w : 0u, p = tile * 64 + lane;
+  const uint32_t rec_t = lane >> 2, swz_own = ((lane >> 2) & 3u) ^ (lane & 2u);
+  const uint32_t lm_tile4 = tile * 256u;
+  float fac[56], cm[28], lm[16];
+  uint32_t cam_i = 0, lmk_i = 0;
+  bool fac_dirty = false;
+  if (has_tile) {
+    cam_i = a.row_cam[p >> 4];
+    lmk_i = a.lmk_idx[p];
+    load_tile<kFacG, false>(a.fac, tile, lane, fac);
+    load_tile<kCmsgG, false>(a.cmsg, tile, lane, cm);
+    GBP_UNROLL
+    for (int k = 0; k < 4; ++k) {   // the wave's 64 landmark-message records: coalesced, transposed through LDS (see k_sweep)
+      const uint32_t r = k * 16 + rec_t;
+      stage[r * 4 + ((lane & 3u) ^ (((r >> 2) & 3u) ^ (r & 2u)))] = a.lmsg[lm_tile4 + (uint32_t)k * 64u + lane];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    GBP_UNROLL
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = stage[lane * 4 + ((uint32_t)q ^ swz_own)];
+      lm[4 * q] = v.x; lm[4 * q + 1] = v.y; lm[4 * q + 2] = v.z; lm[4 * q + 3] = v.w;
+    }
+  }
+  float K[9];
+  GBP_UNROLL
+  for (int i = 0; i < 9; ++i) K[i] = a.K[i];
+
+  // ---- phase-B role: camera v, or landmarks 16 (v - C) .. + 15 (4 lanes each); numbered across the workgroups as in k_persist ----
+  const uint32_t v = wib * nblk + bid;
+  const bool cam_wave = v < nC;
+  const bool lmk_wave = !cam_wave && (v - nC) < A.n_lmk_groups;
+  const uint32_t cj = lane;
+  const bool cam_live = cam_wave && cj < (uint32_t)kCamRec;
+  uint32_t r0 = 0, r1 = 0;
+  float cam_prior_j = 0.f;
+  float4 cam_cur0 = make_float4(0.f, 0.f, 0.f, 0.f), cam_cur1 = cam_cur0;
+  // where element cj of a row's 44-float record sits in the row's tagged record (row16_sums_store: lane q of the row's last quad holds
+  // the groups q, q + 4, q + 8 = twelve floats = four tagged records)
+  const uint32_t rg = cj >> 2, rn = 4u * (rg >> 2) + (cj & 3u);
+  const uint32_t row_f4 = 4u * (rg & 3u) + rn / 3u, row_c = rn % 3u;
+  const uint32_t cb_s0 = flow_camb_src(3u * lane), cb_s1 = flow_camb_src(3u * lane + 1u), cb_s2 = flow_camb_src(3u * lane + 2u);   // lanes 0..9
+  if (cam_wave) {
+    r0 = b.cam_row_ptr[v]; r1 = b.cam_row_ptr[v + 1];
+    if (cam_live) cam_prior_j = b.cam_prior[(size_t)v * kCamRec + cj];
+    cam_cur0 = a.cam_mu[(size_t)v * 4]; cam_cur1 = a.cam_mu[(size_t)v * 4 + 1];
+  }
+  const uint32_t l = lmk_wave ? (v - nC) * 16 + (lane >> 2) : 0u, q4 = lane & 3;
+  const bool lmk_live = lmk_wave && l < nL;
+  uint4 ix = make_uint4(0u, 0u, 0u, 0u);
+  float pr3[3] = {0.f, 0.f, 0.f};
+  float4 lmk_cur = make_float4(0.f, 0.f, 0.f, 0.f);
+  uint32_t lp0 = 0, lp1 = 0;
+  const uint32_t l_e0 = q4 == 0u ? 0u : 4u + 3u * (q4 - 1u);      // first float of this lane's triple in the 16-float landmark record
+  if (lmk_live) {
+    ix = reinterpret_cast<const uint4*>(b.lmk_ix)[(size_t)l * 4 + q4];
+    const float* pr = reinterpret_cast<const float*>(b.lmk_prior) + (size_t)l * 16 + l_e0;
+    pr3[0] = pr[0]; pr3[1] = pr[1]; pr3[2] = pr[2];
+    lmk_cur = a.lmk_mu[(size_t)l * 2];
+    lp0 = b.lmk_ptr[l]; lp1 = b.lmk_ptr[l + 1];
+  }
+  const uint32_t deg = (uint32_t)__shfl((int)ix.x, 0, 4);
+  uint32_t pos[15], pos2[15];
+  GBP_UNROLL
+  for (int k = 0; k < 15; ++k) {
+    const uint32_t e = ((k + 1) & 3) == 0 ? ix.x : ((k + 1) & 3) == 1 ? ix.y : ((k + 1) & 3) == 2 ? ix.z : ix.w;
+    pos[k] = (uint32_t)__shfl((int)e, (k + 1) >> 2, 4);
+  }
+  GBP_UNROLL
+  for (int k = 0; k < 15; ++k) {
+    const uint32_t p2 = b.lmk_fpos[lp0 + (15u + (uint32_t)k < deg ? 15u + (uint32_t)k : 0u)];
+    pos2[k] = (lmk_live && 15u + (uint32_t)k < deg) ? p2 : 0u;
+  }
+
+  // ---- prologue: the beliefs this launch starts from, published as "iteration -1" (half 1, tag0) ----
+  if (cam_wave) {
+    const float* rec = b.camb + (size_t)v * kCamRec;
+    if (lane < kFlowCam4) S_camb.st4((nC + v) * kFlowCam4 + lane, flow_rec(rec[cb_s0], rec[cb_s1], rec[cb_s2], F.tag0));
+    if (lane == 0) {
+      S_cmu.st4((nC + v) * 2u, flow_rec(cam_cur0.x, cam_cur0.y, cam_cur0.z, F.tag0));
+      S_cmu.st4((nC + v) * 2u + 1u, flow_rec(cam_cur0.w, cam_cur1.x, cam_cur1.y, F.tag0));
+      const float* cl = reinterpret_cast<const float*>(a.cam_lin + (size_t)v * kCamLin4);
+      GBP_UNROLL
+      for (int g = 0; g < (int)kFlowClin4; ++g)
+        S_clin.st4((nC + v) * kFlowClin4 + (uint32_t)g, flow_rec(cl[3 * g], cl[3 * g + 1], g < 6 ? cl[3 * g + 2] : 0.f, F.tag0));
+    }
+  } else if (lmk_live) {
+    const float* rec = reinterpret_cast<const float*>(a.lmkb) + (size_t)l * 16;
+    S_lmkb.st4((nL + l) * kFlowLmk4 + q4, flow_rec(rec[l_e0], rec[l_e0 + 1u], rec[l_e0 + 2u], F.tag0));
+    if (q4 == 0) {
+      S_lmkb.st4((nL + l) * kFlowLmk4 + 4u, flow_rec(rec[3], rec[13], rec[14], F.tag0));
+      S_lmu.st4(nL + l, flow_rec(lmk_cur.x, lmk_cur.y, lmk_cur.z, F.tag0));
+    }
+  }
+
+  for (int it = 0; it < A.n_iters; ++it) {
+    const uint32_t h_in = ((uint32_t)it + 1u) & 1u, h_out = (uint32_t)it & 1u;
+    const unsigned t_in = F.tag0 + (unsigned)it, t_out = F.tag0 + (unsigned)it + 1u;
+    const bool last = it + 1 == A.n_iters;
+    // ================= phase A: the sweep of this wave's tile =================
+    if (has_tile) {
+      float4 c4[kFlowCam4], m4[2], q7[kFlowClin4], l5[kFlowLmk4], u4;
+      const uint32_t cb0 = (h_in * nC + cam_i), lb0 = (h_in * nL + lmk_i);
+      // probe: the records the two owners store last (the camera's belief behind its mean and CAM_LIN, the landmark's squared mean changes)
+      if (!flow_wait([&]() { return flow_is(S_camb.ld4(cb0 * kFlowCam4), t_in) && flow_is(S_lmkb.ld4(lb0 * kFlowLmk4 + 4u), t_in); },
+                     A.sync, A.status, A.seq)) return;
+      if (!flow_wait([&]() {
+            bool ok = true;
+            GBP_UNROLL
+            for (int g = 0; g < (int)kFlowCam4; ++g) c4[g] = S_camb.ld4(cb0 * kFlowCam4 + (uint32_t)g);
+            m4[0] = S_cmu.ld4(cb0 * 2u); m4[1] = S_cmu.ld4(cb0 * 2u + 1u);
+            GBP_UNROLL
+            for (int g = 0; g < (int)kFlowClin4; ++g) q7[g] = S_clin.ld4(cb0 * kFlowClin4 + (uint32_t)g);
+            GBP_UNROLL
+            for (int g = 0; g < (int)kFlowLmk4; ++g) l5[g] = S_lmkb.ld4(lb0 * kFlowLmk4 + (uint32_t)g);
+            u4 = S_lmu.ld4(lb0);
+            GBP_UNROLL
+            for (int g = 0; g < (int)kFlowCam4; ++g) ok = ok && flow_is(c4[g], t_in);
+            ok = ok && flow_is(m4[0], t_in) && flow_is(m4[1], t_in);
+            GBP_UNROLL
+            for (int g = 0; g < (int)kFlowClin4; ++g) ok = ok && flow_is(q7[g], t_in);
+            GBP_UNROLL
+            for (int g = 0; g < (int)kFlowLmk4; ++g) ok = ok && flow_is(l5[g], t_in);
+            return ok && flow_is(u4, t_in);
+          }, A.sync, A.status, A.seq)) return;
+      float cb[44], lb[16], mu[12];
+      {
+        float pl[30];
+        GBP_UNROLL
+        for (int g = 0; g < (int)kFlowCam4; ++g) { pl[3 * g] = c4[g].x; pl[3 * g + 1] = c4[g].y; pl[3 * g + 2] = c4[g].z; }
+        GBP_UNROLL
+        for (int i = 0; i < 44; ++i) cb[i] = 0.f;
+        GBP_UNROLL
+        for (int i = 0; i < 7; ++i) cb[i] = pl[i];
+        GBP_UNROLL
+        for (int i = 0; i < 6; ++i) {
+          GBP_UNROLL
+          for (int j = 0; j <= i; ++j) cb[8 + i * 6 + j] = pl[7 + tri(i, j)];
+        }
+      }
+      lb[0] = l5[0].x; lb[1] = l5[0].y; lb[2] = l5[0].z;
+      GBP_UNROLL
+      for (int g = 0; g < 3; ++g) { lb[4 + 3 * g] = l5[1 + g].x; lb[5 + 3 * g] = l5[1 + g].y; lb[6 + 3 * g] = l5[1 + g].z; }
+      lb[3] = l5[4].x; lb[13] = l5[4].y; lb[14] = l5[4].z; lb[15] = 0.f;
+      float damping = lm[3];
+      const int packed = __float_as_int(lm[13]);
+      int count = packed >> 3;
+      uint32_t flags = (uint32_t)packed & 7u;
+      const float var = lm[14];
+      const bool active = (flags & kFlagActive) != 0;
+      float oc_eta[6], oc_lam[36], ol[16];
+      bool relin;
+      factor_update<true>(fac, cm, mu, lm, cb, lb, K, a.hp, damping, count, flags, var, active, oc_eta, oc_lam, ol, relin,
+                             [&](float (&x0c)[6], float (&x0l)[3], CamLin& cl) {
+                               x0c[0] = m4[0].x; x0c[1] = m4[0].y; x0c[2] = m4[0].z; x0c[3] = m4[1].x; x0c[4] = m4[1].y; x0c[5] = m4[1].z;
+                               x0l[0] = u4.x; x0l[1] = u4.y; x0l[2] = u4.z;
+                               float f[21];
+                               GBP_UNROLL
+                               for (int g = 0; g < (int)kFlowClin4; ++g) { f[3 * g] = q7[g].x; f[3 * g + 1] = q7[g].y; f[3 * g + 2] = q7[g].z; }
+                               float4 clq[kCamLin4];
+                               GBP_UNROLL
+                               for (int g = 0; g < kCamLin4; ++g) clq[g] = make_float4(f[4 * g], f[4 * g + 1], f[4 * g + 2], f[4 * g + 3]);
+                               cam_lin_unpack(clq, cl);
+                             });
+      fac_dirty = fac_dirty || (active && relin);
+      ol[3] = damping;
+      ol[13] = __int_as_float((int)(((uint32_t)count << 3) | flags));
+      ol[14] = var;
+      // the tagged landmark messages: eta | Lambda row 0 | row 1 | row 2, through the LDS transpose of k_sweep (coalesced stores)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      stage[lane * 4 + (0u ^ swz_own)] = flow_rec(ol[0], ol[1], ol[2], t_out);
+      GBP_UNROLL
+      for (int q = 1; q < 4; ++q) stage[lane * 4 + ((uint32_t)q ^ swz_own)] = flow_rec(ol[1 + 3 * q], ol[2 + 3 * q], ol[3 + 3 * q], t_out);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      GBP_UNROLL
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t r = k * 16 + rec_t;
+        S_lmsg.st4(h_out * Ep * 4u + lm_tile4 + (uint32_t)k * 64u + lane, stage[r * 4 + ((lane & 3u) ^ (((r >> 2) & 3u) ^ (r & 2u)))]);
+      }
+      {  // camera half of the belief reduction: per-row tree sums (row16_sums_store), the holder's twelve floats as four tagged records
+        float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0;
+        row16_sums_store(oc_eta, oc_lam, lane, [&](uint32_t g, float4 x) {
+          const uint32_t j = g >> 2;
+          if (j == 0u) g0 = x; else if (j == 1u) g1 = x; else g2 = x;
+          if (last) a.rowp[(size_t)(p >> 4) * kCamRec4 + g] = x;
+        });
+        if ((lane & 12u) == 12u) {
+          const uint32_t q = lane & 3u, rp = (h_out * n_rows + (p >> 4)) * kFlowRow4 + 4u * q;
+          S_rowp.st4(rp, flow_rec(g0.x, g0.y, g0.z, t_out));
+          S_rowp.st4(rp + 1u, flow_rec(g0.w, g1.x, g1.y, t_out));
+          S_rowp.st4(rp + 2u, flow_rec(g1.z, g1.w, g2.x, t_out));
+          if (q < 3u) S_rowp.st4(rp + 3u, flow_rec(g2.y, g2.z, g2.w, t_out));
+        }
+      }
+      if (last) {   // the ordinary LMSG tile (with the factor's scalars in its pad slots), as k_sweep leaves it
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        GBP_UNROLL
+        for (int q = 0; q < 4; ++q)
+          stage[lane * 4 + ((uint32_t)q ^ swz_own)] = make_float4(ol[4 * q], ol[4 * q + 1], ol[4 * q + 2], ol[4 * q + 3]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        GBP_UNROLL
+        for (int k = 0; k < 4; ++k) {
+          const uint32_t r = k * 16 + rec_t;
+          a.lmsg[lm_tile4 + (uint32_t)k * 64u + lane] = stage[r * 4 + ((lane & 3u) ^ (((r >> 2) & 3u) ^ (r & 2u)))];
+        }
+      }
+      GBP_UNROLL
+      for (int i = 0; i < 16; ++i) lm[i] = ol[i];
+      GBP_UNROLL
+      for (int i = 0; i < 6; ++i) cm[i] = oc_eta[i];
+      GBP_UNROLL
+      for (int i = 0; i < 6; ++i) {
+        GBP_UNROLL
+        for (int j = 0; j <= i; ++j) cm[6 + tri(i, j)] = oc_lam[i * 6 + j];
+      }
+      cm[27] = 0.f;
+    }
+
+    // ================= phase B: the belief update (arithmetic of k_beliefs, roll = 1) =================
+    if (cam_wave) {
+      float acc = 0.f;
+      if (r1 > r0) {
+        const uint32_t row4 = (h_out * n_rows + r0) * kFlowRow4 + row_f4;          // float4 index of this lane's element in row r0
+        const uint32_t n = r1 - r0;
+        {
+          float4 x;
+          if (!flow_wait([&]() { x = S_rowp.ld4(row4); return !cam_live || flow_is(x, t_out); }, A.sync, A.status, A.seq)) return;
+          acc = flow_pick(x, row_c);
+        }
+        uint32_t r = 1;
+        for (; r + 16 <= n; r += 16) {
+          float4 x[16];
+          if (!flow_wait([&]() {
+                bool ok = true;
+                GBP_UNROLL
+                for (int k = 0; k < 16; ++k) x[k] = S_rowp.ld4(row4 + (r + (uint32_t)k) * kFlowRow4);
+                GBP_UNROLL
+                for (int k = 0; k < 16; ++k) ok = ok && flow_is(x[k], t_out);
+                return !cam_live || ok;
+              }, A.sync, A.status, A.seq)) return;
+          GBP_UNROLL
+          for (int k = 0; k < 16; ++k) acc = acc + flow_pick(x[k], row_c);
+        }
+        {  // tail (< 16 rows): unconditional loads, row index clamped
+          float4 x[16];
+          const uint32_t m = n - r;
+          if (!flow_wait([&]() {
+                bool ok = true;
+                GBP_UNROLL
+                for (int k = 0; k < 16; ++k) x[k] = S_rowp.ld4(row4 + ((uint32_t)k < m ? r + (uint32_t)k : n - 1u) * kFlowRow4);
+                GBP_UNROLL
+                for (int k = 0; k < 16; ++k) ok = ok && flow_is(x[k], t_out);
+                return !cam_live || ok;
+              }, A.sync, A.status, A.seq)) return;
+          GBP_UNROLL
+          for (int k = 0; k < 16; ++k)
+            if ((uint32_t)k < m) acc = acc + flow_pick(x[k], row_c);
+        }
+      }
+      if (cam_live) {
+        if (last) b.cam_local[(size_t)v * kCamRec + cj] = acc;
+        sh[wib][cj] = cam_prior_j + acc;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (lane == 0) {
+        float cb[44], x0c[6];
+        GBP_UNROLL
+        for (int i = 0; i < 44; ++i) cb[i] = sh[wib][i];
+        cam_mean(cb, x0c);
+        const float used[6] = {cam_cur0.x, cam_cur0.y, cam_cur0.z, cam_cur0.w, cam_cur1.x, cam_cur1.y};
+        float S = 0.f;
+        GBP_UNROLL
+        for (int i = 0; i < 6; ++i) S += (used[i] - x0c[i]) * (used[i] - x0c[i]);
+        if (last) { b.cam_mu[(size_t)v * 4 + 2] = cam_cur0; b.cam_mu[(size_t)v * 4 + 3] = cam_cur1; }
+        cam_cur0 = make_float4(x0c[0], x0c[1], x0c[2], x0c[3]);
+        cam_cur1 = make_float4(x0c[4], x0c[5], 0.f, 0.f);
+        S_cmu.st4((h_out * nC + v) * 2u, flow_rec(x0c[0], x0c[1], x0c[2], t_out));
+        S_cmu.st4((h_out * nC + v) * 2u + 1u, flow_rec(x0c[3], x0c[4], x0c[5], t_out));
+        if (last) { b.cam_mu[(size_t)v * 4] = cam_cur0; b.cam_mu[(size_t)v * 4 + 1] = cam_cur1; }
+        {
+          CamLin cl;
+          const float wv[3] = {x0c[3], x0c[4], x0c[5]};
+          cam_lin(wv, cl);
+          float4 q[kCamLin4];
+          cam_lin_pack(cl, q);
+          float f[21];
+          GBP_UNROLL
+          for (int g = 0; g < kCamLin4; ++g) { f[4 * g] = q[g].x; f[4 * g + 1] = q[g].y; f[4 * g + 2] = q[g].z; f[4 * g + 3] = q[g].w; }
+          f[20] = 0.f;
+          GBP_UNROLL
+          for (int g = 0; g < (int)kFlowClin4; ++g)
+            S_clin.st4((h_out * nC + v) * kFlowClin4 + (uint32_t)g, flow_rec(f[3 * g], f[3 * g + 1], f[3 * g + 2], t_out));
+          if (last) {
+            GBP_UNROLL
+            for (int g = 0; g < kCamLin4; ++g) b.cam_lin[(size_t)v * kCamLin4 + g] = q[g];
+          }
+        }
+        sh[wib][6] = S;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (lane < kFlowCam4) S_camb.st4((h_out * nC + v) * kFlowCam4 + lane, flow_rec(sh[wib][cb_s0], sh[wib][cb_s1], sh[wib][cb_s2], t_out));
+      if (last && cam_live) b.camb[(size_t)v * kCamRec + cj] = sh[wib][cj];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // sh[] is rewritten by the next iteration
+      __builtin_amdgcn_wave_barrier();
+    } else if (lmk_wave) {
+      float a3[3] = {pr3[0], pr3[1], pr3[2]};
+      {
+        float4 m[15], m2[15];
+        const bool second = __any(deg > 15u);
+        const uint32_t base = h_out * Ep;
+        if (!flow_wait([&]() {
+              bool ok = true;
+              GBP_UNROLL
+              for (int k = 0; k < 15; ++k) m[k] = S_lmsg.ld4((base + pos[k]) * 4u + q4);
+              if (second) {
+                GBP_UNROLL
+                for (int k = 0; k < 15; ++k) m2[k] = S_lmsg.ld4((base + pos2[k]) * 4u + q4);
+              }
+              GBP_UNROLL
+              for (int k = 0; k < 15; ++k) ok = ok && ((uint32_t)k >= deg || flow_is(m[k], t_out));
+              if (second) {
+                GBP_UNROLL
+                for (int k = 0; k < 15; ++k) ok = ok && (15u + (uint32_t)k >= deg || flow_is(m2[k], t_out));
+              }
+              return !lmk_live || ok;
+            }, A.sync, A.status, A.seq)) return;
+        GBP_UNROLL
+        for (int k = 0; k < 15; ++k)     // adds in slot order
+          if ((uint32_t)k < deg) { a3[0] = a3[0] + m[k].x; a3[1] = a3[1] + m[k].y; a3[2] = a3[2] + m[k].z; }
+        if (second) {
+          GBP_UNROLL
+          for (int k = 0; k < 15; ++k)
+            if (15u + (uint32_t)k < deg) { a3[0] = a3[0] + m2[k].x; a3[1] = a3[1] + m2[k].y; a3[2] = a3[2] + m2[k].z; }
+        }
+      }
+      if (deg > 30u) {
+        for (uint32_t s = lp0 + 30u; s < lp1; s += 8) {
+          uint32_t ps[8];
+          float4 m[8];
+          const uint32_t nleft = lp1 - s;
+          GBP_UNROLL
+          for (int k = 0; k < 8; ++k) ps[k] = b.lmk_fpos[(uint32_t)k < nleft ? s + k : lp1 - 1u];     // clamped, unconditional
+          if (!flow_wait([&]() {
+                bool ok = true;
+                GBP_UNROLL
+                for (int k = 0; k < 8; ++k) m[k] = S_lmsg.ld4((h_out * Ep + ps[k]) * 4u + q4);
+                GBP_UNROLL
+                for (int k = 0; k < 8; ++k) ok = ok && flow_is(m[k], t_out);
+                return ok;
+              }, A.sync, A.status, A.seq)) return;
+          GBP_UNROLL
+          for (int k = 0; k < 8; ++k)
+            if ((uint32_t)k < nleft) { a3[0] = a3[0] + m[k].x; a3[1] = a3[1] + m[k].y; a3[2] = a3[2] + m[k].z; }
+        }
+      }
+      if (lmk_live) S_lmkb.st4((h_out * nL + l) * kFlowLmk4 + q4, flow_rec(a3[0], a3[1], a3[2], t_out));
+      float rec[16];
+      rec[0] = __shfl(a3[0], 0, 4); rec[1] = __shfl(a3[1], 0, 4); rec[2] = __shfl(a3[2], 0, 4);
+      GBP_UNROLL
+      for (int g = 0; g < 3; ++g) {
+        rec[4 + 3 * g] = __shfl(a3[0], 1 + g, 4); rec[5 + 3 * g] = __shfl(a3[1], 1 + g, 4); rec[6 + 3 * g] = __shfl(a3[2], 1 + g, 4);
+      }
+      float u[3] = {0.f, 0.f, 0.f};
+      if (lmk_live && q4 == 0) {
+        float B[9], S3[9], x0l[3];
+        GBP_UNROLL
+        for (int i = 0; i < 9; ++i) B[i] = rec[4 + i];
+        inv3x3(B, S3);
+        GBP_UNROLL
+        for (int i = 0; i < 3; ++i) {
+          float a2 = 0.f;
+          GBP_UNROLL
+          for (int k = 0; k < 3; ++k) a2 += S3[i * 3 + k] * rec[k];
+          x0l[i] = a2;
+        }
+        const float4 used = lmk_cur;
+        u[0] = (used.x - x0l[0]) * (used.x - x0l[0]);
+        u[1] = (used.y - x0l[1]) * (used.y - x0l[1]);
+        u[2] = (used.z - x0l[2]) * (used.z - x0l[2]);
+        lmk_cur = make_float4(x0l[0], x0l[1], x0l[2], 0.f);
+        S_lmu.st4(h_out * nL + l, flow_rec(x0l[0], x0l[1], x0l[2], t_out));
+        S_lmkb.st4((h_out * nL + l) * kFlowLmk4 + 4u, flow_rec(u[0], u[1], u[2], t_out));
+        if (last) { b.lmk_mu[(size_t)l * 2 + 1] = used; b.lmk_mu[(size_t)l * 2] = lmk_cur; }
+      }
+      if (last) {   // the ordinary LMKB record: float4 #q4 of [eta, u0 | Lambda 0..3 | 4..7 | 8, u1, u2, 0]
+        rec[3] = __shfl(u[0], 0, 4); rec[13] = __shfl(u[1], 0, 4); rec[14] = __shfl(u[2], 0, 4); rec[15] = 0.f;
+        float4 o;
+        o.x = q4 == 0u ? rec[0] : q4 == 1u ? rec[4] : q4 == 2u ? rec[8] : rec[12];
+        o.y = q4 == 0u ? rec[1] : q4 == 1u ? rec[5] : q4 == 2u ? rec[9] : rec[13];
+        o.z = q4 == 0u ? rec[2] : q4 == 1u ? rec[6] : q4 == 2u ? rec[10] : rec[14];
+        o.w = q4 == 0u ? rec[3] : q4 == 1u ? rec[7] : q4 == 2u ? rec[11] : rec[15];
+        if (lmk_live) b.lmkb[(size_t)l * 4 + q4] = o;
+      }
+    }
+  }
+
+  // ---- what stayed in registers goes back to its arrays ----
+  if (has_tile) {
+    store_tile<kCmsgG, false>(a.cmsg, tile, lane, cm);
+    if (fac_dirty) store_tile<kFacG, false>(a.fac, tile, lane, fac);
+  }
+}
+
 // Per-factor scalar state (damping, damping_count, flags: pad slots 3 / 13 of the LMSG record) <-> compact
 // per-position arrays, so that READ_PROG's damping / damping_count / robust_flag streams (ba.cpp:912-914) and
 // NEW_KEYFRAME's damping_count / active_flag streams (slam.cpp:920,926) move 8 bytes per factor over PCIe instead of the
@@ -2024,12 +2509,15 @@ hipError_t launch_persist(PersistArgs A, bool cooperative, hipStream_t s) {
   A.n_work_blocks = nb;
   A.spread = (uint32_t)spread;
   const uint32_t grid = spread > 1 ? nb * (uint32_t)spread : spread < -1 ? ((nb + 7) / 8) * (uint32_t)(-spread) * 8 : nb;
+  const bool flow = !A.ev.on && A.f.lmsg != nullptr;      // bursts without the metric: hand-offs through tagged records, no barrier
   if (cooperative) {
     void* args[] = {&A};
-    return hipLaunchCooperativeKernel(A.ev.on ? reinterpret_cast<const void*>(k_persist<true>) : reinterpret_cast<const void*>(k_persist<false>),
+    return hipLaunchCooperativeKernel(A.ev.on ? reinterpret_cast<const void*>(k_persist<true>) :
+                                      flow ? reinterpret_cast<const void*>(k_persist_flow) : reinterpret_cast<const void*>(k_persist<false>),
                                       dim3(grid), dim3(256), args, 0, s);
   }
   if (A.ev.on) hipLaunchKernelGGL((k_persist<true>), dim3(grid), dim3(256), 0, s, A);
+  else if (flow) hipLaunchKernelGGL(k_persist_flow, dim3(grid), dim3(256), 0, s, A);
   else hipLaunchKernelGGL((k_persist<false>), dim3(grid), dim3(256), 0, s, A);
   return hipGetLastError();
 }

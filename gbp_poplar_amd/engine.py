@@ -218,6 +218,11 @@ class GbpEngine:
                   "gbp_debug_get")
         return a, b
 
+    def persist_flow(self, on):
+        """bursts without the metric in the persistent kernel: tagged-record hand-offs (default) or counter barriers (A/B, tests)"""
+        self._need_hooks()
+        self._chk(self.lib.gbp_debug_persist_flow(self.h, int(bool(on))), "gbp_debug_persist_flow")
+
     def factor_potentials(self):
         return self._debug(0, 9 * self.E, 81 * self.E)
 

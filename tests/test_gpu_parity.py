@@ -376,10 +376,12 @@ def _ragged_active(bal):
     return (np.random.default_rng(5).random(bal["n_edges"]) < 0.9).astype(np.uint32)
 
 
+@pytest.mark.parametrize("flow", [1, 0], ids=["tagged_records", "barriers"])
 @pytest.mark.parametrize("name", ["fr2robot2", "fr1xyz", "ragged"])
-def test_persistent_kernel_equals_two_kernel_path(name, oracle_mod):
-    """gbp_iterate(n) through k_persist (sweep + device-wide barrier + beliefs + barrier, n times in ONE launch, per-factor
-    state in registers) leaves EVERY tensor — beliefs, both message sets, potentials, per-factor scalars, hoisted means —
+def test_persistent_kernel_equals_two_kernel_path(name, flow, oracle_mod):
+    """gbp_iterate(n) through the persistent kernel — k_persist_flow (hand-offs through tagged records, the default for bursts
+    without the metric) and k_persist<false> (sweep + device-wide barrier + beliefs + barrier) — n times in ONE launch, per-factor
+    state in registers, leaves EVERY tensor — beliefs, both message sets, potentials, per-factor scalars, hoisted means —
     bit for bit as n x (k_sweep, k_beliefs) do: the ./ba flow with bursts of odd lengths, relinearisations included,
     on the two shipped small sequences and on a ragged synthetic graph (hub landmark of degree > 15, inactive factors,
     cameras with one row, waves with a belief role but no sweep tile)."""
@@ -398,6 +400,7 @@ def test_persistent_kernel_equals_two_kernel_path(name, oracle_mod):
     engs = [GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K, hooks=True,
                       params=_cabi.GbpParams.defaults(persistent=mode, **kw)) for mode in (1, -1)]
     assert engs[0].graph_state() == 2 and engs[1].graph_state() != 2
+    engs[0].persist_flow(flow)
     n_relin = 0
     for e in engs:
         e.upload(state)
