@@ -578,14 +578,16 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
         if (rc == GBP_OK && c->persist_ok) {
           // tagged shadows of the arrays that cross waves inside a launch (k_persist_flow): two halves each
           const size_t Ep = (size_t)c->n_tiles * 64, C_ = c->C, L_ = c->L_loc;
-          const size_t n4[7] = {2 * Ep * 4, 2 * (Ep / 16) * kFlowRow4, 2 * C_ * kFlowCam4, 2 * C_ * 2, 2 * C_ * kFlowClin4, 2 * L_ * kFlowLmk4, 2 * L_};
+          const size_t n4[10] = {2 * Ep * 4, 2 * (Ep / 16) * kFlowRow4, 2 * C_ * kFlowCam4, 2 * C_ * 2, 2 * C_ * kFlowClin4, 2 * L_ * kFlowLmk4, 2 * L_,
+                                 2 * C_ * 4, 2 * L_, (size_t)kSeriesMax};      // (the last: [kSeriesMax][2] 64-bit health words = kSeriesMax float4)
           size_t total = 0;
           for (size_t n : n4) total += n;
           rc = dev_alloc(c, c->pflow, total * 16);
           if (rc == GBP_OK) {
             float4* q = static_cast<float4*>(c->pflow.p);
-            float4** dst[7] = {&c->flow.lmsg, &c->flow.rowp, &c->flow.camb, &c->flow.cmu, &c->flow.clin, &c->flow.lmkb, &c->flow.lmu};
-            for (int i = 0; i < 7; ++i) { *dst[i] = q; q += n4[i]; }
+            float4** dst[9] = {&c->flow.lmsg, &c->flow.rowp, &c->flow.camb, &c->flow.cmu, &c->flow.clin, &c->flow.lmkb, &c->flow.lmu, &c->flow.emc, &c->flow.eml};
+            for (int i = 0; i < 9; ++i) { *dst[i] = q; q += n4[i]; }
+            c->flow.health_iter = reinterpret_cast<unsigned long long*>(q);
             const char* pf = prm ? nullptr : std::getenv("GBP_PERSIST_FLOW");
             if (pf && std::atoi(pf) == 0) c->persist_flow = false;
           } else {
@@ -1068,7 +1070,7 @@ static int launch_persist_burst(gbp_ctx* c, const SweepArgs& a, int n, const Per
   A.epoch_base = c->persist_epoch_base;
   A.seq = c->persist_seq + 1;
   if (ev) A.ev = *ev;
-  const bool flow = !ev && c->persist_flow && c->flow.lmsg != nullptr;      // no metric in the launch: hand-offs through tagged records
+  const bool flow = c->persist_flow && c->flow.lmsg != nullptr;      // hand-offs through tagged records (k_persist_flow)
   if (flow) {
     A.f = c->flow;
     A.f.tag0 = (A.seq & 0x7ffffu) << 13;      // + iteration (<= kPersistChunk) + 1: never the tag of a record an earlier launch left behind
@@ -1102,7 +1104,9 @@ static int launch_persist_burst(gbp_ctx* c, const SweepArgs& a, int n, const Per
     g_persist_last_stream[dev & 15] = c->stream;
   }
   const unsigned nb = persist_blocks(c->n_tiles, c->C, c->L_loc, ev != nullptr && ev->each != 0);      // the grid launch_persist used
-  if (!flow) c->persist_epoch_base += nb * (unsigned)(2 * n - 1 + (ev ? 1 : 0));      // n <= kPersistChunk; the counter wraps, grid_sync compares wrap-safe
+  // arrivals of this launch (n <= kPersistChunk; the counter wraps, grid_sync compares wrap-safe): two hand-offs per iteration — with
+  // tagged records none, and ONE barrier at the end of a launch that carries the metric
+  c->persist_epoch_base += flow ? (ev ? nb : 0u) : nb * (unsigned)(2 * n - 1 + (ev ? 1 : 0));
   c->persist_seq += 1;
   c->persist_log.push_back(gbp_ctx::Burst{c->persist_seq, n, mode, area});
   c->persist_launches += 1;

@@ -174,6 +174,9 @@ struct PersistFlow {
   float4* clin;    // [2][C][7]
   float4* lmkb;    // [2][L][5]
   float4* lmu;     // [2][L][1]          hoisted landmark mean
+  float4* emc;     // [2][C][4]          metric mean of a camera: its rotation (9), its translation (3) (launches that carry the metric)
+  float4* eml;     // [2][L][1]          ... of a landmark
+  unsigned long long* health_iter;   // [kSeriesMax][2] non-finite means / non-PD beliefs of iteration k of the launch (zero between launches)
   unsigned tag0;   // tags of this launch: tag0 (what the prologue publishes), tag0 + 1 + it (what iteration it produces)
 };
 
@@ -181,7 +184,7 @@ struct PersistArgs {
   SweepArgs s;
   BeliefArgs b;
   PersistEval ev;
-  PersistFlow f;           // f.lmsg != NULL and no metric in the launch: k_persist_flow
+  PersistFlow f;           // f.lmsg != NULL: k_persist_flow (tagged records) instead of k_persist (barriers)
   unsigned epoch_base;     // arrivals the barrier counter has already seen (launches of one ctx keep counting: no memset per launch)
   uint32_t n_tiles;        // sweep tiles = waves with a phase-A role
   uint32_t n_lmk_groups;   // ceil(L / 16): waves [C, C + n_lmk_groups) own 16 landmarks each in phase B

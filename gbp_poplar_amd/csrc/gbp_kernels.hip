@@ -1759,7 +1759,12 @@ GBP_DEV uint32_t flow_camb_src(uint32_t k) {
   return 8u + i * 6u + (t - i * (i + 1u) / 2u);
 }
 
+// EV: the launch carries the metric (A.ev, as in k_persist<true>): the metric means of iteration k are tagged records too (F.emc,
+// F.eml), the tile waves evaluate their residuals one iteration later behind their belief-phase role, the health counters are
+// per-iteration device words that block 0 hands to the host's slots behind the ONE barrier such a launch ends with.
+template <bool EV>
 __global__ __launch_bounds__(256) void k_persist_flow(const PersistArgs A) {
+  const bool ev_on = EV && A.ev.on != 0;
   const SweepArgs& a = A.s;
   const BeliefArgs& b = A.b;
   const PersistFlow& F = A.f;
@@ -1780,6 +1785,7 @@ __global__ __launch_bounds__(256) void k_persist_flow(const PersistArgs A) {
   __shared__ float sh[4][48];
   float4* stage = lm_stage[wib];
   const XwBuf S_lmsg(F.lmsg), S_rowp(F.rowp), S_camb(F.camb), S_cmu(F.cmu), S_clin(F.clin), S_lmkb(F.lmkb), S_lmu(F.lmu);
+  const XwBuf S_emc(F.emc), S_eml(F.eml);
   const uint32_t nC = b.n_cams, nL = b.n_lmks, Ep = A.n_tiles * 64u, n_rows = A.n_tiles * 4u;
 
   // ---- phase-A role: sweep tile w; the factor's potential and both of its messages stay in registers ----
@@ -1814,11 +1820,16 @@ __global__ __launch_bounds__(256) void k_persist_flow(const PersistArgs A) {
   for (int i = 0; i < 9; ++i) K[i] = a.K[i];
 
   // ---- phase-B role: camera v, or landmarks 16 (v - C) .. + 15 (4 lanes each); numbered across the workgroups as in k_persist ----
+  // (EV: waves [C + G, 2C + G), where the grid has them, take the METRIC mean of camera v - (C + G): k_persist's metric roles)
   const uint32_t v = wib * nblk + bid;
   const bool cam_wave = v < nC;
   const bool lmk_wave = !cam_wave && (v - nC) < A.n_lmk_groups;
+  const uint32_t v_met0 = nC + A.n_lmk_groups;
+  const bool met_wave = ev_on && v >= v_met0 && v - v_met0 < nC;
+  const bool cam_has_met_wave = cam_wave && ev_on && v_met0 + v < nblk * 4u;
+  const uint32_t camv = met_wave ? v - v_met0 : v;
   const uint32_t cj = lane;
-  const bool cam_live = cam_wave && cj < (uint32_t)kCamRec;
+  const bool cam_live = (cam_wave || met_wave) && cj < (uint32_t)kCamRec;
   uint32_t r0 = 0, r1 = 0;
   float cam_prior_j = 0.f;
   float4 cam_cur0 = make_float4(0.f, 0.f, 0.f, 0.f), cam_cur1 = cam_cur0;
@@ -1827,11 +1838,11 @@ __global__ __launch_bounds__(256) void k_persist_flow(const PersistArgs A) {
   const uint32_t rg = cj >> 2, rn = 4u * (rg >> 2) + (cj & 3u);
   const uint32_t row_f4 = 4u * (rg & 3u) + rn / 3u, row_c = rn % 3u;
   const uint32_t cb_s0 = flow_camb_src(3u * lane), cb_s1 = flow_camb_src(3u * lane + 1u), cb_s2 = flow_camb_src(3u * lane + 2u);   // lanes 0..9
-  if (cam_wave) {
-    r0 = b.cam_row_ptr[v]; r1 = b.cam_row_ptr[v + 1];
-    if (cam_live) cam_prior_j = b.cam_prior[(size_t)v * kCamRec + cj];
-    cam_cur0 = a.cam_mu[(size_t)v * 4]; cam_cur1 = a.cam_mu[(size_t)v * 4 + 1];
+  if (cam_wave || met_wave) {
+    r0 = b.cam_row_ptr[camv]; r1 = b.cam_row_ptr[camv + 1];
+    if (cam_live) cam_prior_j = b.cam_prior[(size_t)camv * kCamRec + cj];
   }
+  if (cam_wave) { cam_cur0 = a.cam_mu[(size_t)v * 4]; cam_cur1 = a.cam_mu[(size_t)v * 4 + 1]; }
   const uint32_t l = lmk_wave ? (v - nC) * 16 + (lane >> 2) : 0u, q4 = lane & 3;
   const bool lmk_live = lmk_wave && l < nL;
   uint4 ix = make_uint4(0u, 0u, 0u, 0u);
@@ -1880,7 +1891,57 @@ __global__ __launch_bounds__(256) void k_persist_flow(const PersistArgs A) {
     }
   }
 
+  // ---- the metric (EV): per-iteration health words in device memory (zero on entry and on exit), the tile waves' partial sums in the
+  // host's slots exactly as k_persist<true> leaves them ----
+  auto health_of = [&](uint32_t kk) -> unsigned long long* { return A.ev.each ? F.health_iter + 2u * kk : A.ev.health; };
+  // (the rotation of the camera's metric mean — eigenso3exp, a function of the camera alone — comes with the mean's record: computed once
+  // by the mean's owner instead of once per factor, the same operations on the same operands, as in the two-kernel path's EvalRide)
+  auto metric = [&](uint32_t kk, int packed, const float (&R)[9], const float (&t)[3], const float (&lmu)[3]) {
+    double s_norm = 0, s_half = 0;
+    const uint32_t flags = (uint32_t)packed & 7u;
+    const bool pad = (flags & kFlagPad) != 0, active = !pad && (flags & kFlagActive) != 0;
+    if (active) eval_residual(R, t, lmu, fac[54], fac[55], a.K, s_norm, s_half);
+    DeviceEval* slots = A.ev.slots + (size_t)(A.ev.each ? kk : 0u) * A.ev.stride;
+    eval_wave_tree(s_norm, s_half);      // the lane tree of every metric, then one record per wave
+    const unsigned long long n_act = (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(active));
+    const unsigned long long n_rel = (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(!pad && (packed >> 3) == -A.ev.num_undamped));
+    const unsigned long long n_rob = (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(!pad && (flags & kFlagRobust) != 0));
+    if (lane == 0) {
+      DeviceEval o;
+      o.sum_norm = s_norm; o.sum_half_sq = s_half; o.n_active = n_act; o.n_relin = n_rel; o.n_robust = n_rob; o.pad = 0;
+      slots[1 + w] = o;
+    }
+  };
+  // the tile wave's share of metric kk (means of iteration kk: half kk & 1, tag0 + kk + 1): c0 / c1 / l0 were loaded early, re-loaded here
+  // only if they had not arrived then
+  auto metric_of = [&](uint32_t kk, int packed, float4 (&c)[4], float4 l0) -> bool {
+    const unsigned tg = F.tag0 + kk + 1u;
+    const uint32_t ec = ((kk & 1u) * nC + cam_i) * 4u, el = (kk & 1u) * nL + lmk_i;
+    if (!__all(flow_is(c[0], tg) && flow_is(c[1], tg) && flow_is(c[2], tg) && flow_is(c[3], tg) && flow_is(l0, tg))) {
+      if (!flow_wait([&]() {
+            GBP_UNROLL
+            for (int g = 0; g < 4; ++g) c[g] = S_emc.ld4(ec + (uint32_t)g);
+            l0 = S_eml.ld4(el);
+            return flow_is(c[0], tg) && flow_is(c[1], tg) && flow_is(c[2], tg) && flow_is(c[3], tg) && flow_is(l0, tg);
+          }, A.sync, A.status, A.seq)) return false;
+    }
+    const float R[9] = {c[0].x, c[0].y, c[0].z, c[1].x, c[1].y, c[1].z, c[2].x, c[2].y, c[2].z};
+    const float t[3] = {c[3].x, c[3].y, c[3].z}, lmu[3] = {l0.x, l0.y, l0.z};
+    metric(kk, packed, R, t, lmu);
+    return true;
+  };
+  auto publish_metric_mean = [&](uint32_t half, uint32_t cam, const float (&xm)[6], unsigned tag) {
+    float R[9];
+    eval_cam_rot(xm, R);
+    GBP_UNROLL
+    for (int g = 0; g < 3; ++g) S_emc.st4((half * nC + cam) * 4u + (uint32_t)g, flow_rec(R[3 * g], R[3 * g + 1], R[3 * g + 2], tag));
+    S_emc.st4((half * nC + cam) * 4u + 3u, flow_rec(xm[0], xm[1], xm[2], tag));
+  };
+
   for (int it = 0; it < A.n_iters; ++it) {
+    const bool ev_means = ev_on && (A.ev.each || it + 1 == A.n_iters);     // this iteration's beliefs are evaluated
+    const bool ev_prev = ev_on && A.ev.each && it > 0 && has_tile;          // this tile wave owes the residuals of iteration it - 1
+    const int ev_packed = __float_as_int(lm[13]);      // the factor's state word as the sweep of iteration it - 1 left it
     const uint32_t h_in = ((uint32_t)it + 1u) & 1u, h_out = (uint32_t)it & 1u;
     const unsigned t_in = F.tag0 + (unsigned)it, t_out = F.tag0 + (unsigned)it + 1u;
     const bool last = it + 1 == A.n_iters;
@@ -2010,7 +2071,17 @@ __global__ __launch_bounds__(256) void k_persist_flow(const PersistArgs A) {
     }
 
     // ================= phase B: the belief update (arithmetic of k_beliefs, roll = 1) =================
-    if (cam_wave) {
+    float4 ev_c[4], ev_l0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    GBP_UNROLL
+    for (int g = 0; g < 4; ++g) ev_c[g] = ev_l0;
+    if (EV && ev_prev) {      // in flight with the role's own loads (measured: the residuals at the end of the phase, not behind the sweep)
+      const uint32_t kk = (uint32_t)it - 1u;
+      GBP_UNROLL
+      for (int g = 0; g < 4; ++g) ev_c[g] = S_emc.ld4(((kk & 1u) * nC + cam_i) * 4u + (uint32_t)g);
+      ev_l0 = S_eml.ld4((kk & 1u) * nL + lmk_i);
+    }
+    unsigned long long* const hw = EV ? health_of((uint32_t)it) : nullptr;
+    if (cam_wave || (EV && met_wave && ev_means)) {
       float acc = 0.f;
       if (r1 > r0) {
         const uint32_t row4 = (h_out * n_rows + r0) * kFlowRow4 + row_f4;          // float4 index of this lane's element in row r0
@@ -2051,16 +2122,33 @@ __global__ __launch_bounds__(256) void k_persist_flow(const PersistArgs A) {
         }
       }
       if (cam_live) {
-        if (last) b.cam_local[(size_t)v * kCamRec + cj] = acc;
+        if (last && cam_wave) b.cam_local[(size_t)v * kCamRec + cj] = acc;
         sh[wib][cj] = cam_prior_j + acc;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (lane == 0) {
+      if (EV && lane == 0 && !cam_wave) {   // metric role: what k_means computes for this camera, from the belief in LDS; then — published
+        float xm[6];                        // first — the health check the camera wave would otherwise run on its critical lane
+        solve_pivot<6>(sh[wib] + 8, 6, sh[wib], xm);
+        publish_metric_mean(h_out, camv, xm, t_out);
+        bool finite = true;
+        GBP_UNROLL
+        for (int i = 0; i < 6; ++i) finite &= (xm[i] - xm[i] == 0.f);
+        if (!finite) atomicAdd(&hw[0], 1ull);
+        if (!ldl_pivots_positive<6>(sh[wib] + 8, 6)) atomicAdd(&hw[1], 1ull);
+      }
+      if (lane == 0 && cam_wave) {
+        const bool ev_here = EV && ev_means && !cam_has_met_wave;     // no wave to spare for this camera's metric mean: solved here
         float cb[44], x0c[6];
         GBP_UNROLL
         for (int i = 0; i < 44; ++i) cb[i] = sh[wib][i];
+        float xm[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        bool pd = true;
+        if (ev_here) {
+          solve_pivot<6>(sh[wib] + 8, 6, sh[wib], xm);
+          pd = ldl_pivots_positive<6>(sh[wib] + 8, 6);
+        }
         cam_mean(cb, x0c);
         const float used[6] = {cam_cur0.x, cam_cur0.y, cam_cur0.z, cam_cur0.w, cam_cur1.x, cam_cur1.y};
         float S = 0.f;
@@ -2090,13 +2178,21 @@ __global__ __launch_bounds__(256) void k_persist_flow(const PersistArgs A) {
             for (int g = 0; g < kCamLin4; ++g) b.cam_lin[(size_t)v * kCamLin4 + g] = q[g];
           }
         }
+        if (ev_here) {
+          publish_metric_mean(h_out, v, xm, t_out);
+          bool finite = true;
+          GBP_UNROLL
+          for (int i = 0; i < 6; ++i) finite &= (xm[i] - xm[i] == 0.f);
+          if (!finite) atomicAdd(&hw[0], 1ull);
+          if (!pd) atomicAdd(&hw[1], 1ull);
+        }
         sh[wib][6] = S;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (lane < kFlowCam4) S_camb.st4((h_out * nC + v) * kFlowCam4 + lane, flow_rec(sh[wib][cb_s0], sh[wib][cb_s1], sh[wib][cb_s2], t_out));
-      if (last && cam_live) b.camb[(size_t)v * kCamRec + cj] = sh[wib][cj];
+      if (cam_wave && lane < kFlowCam4) S_camb.st4((h_out * nC + v) * kFlowCam4 + lane, flow_rec(sh[wib][cb_s0], sh[wib][cb_s1], sh[wib][cb_s2], t_out));
+      if (last && cam_live && cam_wave) b.camb[(size_t)v * kCamRec + cj] = sh[wib][cj];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // sh[] is rewritten by the next iteration
       __builtin_amdgcn_wave_barrier();
     } else if (lmk_wave) {
@@ -2178,6 +2274,16 @@ __global__ __launch_bounds__(256) void k_persist_flow(const PersistArgs A) {
         S_lmu.st4(h_out * nL + l, flow_rec(x0l[0], x0l[1], x0l[2], t_out));
         S_lmkb.st4((h_out * nL + l) * kFlowLmk4 + 4u, flow_rec(u[0], u[1], u[2], t_out));
         if (last) { b.lmk_mu[(size_t)l * 2 + 1] = used; b.lmk_mu[(size_t)l * 2] = lmk_cur; }
+        if (EV && ev_means) {   // metric mean of this landmark (k_means), from the belief record in registers
+          float x[3];
+          solve_pivot<3>(rec + 4, 3, rec, x);
+          S_eml.st4(h_out * nL + l, flow_rec(x[0], x[1], x[2], t_out));
+          bool finite = true;
+          GBP_UNROLL
+          for (int i = 0; i < 3; ++i) finite &= (x[i] - x[i] == 0.f);
+          if (!finite) atomicAdd(&hw[0], 1ull);
+          if (!ldl_pivots_positive<3>(rec + 4, 3)) atomicAdd(&hw[1], 1ull);
+        }
       }
       if (last) {   // the ordinary LMKB record: float4 #q4 of [eta, u0 | Lambda 0..3 | 4..7 | 8, u1, u2, 0]
         rec[3] = __shfl(u[0], 0, 4); rec[13] = __shfl(u[1], 0, 4); rec[14] = __shfl(u[2], 0, 4); rec[15] = 0.f;
@@ -2189,12 +2295,43 @@ __global__ __launch_bounds__(256) void k_persist_flow(const PersistArgs A) {
         if (lmk_live) b.lmkb[(size_t)l * 4 + q4] = o;
       }
     }
+    // the residuals of the PREVIOUS iteration, behind this wave's role (they delay nobody but this wave's next sweep)
+    if (EV && ev_prev)
+      if (!metric_of((uint32_t)it - 1u, ev_packed, ev_c, ev_l0)) return;
   }
 
   // ---- what stayed in registers goes back to its arrays ----
   if (has_tile) {
     store_tile<kCmsgG, false>(a.cmsg, tile, lane, cm);
     if (fac_dirty) store_tile<kFacG, false>(a.fac, tile, lane, fac);
+  }
+
+  // ---- the metric of the last iteration; then the launch's ONE barrier: behind it every owner has counted and block 0 hands the
+  // health words of every metric of the launch to the host's slots (and leaves them zero) ----
+  if (EV && ev_on) {
+    if (has_tile) {
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);      // (tag 0 is nobody's: the records are loaded in metric_of)
+      float4 zc[4] = {z, z, z, z};
+      if (!metric_of((uint32_t)A.n_iters - 1u, __float_as_int(lm[13]), zc, z)) return;
+    }
+    grid_sync(A.sync, A.epoch_base + nblk, A.status, A.seq);
+    if (bid == 0 && threadIdx.x == 0) {
+      if (A.ev.each) {
+        for (int kk = 0; kk < A.n_iters; ++kk) {
+          unsigned long long* out = reinterpret_cast<unsigned long long*>(A.ev.slots + (size_t)kk * A.ev.stride);
+          unsigned long long* h = F.health_iter + 2 * kk;
+          out[0] = __hip_atomic_load(&h[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          out[1] = __hip_atomic_load(&h[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&h[0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&h[1], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      } else {
+        unsigned long long* out = reinterpret_cast<unsigned long long*>(A.ev.slots);
+        out[0] = __hip_atomic_load(&A.ev.health[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        out[1] = __hip_atomic_load(&A.ev.health[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        A.ev.health_next[0] = 0ull; A.ev.health_next[1] = 0ull;
+      }
+    }
   }
 }
 
@@ -2471,13 +2608,13 @@ uint32_t persist_blocks(uint32_t n_tiles, uint32_t n_cams, uint32_t n_lmks, bool
   const uint64_t waves = waves_b > n_tiles ? waves_b : n_tiles;
   const uint32_t nb = (uint32_t)((waves + 3) / 4);
   if (!with_metric) return nb;
-  // a launch that carries the metric after EVERY iteration gets one more wave per camera for the metric roles — as long as that does not cost the
-  // placement (every 4th dispatch slot holds up to 64 working workgroups): fr1xyz 52 -> 56 workgroups, fr2robot2 19 -> 24;
-  // fr1desk would go 61 -> 77 and stays.  Launches without the metric keep the smaller grid (4 more workgroups cost them
-  // 0.45 us per iteration on fr1xyz, profiles/r04_small_graphs.md).
+  // a launch that carries the metric after EVERY iteration gets one more wave per camera for the metric roles: fr1xyz 52 -> 56
+  // workgroups, fr2robot2 19 -> 24, fr1desk 61 -> 77 (every 2nd dispatch slot instead of every 4th; without barriers more workgroups cost
+  // nothing: 16.3 -> 13.9 us per iteration with the metric, round 5) — up to the 96 workgroups the persistent path is chosen for by itself.
+  // Launches without the metric keep the smaller grid.
   const uint64_t waves_m = waves_b + n_cams > n_tiles ? waves_b + n_cams : n_tiles;
   const uint32_t nb_m = (uint32_t)((waves_m + 3) / 4);
-  return nb_m <= 64u ? nb_m : nb;
+  return nb_m <= 96u ? nb_m : nb;
 }
 int persist_max_resident_blocks() {
   int dev = 0, per_cu = 0;
@@ -2509,15 +2646,16 @@ hipError_t launch_persist(PersistArgs A, bool cooperative, hipStream_t s) {
   A.n_work_blocks = nb;
   A.spread = (uint32_t)spread;
   const uint32_t grid = spread > 1 ? nb * (uint32_t)spread : spread < -1 ? ((nb + 7) / 8) * (uint32_t)(-spread) * 8 : nb;
-  const bool flow = !A.ev.on && A.f.lmsg != nullptr;      // bursts without the metric: hand-offs through tagged records, no barrier
+  const bool flow = A.f.lmsg != nullptr;      // hand-offs through tagged records instead of device-wide barriers (PersistFlow)
   if (cooperative) {
     void* args[] = {&A};
-    return hipLaunchCooperativeKernel(A.ev.on ? reinterpret_cast<const void*>(k_persist<true>) :
-                                      flow ? reinterpret_cast<const void*>(k_persist_flow) : reinterpret_cast<const void*>(k_persist<false>),
-                                      dim3(grid), dim3(256), args, 0, s);
+    const void* f = flow ? (A.ev.on ? reinterpret_cast<const void*>(k_persist_flow<true>) : reinterpret_cast<const void*>(k_persist_flow<false>))
+                         : (A.ev.on ? reinterpret_cast<const void*>(k_persist<true>) : reinterpret_cast<const void*>(k_persist<false>));
+    return hipLaunchCooperativeKernel(f, dim3(grid), dim3(256), args, 0, s);
   }
-  if (A.ev.on) hipLaunchKernelGGL((k_persist<true>), dim3(grid), dim3(256), 0, s, A);
-  else if (flow) hipLaunchKernelGGL(k_persist_flow, dim3(grid), dim3(256), 0, s, A);
+  if (flow && A.ev.on) hipLaunchKernelGGL((k_persist_flow<true>), dim3(grid), dim3(256), 0, s, A);
+  else if (flow) hipLaunchKernelGGL((k_persist_flow<false>), dim3(grid), dim3(256), 0, s, A);
+  else if (A.ev.on) hipLaunchKernelGGL((k_persist<true>), dim3(grid), dim3(256), 0, s, A);
   else hipLaunchKernelGGL((k_persist<false>), dim3(grid), dim3(256), 0, s, A);
   return hipGetLastError();
 }
