@@ -2086,38 +2086,52 @@ __global__ __launch_bounds__(256) void k_persist_flow(const PersistArgs A) {
       if (r1 > r0) {
         const uint32_t row4 = (h_out * n_rows + r0) * kFlowRow4 + row_f4;          // float4 index of this lane's element in row r0
         const uint32_t n = r1 - r0;
-        {
-          float4 x;
-          if (!flow_wait([&]() { x = S_rowp.ld4(row4); return !cam_live || flow_is(x, t_out); }, A.sync, A.status, A.seq)) return;
-          acc = flow_pick(x, row_c);
-        }
-        uint32_t r = 1;
-        for (; r + 16 <= n; r += 16) {
-          float4 x[16];
+        // rows per round; rows of the first round.  (measured on the three sequences, round 5: 1 + 16 is as fast as or faster than 2 + 16,
+        // 17 + 16, 9 + 8, 1 + 32 and everything in one round — k_persist's shape, for the same reason: registers)
+        constexpr int RB = 16, RF = 1;
+        uint32_t r = 0;
+        {  // first round: rows 0 .. RF - 1 (clamped, unconditional)
+          float4 x[RF];
           if (!flow_wait([&]() {
                 bool ok = true;
                 GBP_UNROLL
-                for (int k = 0; k < 16; ++k) x[k] = S_rowp.ld4(row4 + (r + (uint32_t)k) * kFlowRow4);
+                for (int k = 0; k < RF; ++k) x[k] = S_rowp.ld4(row4 + ((uint32_t)k < n ? (uint32_t)k : n - 1u) * kFlowRow4);
                 GBP_UNROLL
-                for (int k = 0; k < 16; ++k) ok = ok && flow_is(x[k], t_out);
+                for (int k = 0; k < RF; ++k) ok = ok && flow_is(x[k], t_out);
+                return !cam_live || ok;
+              }, A.sync, A.status, A.seq)) return;
+          acc = flow_pick(x[0], row_c);
+          GBP_UNROLL
+          for (int k = 1; k < RF; ++k)
+            if ((uint32_t)k < n) acc = acc + flow_pick(x[k], row_c);
+          r = n < (uint32_t)RF ? n : (uint32_t)RF;
+        }
+        for (; r + RB <= n; r += RB) {
+          float4 x[RB];
+          if (!flow_wait([&]() {
+                bool ok = true;
+                GBP_UNROLL
+                for (int k = 0; k < RB; ++k) x[k] = S_rowp.ld4(row4 + (r + (uint32_t)k) * kFlowRow4);
+                GBP_UNROLL
+                for (int k = 0; k < RB; ++k) ok = ok && flow_is(x[k], t_out);
                 return !cam_live || ok;
               }, A.sync, A.status, A.seq)) return;
           GBP_UNROLL
-          for (int k = 0; k < 16; ++k) acc = acc + flow_pick(x[k], row_c);
+          for (int k = 0; k < RB; ++k) acc = acc + flow_pick(x[k], row_c);
         }
-        {  // tail (< 16 rows): unconditional loads, row index clamped
-          float4 x[16];
+        if (r < n) {  // tail (< RB rows): unconditional loads, row index clamped
+          float4 x[RB];
           const uint32_t m = n - r;
           if (!flow_wait([&]() {
                 bool ok = true;
                 GBP_UNROLL
-                for (int k = 0; k < 16; ++k) x[k] = S_rowp.ld4(row4 + ((uint32_t)k < m ? r + (uint32_t)k : n - 1u) * kFlowRow4);
+                for (int k = 0; k < RB; ++k) x[k] = S_rowp.ld4(row4 + ((uint32_t)k < m ? r + (uint32_t)k : n - 1u) * kFlowRow4);
                 GBP_UNROLL
-                for (int k = 0; k < 16; ++k) ok = ok && flow_is(x[k], t_out);
+                for (int k = 0; k < RB; ++k) ok = ok && flow_is(x[k], t_out);
                 return !cam_live || ok;
               }, A.sync, A.status, A.seq)) return;
           GBP_UNROLL
-          for (int k = 0; k < 16; ++k)
+          for (int k = 0; k < RB; ++k)
             if ((uint32_t)k < m) acc = acc + flow_pick(x[k], row_c);
         }
       }

@@ -447,19 +447,21 @@ def test_persistent_kernel_full_run_vs_oracle(oracle_mod):
     assert [t[0] for t in tg] == [t[0] for t in to] and [t[3:] for t in tg] == [t[3:] for t in to]
 
 
-def test_iterate_eval_fused_metric_equals_separate_calls(oracle_mod):
-    """gbp_iterate_eval(n) — the iterations AND the metric in one k_persist launch on small graphs (two more phases: what
-    k_means and k_eval compute) — against gbp_iterate(n) followed by gbp_eval(): metric sums, counters, health counters and
+@pytest.mark.parametrize("flow", [1, 0], ids=["tagged_records", "barriers"])
+def test_iterate_eval_fused_metric_equals_separate_calls(flow, oracle_mod):
+    """gbp_iterate_eval(n) — the iterations AND the metric in one launch of the persistent kernel on small graphs (what
+    k_means and k_eval compute; k_persist_flow<true> or k_persist<true>) — against gbp_iterate(n) followed by gbp_eval(): metric sums, counters, health counters and
     every belief identical, single iterations (the reference's default loop) and bursts, two evaluations in flight."""
     from gbp_poplar_amd import _cabi, driver, hostlib
     from gbp_poplar_amd.engine import GbpEngine
     for name in ("fr2robot2", "fr1xyz"):
         bal = _bal(name)
         K, state, _ = driver.build_inputs(bal, driver.Options(), hostlib)
-        a = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K)
+        a = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K, hooks=True)
         b = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K)
         c = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K, params=_cabi.GbpParams.defaults(persistent=-1))
         assert a.graph_state() == 2 and c.graph_state() != 2
+        a.persist_flow(flow)
         for e in (a, b, c):
             e.upload(state)
             e.linearise()
@@ -498,9 +500,10 @@ def test_iterate_eval_fused_metric_equals_separate_calls(oracle_mod):
         assert a.timing()["iterations"] == b.timing()["iterations"]
 
 
-def test_iterate_eval_each_equals_one_iteration_and_one_metric_at_a_time(oracle_mod):
-    """gbp_iterate_eval_each(n): n iterations with the metric after every one — ONE k_persist launch per burst on small graphs,
-    the metric of iteration k computed inside the sweep phase of iteration k + 1 — against n times {gbp_iterate(1); gbp_eval()}:
+@pytest.mark.parametrize("flow", [1, 0], ids=["tagged_records", "barriers"])
+def test_iterate_eval_each_equals_one_iteration_and_one_metric_at_a_time(flow, oracle_mod):
+    """gbp_iterate_eval_each(n): n iterations with the metric after every one — ONE launch of the persistent kernel per burst on
+    small graphs (k_persist_flow<true> or k_persist<true>), the metric of iteration k computed one iteration later — against n times {gbp_iterate(1); gbp_eval()}:
     every metric (sums, counters, health counters) and every belief identical.  Bursts of 1, a few, 129 and 300 (a launch carries
     at most 128 metrics), prior weakening between bursts, then gbp_iterate_eval and plain gbp_eval still work; c is the same
     entry point on the two-kernel path."""
@@ -516,10 +519,11 @@ def test_iterate_eval_each_equals_one_iteration_and_one_metric_at_a_time(oracle_
         K, state, _ = driver.build_inputs(bal, opts, hostlib)
         if name == "ragged":
             state["active_flag"] = _ragged_active(bal)
-        a = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K, params=_cabi.GbpParams.defaults(persistent=1, **kw))
+        a = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K, hooks=True, params=_cabi.GbpParams.defaults(persistent=1, **kw))
         b = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K, params=_cabi.GbpParams.defaults(persistent=-1, **kw))
         c = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K, params=_cabi.GbpParams.defaults(persistent=-1, **kw))
         assert a.graph_state() == 2 and c.graph_state() != 2
+        a.persist_flow(flow)
         for e in (a, b, c):
             e.upload(state)
             e.linearise()
@@ -1248,6 +1252,19 @@ def test_health_counters(oracle_mod):
     orc.linearise()
     g, o = eng.eval(), orc.eval()
     assert g["n_nonpd"] == o["n_nonpd"] == 1 and g["n_nonfinite"] == 0
+    # ... and, counted per iteration, out of the launches of the persistent kernel that carry the metric (their health words travel
+    # from the owners' device counters to the host's slots behind the launch's closing barrier)
+    assert eng.graph_state() == 2
+    ge = eng.iterate_eval_each(3)
+    for k in range(3):
+        orc.iterate(1)
+        oe = orc.eval()
+        assert (ge[k]["n_nonpd"], ge[k]["n_nonfinite"], ge[k]["n_active"]) == (oe["n_nonpd"], oe["n_nonfinite"], oe["n_active"]), (k, ge[k], oe)
+    assert ge[0]["n_nonpd"] >= 1
+    eng.iterate_eval(2)
+    orc.iterate(2)
+    g, o = eng.eval_end(), orc.eval()
+    assert (g["n_nonpd"], g["n_nonfinite"]) == (o["n_nonpd"], o["n_nonfinite"]) and g["n_nonpd"] >= 1
 
 
 # ---- BASELINE.json's full size (S1: 1 000 cams x 100 000 lmks x 1 000 000 factors) ---------------------------------
