@@ -101,12 +101,12 @@ typedef struct {
                                       landmark octile as well (a row stays whole, a camera's rows are added in the camera's own
                                       order: same sums; +2.4 % on the config-5 shard shape)                                                */
   int32_t persistent;          /* gbp_iterate(n >= 2) on a graph small enough that all of its workgroups are resident at once
-                                  (BASELINE configs 1-3) runs the n iterations inside ONE kernel launch (k_persist: per-factor
-                                  state in registers, device-wide barriers instead of kernel boundaries; identical results):
+                                  (BASELINE configs 1-3) runs the n iterations inside ONE kernel launch (k_persist_flow: per-factor
+                                  state in registers, hand-offs through tagged records instead of kernel boundaries; identical results):
                                   0 (default) = automatically up to 96 workgroups (24 576 factor positions; all shipped sequences need <= 61), 1 = whenever the graph is
                                   co-resident, -1 = never.  Single-GPU ctx with hoisted means only.
-                                  The device-wide barriers inside that kernel need all of its workgroups resident at once; two things
-                                  stand behind that (persist_coop below) and a third behind both: a barrier that waits longer than
+                                  The waits inside that kernel need all of its workgroups resident at once; two things
+                                  stand behind that (persist_coop below) and a third behind both: a wait that lasts longer than
                                   1.5 s gives up, every later launch of the ctx returns at once, and the library — at the next call
                                   that synchronises anyway — restores the snapshot taken before the failed launch, replays the
                                   affected bursts on the two-kernel path (identical results), returns GBP_OK and leaves a warning in
