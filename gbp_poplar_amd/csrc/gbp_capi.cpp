@@ -502,9 +502,11 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
     const char* pc = prm ? nullptr : std::getenv("GBP_PERSIST_COOP");
     const int coop_mode = pc ? std::atoi(pc) : c->prm.persist_coop;  // 1 = cooperative launch, else (default) plain launch + probe + recovery
     const uint32_t nb = persist_blocks(c->n_tiles, c->C, c->L_loc, true);
-    // measured (profiles/r03_small_graphs.md): the shipped sequences (19 - 61 workgroups, relinearising in every sweep) run
-    // 1.55 - 1.82x faster in k_persist; converging synthetic graphs 1.21x at 63 workgroups, break even at 125
-    const uint32_t auto_limit = 96;
+    // measured (profiles/persist_crossover.py, round 5): with hand-offs through tagged records the persistent kernel is faster than
+    // the two-kernel path on every graph it is co-resident for — the shipped sequences (14 - 61 workgroups) 1.36 - 1.55x, synthetic
+    // graphs 1.16 - 1.43x up to 250 workgroups (64 000 factors: 12.2 against 16.2 us per iteration; round 4's barrier kernel broke
+    // even at 125 workgroups and took 24.8 us there).  So: every graph of at most one workgroup per CU of an MI355X.
+    const uint32_t auto_limit = 256;
     // (k_persist sweeps tile w on wave w and its camera role adds rows cam_row_ptr[c] .. cam_row_ptr[c + 1] where camera-major order
     // puts them: a graph with a tile permutation or with rows placed by landmark class never runs in it, whatever the size
     // thresholds of the three features say)

@@ -2624,11 +2624,11 @@ uint32_t persist_blocks(uint32_t n_tiles, uint32_t n_cams, uint32_t n_lmks, bool
   if (!with_metric) return nb;
   // a launch that carries the metric after EVERY iteration gets one more wave per camera for the metric roles: fr1xyz 52 -> 56
   // workgroups, fr2robot2 19 -> 24, fr1desk 61 -> 77 (every 2nd dispatch slot instead of every 4th; without barriers more workgroups cost
-  // nothing: 16.3 -> 13.9 us per iteration with the metric, round 5) — up to the 96 workgroups the persistent path is chosen for by itself.
+  // nothing: 16.3 -> 13.9 us per iteration with the metric, round 5) — as long as the larger grid still is one workgroup per CU.
   // Launches without the metric keep the smaller grid.
   const uint64_t waves_m = waves_b + n_cams > n_tiles ? waves_b + n_cams : n_tiles;
   const uint32_t nb_m = (uint32_t)((waves_m + 3) / 4);
-  return nb_m <= 96u ? nb_m : nb;
+  return nb_m <= 256u ? nb_m : nb;
 }
 int persist_max_resident_blocks() {
   int dev = 0, per_cu = 0;

@@ -103,7 +103,7 @@ typedef struct {
   int32_t persistent;          /* gbp_iterate(n >= 2) on a graph small enough that all of its workgroups are resident at once
                                   (BASELINE configs 1-3) runs the n iterations inside ONE kernel launch (k_persist_flow: per-factor
                                   state in registers, hand-offs through tagged records instead of kernel boundaries; identical results):
-                                  0 (default) = automatically up to 96 workgroups (24 576 factor positions; all shipped sequences need <= 61), 1 = whenever the graph is
+                                  0 (default) = automatically up to 256 workgroups (65 536 factor positions; all shipped sequences need <= 61), 1 = whenever the graph is
                                   co-resident, -1 = never.  Single-GPU ctx with hoisted means only.
                                   The waits inside that kernel need all of its workgroups resident at once; two things
                                   stand behind that (persist_coop below) and a third behind both: a wait that lasts longer than

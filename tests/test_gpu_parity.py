@@ -377,7 +377,7 @@ def _ragged_active(bal):
 
 
 @pytest.mark.parametrize("flow", [1, 0], ids=["tagged_records", "barriers"])
-@pytest.mark.parametrize("name", ["fr2robot2", "fr1xyz", "ragged"])
+@pytest.mark.parametrize("name", ["fr2robot2", "fr1xyz", "ragged", "all_cus"])
 def test_persistent_kernel_equals_two_kernel_path(name, flow, oracle_mod):
     """gbp_iterate(n) through the persistent kernel — k_persist_flow (hand-offs through tagged records, the default for bursts
     without the metric) and k_persist<false> (sweep + device-wide barrier + beliefs + barrier) — n times in ONE launch, per-factor
@@ -392,13 +392,15 @@ def test_persistent_kernel_equals_two_kernel_path(name, flow, oracle_mod):
     if name == "ragged":
         bal, kw = _ragged_bal()
         opts.undamped_start = 2
+    elif name == "all_cus":      # 64 000 factors = 250 workgroups: one per CU, no dispatch spread (the automatic choice since round 5)
+        bal = hostlib.synth_generate(100, 6400, 10, 7)
     else:
         bal = _bal(name)
     K, state, _ = driver.build_inputs(bal, opts, hostlib)
     if name == "ragged":
         state["active_flag"] = _ragged_active(bal)
     engs = [GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K, hooks=True,
-                      params=_cabi.GbpParams.defaults(persistent=mode, **kw)) for mode in (1, -1)]
+                      params=_cabi.GbpParams.defaults(persistent=mode, **kw)) for mode in (0 if name == "all_cus" else 1, -1)]
     assert engs[0].graph_state() == 2 and engs[1].graph_state() != 2
     engs[0].persist_flow(flow)
     n_relin = 0
