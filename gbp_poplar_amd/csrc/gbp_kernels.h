@@ -203,7 +203,7 @@ struct CopySegs {
   void* dst[kMaxCopySegs];
   size_t n4[kMaxCopySegs];     // float4 elements of each segment
 };
-constexpr int kSeriesMax = 128;         // metrics per launch of gbp_iterate_eval_each (longer bursts are split)
+constexpr int kSeriesMax = 512;         // metrics per launch of gbp_iterate_eval_each (longer bursts are split)
 constexpr int kPersistSyncWords = 16 * 32;
 
 struct DeviceEval {  // per-block partials, summed on the host in block order

@@ -2329,9 +2329,9 @@ __global__ __launch_bounds__(256) void k_persist_flow(const PersistArgs A) {
       if (!metric_of((uint32_t)A.n_iters - 1u, __float_as_int(lm[13]), zc, z)) return;
     }
     grid_sync(A.sync, A.epoch_base + nblk, A.status, A.seq);
-    if (bid == 0 && threadIdx.x == 0) {
+    if (bid == 0 && (threadIdx.x == 0 || A.ev.each)) {
       if (A.ev.each) {
-        for (int kk = 0; kk < A.n_iters; ++kk) {
+        for (int kk = (int)threadIdx.x; kk < A.n_iters; kk += 256) {
           unsigned long long* out = reinterpret_cast<unsigned long long*>(A.ev.slots + (size_t)kk * A.ev.stride);
           unsigned long long* h = F.health_iter + 2 * kk;
           out[0] = __hip_atomic_load(&h[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

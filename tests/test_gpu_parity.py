@@ -506,8 +506,8 @@ def test_iterate_eval_fused_metric_equals_separate_calls(flow, oracle_mod):
 def test_iterate_eval_each_equals_one_iteration_and_one_metric_at_a_time(flow, oracle_mod):
     """gbp_iterate_eval_each(n): n iterations with the metric after every one — ONE launch of the persistent kernel per burst on
     small graphs (k_persist_flow<true> or k_persist<true>), the metric of iteration k computed one iteration later — against n times {gbp_iterate(1); gbp_eval()}:
-    every metric (sums, counters, health counters) and every belief identical.  Bursts of 1, a few, 129 and 300 (a launch carries
-    at most 128 metrics), prior weakening between bursts, then gbp_iterate_eval and plain gbp_eval still work; c is the same
+    every metric (sums, counters, health counters) and every belief identical.  Bursts of 1, a few, 129 and 600 (a launch carries
+    at most 512 metrics), prior weakening between bursts, then gbp_iterate_eval and plain gbp_eval still work; c is the same
     entry point on the two-kernel path."""
     from gbp_poplar_amd import _cabi, driver, hostlib
     from gbp_poplar_amd.engine import GbpEngine
@@ -530,7 +530,7 @@ def test_iterate_eval_each_equals_one_iteration_and_one_metric_at_a_time(flow, o
             e.upload(state)
             e.linearise()
         it = 0
-        for n in (1, 1, 2, 2, 2, 2, 5, 1, 129, 0, 300 if name == "fr1xyz" else 40):
+        for n in (1, 1, 2, 2, 2, 2, 5, 1, 129, 0, 600 if name == "fr1xyz" else 40):
             if it in (1, 3, 5, 7, 9):
                 for e in (a, b, c):
                     e.weaken_priors()
