@@ -436,7 +436,7 @@ def small_config_gpu(name):
                            "us_per_iter_device": round(1e3 * rep100["device_ms"] / max(rep100["device_iterations"], 1), 2),
                            "final_mean_reproj_px": rep100.get("final_mean_reproj_px"), "graph_state": rep100["graph_state"]},
         "graph_state": rep["graph_state"],
-        "path": {2: "k_persist (bursts inside one launch)", 1: "hipGraph replay", 0: "direct launches", -1: "direct launches (capture failed)"}.get(rep["graph_state"]),
+        "path": {2: "k_persist_flow (bursts inside one launch, hand-offs through tagged records)", 1: "hipGraph replay", 0: "direct launches", -1: "direct launches (capture failed)"}.get(rep["graph_state"]),
         "final_mean_reproj_px": rep.get("final_mean_reproj_px"), "final_cost": rep.get("final_cost"), "rmse_px": rep.get("final_rmse_px"),
         "n_active": rep.get("n_active"), "n_relin_final": rep.get("n_relin"), "n_robust_final": rep.get("n_robust"),
         "nonfinite_beliefs": rep.get("n_nonfinite"),

@@ -29,6 +29,7 @@ from gbp_poplar_amd import hostlib
 hostlib.bal_write("/tmp/s1.txt", hostlib.synth_generate(1000, 100000, 10, 20200303))
 PY
 for ev in 1 100; do for rep in 1 2; do gbp_poplar_amd/bin/ba --bal_file /tmp/s1.txt --n_iters 300 --eval_every $ev > $OUT/ba_S1_every$ev.log 2>&1; done; done
+for s in fr1xyz fr2robot2 fr1desk; do python3 profiles/time_bursts.py $s 10 2>/dev/null | tail -1; python3 profiles/time_bursts.py $s 10 flow=0 2>/dev/null | tail -1; done > $OUT/persist_bursts.txt
 python3 profiles/time_default_loop.py > $OUT/default_loop_S1.txt 2>&1
 python3 profiles/time_default_loop.py 8000 125000 > $OUT/default_loop_c5shape.txt 2>&1
 python3 profiles/beliefs_mall.py > $OUT/beliefs_mall_S1.txt 2>&1
