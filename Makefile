@@ -17,7 +17,7 @@ $(LIB): $(CSRC)/gbp_kernels.hip $(CSRC)/gbp_capi.cpp $(CSRC)/gbp_layout.cpp $(CS
 
 $(PKG)/bin/%: $(CSRC)/%_main.cpp $(CSRC)/cli_common.hpp $(LIB)
 	@mkdir -p $(PKG)/bin
-	$(CXX) -o $@ -O2 -std=c++17 -ffp-contract=off $< -L$(PKG) -lgbp_mi355x '-Wl,-rpath,$$ORIGIN/..'
+	$(CXX) -o $@ -O2 -std=c++17 -ffp-contract=off -pthread $< -L$(PKG) -lgbp_mi355x '-Wl,-rpath,$$ORIGIN/..'
 
 oracle:
 	$(MAKE) -C oracle

@@ -71,7 +71,7 @@ def build(force=False, verbose=False, test_hooks=True):
         exe = os.path.join(BIN, name)
         if os.path.exists(path) and (force or _stale(exe, deps + [LIB])):
             # the CLIs are plain C++ on top of the C-ABI: host compiler, linked against the in-tree library
-            cmd = [shutil.which("g++") or "g++", "-o", exe, "-O2", "-std=c++17", "-ffp-contract=off", path,
+            cmd = [shutil.which("g++") or "g++", "-o", exe, "-O2", "-std=c++17", "-ffp-contract=off", "-pthread", path,
                    "-L" + HERE, "-lgbp_mi355x", "-Wl,-rpath,$ORIGIN/.."]
             if verbose:
                 print(" ".join(cmd))

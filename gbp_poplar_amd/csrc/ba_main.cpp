@@ -37,16 +37,21 @@ static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
   pipe.on = !rk.region && !o.verbose;
   unsigned iter = 0;
   cli::RunReport rep;
-  const auto print_iter = [&rep](unsigned it_now, const gbp_eval_out& e) {   // ba.cpp:1020-1024
-    rep.last = e; rep.have_metric = true;
+  const auto write_iter = [](unsigned it_now, const gbp_eval_out& e) {   // ba.cpp:1020-1024
     std::cout << "Iter " << it_now << " // Reprojection error " << (float)(e.sum_norm / (double)e.n_active);
     std::cout << " // Cost " << (float)e.sum_half_sq << " // n relins: " << e.n_relin;
     std::cout << " // n robust edges " << e.n_robust << "\n";
     if (e.n_nonfinite) std::cout << "warning: " << e.n_nonfinite << " beliefs are non-finite\n";
   };
+  const auto print_iter = [&rep, &write_iter](unsigned it_now, const gbp_eval_out& e) {
+    rep.last = e; rep.have_metric = true;
+    write_iter(it_now, e);
+  };
+  cli::AsyncLines lines;      // cli_common.hpp: the per-iteration lines are written while the next burst runs
   std::vector<gbp_eval_out> series;
   for (int i = 0; i < o.n_iters; ++i) {
     if (((iter + 1) % 2 == 0) && (iter < o.steps * 2)) {       // ba.cpp:1003-1006
+      lines.drain();
       pipe.line("Weakening priors \n");
       CLI_CHECK(ctx, gbp_weaken_priors(ctx));
     }
@@ -58,7 +63,10 @@ static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
       while (burst < 128 && i + burst < o.n_iters && !(((iter + burst + 1) % 2 == 0) && (iter + burst < o.steps * 2))) ++burst;
       series.resize((size_t)burst);
       CLI_CHECK(ctx, gbp_iterate_eval_each(ctx, burst, series.data()));
-      for (int k = 0; k < burst; ++k) print_iter(iter + (unsigned)k, series[(size_t)k]);
+      rep.last = series.back(); rep.have_metric = true;
+      lines.post([first = iter, batch = series, &write_iter] {      // (bursts of 128 rather than 512: the last burst's lines are the ones nothing overlaps)
+        for (size_t k = 0; k < batch.size(); ++k) write_iter(first + (unsigned)k, batch[k]);
+      });
       i += burst - 1;
       iter += (unsigned)burst;
       continue;
@@ -83,6 +91,7 @@ static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
     }
     iter += 1;
   }
+  lines.finish();
   CLI_CHECK(ctx, pipe.flush());
   std::cout << "\n Finished GBP.\n";
   const auto t_end = std::chrono::steady_clock::now();

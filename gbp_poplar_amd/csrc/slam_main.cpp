@@ -42,17 +42,22 @@ static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
   pipe.ctx = ctx;
   pipe.on = !rk.region && !o.verbose;
   cli::RunReport rep;
-  const auto print_iter = [&rep](unsigned total, unsigned since, const gbp_eval_out& e) {
-    rep.last = e; rep.have_metric = true;
+  const auto write_iter = [](unsigned total, unsigned since, const gbp_eval_out& e) {
     std::cout << "Iters " << total;
     std::cout << " (since last kf " << since << ") // Reprojection error " << (float)(e.sum_norm / (double)e.n_active);
     std::cout << " // Cost " << (float)e.sum_half_sq << " // n relins: " << e.n_relin;
     std::cout << " // n robust edges " << e.n_robust << "\n";
   };
+  const auto print_iter = [&rep, &write_iter](unsigned total, unsigned since, const gbp_eval_out& e) {
+    rep.last = e; rep.have_metric = true;
+    write_iter(total, since, e);
+  };
+  cli::AsyncLines lines;      // cli_common.hpp: the per-iteration lines are written while the next burst runs
   std::vector<gbp_eval_out> series;
   for (unsigned i = 0; i < niters; ++i) {
     if ((i + 1) % (unsigned)o.iters_between_kfs == 0) {         // slam.cpp:1020-1046
       CLI_CHECK(ctx, pipe.flush());                             // the keyframe logic reads beliefs back: no metric in flight
+      lines.drain();
       iter = 0;
       data_counter += 1;
       int32_t n_new = 0;
@@ -73,6 +78,7 @@ static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
       CLI_CHECK(ctx, gbp_new_keyframe(ctx, &up));
     }
     if (((iter + 1) % 2 == 0) && (iter < o.steps * 2)) {
+      lines.drain();
       pipe.line("Weakening priors \n");
       CLI_CHECK(ctx, gbp_weaken_priors(ctx));
     }
@@ -85,7 +91,10 @@ static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
         ++nb;
       series.resize(nb);
       CLI_CHECK(ctx, gbp_iterate_eval_each(ctx, (int)nb, series.data()));
-      for (unsigned k = 0; k < nb; ++k) print_iter((unsigned)o.iters_between_kfs * data_counter + iter + k, iter + k, series[k]);
+      rep.last = series.back(); rep.have_metric = true;
+      lines.post([total0 = (unsigned)o.iters_between_kfs * data_counter + iter, since0 = iter, batch = series, &write_iter] {
+        for (size_t k = 0; k < batch.size(); ++k) write_iter(total0 + (unsigned)k, since0 + (unsigned)k, batch[k]);
+      });
       i += nb - 1;
       iter += nb;
       continue;
@@ -109,6 +118,7 @@ static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
     }
     iter += 1;
   }
+  lines.finish();
   CLI_CHECK(ctx, pipe.flush());
   std::cout << "\n Finished GBP.\n";
   const auto t_end = std::chrono::steady_clock::now();
