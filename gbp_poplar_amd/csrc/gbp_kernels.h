@@ -185,6 +185,8 @@ struct PersistArgs {
   BeliefArgs b;
   PersistEval ev;
   PersistFlow f;           // f.lmsg != NULL: k_persist_flow (tagged records) instead of k_persist (barriers)
+  uint32_t separate;       // k_persist_flow: 1 = cameras (and metric means) are owned by waves WITHOUT a tile (persist_blocks sized the grid for it)
+  uint32_t n_met;          // ... and this many metric roles follow the camera roles (0 or C)
   unsigned epoch_base;     // arrivals the barrier counter has already seen (launches of one ctx keep counting: no memset per launch)
   uint32_t n_tiles;        // sweep tiles = waves with a phase-A role
   uint32_t n_lmk_groups;   // ceil(L / 16): waves [C, C + n_lmk_groups) own 16 landmarks each in phase B

@@ -1821,12 +1821,22 @@ __global__ __launch_bounds__(256) void k_persist_flow(const PersistArgs A) {
 
   // ---- phase-B role: camera v, or landmarks 16 (v - C) .. + 15 (4 lanes each); numbered across the workgroups as in k_persist ----
   // (EV: waves [C + G, 2C + G), where the grid has them, take the METRIC mean of camera v - (C + G): k_persist's metric roles)
-  const uint32_t v = wib * nblk + bid;
+  // A.separate: the roles are dealt to the waves WITHOUT a tile first (whole workgroups behind the tiles', one role per workgroup
+  // before a second one), cameras, then metric means, then landmark groups: a wave that owns a camera then sweeps no tile, and
+  // nothing it does behind its publication (the metric's residuals, the fp64 solves of a metric mean) delays a sweep that every
+  // camera waits for.  v below is the role in k_persist's numbering either way.
+  const uint32_t v_met0 = nC + A.n_lmk_groups;
+  uint32_t v = wib * nblk + bid;
+  if (A.separate) {
+    const uint32_t tw = A.n_tiles / 4u;                                     // workgroups that hold tiles (n_tiles is a multiple of 4)
+    const uint32_t r = bid >= tw ? wib * (nblk - tw) + (bid - tw) : (nblk - tw) * 4u + w;
+    v = r < nC ? r : r < nC + A.n_met ? v_met0 + (r - nC) : nC + (r - nC - A.n_met);
+    if (r >= nC + A.n_met && v >= v_met0) v = ~0u;                          // no role left for this wave
+  }
   const bool cam_wave = v < nC;
   const bool lmk_wave = !cam_wave && (v - nC) < A.n_lmk_groups;
-  const uint32_t v_met0 = nC + A.n_lmk_groups;
   const bool met_wave = ev_on && v >= v_met0 && v - v_met0 < nC;
-  const bool cam_has_met_wave = cam_wave && ev_on && v_met0 + v < nblk * 4u;
+  const bool cam_has_met_wave = cam_wave && ev_on && (A.separate ? A.n_met != 0u : v_met0 + v < nblk * 4u);
   const uint32_t camv = met_wave ? v - v_met0 : v;
   const uint32_t cj = lane;
   const bool cam_live = (cam_wave || met_wave) && cj < (uint32_t)kCamRec;
@@ -2617,7 +2627,18 @@ bool persist_probe(uint32_t n_tiles, uint32_t n_cams, uint32_t n_lmks, unsigned*
   return ok;
 }
 
+// role separation of k_persist_flow (PersistArgs.separate): the grid has a tile-less wave for every camera (and metric mean) as long
+// as that still is at most one workgroup per CU (0: it is not — roles and tiles share waves as in k_persist).  Measured
+// (profiles/r05_persist_flow.md): with the metric after every iteration fr1xyz 13.1 -> 12.3 us per iteration, fr2robot2 12.3 -> 11.4,
+// fr1desk unchanged; plain bursts 0.1 - 0.2 us faster.
+static uint32_t persist_blocks_separate(uint32_t n_tiles, uint32_t n_cams, uint32_t n_lmks, bool with_metric) {
+  const uint64_t cx = (uint64_t)n_cams * (with_metric ? 2u : 1u), g = ((uint64_t)n_lmks + 15) / 16;
+  const uint64_t waves = n_tiles + cx > cx + g ? n_tiles + cx : cx + g;
+  const uint64_t nb = (waves + 3) / 4;
+  return nb <= 256u ? (uint32_t)nb : 0u;
+}
 uint32_t persist_blocks(uint32_t n_tiles, uint32_t n_cams, uint32_t n_lmks, bool with_metric) {
+  if (const uint32_t nbs = persist_blocks_separate(n_tiles, n_cams, n_lmks, with_metric)) return nbs;
   const uint64_t waves_b = (uint64_t)n_cams + ((uint64_t)n_lmks + 15) / 16;
   const uint64_t waves = waves_b > n_tiles ? waves_b : n_tiles;
   const uint32_t nb = (uint32_t)((waves + 3) / 4);
@@ -2659,6 +2680,11 @@ hipError_t launch_persist(PersistArgs A, bool cooperative, hipStream_t s) {
 #endif
   A.n_work_blocks = nb;
   A.spread = (uint32_t)spread;
+  {
+    const bool wm = A.ev.on != 0 && A.ev.each != 0;
+    A.separate = persist_blocks_separate(A.n_tiles, A.b.n_cams, A.b.n_lmks, wm) != 0u ? 1u : 0u;
+    A.n_met = A.separate && wm ? A.b.n_cams : 0u;
+  }
   const uint32_t grid = spread > 1 ? nb * (uint32_t)spread : spread < -1 ? ((nb + 7) / 8) * (uint32_t)(-spread) * 8 : nb;
   const bool flow = A.f.lmsg != nullptr;      // hand-offs through tagged records instead of device-wide barriers (PersistFlow)
   if (cooperative) {
