@@ -561,7 +561,8 @@ def test_iterate_eval_each_equals_one_iteration_and_one_metric_at_a_time(flow, o
 
 @pytest.mark.parametrize("shape", ["tiles_permuted", "rows_placed", "per_factor_mu"])
 def test_iterate_eval_each_rides_in_the_two_kernel_path(shape, oracle_mod):
-    """gbp_iterate_eval_each on graphs that do NOT run in k_persist (more than 96 workgroups): the metric of iteration k rides in
+    """gbp_iterate_eval_each on graphs that do NOT run in the persistent kernel (more than 256 workgroups, a permuted tile order, placed rows,
+    per-factor means): the metric of iteration k rides in
     the sweep of iteration k + 1 (k_sweep<EV> / k_beliefs<EV>, bursts replayed from a hipGraph, one k_eval_fold per piece) —
     against n times {gbp_iterate(1); gbp_eval()} on a second engine: every metric (sums, counters, health counters) and every
     belief IDENTICAL; against the oracle: counters equal, sums within fp64 reassociation.  Shapes: a 200-camera graph whose

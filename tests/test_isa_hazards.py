@@ -81,5 +81,5 @@ def test_no_dpp_operand_is_read_within_two_wait_states_of_its_write(libname):
             n_kernels += 1
             n_dpp += here
     if libname == "libgbp_mi355x.so":
-        # k_sweep<true>, k_sweep<false>, k_persist<0,true>, k_persist<0,false>: 60 tree nodes each
+        # k_sweep<..>, k_persist<true|false>, k_persist_flow<true|false>: 60 tree nodes each
         assert n_kernels >= 4 and n_dpp >= 240, (n_kernels, n_dpp)
