@@ -2098,7 +2098,10 @@ __global__ __launch_bounds__(256) void k_persist_flow(const PersistArgs A) {
         const uint32_t n = r1 - r0;
         // rows per round; rows of the first round.  (measured on the three sequences, round 5: 1 + 16 is as fast as or faster than 2 + 16,
         // 17 + 16, 9 + 8, 1 + 32 and everything in one round — k_persist's shape, for the same reason: registers)
-        constexpr int RB = 16, RF = 1;
+        // (... and once the cameras had waves of their own, measured again: the instantiation with the metric is faster with two rounds for
+        // up to 28 rows, 12 + 16 — fr1xyz 12.28 -> 11.94 us per iteration, fr1desk 12.47 -> 12.29, fr2robot2 11.45 -> 11.3; 4 + 24, 8 + 20,
+        // 14 + 14 about the same — the plain one stays fastest with 1 + 16: 11.52 against 11.8 - 12.0)
+        constexpr int RB = 16, RF = EV ? 12 : 1;
         uint32_t r = 0;
         {  // first round: rows 0 .. RF - 1 (clamped, unconditional)
           float4 x[RF];
