@@ -1177,6 +1177,9 @@ struct XwBuf {
     const v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(i4 * 16u), 0, kSc1);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
   }
+  // float4 #kNone4 lies beyond the descriptor's range (0x7fffffff bytes): the hardware returns zeros WITHOUT a memory access — what a
+  // slot that is not needed loads (a clamped duplicate would be one more trip through the fabric; a conditional load a branch)
+  static constexpr uint32_t kNone4 = 0x0fffffffu;
   GBP_DEV void st4(uint32_t i4, const float4 v) const {
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
     const v4u x = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
@@ -2103,14 +2106,14 @@ __global__ __launch_bounds__(256) void k_persist_flow(const PersistArgs A) {
         // 14 + 14 about the same — the plain one stays fastest with 1 + 16: 11.52 against 11.8 - 12.0)
         constexpr int RB = 16, RF = EV ? 12 : 1;
         uint32_t r = 0;
-        {  // first round: rows 0 .. RF - 1 (clamped, unconditional)
+        {  // first round: rows 0 .. RF - 1 (unconditional; rows the camera does not have: out of range, no access)
           float4 x[RF];
           if (!flow_wait([&]() {
                 bool ok = true;
                 GBP_UNROLL
-                for (int k = 0; k < RF; ++k) x[k] = S_rowp.ld4(row4 + ((uint32_t)k < n ? (uint32_t)k : n - 1u) * kFlowRow4);
+                for (int k = 0; k < RF; ++k) x[k] = S_rowp.ld4((uint32_t)k < n ? row4 + (uint32_t)k * kFlowRow4 : XwBuf::kNone4);
                 GBP_UNROLL
-                for (int k = 0; k < RF; ++k) ok = ok && flow_is(x[k], t_out);
+                for (int k = 0; k < RF; ++k) ok = ok && ((uint32_t)k >= n || flow_is(x[k], t_out));
                 return !cam_live || ok;
               }, A.sync, A.status, A.seq)) return;
           acc = flow_pick(x[0], row_c);
@@ -2132,15 +2135,15 @@ __global__ __launch_bounds__(256) void k_persist_flow(const PersistArgs A) {
           GBP_UNROLL
           for (int k = 0; k < RB; ++k) acc = acc + flow_pick(x[k], row_c);
         }
-        if (r < n) {  // tail (< RB rows): unconditional loads, row index clamped
+        if (r < n) {  // tail (< RB rows): unconditional loads, the rows beyond the camera's out of range
           float4 x[RB];
           const uint32_t m = n - r;
           if (!flow_wait([&]() {
                 bool ok = true;
                 GBP_UNROLL
-                for (int k = 0; k < RB; ++k) x[k] = S_rowp.ld4(row4 + ((uint32_t)k < m ? r + (uint32_t)k : n - 1u) * kFlowRow4);
+                for (int k = 0; k < RB; ++k) x[k] = S_rowp.ld4((uint32_t)k < m ? row4 + (r + (uint32_t)k) * kFlowRow4 : XwBuf::kNone4);
                 GBP_UNROLL
-                for (int k = 0; k < RB; ++k) ok = ok && flow_is(x[k], t_out);
+                for (int k = 0; k < RB; ++k) ok = ok && ((uint32_t)k >= m || flow_is(x[k], t_out));
                 return !cam_live || ok;
               }, A.sync, A.status, A.seq)) return;
           GBP_UNROLL
@@ -2231,10 +2234,10 @@ __global__ __launch_bounds__(256) void k_persist_flow(const PersistArgs A) {
         if (!flow_wait([&]() {
               bool ok = true;
               GBP_UNROLL
-              for (int k = 0; k < 15; ++k) m[k] = S_lmsg.ld4((base + pos[k]) * 4u + q4);
+              for (int k = 0; k < 15; ++k) m[k] = S_lmsg.ld4((uint32_t)k < deg ? (base + pos[k]) * 4u + q4 : XwBuf::kNone4);
               if (second) {
                 GBP_UNROLL
-                for (int k = 0; k < 15; ++k) m2[k] = S_lmsg.ld4((base + pos2[k]) * 4u + q4);
+                for (int k = 0; k < 15; ++k) m2[k] = S_lmsg.ld4(15u + (uint32_t)k < deg ? (base + pos2[k]) * 4u + q4 : XwBuf::kNone4);
               }
               GBP_UNROLL
               for (int k = 0; k < 15; ++k) ok = ok && ((uint32_t)k >= deg || flow_is(m[k], t_out));
