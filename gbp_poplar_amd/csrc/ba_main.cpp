@@ -51,20 +51,23 @@ static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
   std::vector<gbp_eval_out> series;
   for (int i = 0; i < o.n_iters; ++i) {
     if (((iter + 1) % 2 == 0) && (iter < o.steps * 2)) {       // ba.cpp:1003-1006
-      lines.drain();
-      pipe.line("Weakening priors \n");
+      if (pipe.on && o.eval_every == 1) lines.post([] { std::cout << "Weakening priors \n"; });      // in order, behind the lines of the burst before it
+      else pipe.line("Weakening priors \n");
       CLI_CHECK(ctx, gbp_weaken_priors(ctx));
     }
     if (pipe.on && o.eval_every == 1) {
       // the reference's default: the metric after EVERY iteration.  All iterations up to the next prior weakening go down in
       // one call (gbp_iterate_eval_each: one launch on a graph that runs in the persistent kernel), at most 128 at a time so
-      // that the lines keep coming on a large graph
+      // that the lines keep coming on a large graph — 512 where an iteration takes microseconds (the persistent kernel: every
+      // launch boundary is ~60 us of idle GPU), but the LAST burst of the run short: its lines are the ones no launch overlaps
+      const int cap = gbp_graph_state(ctx) == 2 ? 512 : 128;
       int burst = 1;
-      while (burst < 128 && i + burst < o.n_iters && !(((iter + burst + 1) % 2 == 0) && (iter + burst < o.steps * 2))) ++burst;
+      while (burst < cap && i + burst < o.n_iters && !(((iter + burst + 1) % 2 == 0) && (iter + burst < o.steps * 2))) ++burst;
+      if (cap == 512 && i + burst == o.n_iters && burst > 96) burst -= 64;      // ... so the run ends with a burst of 64
       series.resize((size_t)burst);
       CLI_CHECK(ctx, gbp_iterate_eval_each(ctx, burst, series.data()));
       rep.last = series.back(); rep.have_metric = true;
-      lines.post([first = iter, batch = series, &write_iter] {      // (bursts of 128 rather than 512: the last burst's lines are the ones nothing overlaps)
+      lines.post([first = iter, batch = series, &write_iter] {
         for (size_t k = 0; k < batch.size(); ++k) write_iter(first + (unsigned)k, batch[k]);
       });
       i += burst - 1;

@@ -57,15 +57,18 @@ static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
   for (unsigned i = 0; i < niters; ++i) {
     if ((i + 1) % (unsigned)o.iters_between_kfs == 0) {         // slam.cpp:1020-1046
       CLI_CHECK(ctx, pipe.flush());                             // the keyframe logic reads beliefs back: no metric in flight
-      lines.drain();
       iter = 0;
       data_counter += 1;
       int32_t n_new = 0;
       gbp_slam_update_flags(&P.prob, steps, data_counter, P.active.data(), P.lwf.data(), P.cwf.data(), lmk_active.data(), &n_new);
-      std::cout << "\n**********************************************************";
-      std::cout << "\n Adding keyframe " << data_counter + 1;
-      std::cout << "\n Adding " << n_new << " new landmarks";
-      std::cout << "\n**********************************************************\n\n";
+      const auto banner = [kf = data_counter + 1, n_new] {
+        std::cout << "\n**********************************************************";
+        std::cout << "\n Adding keyframe " << kf;
+        std::cout << "\n Adding " << n_new << " new landmarks";
+        std::cout << "\n**********************************************************\n\n";
+      };
+      if (pipe.on && o.eval_every == 1) lines.post(banner);     // through the writer: in order behind the lines of the burst before it
+      else banner();
       CLI_CHECK(ctx, gbp_read_priors(ctx, &po));
       CLI_CHECK(ctx, gbp_read(ctx, &rb.out));
       gbp_slam_initialise_new_kf(data_counter, rb.cbe.data(), rb.cbl.data(), P.cpl.data(), P.cpe.data());
@@ -78,17 +81,19 @@ static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
       CLI_CHECK(ctx, gbp_new_keyframe(ctx, &up));
     }
     if (((iter + 1) % 2 == 0) && (iter < o.steps * 2)) {
-      lines.drain();
-      pipe.line("Weakening priors \n");
+      if (pipe.on && o.eval_every == 1) lines.post([] { std::cout << "Weakening priors \n"; });
+      else { lines.drain(); pipe.line("Weakening priors \n"); }
       CLI_CHECK(ctx, gbp_weaken_priors(ctx));
     }
     if (pipe.on && o.eval_every == 1) {
       // the reference's default, the metric after EVERY iteration: everything up to the next keyframe / prior weakening in
       // one call (gbp_iterate_eval_each, see ba_main.cpp)
+      const unsigned cap = gbp_graph_state(ctx) == 2 ? 512u : 128u;      // (see ba_main.cpp)
       unsigned nb = 1;
-      while (nb < 128 && i + nb < niters && (i + nb + 1) % (unsigned)o.iters_between_kfs != 0 &&
+      while (nb < cap && i + nb < niters && (i + nb + 1) % (unsigned)o.iters_between_kfs != 0 &&
              !(((iter + nb + 1) % 2 == 0) && (iter + nb < o.steps * 2)))
         ++nb;
+      if (cap == 512u && i + nb == niters && nb > 96u) nb -= 64u;      // the run ends with a burst of 64 (its lines are the ones no launch overlaps)
       series.resize(nb);
       CLI_CHECK(ctx, gbp_iterate_eval_each(ctx, (int)nb, series.data()));
       rep.last = series.back(); rep.have_metric = true;
