@@ -96,6 +96,7 @@ _DEBUG_SIGS = {
     "gbp_debug_layout_options": (C.c_int, [C.POINTER(cabi.GbpLayoutOptions)]),
     "gbp_debug_force_sweep_policy": (C.c_int, [C.c_int]),
     "gbp_debug_persist_flow": (C.c_int, [C.c_void_p, C.c_int]),
+    "gbp_debug_persist_roles": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32]),
     "gbp_debug_layout_build": (C.c_int, [C.POINTER(cabi.GbpProblem), C.c_int, C.POINTER(cabi.GbpShard),
                                          C.POINTER(cabi.GbpLayoutOptions), C.POINTER(C.c_void_p)]),
     "gbp_debug_layout_dims": (C.c_int, [C.c_void_p, cabi.c_u32p]),

@@ -1729,6 +1729,17 @@ void gbp_debug_layout_default_options(gbp_layout_options* o) {
 }
 int gbp_debug_layout_options(const gbp_layout_options* o) { g_layout_options = to_options(o); return GBP_OK; }
 int gbp_debug_force_sweep_policy(int policy) { g_force_sweep_policy = policy; return GBP_OK; }
+int gbp_debug_persist_roles(uint32_t n_tiles, uint32_t n_cams, uint32_t n_lmks, int with_metric, uint32_t* dims, uint32_t* role, uint32_t cap) {
+  if (!dims) return GBP_ERR_INVALID;
+  const PersistGrid pg = persist_grid(n_tiles, n_cams, n_lmks, with_metric != 0);
+  dims[0] = pg.nb; dims[1] = pg.separate; dims[2] = pg.n_met; dims[3] = (n_lmks + 15) / 16;
+  if (role) {
+    if (cap < pg.nb * 4u) return GBP_ERR_INVALID;
+    for (uint32_t b = 0; b < pg.nb; ++b)
+      for (uint32_t w = 0; w < 4; ++w) role[b * 4 + w] = persist_role(b, w, pg.nb, n_tiles, n_cams, dims[3], pg.n_met, pg.separate);
+  }
+  return GBP_OK;
+}
 int gbp_debug_persist_flow(gbp_ctx* c, int on) {
   if (!c) return GBP_ERR_INVALID;
   c->persist_flow = on != 0;

@@ -180,6 +180,31 @@ struct PersistFlow {
   unsigned tag0;   // tags of this launch: tag0 (what the prologue publishes), tag0 + 1 + it (what iteration it produces)
 };
 
+// Which belief-phase role the wave (workgroup bid of nblk, wave wib of 4) of a k_persist_flow launch has, in k_persist's numbering:
+// v < C camera v;  C <= v < C + G landmark group v - C;  C + G <= v < 2C + G metric mean of camera v - (C + G);  ~0u none.
+// separate = 0: v = wib * nblk + bid (roles and tiles share waves).  separate = 1: the roles are dealt to the waves WITHOUT a tile first
+// (whole workgroups behind the n_tiles / 4 that hold tiles, one role per workgroup before a second one): cameras, then n_met metric
+// means, then landmark groups.  Host and device (gbp_debug_persist_roles evaluates it on the host: tests/test_persist_roles.py).
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define GBP_HD __host__ __device__ inline
+#else
+#define GBP_HD inline
+#endif
+GBP_HD uint32_t persist_role(uint32_t bid, uint32_t wib, uint32_t nblk, uint32_t n_tiles, uint32_t n_cams, uint32_t n_lmk_groups,
+                             uint32_t n_met, uint32_t separate) {
+  if (!separate) return wib * nblk + bid;
+  const uint32_t v_met0 = n_cams + n_lmk_groups;
+  const uint32_t tw = n_tiles / 4u;                                     // workgroups that hold tiles (n_tiles is a multiple of 4)
+  const uint32_t r = bid >= tw ? wib * (nblk - tw) + (bid - tw) : (nblk - tw) * 4u + (bid * 4u + wib);
+  if (r < n_cams) return r;
+  if (r < n_cams + n_met) return v_met0 + (r - n_cams);
+  const uint32_t g = r - n_cams - n_met;
+  return g < n_lmk_groups ? n_cams + g : ~0u;                           // no role left for this wave
+}
+// grid of a launch: workgroups, whether the roles are separated, how many metric roles (persist_blocks / launch_persist use it)
+struct PersistGrid { uint32_t nb, separate, n_met; };
+PersistGrid persist_grid(uint32_t n_tiles, uint32_t n_cams, uint32_t n_lmks, bool with_metric);
+
 struct PersistArgs {
   SweepArgs s;
   BeliefArgs b;

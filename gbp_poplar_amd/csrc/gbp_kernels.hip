@@ -1829,13 +1829,7 @@ __global__ __launch_bounds__(256) void k_persist_flow(const PersistArgs A) {
   // nothing it does behind its publication (the metric's residuals, the fp64 solves of a metric mean) delays a sweep that every
   // camera waits for.  v below is the role in k_persist's numbering either way.
   const uint32_t v_met0 = nC + A.n_lmk_groups;
-  uint32_t v = wib * nblk + bid;
-  if (A.separate) {
-    const uint32_t tw = A.n_tiles / 4u;                                     // workgroups that hold tiles (n_tiles is a multiple of 4)
-    const uint32_t r = bid >= tw ? wib * (nblk - tw) + (bid - tw) : (nblk - tw) * 4u + w;
-    v = r < nC ? r : r < nC + A.n_met ? v_met0 + (r - nC) : nC + (r - nC - A.n_met);
-    if (r >= nC + A.n_met && v >= v_met0) v = ~0u;                          // no role left for this wave
-  }
+  const uint32_t v = persist_role(bid, wib, nblk, A.n_tiles, nC, A.n_lmk_groups, A.n_met, A.separate);
   const bool cam_wave = v < nC;
   const bool lmk_wave = !cam_wave && (v - nC) < A.n_lmk_groups;
   const bool met_wave = ev_on && v >= v_met0 && v - v_met0 < nC;
@@ -2648,6 +2642,11 @@ static uint32_t persist_blocks_separate(uint32_t n_tiles, uint32_t n_cams, uint3
   const uint64_t nb = (waves + 3) / 4;
   return nb <= 256u ? (uint32_t)nb : 0u;
 }
+PersistGrid persist_grid(uint32_t n_tiles, uint32_t n_cams, uint32_t n_lmks, bool with_metric) {
+  const uint32_t nbs = persist_blocks_separate(n_tiles, n_cams, n_lmks, with_metric);
+  if (nbs) return PersistGrid{nbs, 1u, with_metric ? n_cams : 0u};
+  return PersistGrid{persist_blocks(n_tiles, n_cams, n_lmks, with_metric), 0u, 0u};
+}
 uint32_t persist_blocks(uint32_t n_tiles, uint32_t n_cams, uint32_t n_lmks, bool with_metric) {
   if (const uint32_t nbs = persist_blocks_separate(n_tiles, n_cams, n_lmks, with_metric)) return nbs;
   const uint64_t waves_b = (uint64_t)n_cams + ((uint64_t)n_lmks + 15) / 16;
@@ -2692,9 +2691,9 @@ hipError_t launch_persist(PersistArgs A, bool cooperative, hipStream_t s) {
   A.n_work_blocks = nb;
   A.spread = (uint32_t)spread;
   {
-    const bool wm = A.ev.on != 0 && A.ev.each != 0;
-    A.separate = persist_blocks_separate(A.n_tiles, A.b.n_cams, A.b.n_lmks, wm) != 0u ? 1u : 0u;
-    A.n_met = A.separate && wm ? A.b.n_cams : 0u;
+    const PersistGrid pg = persist_grid(A.n_tiles, A.b.n_cams, A.b.n_lmks, A.ev.on != 0 && A.ev.each != 0);
+    A.separate = pg.separate;
+    A.n_met = pg.n_met;
   }
   const uint32_t grid = spread > 1 ? nb * (uint32_t)spread : spread < -1 ? ((nb + 7) / 8) * (uint32_t)(-spread) * 8 : nb;
   const bool flow = A.f.lmsg != nullptr;      // hand-offs through tagged records instead of device-wide barriers (PersistFlow)

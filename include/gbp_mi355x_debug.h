@@ -66,6 +66,11 @@ GBP_API int gbp_debug_force_sweep_policy(int policy);
 /* bursts without the metric on a graph that runs in the persistent kernel: 1 (default) = k_persist_flow (hand-offs through tagged
  * records, no device-wide barrier), 0 = k_persist<false> (counter barriers); identical results — A/B measurements and tests */
 GBP_API int gbp_debug_persist_flow(gbp_ctx* ctx, int on);
+/* the grid and the belief-phase roles of a launch of the persistent kernel for a graph of n_tiles sweep tiles (a multiple of 4), n_cams
+ * cameras, n_lmks landmarks, without / with the metric after every iteration (host evaluation of the function the kernel uses; no GPU):
+ * dims[4] = workgroups, roles separated from the tiles (0 / 1), metric roles, landmark groups;  role[4 * workgroups] (may be NULL): per
+ * wave 4 * workgroup + wave-in-workgroup: v < n_cams camera v, < n_cams + groups landmark group, < 2 n_cams + groups metric mean, ~0 none */
+GBP_API int gbp_debug_persist_roles(uint32_t n_tiles, uint32_t n_cams, uint32_t n_lmks, int with_metric, uint32_t* dims, uint32_t* role, uint32_t cap);
 GBP_API int gbp_debug_layout_build(const gbp_problem* problem, int tile_order, const gbp_shard* shard /*NULL = whole graph*/,
                            const gbp_layout_options* opt /*NULL = the process's current options*/, gbp_layout** out);
 /* dims[11] = C, L, E, lmk_begin, lmk_end, L_loc, E_loc, n_rows, n_tiles, Ep, row_window */

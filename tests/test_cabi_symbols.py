@@ -65,7 +65,7 @@ def test_test_hooks_library_exports_the_debug_header():
     from gbp_poplar_amd import _lib
     lib = _lib.load(hooks=True)
     names = declared_functions("gbp_mi355x_debug.h")
-    assert names == sorted(_lib.debug_symbols()) and len(names) == 14
+    assert names == sorted(_lib.debug_symbols()) and len(names) == 15
     for n in names + declared_functions():
         assert hasattr(lib, n), "libgbp_mi355x_test.so does not export %s" % n
 
