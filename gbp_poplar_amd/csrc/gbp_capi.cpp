@@ -133,8 +133,8 @@ struct gbp_ctx {
   // restores the snapshot and replays the logged launches from the first failed one on.
   struct Burst { unsigned seq; int n; int mode; int area; };   // mode 0 = gbp_iterate, 1 = gbp_iterate_eval (metric in eval area `area`), 2 = eval_each (blocking)
   DevBuf pflow;                        // tagged shadows of k_persist_flow (PersistFlow), one allocation
-  PersistFlow flow{};                  // flow.lmsg == NULL: bursts without the metric run in k_persist<false> (barriers)
-  bool persist_flow = true;            // gbp_debug_set_persist_flow / GBP_PERSIST_FLOW=0: keep the barrier kernel (A/B measurements)
+  PersistFlow flow{};                  // the tagged shadows of k_persist_flow
+  bool persist_flow = true;            // test-hooks build: gbp_debug_persist_flow(ctx, 0) / GBP_PERSIST_FLOW=0 run the barrier kernel of rounds 3-4 instead
   std::vector<Burst> persist_log;      // launched, completion not yet validated
   unsigned persist_seq = 0;
   DevBuf psnap;                        // snapshot arena
@@ -590,8 +590,10 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
             float4** dst[9] = {&c->flow.lmsg, &c->flow.rowp, &c->flow.camb, &c->flow.cmu, &c->flow.clin, &c->flow.lmkb, &c->flow.lmu, &c->flow.emc, &c->flow.eml};
             for (int i = 0; i < 9; ++i) { *dst[i] = q; q += n4[i]; }
             c->flow.health_iter = reinterpret_cast<unsigned long long*>(q);
-            const char* pf = prm ? nullptr : std::getenv("GBP_PERSIST_FLOW");
+#ifdef GBP_BUILD_TEST_HOOKS
+            const char* pf = prm ? nullptr : std::getenv("GBP_PERSIST_FLOW");      // (the barrier kernel exists in the test-hooks build only)
             if (pf && std::atoi(pf) == 0) c->persist_flow = false;
+#endif
           } else {
             g_create_error = c->err;
           }
