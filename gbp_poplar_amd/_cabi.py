@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-GBP_ABI_VERSION = 5          # include/gbp_mi355x.h
+GBP_ABI_VERSION = 6          # include/gbp_mi355x.h
 
 c_f32p = C.POINTER(C.c_float)
 c_f64p = C.POINTER(C.c_double)

@@ -36,6 +36,7 @@ _SIGS = {
     "gbp_eval_end": (C.c_int, [C.c_void_p, C.POINTER(cabi.GbpEvalOut)]),
     "gbp_iterate_eval": (C.c_int, [C.c_void_p, C.c_int]),
     "gbp_iterate_eval_each": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(cabi.GbpEvalOut)]),
+    "gbp_ba_loop": (C.c_int, [C.c_void_p, C.c_int, C.c_uint, C.c_uint, C.POINTER(cabi.GbpEvalOut)]),
     "gbp_sync": (C.c_int, [C.c_void_p]),
     "gbp_timing": (C.c_int, [C.c_void_p, C.POINTER(cabi.GbpTimingOut), C.c_int]),
     "gbp_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),

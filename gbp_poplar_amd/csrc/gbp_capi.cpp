@@ -558,18 +558,20 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
         }
         if (rc == GBP_OK && c->persist_ok) {
           // snapshot arena: one slot for every array a k_persist launch mutates
-          DevBuf* segs[] = {&c->lmsg, &c->cmsg, &c->fac, &c->rowp, &c->camb, &c->lmkb, &c->hmu_c, &c->hmu_l, &c->clin, &c->local};
+          // (+ the priors and the weaken flags: a launch of gbp_ba_loop weakens priors itself)
+          DevBuf* segs[] = {&c->lmsg, &c->cmsg, &c->fac, &c->rowp, &c->camb, &c->lmkb, &c->hmu_c, &c->hmu_l, &c->clin, &c->local,
+                            &c->camp, &c->lmkp, &c->cwf, &c->lwf};
           size_t total = 0;
-          for (DevBuf* b : segs) total += b->bytes;
+          for (DevBuf* b : segs) total += (b->bytes + 15) / 16 * 16;
           rc = dev_alloc(c, c->psnap, total);
           if (rc == GBP_OK) {
             size_t off = 0;
             int i = 0;
             for (DevBuf* b : segs) {
               void* slot = static_cast<char*>(c->psnap.p) + off;
-              c->snap_save.src[i] = b->p; c->snap_save.dst[i] = slot; c->snap_save.n4[i] = b->bytes / 16;
-              c->snap_restore.src[i] = slot; c->snap_restore.dst[i] = b->p; c->snap_restore.n4[i] = b->bytes / 16;
-              off += b->bytes;
+              c->snap_save.src[i] = b->p; c->snap_save.dst[i] = slot; c->snap_save.n4[i] = (b->bytes + 15) / 16;      // (hipMalloc granules are larger)
+              c->snap_restore.src[i] = slot; c->snap_restore.dst[i] = b->p; c->snap_restore.n4[i] = (b->bytes + 15) / 16;
+              off += (b->bytes + 15) / 16 * 16;
               ++i;
             }
             c->snap_save.n = c->snap_restore.n = i;
@@ -590,6 +592,12 @@ static int create_impl(const gbp_problem* pr, const gbp_params* prm, const gbp_s
             float4** dst[9] = {&c->flow.lmsg, &c->flow.rowp, &c->flow.camb, &c->flow.cmu, &c->flow.clin, &c->flow.lmkb, &c->flow.lmu, &c->flow.emc, &c->flow.eml};
             for (int i = 0; i < 9; ++i) { *dst[i] = q; q += n4[i]; }
             c->flow.health_iter = reinterpret_cast<unsigned long long*>(q);
+            // the host-mapped slots of gbp_iterate_eval_each / gbp_ba_loop: here, not inside the first timed burst (pinning 5 MB takes
+            // ~0.5 ms, a twentieth of a default `ba fr1xyz` run)
+            if (!c->series_host) {
+              CK(hipHostMalloc(&c->series_host, sizeof(DeviceEval) * (size_t)(c->n_tiles + 1) * kSeriesMax, hipHostMallocMapped), "hipHostMalloc");
+              if (rc == GBP_OK) CK(hipHostGetDevicePointer(&c->series_dev, c->series_host, 0), "hipHostGetDevicePointer");
+            }
 #ifdef GBP_BUILD_TEST_HOOKS
             const char* pf = prm ? nullptr : std::getenv("GBP_PERSIST_FLOW");      // (the barrier kernel exists in the test-hooks build only)
             if (pf && std::atoi(pf) == 0) c->persist_flow = false;
@@ -1062,11 +1070,17 @@ constexpr int kNotLaunched = 1;    // launch_persist_burst: nothing ran, the ctx
 
 // n iterations inside ONE k_persist launch (+ the metric phases when `ev` is given).  The barrier counter keeps counting
 // across the launches of a ctx (no memset per launch): the host tracks how many arrivals it has seen.
-static int launch_persist_burst(gbp_ctx* c, const SweepArgs& a, int n, const PersistEval* ev, int mode, int area) {
+static int launch_persist_burst(gbp_ctx* c, const SweepArgs& a, int n, const PersistEval* ev, int mode, int area,
+                                uint32_t w_first = 0, uint32_t w_steps2 = 0) {
   PersistArgs A{};
   A.s = a;
   A.b = belief_args(c);
   A.b.roll = 1;
+  if (w_steps2) {      // WEAKEN_PRIORS inside the launch (gbp_ba_loop)
+    A.w_first = w_first; A.w_steps2 = w_steps2;
+    A.b.cam_prior_rw = P<float>(c->camp); A.b.cam_scale = P<float>(c->cscale); A.b.cam_wflag = P<uint32_t>(c->cwf);
+    A.b.lmk_prior_rw = P<float4>(c->lmkp); A.b.lmk_scale = P<float>(c->lscale); A.b.lmk_wflag = P<uint32_t>(c->lwf);
+  }
   A.n_tiles = c->n_tiles;
   A.n_iters = n;
   A.sync = P<unsigned>(c->psync);
@@ -1200,11 +1214,12 @@ static int iterate_impl(gbp_ctx* c, int n) {
 }
 
 // WEAKEN_PRIORS (ba.cpp:863-865): WeakenPriorVertex on every variable, then prog_ub.
-int gbp_weaken_priors(gbp_ctx* c) {
+static int weaken_priors_impl(gbp_ctx* c) {
   if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "gbp_weaken_priors: upload first");
   if (int rc = settle(c)) return rc;
   return refresh_beliefs_from_partials(c, false, true, /*weaken=*/true);      // ONE launch: the prior owners scale on their way into the sums
 }
+int gbp_weaken_priors(gbp_ctx* c) { return weaken_priors_impl(c); }
 
 // READ_PROG (ba.cpp:908-916)
 static int read_impl(gbp_ctx* c, gbp_state_out* o) {
@@ -1583,6 +1598,71 @@ static int iterate_eval_each_impl(gbp_ctx* c, int n, gbp_eval_out* out) {
     if (c->eval_pending == 2) { if (int rc = eval_end_impl(c, out + collected)) return rc; ++collected; }
   }
   while (collected < n) { if (int rc = eval_end_impl(c, out + collected)) return rc; ++collected; }
+  return GBP_OK;
+}
+
+// n passes of the body of the reference's iteration loop (ba.cpp:1001-1028) from loop index iter0: WEAKEN_PRIORS in front of pass i
+// iff (i + 1) % 2 == 0 and i < 2 * steps, GBP_PROG, the metric.  On a graph that runs in the persistent kernel the passes between two
+// host events are ONE launch however many weakenings lie between them (k_persist_flow applies WeakenPriorVertex itself, in front of
+// the iterations the loop weakens before; only a weakening in front of a launch's FIRST iteration is a launch of its own);
+// everywhere else — and after a recovered time-out — it is the calls it stands for, in the loop's order.
+static int ba_loop_impl(gbp_ctx* c, int n, unsigned iter0, unsigned steps, gbp_eval_out* out) {
+  if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "gbp_ba_loop: upload first");
+  if (n < 0 || (n > 0 && !out)) return fail(c, GBP_ERR_INVALID, "gbp_ba_loop: n >= 0 and an array of n results");
+  if (c->eval_pending) return fail(c, GBP_ERR_STATE, "gbp_ba_loop: finish the evaluations in flight (gbp_eval_end) first");
+  const auto weak = [&](unsigned i) { return ((i + 1u) % 2u == 0u) && i < 2u * steps; };
+  int done = 0;
+  while (done < n) {
+    const unsigned i0 = iter0 + (unsigned)done;
+    if (weak(i0))
+      if (int rc = weaken_priors_impl(c)) return rc;
+    bool fused = false;
+    const uint32_t nb = eval_blocks(c->n_tiles);
+    if (int rc = settle(c)) return rc;
+    if (nb == (c->n_tiles + 3) / 4 && c->persist_flow && c->flow.lmsg)
+      if (int rc = persist_ready(c, &fused)) return rc;
+    if (fused) {
+      const uint32_t stride = c->n_tiles + 1;
+      if (!c->series_host) {
+        HIPCHK(c, hipHostMalloc(&c->series_host, sizeof(DeviceEval) * (size_t)stride * kSeriesMax, hipHostMallocMapped));
+        HIPCHK(c, hipHostGetDevicePointer(&c->series_dev, c->series_host, 0));
+      }
+      const int area = c->eval_parity & 1;
+      const int m = std::min(n - done, (int)kSeriesMax);
+      PersistEval ev{};
+      ev.on = 1; ev.each = 1; ev.stride = stride;
+      ev.cam_mu = P<float>(c->cam_mu); ev.lmk_mu = P<float>(c->lmk_mu);
+      ev.num_undamped = c->prm.num_undamped_iters;
+      ev.slots = static_cast<DeviceEval*>(c->series_dev);
+      ev.health = P<unsigned long long>(c->health) + 2 * area;
+      ev.health_next = P<unsigned long long>(c->health) + 2 * (area ^ 1);
+      ev.health_each = P<unsigned long long>(c->health);
+      gbp_ctx::Span sp{};
+      if (int rc = span_begin(c, sp)) return rc;
+      const int lrc = launch_persist_burst(c, sweep_args(c), m, &ev, 2, area, i0, 2u * steps);
+      if (lrc == GBP_OK) {
+        if (int rc = span_end(c, sp)) return rc;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        const bool failed = *static_cast<volatile unsigned*>(c->pstatus_host) != 0u;
+        if (int rc = persist_check(c, 0)) return rc;      // a time-out: state (priors and flags too) restored to the start of this burst
+        if (!failed) {
+          c->timed_iters += (uint64_t)m;
+          c->beliefs_valid = true;
+          for (int k = 0; k < m; ++k) sum_eval(c, static_cast<const DeviceEval*>(c->series_host) + (size_t)k * stride, nb, out + done + k, true);
+          done += m;
+          continue;
+        }
+      } else {
+        c->span_pool.push_back(sp);
+        if (lrc != kNotLaunched) return lrc;
+      }
+    }
+    // the calls the loop stands for, up to (not including) its next weakening
+    int m = 1;
+    while (done + m < n && !weak(iter0 + (unsigned)(done + m))) ++m;
+    if (int rc = iterate_eval_each_impl(c, m, out + done)) return rc;
+    done += m;
+  }
   return GBP_OK;
 }
 
@@ -2033,6 +2113,9 @@ int gbp_eval_end(gbp_ctx* c, gbp_eval_out* o) { return guarded(c, "gbp_eval_end"
 int gbp_iterate_eval(gbp_ctx* c, int n) { return guarded(c, "gbp_iterate_eval", [&] { return iterate_eval_impl(c, n); }); }
 int gbp_iterate_eval_each(gbp_ctx* c, int n, gbp_eval_out* out) {
   return guarded(c, "gbp_iterate_eval_each", [&] { return iterate_eval_each_impl(c, n, out); });
+}
+int gbp_ba_loop(gbp_ctx* c, int n, unsigned iter0, unsigned steps, gbp_eval_out* out) {
+  return guarded(c, "gbp_ba_loop", [&] { return ba_loop_impl(c, n, iter0, steps, out); });
 }
 #ifdef GBP_BUILD_TEST_HOOKS
 int gbp_debug_get(gbp_ctx* c, int what, float* a, float* b) { return guarded(c, "gbp_debug_get", [&] { return debug_get_impl(c, what, a, b); }); }

@@ -212,6 +212,11 @@ struct PersistArgs {
   PersistFlow f;           // f.lmsg != NULL: k_persist_flow (tagged records) instead of k_persist (barriers)
   uint32_t separate;       // k_persist_flow: 1 = cameras (and metric means) are owned by waves WITHOUT a tile (persist_blocks sized the grid for it)
   uint32_t n_met;          // ... and this many metric roles follow the camera roles (0 or C)
+  // WEAKEN_PRIORS inside the launch (gbp_ba_loop): iteration `it` of the launch is loop index w_first + it of the reference's loop
+  // (ba.cpp:1001-1008); WeakenPriorVertex runs in front of it iff (w_first + it + 1) % 2 == 0 and w_first + it < w_steps2 — for it >= 1
+  // (a weakening in front of the launch's first iteration is the host's: an ordinary gbp_weaken_priors).  w_steps2 = 0: none.
+  // Scalings, flags and the priors to write back: b.cam_scale / cam_wflag / cam_prior_rw and the lmk_ ones.
+  uint32_t w_first, w_steps2;
   unsigned epoch_base;     // arrivals the barrier counter has already seen (launches of one ctx keep counting: no memset per launch)
   uint32_t n_tiles;        // sweep tiles = waves with a phase-A role
   uint32_t n_lmk_groups;   // ceil(L / 16): waves [C, C + n_lmk_groups) own 16 landmarks each in phase B
@@ -223,7 +228,7 @@ struct PersistArgs {
   unsigned seq;            // number of this launch in the ctx (>= 1): tells the host WHICH launch failed first (later ones return at once)
 };
 // snapshot / restore of the arrays a k_persist launch mutates (k_copy_segments)
-constexpr int kMaxCopySegs = 12;
+constexpr int kMaxCopySegs = 16;
 struct CopySegs {
   int n;
   const void* src[kMaxCopySegs];

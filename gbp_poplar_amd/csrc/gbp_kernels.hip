@@ -1389,6 +1389,14 @@ __global__ __launch_bounds__(256) void k_persist_flow(const PersistArgs A) {
     if (cam_live) cam_prior_j = b.cam_prior[(size_t)camv * kCamRec + cj];
   }
   if (cam_wave) { cam_cur0 = a.cam_mu[(size_t)v * 4]; cam_cur1 = a.cam_mu[(size_t)v * 4 + 1]; }
+  // WEAKEN_PRIORS inside the launch (PersistArgs.w_first / w_steps2): every wave that holds a prior keeps its variable's flag and
+  // scaling in registers and applies WeakenPriorVertex (gbp_codelets.cpp:176-197: a flag in 1 .. 5 scales the prior and counts down) in
+  // front of the iterations the reference's loop weakens before; the owners write prior and flag back with the last iteration
+  const bool weakens = A.w_steps2 != 0u;
+  uint32_t wf = 0;              // the camera's / the landmark's weaken flag
+  float wscale = 1.f;
+  bool weakened = false;        // did this launch change this wave's prior?
+  if (weakens && (cam_wave || met_wave)) { wf = b.cam_wflag[camv]; wscale = b.cam_scale[camv]; }
   const uint32_t l = lmk_wave ? (v - nC) * 16 + (lane >> 2) : 0u, q4 = lane & 3;
   const bool lmk_live = lmk_wave && l < nL;
   uint4 ix = make_uint4(0u, 0u, 0u, 0u);
@@ -1402,6 +1410,7 @@ __global__ __launch_bounds__(256) void k_persist_flow(const PersistArgs A) {
     pr3[0] = pr[0]; pr3[1] = pr[1]; pr3[2] = pr[2];
     lmk_cur = a.lmk_mu[(size_t)l * 2];
     lp0 = b.lmk_ptr[l]; lp1 = b.lmk_ptr[l + 1];
+    if (weakens) { wf = b.lmk_wflag[l]; wscale = b.lmk_scale[l]; }
   }
   const uint32_t deg = (uint32_t)__shfl((int)ix.x, 0, 4);
   uint32_t pos[15], pos2[15];
@@ -1491,6 +1500,9 @@ __global__ __launch_bounds__(256) void k_persist_flow(const PersistArgs A) {
     const uint32_t h_in = ((uint32_t)it + 1u) & 1u, h_out = (uint32_t)it & 1u;
     const unsigned t_in = F.tag0 + (unsigned)it, t_out = F.tag0 + (unsigned)it + 1u;
     const bool last = it + 1 == A.n_iters;
+    // WeakenPriorVertex in front of the NEXT iteration: the owners then publish the beliefs of the weakened priors (what WEAKEN_PRIORS'
+    // belief refresh leaves: same messages, same order, the means against the one the last sweep used), the metric keeps this iteration's
+    const bool weak_next = weakens && !last && (((A.w_first + (uint32_t)it) & 1u) == 0u) && (A.w_first + (uint32_t)it + 1u < A.w_steps2);
     // ================= phase A: the sweep of this wave's tile =================
     if (has_tile) {
       float4 c4[kFlowCam4], m4[2], q7[kFlowClin4], l5[kFlowLmk4], u4;
@@ -1701,17 +1713,30 @@ __global__ __launch_bounds__(256) void k_persist_flow(const PersistArgs A) {
         if (!finite) atomicAdd(&hw[0], 1ull);
         if (!ldl_pivots_positive<6>(sh[wib] + 8, 6)) atomicAdd(&hw[1], 1ull);
       }
+      float xm[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      bool pd = true;
+      const bool ev_here = EV && ev_means && cam_wave && !cam_has_met_wave;     // no wave to spare for this camera's metric mean: solved here
+      if (lane == 0 && ev_here) {      // ... from this iteration's belief, before a weakening replaces it below
+        solve_pivot<6>(sh[wib] + 8, 6, sh[wib], xm);
+        pd = ldl_pivots_positive<6>(sh[wib] + 8, 6);
+      }
+      if (weak_next) {      // WeakenPriorVertex on this camera's prior (every wave that holds a copy, the metric waves too)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (wf >= 1u && wf <= 5u) {
+          if (cam_live) cam_prior_j *= wscale;
+          wf -= 1u;
+          weakened = true;
+        }
+        if (cam_live && cam_wave) sh[wib][cj] = cam_prior_j + acc;      // the belief the next sweep consumes
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
       if (lane == 0 && cam_wave) {
-        const bool ev_here = EV && ev_means && !cam_has_met_wave;     // no wave to spare for this camera's metric mean: solved here
         float cb[44], x0c[6];
         GBP_UNROLL
         for (int i = 0; i < 44; ++i) cb[i] = sh[wib][i];
-        float xm[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        bool pd = true;
-        if (ev_here) {
-          solve_pivot<6>(sh[wib] + 8, 6, sh[wib], xm);
-          pd = ldl_pivots_positive<6>(sh[wib] + 8, 6);
-        }
         cam_mean(cb, x0c);
         const float used[6] = {cam_cur0.x, cam_cur0.y, cam_cur0.z, cam_cur0.w, cam_cur1.x, cam_cur1.y};
         float S = 0.f;
@@ -1756,10 +1781,18 @@ __global__ __launch_bounds__(256) void k_persist_flow(const PersistArgs A) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       if (cam_wave && lane < kFlowCam4) S_camb.st4((h_out * nC + v) * kFlowCam4 + lane, flow_rec(sh[wib][cb_s0], sh[wib][cb_s1], sh[wib][cb_s2], t_out));
       if (last && cam_live && cam_wave) b.camb[(size_t)v * kCamRec + cj] = sh[wib][cj];
+      if (last && weakened && cam_wave) {
+        if (cam_live) b.cam_prior_rw[(size_t)v * kCamRec + cj] = cam_prior_j;
+        if (lane == 0) b.cam_wflag[v] = wf;
+      }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // sh[] is rewritten by the next iteration
       __builtin_amdgcn_wave_barrier();
     } else if (lmk_wave) {
       float a3[3] = {pr3[0], pr3[1], pr3[2]};
+      const bool lw = weak_next && wf >= 1u && wf <= 5u;      // this landmark's prior is weakened in front of the next iteration
+      if (lw) { pr3[0] *= wscale; pr3[1] *= wscale; pr3[2] *= wscale; }
+      if (weak_next && wf >= 1u && wf <= 5u) { wf -= 1u; weakened = true; }
+      float a3w[3] = {pr3[0], pr3[1], pr3[2]};                 // the same sums from the weakened prior (== a3 without a weakening)
       {
         float4 m[15], m2[15];
         const bool second = __any(deg > 15u);
@@ -1788,6 +1821,16 @@ __global__ __launch_bounds__(256) void k_persist_flow(const PersistArgs A) {
           for (int k = 0; k < 15; ++k)
             if (15u + (uint32_t)k < deg) { a3[0] = a3[0] + m2[k].x; a3[1] = a3[1] + m2[k].y; a3[2] = a3[2] + m2[k].z; }
         }
+        if (weak_next) {      // (wave-uniform)
+          GBP_UNROLL
+          for (int k = 0; k < 15; ++k)
+            if ((uint32_t)k < deg) { a3w[0] = a3w[0] + m[k].x; a3w[1] = a3w[1] + m[k].y; a3w[2] = a3w[2] + m[k].z; }
+          if (second) {
+            GBP_UNROLL
+            for (int k = 0; k < 15; ++k)
+              if (15u + (uint32_t)k < deg) { a3w[0] = a3w[0] + m2[k].x; a3w[1] = a3w[1] + m2[k].y; a3w[2] = a3w[2] + m2[k].z; }
+          }
+        }
       }
       if (deg > 30u) {
         for (uint32_t s = lp0 + 30u; s < lp1; s += 8) {
@@ -1806,15 +1849,30 @@ __global__ __launch_bounds__(256) void k_persist_flow(const PersistArgs A) {
               }, A.sync, A.status, A.seq)) return;
           GBP_UNROLL
           for (int k = 0; k < 8; ++k)
-            if ((uint32_t)k < nleft) { a3[0] = a3[0] + m[k].x; a3[1] = a3[1] + m[k].y; a3[2] = a3[2] + m[k].z; }
+            if ((uint32_t)k < nleft) {
+              a3[0] = a3[0] + m[k].x; a3[1] = a3[1] + m[k].y; a3[2] = a3[2] + m[k].z;
+              a3w[0] = a3w[0] + m[k].x; a3w[1] = a3w[1] + m[k].y; a3w[2] = a3w[2] + m[k].z;
+            }
         }
       }
-      if (lmk_live) S_lmkb.st4((h_out * nL + l) * kFlowLmk4 + q4, flow_rec(a3[0], a3[1], a3[2], t_out));
+      if (!weak_next) { a3w[0] = a3[0]; a3w[1] = a3[1]; a3w[2] = a3[2]; }      // (the tail loop above adds to both)
+      // a3: this iteration's belief (the metric's); a3w: what the next sweep consumes
+      if (lmk_live) S_lmkb.st4((h_out * nL + l) * kFlowLmk4 + q4, flow_rec(a3w[0], a3w[1], a3w[2], t_out));
       float rec[16];
-      rec[0] = __shfl(a3[0], 0, 4); rec[1] = __shfl(a3[1], 0, 4); rec[2] = __shfl(a3[2], 0, 4);
+      rec[0] = __shfl(a3w[0], 0, 4); rec[1] = __shfl(a3w[1], 0, 4); rec[2] = __shfl(a3w[2], 0, 4);
       GBP_UNROLL
       for (int g = 0; g < 3; ++g) {
-        rec[4 + 3 * g] = __shfl(a3[0], 1 + g, 4); rec[5 + 3 * g] = __shfl(a3[1], 1 + g, 4); rec[6 + 3 * g] = __shfl(a3[2], 1 + g, 4);
+        rec[4 + 3 * g] = __shfl(a3w[0], 1 + g, 4); rec[5 + 3 * g] = __shfl(a3w[1], 1 + g, 4); rec[6 + 3 * g] = __shfl(a3w[2], 1 + g, 4);
+      }
+      float recm[16];      // the record the metric mean is solved from
+      GBP_UNROLL
+      for (int g = 0; g < 16; ++g) recm[g] = rec[g];
+      if (EV && weak_next) {
+        recm[0] = __shfl(a3[0], 0, 4); recm[1] = __shfl(a3[1], 0, 4); recm[2] = __shfl(a3[2], 0, 4);
+        GBP_UNROLL
+        for (int g = 0; g < 3; ++g) {
+          recm[4 + 3 * g] = __shfl(a3[0], 1 + g, 4); recm[5 + 3 * g] = __shfl(a3[1], 1 + g, 4); recm[6 + 3 * g] = __shfl(a3[2], 1 + g, 4);
+        }
       }
       float u[3] = {0.f, 0.f, 0.f};
       if (lmk_live && q4 == 0) {
@@ -1839,13 +1897,13 @@ __global__ __launch_bounds__(256) void k_persist_flow(const PersistArgs A) {
         if (last) { b.lmk_mu[(size_t)l * 2 + 1] = used; b.lmk_mu[(size_t)l * 2] = lmk_cur; }
         if (EV && ev_means) {   // metric mean of this landmark (k_means), from the belief record in registers
           float x[3];
-          solve_pivot<3>(rec + 4, 3, rec, x);
+          solve_pivot<3>(recm + 4, 3, recm, x);
           S_eml.st4(h_out * nL + l, flow_rec(x[0], x[1], x[2], t_out));
           bool finite = true;
           GBP_UNROLL
           for (int i = 0; i < 3; ++i) finite &= (x[i] - x[i] == 0.f);
           if (!finite) atomicAdd(&hw[0], 1ull);
-          if (!ldl_pivots_positive<3>(rec + 4, 3)) atomicAdd(&hw[1], 1ull);
+          if (!ldl_pivots_positive<3>(recm + 4, 3)) atomicAdd(&hw[1], 1ull);
         }
       }
       if (last) {   // the ordinary LMKB record: float4 #q4 of [eta, u0 | Lambda 0..3 | 4..7 | 8, u1, u2, 0]
@@ -1856,6 +1914,11 @@ __global__ __launch_bounds__(256) void k_persist_flow(const PersistArgs A) {
         o.z = q4 == 0u ? rec[2] : q4 == 1u ? rec[6] : q4 == 2u ? rec[10] : rec[14];
         o.w = q4 == 0u ? rec[3] : q4 == 1u ? rec[7] : q4 == 2u ? rec[11] : rec[15];
         if (lmk_live) b.lmkb[(size_t)l * 4 + q4] = o;
+        if (lmk_live && weakened) {
+          float* pw = reinterpret_cast<float*>(b.lmk_prior_rw) + (size_t)l * 16 + l_e0;
+          pw[0] = pr3[0]; pw[1] = pr3[1]; pw[2] = pr3[2];
+          if (q4 == 0) b.lmk_wflag[l] = wf;
+        }
       }
     }
     // the residuals of the PREVIOUS iteration, behind this wave's role (they delay nobody but this wave's next sweep)

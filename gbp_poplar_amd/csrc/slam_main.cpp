@@ -80,6 +80,26 @@ static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
       up.active_flag = P.active.data(); up.cam_weaken_flag = P.cwf.data(); up.lmk_weaken_flag = P.lwf.data();
       CLI_CHECK(ctx, gbp_new_keyframe(ctx, &up));
     }
+    if (pipe.on && o.eval_every == 1 && o.steps >= 0.f && o.steps == (float)(unsigned)o.steps) {
+      // the loop's body up to the next keyframe as gbp_ba_loop (see ba_main.cpp): prior weakening, iteration, metric — one call
+      const unsigned cap = gbp_graph_state(ctx) == 2 ? 512u : 128u;
+      unsigned nb = 1;
+      while (nb < cap && i + nb < niters && (i + nb + 1) % (unsigned)o.iters_between_kfs != 0) ++nb;
+      if (cap == 512u && i + nb == niters && nb > 96u) nb -= 64u;
+      series.resize(nb);
+      CLI_CHECK(ctx, gbp_ba_loop(ctx, (int)nb, iter, (unsigned)o.steps, series.data()));
+      rep.last = series.back(); rep.have_metric = true;
+      lines.post([total0 = (unsigned)o.iters_between_kfs * data_counter + iter, since0 = iter, steps2 = 2u * (unsigned)o.steps, batch = series, &write_iter] {
+        for (size_t k = 0; k < batch.size(); ++k) {
+          const unsigned since = since0 + (unsigned)k;
+          if ((since + 1) % 2 == 0 && since < steps2) std::cout << "Weakening priors \n";
+          write_iter(total0 + (unsigned)k, since, batch[k]);
+        }
+      });
+      i += nb - 1;
+      iter += nb;
+      continue;
+    }
     if (((iter + 1) % 2 == 0) && (iter < o.steps * 2)) {
       if (pipe.on && o.eval_every == 1) lines.post([] { std::cout << "Weakening priors \n"; });
       else { lines.drain(); pipe.line("Weakening priors \n"); }

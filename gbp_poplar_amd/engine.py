@@ -119,6 +119,14 @@ class GbpEngine:
         self._chk(self.lib.gbp_iterate_eval_each(self.h, n, arr), "gbp_iterate_eval_each")
         return [{k: getattr(arr[i], k) for k, _ in arr[i]._fields_} for i in range(n)]
 
+    def ba_loop(self, n, iter0, steps):
+        """n passes of the body of the reference's loop from loop index iter0 (prior weakening where the loop weakens, the iteration,
+        the metric): gbp_ba_loop.  Returns a list of n dicts like eval()."""
+        n = int(n)
+        arr = (cabi.GbpEvalOut * max(n, 1))()
+        self._chk(self.lib.gbp_ba_loop(self.h, n, int(iter0), int(steps), arr), "gbp_ba_loop")
+        return [{k: getattr(arr[i], k) for k, _ in arr[i]._fields_} for i in range(n)]
+
     def eval_end(self):
         o = cabi.GbpEvalOut()
         self._chk(self.lib.gbp_eval_end(self.h, C.byref(o)), "gbp_eval_end")

@@ -38,8 +38,10 @@ extern "C" {
  *    exchange (gbp_set_exchange_chunks / gbp_iterate_begin_chunk: measured slower than the plain one in every configuration) is
  *    gone, gbp_tile_order_local moved to the test-hooks header; gbp_iterate_eval_each keeps the metric on the device on graphs
  *    of any size.
+ * 6: gbp_ba_loop (the body of the reference's loop, prior weakening included, in one call); graphs of up to 256 workgroups run in the
+ *    persistent kernel, which hands over through tagged records instead of device-wide barriers.
  * Callers compare gbp_abi_version() with the header they were built against. */
-#define GBP_ABI_VERSION 5
+#define GBP_ABI_VERSION 6
 
 typedef enum {
   GBP_OK = 0,
@@ -238,6 +240,13 @@ GBP_API int gbp_iterate_eval(gbp_ctx* ctx, int n_iters);
  * (prior weakening, a new keyframe) is ONE launch on a graph that runs in the persistent kernel — the metric of iteration k
  * is computed inside the sweep phase of iteration k + 1 — and the plain loop elsewhere.  No evaluation may be in flight. */
 GBP_API int gbp_iterate_eval_each(gbp_ctx* ctx, int n_iters, gbp_eval_out* out /* [n_iters] */);
+/* n passes of the BODY of the reference's iteration loop (ba.cpp:1001-1028, slam.cpp:1048-1103), blocking, from loop index iter0:
+ *   if ((i + 1) % 2 == 0 && i < 2 * steps) WEAKEN_PRIORS;  GBP_PROG;  out[i - iter0] = the metric      for i = iter0 .. iter0 + n - 1
+ * (steps = the reference's --steps).  Exactly the calls it stands for (gbp_weaken_priors / gbp_iterate_eval_each, identical results);
+ * on a graph that runs in the persistent kernel the passes are ONE launch however many weakenings lie between them (the kernel applies
+ * WeakenPriorVertex itself in front of the iterations the loop weakens before) — the ten short launches of a run's, or a SLAM
+ * keyframe's, weakening phase become one.  No evaluation may be in flight. */
+GBP_API int gbp_ba_loop(gbp_ctx* ctx, int n_passes, unsigned iter0, unsigned steps, gbp_eval_out* out /* [n_passes] */);
 GBP_API int gbp_sync(gbp_ctx* ctx);                                    /* wait for queued device work     */
 GBP_API int gbp_timing(gbp_ctx* ctx, gbp_timing_out* out, int reset);  /* ba.cpp:980,1056-1058            */
 

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "libgbp_mi355x.so does not export %s" % n
     assert sorted(_lib.symbols()) == names, set(names) ^ set(_lib.symbols())
-    assert lib.gbp_abi_version() == _cabi.GBP_ABI_VERSION == 5
+    assert lib.gbp_abi_version() == _cabi.GBP_ABI_VERSION == 6
 
 
 def _exported(path):

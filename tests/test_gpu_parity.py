@@ -559,6 +559,69 @@ def test_iterate_eval_each_equals_one_iteration_and_one_metric_at_a_time(flow, o
         a.eval_end()
 
 
+@pytest.mark.parametrize("name", ["fr2robot2", "fr1xyz", "ragged"])
+def test_ba_loop_equals_the_calls_it_stands_for(name, oracle_mod):
+    """gbp_ba_loop(n, iter0, steps) — the body of the reference's loop, prior weakening included: ONE launch of the persistent kernel
+    however many weakenings lie inside (WeakenPriorVertex applied by the kernel itself) — against the calls it stands for, one at a
+    time on the two-kernel path: {gbp_weaken_priors where the loop weakens; gbp_iterate(1); gbp_eval()}.  Every metric, every tensor,
+    the priors (READ_PRIORS) identical after calls that start inside, in front of and behind the weakening phase; c is the same entry
+    point on the two-kernel path (its fall-back)."""
+    from gbp_poplar_amd import _cabi, driver, hostlib
+    from gbp_poplar_amd.engine import GbpEngine
+    opts, kw = driver.Options(), {}
+    if name == "ragged":
+        bal, kw = _ragged_bal()
+        opts.undamped_start = 2
+    else:
+        bal = _bal(name)
+    K, state, _ = driver.build_inputs(bal, opts, hostlib)
+    if name == "ragged":
+        state["active_flag"] = _ragged_active(bal)
+    steps = int(opts.steps)
+    a = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K, hooks=True, params=_cabi.GbpParams.defaults(persistent=1, **kw))
+    b = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K, hooks=True, params=_cabi.GbpParams.defaults(persistent=-1, **kw))
+    c = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K, hooks=True, params=_cabi.GbpParams.defaults(persistent=-1, **kw))
+    assert a.graph_state() == 2 and b.graph_state() != 2
+    for e in (a, b, c):
+        e.upload(state)
+        e.linearise()
+    it = 0
+    for n in (2, 1, 4, 9, 1, 0, 40, 600 if name == "fr1xyz" else 30):      # 2: one weakening inside; 4: two; 9: crosses the end of the phase; 600: two launches
+        ea = a.ba_loop(n, it, steps)
+        ec = c.ba_loop(n, it, steps)
+        eb = []
+        for i in range(it, it + n):
+            if (i + 1) % 2 == 0 and i < 2 * steps:
+                b.weaken_priors()
+            b.iterate(1)
+            eb.append(b.eval())
+        assert len(ea) == n and ea == eb, (name, it, n, [i for i in range(n) if ea[i] != eb[i]][:5])
+        assert ec == eb, (name, it, n)
+        it += n
+        sa, sb = _full_snapshot(a), _full_snapshot(b)
+        for k in sa:
+            assert np.array_equal(sa[k], sb[k], equal_nan=True), (name, it, k)
+        pa, pb = a.read_priors(), b.read_priors()
+        for k in pa:
+            assert np.array_equal(pa[k], pb[k]), (name, it, k)
+    # a run that starts again (new upload: flags back to `steps`), the whole weakening phase and beyond in ONE call
+    for e in (a, b):
+        e.upload(state)
+        e.linearise()
+    ea = a.ba_loop(25, 0, steps)
+    eb = []
+    for i in range(25):
+        if (i + 1) % 2 == 0 and i < 2 * steps:
+            b.weaken_priors()
+        b.iterate(1)
+        eb.append(b.eval())
+    assert ea == eb
+    pa, pb = a.read_priors(), b.read_priors()
+    for k in pa:
+        assert np.array_equal(pa[k], pb[k]), k
+    assert a.timing()["iterations"] == b.timing()["iterations"]
+
+
 @pytest.mark.parametrize("shape", ["tiles_permuted", "rows_placed", "per_factor_mu"])
 def test_iterate_eval_each_rides_in_the_two_kernel_path(shape, oracle_mod):
     """gbp_iterate_eval_each on graphs that do NOT run in the persistent kernel (more than 256 workgroups, a permuted tile order, placed rows,
