@@ -76,6 +76,11 @@ def flow(e):
         st = e.read()
         out.extend(e.iterate_eval_each(13))
         return out, st
+    if %(first)r == "loop":                         # gbp_ba_loop: the launch that times out weakens priors itself (loop indices 3, 5, 7, 9):
+        out.extend(e.ba_loop(13, 1, 5))             # the snapshot holds priors and flags too, the fall-back redoes the burst call by call
+        st = e.read()
+        st.update({"prior_" + k: v for k, v in e.read_priors().items()})
+        return out, st
     order = {"plain": ("plain", "eval", "each"), "eval": ("eval", "each", "plain"), "each": ("each", "plain", "eval")}[%(first)r]
     for k in order:                                 # the FIRST of them is the launch that times out / is refused
         steps[k]()
@@ -101,7 +106,7 @@ print('RECOVERED %%.1f s graph_state_after_upload %%d :: %%s' %% (dt, eng.graph_
 
 
 @pytest.mark.skipif(not _exp_lib_present(), reason="experiments build absent (python -m gbp_poplar_amd.build --experiments)")
-@pytest.mark.parametrize("coop,first", [(0, "plain"), (0, "eval"), (0, "each"), (1, "plain"), (0, "read")])
+@pytest.mark.parametrize("coop,first", [(0, "plain"), (0, "eval"), (0, "each"), (1, "plain"), (0, "read"), (0, "loop")])
 def test_persistent_kernel_time_out_is_recovered(coop, first):
     """A k_persist launch whose workgroups can NOT all be resident (forced: every 8th dispatch slot = one XCD = 32 CUs for the
     52 workgroups of fr1xyz; experiments build) must not hang and must not lose the run:
@@ -109,7 +114,8 @@ def test_persistent_kernel_time_out_is_recovered(coop, first):
         the snapshot taken before the failed launch and replays the bursts on the two-kernel path;
       * cooperative launch (persist_coop = 1): the runtime refuses the grid before anything runs, same fallback.
     The launch that fails is a plain burst, a burst with the metric at its end, or an every-iteration burst (`first`); "read": a
-    plain burst followed by gbp_read with no synchronisation of the caller's in between.
+    plain burst followed by gbp_read with no synchronisation of the caller's in between; "loop": gbp_ba_loop, whose launch weakens
+    priors itself (priors and flags are restored with the rest and compared too).
     Either way: rc 0 everywhere, every belief / damping / counter and every metric equal to the two-kernel path's, a warning in
     gbp_last_error, and the persistent path back after the next gbp_upload."""
     import subprocess
