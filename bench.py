@@ -506,10 +506,18 @@ def small_config_cpu(name, gpu_rows):
 
 def ba_flow(run, opts, it0, n):
     """Iterations it0 .. it0 + n - 1 of the ./ba flow (ba.cpp:1001-1008): WEAKEN_PRIORS before iterations 1, 3, 5, 7, 9, the
-    iterations between two such host events in ONE gbp_iterate call (hipGraph replays + remainder).  EVERY phase of the bench —
+    iterations between two such host events in ONE gbp_iterate call (hipGraph replays + remainder) — or, where the engine has it, all
+    of that as one gbp_ba_loop call.  EVERY phase of the bench —
     warm-up, timed region, profiled iterations, the further windows, the PMC children — advances the run with this function, so
     iteration k of the bench is iteration k of the run `./ba` does.  Returns the iterations in front of which the priors were weakened."""
     weak, it, end = [], it0, it0 + n
+    if hasattr(run, "ba_loop") and float(opts.steps).is_integer():
+        # the same passes as ONE call of the C-ABI (gbp_ba_loop without the metric: what the loop below issues, a weakening riding in
+        # the belief update of the iteration in front of it instead of a launch of its own; identical results)
+        weak = [i for i in range(it0, end) if (i + 1) % 2 == 0 and i < opts.steps * 2]
+        if n > 0:
+            run.ba_loop(n, it0, int(opts.steps), metrics=False)
+        return weak
     while it < end:
         if ((it + 1) % 2 == 0) and (it < opts.steps * 2):
             run.weaken_priors()

@@ -131,7 +131,9 @@ struct gbp_ctx {
   // two-kernel path: every launch is preceded by a snapshot of the arrays it mutates (one copy kernel, skipped once the abort
   // word is set), later launches of the ctx return at once, and the host — at the next point where it synchronises anyway —
   // restores the snapshot and replays the logged launches from the first failed one on.
-  struct Burst { unsigned seq; int n; int mode; int area; };   // mode 0 = gbp_iterate, 1 = gbp_iterate_eval (metric in eval area `area`), 2 = eval_each (blocking)
+  // mode 0 = gbp_iterate, 1 = gbp_iterate_eval (metric in eval area `area`), 2 = eval_each / gbp_ba_loop with metrics (blocking);
+  // w_steps2 != 0: the launch weakens priors itself (gbp_ba_loop: loop index of its first iteration, twice the --steps)
+  struct Burst { unsigned seq; int n; int mode; int area; unsigned w_first = 0, w_steps2 = 0; };
   DevBuf pflow;                        // tagged shadows of k_persist_flow (PersistFlow), one allocation
   PersistFlow flow{};                  // the tagged shadows of k_persist_flow
   bool persist_flow = true;            // test-hooks build: gbp_debug_persist_flow(ctx, 0) / GBP_PERSIST_FLOW=0 run the barrier kernel of rounds 3-4 instead
@@ -254,10 +256,18 @@ EvalRide eval_ride(gbp_ctx* c) {
 }
 
 // one iteration: k_sweep + k_beliefs; ev: the instantiations that carry the metric (a.ev filled in by the caller)
-void enqueue_iteration(gbp_ctx* c, const SweepArgs& a, bool ev = false) {
+// weaken_after: WEAKEN_PRIORS follows this iteration with nothing reading the beliefs in between — its belief update takes the
+// weakened priors straight away (WeakenPriorVertex rides in k_beliefs as in gbp_weaken_priors): the same beliefs, means and
+// mean changes as {k_beliefs; k_beliefs(weaken)} leave, in one launch
+void enqueue_iteration(gbp_ctx* c, const SweepArgs& a, bool ev = false, bool weaken_after = false) {
   launch_sweep(a, c->n_tiles, c->hoist, c->stream, ev);
   BeliefArgs b = belief_args(c);
   b.roll = 1;
+  if (weaken_after) {
+    b.weaken = 1;
+    b.cam_prior_rw = P<float>(c->camp); b.cam_scale = P<float>(c->cscale); b.cam_wflag = P<uint32_t>(c->cwf);
+    b.lmk_prior_rw = P<float4>(c->lmkp); b.lmk_scale = P<float>(c->lscale); b.lmk_wflag = P<uint32_t>(c->lwf);
+  }
   if (ev) b.ev = a.ev;
   launch_beliefs(b, true, true, c->stream, ev);
 }
@@ -999,6 +1009,27 @@ static int iterate_plain(gbp_ctx* c, const SweepArgs& a, int n, bool ev = false)
 
 static int eval_enqueue(gbp_ctx* c, int area);
 
+// Passes i0 .. i0 + n - 1 of the reference's loop WITHOUT the metric on the two-kernel path of a single-GPU ctx, the weakening in
+// front of pass i0 (if any) already done by the caller: a weakening in front of a later pass rides in the belief update of the
+// iteration before it (enqueue_iteration: weaken_after), the runs between them replay from the hipGraph.
+static int iterate_weaken_plain(gbp_ctx* c, const SweepArgs& a, int n, unsigned i0, unsigned steps2) {
+  const auto weak = [&](unsigned i) { return ((i + 1u) % 2u == 0u) && i < steps2; };
+  int k = 0;
+  while (k < n) {
+    int run = 0;      // iterations whose successor (inside this call) is not weakened
+    while (k + run < n && !(k + run + 1 < n && weak(i0 + (unsigned)(k + run) + 1u))) ++run;
+    if (run)
+      if (int rc = iterate_plain(c, a, run)) return rc;
+    k += run;
+    if (k < n) {      // ... and the one whose belief update takes the weakened priors
+      enqueue_iteration(c, a, false, true);
+      HIPCHK(c, hipGetLastError());
+      ++k;
+    }
+  }
+  return GBP_OK;
+}
+
 // A k_persist launch gave up at a barrier (*pstatus_host = its number): undo it and everything queued behind it, replay
 // on the two-kernel path.  The snapshot kernel of every later launch saw the abort word and left the arena alone, so the
 // arena holds the state the first failed launch started from.
@@ -1022,7 +1053,8 @@ static int persist_recover(gbp_ctx* c) {
   long iters = 0;
   for (const gbp_ctx::Burst& b : redo) {
     if (b.mode == 2) continue;                        // gbp_iterate_eval_each is blocking: it replays its own burst
-    if (int rc = iterate_plain(c, a, b.n)) return rc;
+    if (b.w_steps2) { if (int rc = iterate_weaken_plain(c, a, b.n, b.w_first, b.w_steps2)) return rc; }
+    else if (int rc = iterate_plain(c, a, b.n)) return rc;
     iters += b.n;
     if (b.mode == 1)
       if (int rc = eval_enqueue(c, b.area)) return rc;
@@ -1126,7 +1158,7 @@ static int launch_persist_burst(gbp_ctx* c, const SweepArgs& a, int n, const Per
   // tagged records none, and ONE barrier at the end of a launch that carries the metric
   c->persist_epoch_base += flow ? (ev ? nb : 0u) : nb * (unsigned)(2 * n - 1 + (ev ? 1 : 0));
   c->persist_seq += 1;
-  c->persist_log.push_back(gbp_ctx::Burst{c->persist_seq, n, mode, area});
+  c->persist_log.push_back(gbp_ctx::Burst{c->persist_seq, n, mode, area, w_first, w_steps2});
   c->persist_launches += 1;
   return GBP_OK;
 }
@@ -1608,9 +1640,44 @@ static int iterate_eval_each_impl(gbp_ctx* c, int n, gbp_eval_out* out) {
 // everywhere else — and after a recovered time-out — it is the calls it stands for, in the loop's order.
 static int ba_loop_impl(gbp_ctx* c, int n, unsigned iter0, unsigned steps, gbp_eval_out* out) {
   if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "gbp_ba_loop: upload first");
-  if (n < 0 || (n > 0 && !out)) return fail(c, GBP_ERR_INVALID, "gbp_ba_loop: n >= 0 and an array of n results");
-  if (c->eval_pending) return fail(c, GBP_ERR_STATE, "gbp_ba_loop: finish the evaluations in flight (gbp_eval_end) first");
+  if (n < 0) return fail(c, GBP_ERR_INVALID, "gbp_ba_loop: n >= 0");
   const auto weak = [&](unsigned i) { return ((i + 1u) % 2u == 0u) && i < 2u * steps; };
+  if (!out) {
+    // without the metric (out == NULL): not blocking, like gbp_iterate.  The weakening in front of the first pass is a launch of its
+    // own; every later one rides in the launch of the persistent kernel, or — two-kernel path, single-GPU ctx — in the belief update
+    // of the iteration before it.  A sharded ctx takes the calls one by one.
+    int done = 0;
+    while (done < n) {
+      const unsigned i0 = iter0 + (unsigned)done;
+      if (weak(i0))
+        if (int rc = weaken_priors_impl(c)) return rc;
+      if (c->comm || c->world != 1 || c->profile_stages || stream_is_capturing(c)) {      // (per-stage timing and a caller's capture keep their own paths)
+        int m = 1;
+        while (done + m < n && !weak(iter0 + (unsigned)(done + m))) ++m;
+        if (int rc = iterate_impl(c, m)) return rc;
+        done += m;
+        continue;
+      }
+      const int m = std::min(n - done, kPersistChunk);
+      bool persist = false;
+      if (m >= 2 && c->persist_flow && c->flow.lmsg)      // (a single iteration is as fast from two launches: gbp_iterate's rule)
+        if (int rc = persist_ready(c, &persist)) return rc;
+      if (!persist)
+        if (int rc = settle(c)) return rc;
+      gbp_ctx::Span sp{};
+      if (int rc = span_begin(c, sp)) return rc;
+      int lrc = kNotLaunched;
+      if (persist) lrc = launch_persist_burst(c, sweep_args(c), m, nullptr, 0, 0, i0, 2u * steps);
+      if (lrc == kNotLaunched) lrc = iterate_weaken_plain(c, sweep_args(c), m, i0, 2u * steps);
+      if (lrc != GBP_OK) { c->span_pool.push_back(sp); return lrc; }
+      if (int rc = span_end(c, sp)) return rc;
+      c->timed_iters += (uint64_t)m;
+      c->beliefs_valid = true;
+      done += m;
+    }
+    return GBP_OK;
+  }
+  if (c->eval_pending) return fail(c, GBP_ERR_STATE, "gbp_ba_loop: finish the evaluations in flight (gbp_eval_end) first");
   int done = 0;
   while (done < n) {
     const unsigned i0 = iter0 + (unsigned)done;

@@ -119,10 +119,13 @@ class GbpEngine:
         self._chk(self.lib.gbp_iterate_eval_each(self.h, n, arr), "gbp_iterate_eval_each")
         return [{k: getattr(arr[i], k) for k, _ in arr[i]._fields_} for i in range(n)]
 
-    def ba_loop(self, n, iter0, steps):
+    def ba_loop(self, n, iter0, steps, metrics=True):
         """n passes of the body of the reference's loop from loop index iter0 (prior weakening where the loop weakens, the iteration,
         the metric): gbp_ba_loop.  Returns a list of n dicts like eval()."""
         n = int(n)
+        if not metrics:      # the passes without the metric: not blocking, returns nothing
+            self._chk(self.lib.gbp_ba_loop(self.h, n, int(iter0), int(steps), None), "gbp_ba_loop")
+            return None
         arr = (cabi.GbpEvalOut * max(n, 1))()
         self._chk(self.lib.gbp_ba_loop(self.h, n, int(iter0), int(steps), arr), "gbp_ba_loop")
         return [{k: getattr(arr[i], k) for k, _ in arr[i]._fields_} for i in range(n)]

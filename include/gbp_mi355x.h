@@ -245,7 +245,9 @@ GBP_API int gbp_iterate_eval_each(gbp_ctx* ctx, int n_iters, gbp_eval_out* out /
  * (steps = the reference's --steps).  Exactly the calls it stands for (gbp_weaken_priors / gbp_iterate_eval_each, identical results);
  * on a graph that runs in the persistent kernel the passes are ONE launch however many weakenings lie between them (the kernel applies
  * WeakenPriorVertex itself in front of the iterations the loop weakens before) — the ten short launches of a run's, or a SLAM
- * keyframe's, weakening phase become one.  No evaluation may be in flight. */
+ * keyframe's, weakening phase become one.  No evaluation may be in flight.
+ * out == NULL: the passes WITHOUT the metric, not blocking (like gbp_iterate): a weakening then rides in the launch of the persistent
+ * kernel or, on the two-kernel path, in the belief update of the iteration in front of it (one launch instead of two). */
 GBP_API int gbp_ba_loop(gbp_ctx* ctx, int n_passes, unsigned iter0, unsigned steps, gbp_eval_out* out /* [n_passes] */);
 GBP_API int gbp_sync(gbp_ctx* ctx);                                    /* wait for queued device work     */
 GBP_API int gbp_timing(gbp_ctx* ctx, gbp_timing_out* out, int reset);  /* ba.cpp:980,1056-1058            */

@@ -622,6 +622,53 @@ def test_ba_loop_equals_the_calls_it_stands_for(name, oracle_mod):
     assert a.timing()["iterations"] == b.timing()["iterations"]
 
 
+@pytest.mark.parametrize("name", ["fr2robot2", "fr1xyz", "ragged", "two_kernels_40k_factors"])
+def test_ba_loop_without_the_metric_equals_the_calls_it_stands_for(name, oracle_mod):
+    """gbp_ba_loop(n, iter0, steps, NULL): the passes without the metric, not blocking.  A weakening then rides in the launch of the
+    persistent kernel (a) or, on the two-kernel path (c; and a graph too large for anything else), in the belief update of the
+    iteration in front of it — against {gbp_weaken_priors where the loop weakens; gbp_iterate(1)} call by call (b): every tensor,
+    the priors and the metric identical after calls that start inside, in front of and behind the weakening phase."""
+    from gbp_poplar_amd import _cabi, driver, hostlib
+    from gbp_poplar_amd.engine import GbpEngine
+    opts, kw = driver.Options(), {}
+    if name == "ragged":
+        bal, kw = _ragged_bal()
+        opts.undamped_start = 2
+    elif name == "two_kernels_40k_factors":
+        bal = hostlib.synth_generate(40, 4000, 10, 5)
+    else:
+        bal = _bal(name)
+    K, state, _ = driver.build_inputs(bal, opts, hostlib)
+    if name == "ragged":
+        state["active_flag"] = _ragged_active(bal)
+    steps = int(opts.steps)
+    modes = (-1, -1, -1) if name == "two_kernels_40k_factors" else (1, -1, -1)
+    a, b, c = [GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K, hooks=True,
+                         params=_cabi.GbpParams.defaults(persistent=m, **kw)) for m in modes]
+    for e in (a, b, c):
+        e.upload(state)
+        e.linearise()
+    it = 0
+    for n in (2, 1, 4, 9, 1, 0, 40, 25):
+        a.ba_loop(n, it, steps, metrics=False)
+        c.ba_loop(n, it, steps, metrics=False)
+        for i in range(it, it + n):
+            if (i + 1) % 2 == 0 and i < 2 * steps:
+                b.weaken_priors()
+            b.iterate(1)
+        it += n
+        sb = _full_snapshot(b)
+        pb = b.read_priors()
+        for e in (a, c):
+            se, pe = _full_snapshot(e), e.read_priors()
+            for k in sb:
+                assert np.array_equal(se[k], sb[k], equal_nan=True), (name, it, k)
+            for k in pb:
+                assert np.array_equal(pe[k], pb[k]), (name, it, k)
+        assert a.eval() == b.eval() == c.eval()
+    assert a.timing()["iterations"] == b.timing()["iterations"] == c.timing()["iterations"]
+
+
 @pytest.mark.parametrize("shape", ["tiles_permuted", "rows_placed", "per_factor_mu"])
 def test_iterate_eval_each_rides_in_the_two_kernel_path(shape, oracle_mod):
     """gbp_iterate_eval_each on graphs that do NOT run in the persistent kernel (more than 256 workgroups, a permuted tile order, placed rows,
