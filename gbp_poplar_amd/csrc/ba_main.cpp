@@ -72,6 +72,26 @@ static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
       iter += (unsigned)burst;
       continue;
     }
+    if (o.eval_every > 1 && !o.verbose && o.steps >= 0.f && o.steps == (float)(unsigned)o.steps) {
+      // --eval_every N: everything up to the next metric in one call, the prior weakenings inside included (gbp_ba_loop without the
+      // metric); the pass the metric follows goes down with it (pipe.submit: gbp_iterate_eval)
+      const auto weak = [&](unsigned it_) { return (it_ + 1) % 2 == 0 && it_ < 2u * (unsigned)o.steps; };
+      int burst = 1;
+      while (i + burst < o.n_iters && (i + burst) % o.eval_every != 0) ++burst;
+      const bool eval_now = (i + burst) % o.eval_every == 0 || i + burst == o.n_iters;
+      for (int k = 0; k < burst; ++k)
+        if (weak(iter + (unsigned)k)) pipe.line("Weakening priors \n");
+      const int head = eval_now ? burst - 1 : burst;
+      if (head > 0) CLI_CHECK(ctx, gbp_ba_loop(ctx, head, iter, (unsigned)o.steps, nullptr));
+      if (eval_now) {
+        const unsigned it_now = iter + (unsigned)burst - 1u;
+        if (weak(it_now)) CLI_CHECK(ctx, gbp_weaken_priors(ctx));
+        CLI_CHECK(ctx, pipe.submit([it_now, &print_iter](const gbp_eval_out& e) { print_iter(it_now, e); }, 1));
+      }
+      i += burst - 1;
+      iter += (unsigned)burst;
+      continue;
+    }
     if (((iter + 1) % 2 == 0) && (iter < o.steps * 2)) {       // ba.cpp:1003-1006
       if (pipe.on && o.eval_every == 1) lines.post([] { std::cout << "Weakening priors \n"; });      // in order, behind the lines of the burst before it
       else pipe.line("Weakening priors \n");

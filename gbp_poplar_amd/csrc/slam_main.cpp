@@ -100,6 +100,25 @@ static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
       iter += nb;
       continue;
     }
+    if (o.eval_every > 1 && !o.verbose && o.steps >= 0.f && o.steps == (float)(unsigned)o.steps) {
+      // --eval_every N: everything up to the next metric / keyframe in one call, the prior weakenings inside included (see ba_main.cpp)
+      const auto weak = [&](unsigned it_) { return (it_ + 1) % 2 == 0 && it_ < 2u * (unsigned)o.steps; };
+      unsigned burst = 1;
+      while (i + burst < niters && (i + burst + 1) % (unsigned)o.iters_between_kfs != 0 && (i + burst) % (unsigned)o.eval_every != 0) ++burst;
+      const bool eval_now = (i + burst) % (unsigned)o.eval_every == 0 || i + burst == niters;
+      for (unsigned k = 0; k < burst; ++k)
+        if (weak(iter + k)) pipe.line("Weakening priors \n");
+      const unsigned head = eval_now ? burst - 1 : burst;
+      if (head > 0) CLI_CHECK(ctx, gbp_ba_loop(ctx, (int)head, iter, (unsigned)o.steps, nullptr));
+      if (eval_now) {
+        const unsigned since = iter + burst - 1u, total = (unsigned)o.iters_between_kfs * data_counter + since;
+        if (weak(since)) CLI_CHECK(ctx, gbp_weaken_priors(ctx));
+        CLI_CHECK(ctx, pipe.submit([total, since, &print_iter](const gbp_eval_out& e) { print_iter(total, since, e); }, 1));
+      }
+      i += burst - 1;
+      iter += burst;
+      continue;
+    }
     if (((iter + 1) % 2 == 0) && (iter < o.steps * 2)) {
       if (pipe.on && o.eval_every == 1) lines.post([] { std::cout << "Weakening priors \n"; });
       else { lines.drain(); pipe.line("Weakening priors \n"); }
