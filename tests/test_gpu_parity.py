@@ -622,6 +622,43 @@ def test_ba_loop_equals_the_calls_it_stands_for(name, oracle_mod):
     assert a.timing()["iterations"] == b.timing()["iterations"]
 
 
+@pytest.mark.parametrize("steps", [0, 3, 8])
+def test_ba_loop_with_other_weakening_schedules(steps, oracle_mod):
+    """--steps 0 (no weakening at all), 3 and 8 (weaken flags that start above five: WeakenPriorVertex acts on flags 1 .. 5 only): gbp_ba_loop
+    with and without the metric, on the persistent path and on the two-kernel path, against the calls it stands for."""
+    from gbp_poplar_amd import _cabi, driver, hostlib
+    from gbp_poplar_amd.engine import GbpEngine
+    bal = _bal("fr2robot2")
+    opts = driver.Options()
+    opts.steps = float(steps)
+    K, state, _ = driver.build_inputs(bal, opts, hostlib)
+    engs = [GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K, hooks=True,
+                      params=_cabi.GbpParams.defaults(persistent=m)) for m in (1, -1, 1, -1)]
+    a, c, ap, b = engs          # a, c: with the metric (persistent / two-kernel); ap: without, persistent; b: call by call
+    for e in engs:
+        e.upload(state)
+        e.linearise()
+    it = 0
+    for n in (5, 2, 14, 9):
+        ea, ec = a.ba_loop(n, it, steps), c.ba_loop(n, it, steps)
+        ap.ba_loop(n, it, steps, metrics=False)
+        eb = []
+        for i in range(it, it + n):
+            if (i + 1) % 2 == 0 and i < 2 * steps:
+                b.weaken_priors()
+            b.iterate(1)
+            eb.append(b.eval())
+        assert ea == eb == ec, (steps, it, n)
+        it += n
+        sb, pb = _full_snapshot(b), b.read_priors()
+        for e in (a, c, ap):
+            se, pe = _full_snapshot(e), e.read_priors()
+            for k in sb:
+                assert np.array_equal(se[k], sb[k], equal_nan=True), (steps, it, k)
+            for k in pb:
+                assert np.array_equal(pe[k], pb[k]), (steps, it, k)
+
+
 @pytest.mark.parametrize("name", ["fr2robot2", "fr1xyz", "ragged", "two_kernels_40k_factors"])
 def test_ba_loop_without_the_metric_equals_the_calls_it_stands_for(name, oracle_mod):
     """gbp_ba_loop(n, iter0, steps, NULL): the passes without the metric, not blocking.  A weakening then rides in the launch of the
