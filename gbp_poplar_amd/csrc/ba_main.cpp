@@ -99,7 +99,7 @@ static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
     }
     if (pipe.on && o.eval_every == 1) {
       // the reference's default: the metric after EVERY iteration.  All iterations up to the next prior weakening go down in
-      // one call (gbp_iterate_eval_each: one launch on a graph that runs in the persistent kernel), at most 128 at a time so
+      // one call (gbp_ba_loop: one launch on a graph that runs in the persistent kernel), at most 128 at a time so
       // that the lines keep coming on a large graph — 512 where an iteration takes microseconds (the persistent kernel: every
       // launch boundary is ~60 us of idle GPU), but the LAST burst of the run short: its lines are the ones no launch overlaps
       const int cap = gbp_graph_state(ctx) == 2 ? 512 : 128;
@@ -107,7 +107,7 @@ static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
       while (burst < cap && i + burst < o.n_iters && !(((iter + burst + 1) % 2 == 0) && (iter + burst < o.steps * 2))) ++burst;
       if (cap == 512 && i + burst == o.n_iters && burst > 96) burst -= 64;      // ... so the run ends with a burst of 64
       series.resize((size_t)burst);
-      CLI_CHECK(ctx, gbp_iterate_eval_each(ctx, burst, series.data()));
+      CLI_CHECK(ctx, gbp_ba_loop(ctx, burst, iter, 0u, series.data()));      // steps = 0: the weakenings are this loop's own calls
       rep.last = series.back(); rep.have_metric = true;
       lines.post([first = iter, batch = series, &write_iter] {
         for (size_t k = 0; k < batch.size(); ++k) write_iter(first + (unsigned)k, batch[k]);

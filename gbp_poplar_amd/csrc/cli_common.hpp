@@ -13,6 +13,8 @@
 //     dataio.cpp:334,349,406); `--eval_every K` thins the per-iteration read-back + metric (default 1).
 #pragma once
 #include "../../include/gbp_mi355x.h"
+#include "../../include/gbp_mi355x_multi.h"       // --ipus N: one forked rank per GPU
+#include "../../include/gbp_mi355x_compat.h"      // MetricPipe: the metric in two halves (gbp_iterate_eval / gbp_eval_end), so that printing overlaps the next iterations
 
 #include <condition_variable>
 #include <deque>

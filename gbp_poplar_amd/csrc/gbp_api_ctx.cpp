@@ -1,0 +1,488 @@
+// gbp_api_ctx.cpp — life cycle of a ctx and the programs that move host streams (include/gbp_mi355x.h):
+//   gbp_create / gbp_destroy   graph build + Engine ctor/load        reference ba/ba.cpp:659-937
+//   gbp_upload                 WRITE_PROG                            ba.cpp:868-886
+//   gbp_read                   READ_PROG                             ba.cpp:908-916
+//   gbp_read_priors            READ_PRIORS                           slam.cpp:913-917
+//   gbp_new_keyframe           NEW_KEYFRAME                          slam.cpp:919-928
+//   gbp_sync, gbp_set_stream, gbp_timing, gbp_set_profiling
+// gbp_create sorts the factors into device order (gbp_layout.cpp, pure host code) and only then touches the GPU.
+#include "gbp_ctx.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
+using namespace gbp;
+using namespace gbp::api;
+
+namespace gbp {
+namespace api {
+
+LayoutOptions g_layout_options;
+int g_force_sweep_policy = -1;
+
+std::string& create_error() {
+  thread_local std::string g_create_error;
+  return g_create_error;
+}
+
+int fail(gbp_ctx* c, int code, const std::string& msg) {
+  if (c) c->err = msg; else create_error() = msg;
+  return code;
+}
+
+// Zero-filled device memory owned by the ctx.  The fill runs on the ctx's stream — the stream every later use of the buffer is
+// queued on — so no device-wide synchronisation is needed behind an allocation (a fill on the NULL stream is not ordered against a
+// non-blocking stream and may still be running when hipMemset returns; blocking copies into a fresh buffer wait for the stream first).
+int dev_alloc(gbp_ctx* c, DevBuf& b, size_t bytes) {
+  b.bytes = bytes < 256 ? 256 : bytes;   // >= one camera / landmark record: pad lanes of an empty shard read index 0
+  HIPCHK(c, hipMalloc(&b.p, b.bytes));
+  c->all.push_back(&b);
+  c->dev_bytes += b.bytes;
+  HIPCHK(c, hipMemsetAsync(b.p, 0, b.bytes, c->stream));
+  return GBP_OK;
+}
+
+// timing brackets of gbp_iterate calls: read the finished ones without blocking anything that is still queued
+int resolve_spans(gbp_ctx* c, bool wait) {
+  size_t done = 0;
+  for (; done < c->spans.size(); ++done) {
+    const gbp_ctx::Span sp = c->spans[done];
+    if (wait) { if (hipEventSynchronize(sp.b) != hipSuccess) break; }
+    else if (hipEventQuery(sp.b) != hipSuccess) break;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) c->total_ms += ms;
+    c->span_pool.push_back(sp);
+  }
+  c->spans.erase(c->spans.begin(), c->spans.begin() + (long)done);
+  return GBP_OK;
+}
+int span_begin(gbp_ctx* c, gbp_ctx::Span& sp) {
+  if (c->spans.size() >= 64) resolve_spans(c, true);
+  if (!c->span_pool.empty()) { sp = c->span_pool.back(); c->span_pool.pop_back(); }
+  else {
+    HIPCHK(c, hipEventCreate(&sp.a));
+    if (hipError_t e_ = hipEventCreate(&sp.b); e_ != hipSuccess) { (void)hipEventDestroy(sp.a); return fail(c, GBP_ERR_HIP, "hipEventCreate"); }
+  }
+  HIPCHK(c, hipEventRecord(sp.a, c->stream));
+  return GBP_OK;
+}
+int span_end(gbp_ctx* c, const gbp_ctx::Span& sp) {
+  HIPCHK(c, hipEventRecord(sp.b, c->stream));
+  c->spans.push_back(sp);
+  return GBP_OK;
+}
+
+int event_pair(gbp_ctx* c, hipEvent_t* a, hipEvent_t* b) {
+  HIPCHK(c, hipEventCreate(a));
+  if (hipError_t e_ = hipEventCreate(b); e_ != hipSuccess) {
+    (void)hipEventDestroy(*a);
+    *a = nullptr;
+    return fail(c, GBP_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e_));
+  }
+  return GBP_OK;
+}
+
+// split-phase profiling: read (and free) the sweep brackets recorded by gbp_iterate_begin
+void drain_sweep_events(gbp_ctx* c) {
+  for (auto& pr : c->pending_sweep_ev) {
+    float ms = 0;
+    if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+      c->sweep_ms += ms;
+      c->timed_iters += 1;
+    }
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
+  c->pending_sweep_ev.clear();
+  for (auto& pr : c->pending_exch_ev) {
+    float ms = 0;
+    if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) c->exchange_ms += ms;
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
+  c->pending_exch_ev.clear();
+}
+
+}  // namespace api
+}  // namespace gbp
+
+namespace {
+
+// Cache policy of the sweep's two message streams for a graph of C cameras and n_tiles tiles (SweepArgs.policy).
+// Camera messages loaded with the default policy instead of the non-temporal hint: few cameras (their belief table small beside
+// an XCD's 4 MiB L2) AND both message streams of this rank (176 B per factor slot) within ~3/4 of the 256 MiB Infinity Cache,
+// where the lines loaded this sweep are still found by the next: measured on 1 M factors x 100 000 landmarks +1.3 % iterations/s
+// with 500 cameras, +0.6 % with 1 000, +0.25 % with 2 000, -0.1 % with 4 000, -0.3 % with 8 000 (-1.4 % on the config-5 shard
+// shape); 1 000 cameras, factor count scanned: +1.4 % at 0.5 M, +0...2 % at 1 M (the edge), -0.5 % at 1.25 M, -2 % at 1.5 M,
+// -5.5 % at 2 M (profiles/r04_alu_diet.md section 6).
+uint32_t sweep_policy_for(uint32_t C, uint32_t n_tiles) {
+  uint32_t pol = 0;
+  if (C <= 2048u && (uint64_t)n_tiles * 64u * 176u <= 200000000ull) pol |= kPolCmsgLoadCached;
+  return pol;
+}
+
+void pack_cam(const float* eta, const float* lam, uint32_t C, std::vector<float>& out) {
+  out.assign((size_t)C * kCamRec, 0.f);
+  for (uint32_t c = 0; c < C; ++c) {
+    std::memcpy(&out[(size_t)c * kCamRec], eta + (size_t)c * 6, 6 * 4);
+    std::memcpy(&out[(size_t)c * kCamRec + 8], lam + (size_t)c * 36, 36 * 4);
+  }
+}
+void pack_lmk(const float* eta, const float* lam, uint32_t l0, uint32_t n, std::vector<float>& out) {
+  out.assign((size_t)n * 16, 0.f);
+  for (uint32_t i = 0; i < n; ++i) {
+    std::memcpy(&out[(size_t)i * 16], eta + (size_t)(l0 + i) * 3, 3 * 4);
+    std::memcpy(&out[(size_t)i * 16 + 4], lam + (size_t)(l0 + i) * 9, 9 * 4);
+  }
+}
+
+}  // namespace
+
+GBP_EXPORT_T(int, 0, gbp_abi_version, (void), ()) { return GBP_ABI_VERSION; }
+
+GBP_EXPORT_VOID(gbp_default_params, (gbp_params* p), (p)) {
+  if (!p) return;
+  std::memset(p, 0, sizeof(*p));
+  p->maxeta_damping = 0.4f; p->num_undamped_iters = 8; p->dmu_threshold = 3e-3f; p->min_linear_iters = 10;
+  p->nstds = 2.5f; p->relin_mode = 0; p->graph_unroll = 0;
+}
+
+GBP_EXPORT_T(const char*, "", gbp_last_error, (const gbp_ctx* ctx), (ctx)) { return ctx ? ctx->err.c_str() : create_error().c_str(); }
+
+GBP_EXPORT_VOID(gbp_destroy, (gbp_ctx* c), (c)) {
+  if (!c) return;
+  drop_graph(c);
+  persist_forget(c);
+  if (c->comm) { (void)hipStreamSynchronize(c->stream); if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream); delete c->comm; c->comm = nullptr; }
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
+  for (auto* v : {&c->pending_sweep_ev, &c->pending_exch_ev})
+    for (auto& pr : *v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  for (DevBuf* b : c->all) if (b->p) (void)hipFree(b->p);
+  for (auto& v : {&c->spans, &c->span_pool})
+    for (auto& sp : *v) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+  if (c->eval_host) (void)hipHostFree(c->eval_host);
+  if (c->ev_host) (void)hipHostFree(c->ev_host);
+  if (c->series_host) (void)hipHostFree(c->series_host);
+  if (c->pstatus_host) (void)hipHostFree(c->pstatus_host);
+  for (hipEvent_t e : c->eval_ev) if (e) (void)hipEventDestroy(e);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->ev2) (void)hipEventDestroy(c->ev2);
+  if (c->ev3) (void)hipEventDestroy(c->ev3);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+
+GBP_EXPORT(gbp_create, nullptr, (const gbp_problem* pr, const gbp_params* prm, const gbp_shard* sh, gbp_ctx** out), (pr, prm, sh, out)) {
+  if (!pr || !out || !pr->cam_id || !pr->lmk_id || pr->n_cams == 0 || pr->n_lmks == 0 || pr->n_edges == 0)
+    return fail(nullptr, GBP_ERR_INVALID, "gbp_create: null or empty problem");
+  // ---- device order: pure host code (gbp_layout.cpp), built and validated before anything touches the GPU ----
+  Layout lay;
+  {
+    gbp_params dflt;
+    gbp_default_params(&dflt);
+    std::string lerr;
+    if (int lrc = layout_build(pr, (prm ? prm : &dflt)->tile_order, sh, g_layout_options, lay, lerr)) return fail(nullptr, lrc, lerr);
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(nullptr, GBP_ERR_NO_DEVICE, "gbp_create: no HIP device (the product has no CPU fallback)");
+  gbp_ctx* c = new gbp_ctx();
+  struct Owner { gbp_ctx* p; ~Owner() { if (p) gbp_destroy(p); } } owner{c};   // released on success only
+  c->lay = std::move(lay);
+  c->C = pr->n_cams; c->L = pr->n_lmks; c->E = pr->n_edges;
+  std::memcpy(c->K, pr->K, sizeof(c->K));
+  if (prm) c->prm = *prm; else gbp_default_params(&c->prm);
+  if (const char* gu = prm ? nullptr : std::getenv("GBP_GRAPH_UNROLL")) c->prm.graph_unroll = std::atoi(gu);   // measurements through callers that pass NO params (the CLIs); explicit params always win
+  c->sharded_graph = c->prm.graph_unroll > 0;                // a sharded iteration is captured only on explicit request
+  if (c->prm.graph_unroll == 0) c->prm.graph_unroll = 10;   // < 0: never capture, always direct launches
+  c->hoist = c->prm.per_factor_mu == 0;
+  c->rank = sh ? sh->rank : 0;
+  c->world = sh ? sh->world : 1;
+  c->lmk_begin = sh ? sh->lmk_begin : 0;
+  c->lmk_end = sh ? sh->lmk_end : c->L;
+  c->L_loc = c->lmk_end - c->lmk_begin;      // (the shard was validated by layout_build)
+
+  const Layout& y = c->lay;
+  c->E_loc = y.E_loc; c->n_rows = y.n_rows; c->Ep = y.Ep; c->n_tiles = y.n_tiles;
+  const uint32_t C = c->C;
+  c->sweep_policy = g_force_sweep_policy >= 0 ? (uint32_t)g_force_sweep_policy : sweep_policy_for(c->C, c->n_tiles);
+
+
+  int rc = GBP_OK;
+  auto CK = [&](hipError_t e, const char* what) {
+    if (e != hipSuccess && rc == GBP_OK) { create_error() = std::string(what) + ": " + hipGetErrorString(e); rc = GBP_ERR_HIP; }
+  };
+  CK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking), "hipStreamCreate");
+  if (rc != GBP_OK) return rc;
+  c->stream = c->own_stream;
+  // ---- device allocations (zero-filled on the ctx's stream) ----
+  auto A = [&](DevBuf& b, size_t bytes) { if (rc == GBP_OK) rc = dev_alloc(c, b, bytes); };
+  const size_t Ep = c->Ep;
+  A(c->row_cam, (Ep / kRow) * 4); A(c->lmk_idx, Ep * 4); A(c->fac, Ep * kFacG * 16); A(c->cmsg, Ep * kCmsgG * 16);
+  A(c->mu, c->hoist ? 0 : Ep * kMuG * 16);   // literal mu/oldmu tensor: only with per_factor_mu
+  A(c->lmsg, Ep * 64); A(c->d_lmk_fpos, (size_t)c->E_loc * 4); A(c->d_lmk_ix, (size_t)c->L_loc * 64);
+  A(c->camb, (size_t)C * kCamRec * 4); A(c->camp, (size_t)C * kCamRec * 4); A(c->local, (size_t)C * kCamRec * 4);
+  A(c->lmkb, (size_t)c->L_loc * 64); A(c->lmkp, (size_t)c->L_loc * 64);
+  A(c->rowp, (Ep / kRow) * kCamRec * 4);
+  A(c->d_cam_row_ptr, (size_t)(C + 1) * 4); A(c->d_lmk_ptr, (size_t)(c->L_loc + 1) * 4);
+  A(c->d_row_slot, y.row_slot.size() * 4);
+  A(c->cwf, (size_t)C * 4); A(c->lwf, (size_t)c->L_loc * 4); A(c->cscale, (size_t)C * 4); A(c->lscale, (size_t)c->L_loc * 4);
+  A(c->cam_mu, (size_t)C * 6 * 4 * 2); A(c->lmk_mu, (size_t)c->L_loc * 3 * 4 * 2);   // metric means; k_persist alternates between the two halves
+  A(c->dK, 16 * 4);
+  A(c->evalp, sizeof(DeviceEval) * 16); A(c->health, 32);
+  A(c->hmu_c, (size_t)C * 4 * 16); A(c->hmu_l, (size_t)c->L_loc * 2 * 16); A(c->clin, (size_t)C * 5 * 16);
+  A(c->st_a, Ep * 4); A(c->st_b, Ep * 4);
+  if (rc == GBP_OK && !y.tile_perm.empty()) A(c->tile_perm, (size_t)y.n_tiles * 4);
+  if (rc != GBP_OK) { create_error() = c->err; return rc; }
+  CK(hipEventCreate(&c->ev0), "hipEventCreate"); CK(hipEventCreate(&c->ev1), "hipEventCreate");
+  CK(hipEventCreate(&c->ev2), "hipEventCreate"); CK(hipEventCreate(&c->ev3), "hipEventCreate");
+  CK(hipStreamSynchronize(c->stream), "hipStreamSynchronize");      // the fills have landed: blocking copies into the fresh buffers follow
+  CK(hipMemcpy(c->d_cam_row_ptr.p, y.cam_row_ptr.data(), (size_t)(C + 1) * 4, hipMemcpyHostToDevice), "copy cam_row_ptr");
+  CK(hipMemcpy(c->d_lmk_ptr.p, y.lmk_ptr.data(), (size_t)(c->L_loc + 1) * 4, hipMemcpyHostToDevice), "copy lmk_ptr");
+  if (!y.row_slot.empty()) CK(hipMemcpy(c->d_row_slot.p, y.row_slot.data(), y.row_slot.size() * 4, hipMemcpyHostToDevice), "copy row_slot");
+  CK(hipMemcpy(c->dK.p, c->K, 9 * 4, hipMemcpyHostToDevice), "copy K");
+  if (c->E_loc) CK(hipMemcpy(c->d_lmk_fpos.p, y.lmk_fpos.data(), (size_t)c->E_loc * 4, hipMemcpyHostToDevice), "copy lmk_fpos");
+  if (c->L_loc) CK(hipMemcpy(c->d_lmk_ix.p, y.lmk_ix.data(), (size_t)c->L_loc * 64, hipMemcpyHostToDevice), "copy lmk_ix");
+  CK(hipMemcpy(c->row_cam.p, y.row_cam.data(), y.row_cam.size() * 4, hipMemcpyHostToDevice), "copy row_cam");
+  CK(hipMemcpy(c->lmk_idx.p, y.pos_lmk_loc.data(), Ep * 4, hipMemcpyHostToDevice), "copy lmk_idx");
+  if (!y.tile_perm.empty()) {
+    // the XCD-aware execution order of the sweep: wave slot -> tile (gbp_layout.cpp); read once per wave with a scalar load
+    CK(hipMemcpy(c->tile_perm.p, y.tile_perm.data(), (size_t)y.n_tiles * 4, hipMemcpyHostToDevice), "copy tile_perm");
+    c->use_tile_perm = rc == GBP_OK;
+  }
+  if (rc != GBP_OK) return rc;
+  // ---- persistent iteration kernel: only where every workgroup of the graph is resident at once (gbp_api_persist.cpp) ----
+  rc = persist_setup(c, prm, sh != nullptr);
+  if (rc != GBP_OK) { if (create_error().empty()) create_error() = c->err; return rc; }
+  CK(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+  if (rc != GBP_OK) return rc;
+  owner.p = nullptr;
+  *out = c;
+  return GBP_OK;
+}
+
+GBP_EXPORT(gbp_set_stream, c, (gbp_ctx* c, void* s), (c, s)) {
+  if (!c) return GBP_ERR_INVALID;
+  if (int rc = settle(c)) return rc;
+  drop_graph(c);
+  c->stream = s ? static_cast<hipStream_t>(s) : c->own_stream;
+  return GBP_OK;
+}
+
+GBP_EXPORT(gbp_set_exchange_buffers, c, (gbp_ctx* c, void* send_dev, void* recv_dev), (c, send_dev, recv_dev)) {
+  if (!c) return GBP_ERR_INVALID;
+  c->send_dev = send_dev; c->recv_dev = recv_dev;
+  return GBP_OK;
+}
+
+GBP_EXPORT(gbp_sync, c, (gbp_ctx* c), (c)) {
+  if (!c) return GBP_ERR_INVALID;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return persist_check(c, 0);
+}
+
+// WRITE_PROG (ba.cpp:868-886).  Also zeroes every tensor the reference leaves uninitialised
+// (messages, factor potentials, beliefs: ba.cpp:668-687,759-775).
+GBP_EXPORT(gbp_upload, c, (gbp_ctx* c, const gbp_state_in* in), (c, in)) {
+  if (!c || !in) return GBP_ERR_INVALID;
+  if (!in->cam_priors_eta || !in->cam_priors_lambda || !in->lmk_priors_eta || !in->lmk_priors_lambda ||
+      !in->measurements || !in->meas_variances || !in->active_flag)
+    return fail(c, GBP_ERR_INVALID, "gbp_upload: priors, measurements, meas_variances and active_flag are required");
+  if (in->mu && in->oldmu && std::memcmp(in->mu, in->oldmu, (size_t)c->E * 9 * 4) != 0)
+    return fail(c, GBP_ERR_INVALID, "gbp_upload: mu != oldmu is not supported (the reference uploads zeros for both, ba.cpp:582-583)");
+  if (c->hoist) {
+    const float* om = in->oldmu ? in->oldmu : in->mu;
+    if (om)
+      for (size_t i = 0; i < (size_t)c->E * 9; ++i)
+        if (om[i] != 0.f)
+          return fail(c, GBP_ERR_INVALID, "gbp_upload: non-zero oldmu needs gbp_params.per_factor_mu = 1 (the reference uploads zeros, ba.cpp:582-583)");
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (int rc = persist_reset(c)) return rc;      // a fresh start for the persistent kernel too
+  const size_t Ep = c->Ep;
+  std::vector<float> rec0(Ep * 16, 0.f), fac(Ep * kFacG * 4, 0.f), mu(c->hoist ? 0 : Ep * kMuG * 4, 0.f);
+  c->active_host.assign(Ep, 0);
+  for (size_t p = 0; p < Ep; ++p) {
+    const uint32_t e = c->lay.pos_edge[p];
+    HostState h{0.f, 0, kFlagPad, 0.f};
+    if (e != ~0u) {
+      h.flags = (in->active_flag[e] == 1) ? kFlagActive : 0u;
+      c->active_host[p] = in->active_flag[e] == 1;
+      h.damping = in->damping ? in->damping[e] : 0.f;
+      h.count = in->damping_count ? in->damping_count[e] : 0;
+      h.var = in->meas_variances[e];
+      fac[tile_off((uint32_t)p, kFacG, 54)] = in->measurements[2 * (size_t)e];
+      fac[tile_off((uint32_t)p, kFacG, 55)] = in->measurements[2 * (size_t)e + 1];
+      const float* om = in->oldmu ? in->oldmu : in->mu;
+      if (om && !c->hoist) for (int i = 0; i < 9; ++i) mu[tile_off((uint32_t)p, kMuG, i)] = om[(size_t)e * 9 + i];
+    }
+    put_state(rec0, p, h);
+  }
+  HIPCHK(c, hipMemcpy(c->lmsg.p, rec0.data(), rec0.size() * 4, hipMemcpyHostToDevice));   // zero messages + state
+  HIPCHK(c, hipMemcpy(c->fac.p, fac.data(), fac.size() * 4, hipMemcpyHostToDevice));
+  if (!c->hoist) HIPCHK(c, hipMemcpy(c->mu.p, mu.data(), mu.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemsetAsync(c->cmsg.p, 0, c->cmsg.bytes, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->rowp.p, 0, c->rowp.bytes, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->local.p, 0, c->local.bytes, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->camb.p, 0, c->camb.bytes, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->lmkb.p, 0, c->lmkb.bytes, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->hmu_c.p, 0, c->hmu_c.bytes, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->hmu_l.p, 0, c->hmu_l.bytes, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->clin.p, 0, c->clin.bytes, c->stream));
+  std::vector<float> rec;
+  pack_cam(in->cam_priors_eta, in->cam_priors_lambda, c->C, rec);
+  HIPCHK(c, hipMemcpy(c->camp.p, rec.data(), rec.size() * 4, hipMemcpyHostToDevice));
+  pack_lmk(in->lmk_priors_eta, in->lmk_priors_lambda, c->lmk_begin, c->L_loc, rec);
+  if (c->L_loc) HIPCHK(c, hipMemcpy(c->lmkp.p, rec.data(), rec.size() * 4, hipMemcpyHostToDevice));
+  std::vector<float> zf(std::max(c->C, c->L), 0.f);
+  std::vector<uint32_t> zu(std::max(c->C, c->L), 0u);
+  HIPCHK(c, hipMemcpy(c->cscale.p, in->cam_scaling ? in->cam_scaling : zf.data(), (size_t)c->C * 4, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->cwf.p, in->cam_weaken_flag ? in->cam_weaken_flag : zu.data(), (size_t)c->C * 4, hipMemcpyHostToDevice));
+  if (c->L_loc) {
+    HIPCHK(c, hipMemcpy(c->lscale.p, in->lmk_scaling ? in->lmk_scaling + c->lmk_begin : zf.data(), (size_t)c->L_loc * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->lwf.p, in->lmk_weaken_flag ? in->lmk_weaken_flag + c->lmk_begin : zu.data(), (size_t)c->L_loc * 4, hipMemcpyHostToDevice));
+  }
+  if (exch(c) && c->recv_dev) HIPCHK(c, hipMemsetAsync(c->recv_dev, 0, (size_t)c->world * c->C * kCamRec * 4, c->stream));
+  c->uploaded = true;
+  c->beliefs_valid = false;
+  return GBP_OK;
+}
+
+// READ_PROG (ba.cpp:908-916)
+GBP_EXPORT(gbp_read, c, (gbp_ctx* c, gbp_state_out* o), (c, o)) {
+  if (!c || !o) return GBP_ERR_INVALID;
+  if (int rc = gbp_sync(c)) return rc;
+  if (o->cam_beliefs_eta || o->cam_beliefs_lambda) {
+    std::vector<float> rec((size_t)c->C * kCamRec);
+    HIPCHK(c, hipMemcpy(rec.data(), c->camb.p, rec.size() * 4, hipMemcpyDeviceToHost));
+    for (uint32_t k = 0; k < c->C; ++k) {
+      if (o->cam_beliefs_eta) std::memcpy(o->cam_beliefs_eta + (size_t)k * 6, &rec[(size_t)k * kCamRec], 6 * 4);
+      if (o->cam_beliefs_lambda) std::memcpy(o->cam_beliefs_lambda + (size_t)k * 36, &rec[(size_t)k * kCamRec + 8], 36 * 4);
+    }
+  }
+  if ((o->lmk_beliefs_eta || o->lmk_beliefs_lambda) && c->L_loc) {
+    std::vector<float> rec((size_t)c->L_loc * 16);
+    HIPCHK(c, hipMemcpy(rec.data(), c->lmkb.p, rec.size() * 4, hipMemcpyDeviceToHost));
+    for (uint32_t l = 0; l < c->L_loc; ++l) {
+      if (o->lmk_beliefs_eta) std::memcpy(o->lmk_beliefs_eta + (size_t)(c->lmk_begin + l) * 3, &rec[(size_t)l * 16], 3 * 4);
+      if (o->lmk_beliefs_lambda) std::memcpy(o->lmk_beliefs_lambda + (size_t)(c->lmk_begin + l) * 9, &rec[(size_t)l * 16 + 4], 9 * 4);
+    }
+  }
+  if (o->damping || o->damping_count || o->robust_flag) {
+    // per-factor scalars ride in the message records: a small kernel extracts them into two compact arrays
+    launch_state_get(P<float4>(c->lmsg), P<float>(c->st_a), P<int>(c->st_b), c->Ep, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<float> damp(c->Ep);
+    std::vector<int32_t> packed(c->Ep);
+    HIPCHK(c, hipMemcpy(damp.data(), c->st_a.p, (size_t)c->Ep * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(packed.data(), c->st_b.p, (size_t)c->Ep * 4, hipMemcpyDeviceToHost));
+    for (size_t p = 0; p < c->Ep; ++p) {
+      const uint32_t e = c->lay.pos_edge[p];
+      if (e == ~0u) continue;
+      if (o->damping) o->damping[e] = damp[p];
+      if (o->damping_count) o->damping_count[e] = packed[p] >> 3;
+      if (o->robust_flag) o->robust_flag[e] = ((uint32_t)packed[p] & kFlagRobust) ? 1u : 0u;
+    }
+  }
+  return GBP_OK;
+}
+
+// READ_PRIORS (slam.cpp:913-917)
+GBP_EXPORT(gbp_read_priors, c, (gbp_ctx* c, gbp_priors_out* o), (c, o)) {
+  if (!c || !o) return GBP_ERR_INVALID;
+  if (int rc = gbp_sync(c)) return rc;
+  std::vector<float> rec((size_t)c->C * kCamRec);
+  HIPCHK(c, hipMemcpy(rec.data(), c->camp.p, rec.size() * 4, hipMemcpyDeviceToHost));
+  for (uint32_t k = 0; k < c->C; ++k) {
+    if (o->cam_priors_eta) std::memcpy(o->cam_priors_eta + (size_t)k * 6, &rec[(size_t)k * kCamRec], 6 * 4);
+    if (o->cam_priors_lambda) std::memcpy(o->cam_priors_lambda + (size_t)k * 36, &rec[(size_t)k * kCamRec + 8], 36 * 4);
+  }
+  if (c->L_loc) {
+    rec.resize((size_t)c->L_loc * 16);
+    HIPCHK(c, hipMemcpy(rec.data(), c->lmkp.p, rec.size() * 4, hipMemcpyDeviceToHost));
+    for (uint32_t l = 0; l < c->L_loc; ++l) {
+      if (o->lmk_priors_eta) std::memcpy(o->lmk_priors_eta + (size_t)(c->lmk_begin + l) * 3, &rec[(size_t)l * 16], 3 * 4);
+      if (o->lmk_priors_lambda) std::memcpy(o->lmk_priors_lambda + (size_t)(c->lmk_begin + l) * 9, &rec[(size_t)l * 16 + 4], 9 * 4);
+    }
+  }
+  return GBP_OK;
+}
+
+// NEW_KEYFRAME (slam.cpp:919-928): re-upload damping_count, priors, flags; then prog_ub.
+GBP_EXPORT(gbp_new_keyframe, c, (gbp_ctx* c, const gbp_kf_update* u), (c, u)) {
+  if (!c || !u || !c->uploaded) return fail(c, GBP_ERR_STATE, "gbp_new_keyframe: upload first");
+  if (int rc = gbp_sync(c)) return rc;
+  if (u->damping_count || u->active_flag) {
+    // edit the per-factor scalars in place on the device: 8 bytes per factor go over PCIe, not the 64-byte records
+    std::vector<int32_t> cnt(c->Ep, 0);
+    std::vector<uint32_t> ctl(c->Ep, 0u);
+    const int thr = c->prm.min_linear_iters - c->prm.num_undamped_iters;
+    for (size_t p = 0; p < c->Ep; ++p) {
+      const uint32_t e = c->lay.pos_edge[p];
+      if (e == ~0u) continue;
+      if (u->damping_count) { cnt[p] = u->damping_count[e]; ctl[p] |= 1u; }
+      if (u->active_flag) {
+        const bool on = u->active_flag[e] == 1;
+        // Hoisted means (k_sweep<HOIST>): a factor's FIRST active sweep measures dmu against the variable's previous
+        // mean where the reference measures it against the factor's own zero-initialised oldmu (ba.cpp:582-583).  The
+        // two agree as long as that sweep cannot relinearise, i.e. count + 1 <= min_linear_iters - num_undamped_iters
+        // (gbp_codelets.cpp:280) — true for the reference's re-arm value -15 (slam.cpp:1040) and its defaults.
+        if (c->hoist && on && !c->active_host[p] && u->damping_count && u->damping_count[e] + 1 > thr)
+          return fail(c, GBP_ERR_INVALID, "gbp_new_keyframe: a factor activated with damping_count + 1 > min_linear_iters - "
+                                          "num_undamped_iters could relinearise on its first sweep; that needs gbp_params.per_factor_mu = 1");
+        ctl[p] |= 2u | (on ? 4u : 0u);
+      }
+    }
+    HIPCHK(c, hipMemcpy(c->st_b.p, cnt.data(), (size_t)c->Ep * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->st_a.p, ctl.data(), (size_t)c->Ep * 4, hipMemcpyHostToDevice));
+    launch_state_set(P<float4>(c->lmsg), P<int>(c->st_b), P<uint32_t>(c->st_a), c->Ep, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (u->active_flag)
+      for (size_t p = 0; p < c->Ep; ++p)
+        if (c->lay.pos_edge[p] != ~0u) c->active_host[p] = u->active_flag[c->lay.pos_edge[p]] == 1;
+  }
+  if (u->cam_priors_eta && u->cam_priors_lambda) {
+    std::vector<float> rec;
+    pack_cam(u->cam_priors_eta, u->cam_priors_lambda, c->C, rec);
+    HIPCHK(c, hipMemcpy(c->camp.p, rec.data(), rec.size() * 4, hipMemcpyHostToDevice));
+  }
+  if (u->lmk_priors_eta && u->lmk_priors_lambda && c->L_loc) {
+    std::vector<float> rec;
+    pack_lmk(u->lmk_priors_eta, u->lmk_priors_lambda, c->lmk_begin, c->L_loc, rec);
+    HIPCHK(c, hipMemcpy(c->lmkp.p, rec.data(), rec.size() * 4, hipMemcpyHostToDevice));
+  }
+  if (u->cam_weaken_flag) HIPCHK(c, hipMemcpy(c->cwf.p, u->cam_weaken_flag, (size_t)c->C * 4, hipMemcpyHostToDevice));
+  if (u->lmk_weaken_flag && c->L_loc)
+    HIPCHK(c, hipMemcpy(c->lwf.p, u->lmk_weaken_flag + c->lmk_begin, (size_t)c->L_loc * 4, hipMemcpyHostToDevice));
+  return refresh_beliefs_from_partials(c, false);
+}
+
+GBP_EXPORT(gbp_timing, c, (gbp_ctx* c, gbp_timing_out* t, int reset), (c, t, reset)) {
+  if (!c || !t) return GBP_ERR_INVALID;
+  drain_sweep_events(c);   // split-phase brackets recorded by gbp_iterate_begin
+  resolve_spans(c, true);  // gbp_iterate brackets still in flight
+  t->sweep_ms = c->sweep_ms; t->belief_ms = c->belief_ms; t->total_ms = c->total_ms; t->iterations = c->timed_iters;
+  t->exchange_ms = c->exchange_ms;
+  t->algorithmic_bytes_per_iter = 1112ull * c->E_loc + 336ull * c->C + 96ull * c->L_loc;
+  t->device_bytes_allocated = c->dev_bytes;
+  if (reset) { c->sweep_ms = c->belief_ms = c->total_ms = c->exchange_ms = 0; c->timed_iters = 0; }
+  return GBP_OK;
+}
+
+// ---- extras declared below the main program list -------------------------------------------------
+GBP_EXPORT(gbp_set_profiling, c, (gbp_ctx* c, int per_stage_events), (c, per_stage_events)) {
+  if (!c) return GBP_ERR_INVALID;
+  c->profile_stages = per_stage_events != 0;
+  return GBP_OK;
+}
+
+GBP_EXPORT_T(int, 0, gbp_graph_state, (const gbp_ctx* c), (c)) {
+  return !c ? 0 : (c->persist_ok ? 2 : ((c->graph_exec || c->graph_exec_ev) ? 1 : (c->graph_failed ? -1 : 0)));
+}

@@ -15,6 +15,8 @@
 // single O(E) passes with identical results.  Eigen is not used; where the reference calls
 // Eigen's general inverse we solve in fp64 with partial pivoting.
 #include "../../include/gbp_mi355x.h"
+#include "../../include/gbp_mi355x_multi.h"      // gbp_landmark_partition
+#include "gbp_export.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -152,9 +154,8 @@ struct NoiseGen {
 
 }  // namespace
 
-extern "C" {
-
-int gbp_bal_read_header(const char* path, gbp_bal* h) {
+GBP_EXPORT(gbp_bal_read_header, nullptr, (const char* path, gbp_bal* h),
+           (path, h)) {
   if (!path || !h) return GBP_ERR_INVALID;
   FILE* f = std::fopen(path, "r");
   if (!f) return GBP_ERR_IO;
@@ -170,7 +171,8 @@ int gbp_bal_read_header(const char* path, gbp_bal* h) {
 }
 
 // Unlike the reference (FscanfOrDie only prints, dataio.cpp:59-65) a malformed file is an error.
-int gbp_bal_read(const char* path, gbp_bal* b) {
+GBP_EXPORT(gbp_bal_read, nullptr, (const char* path, gbp_bal* b),
+           (path, b)) {
   if (!path || !b || !b->cam_id || !b->lmk_id || !b->observations || !b->cameras || !b->points) return GBP_ERR_INVALID;
   FILE* f = std::fopen(path, "r");
   if (!f) return GBP_ERR_IO;
@@ -191,7 +193,8 @@ int gbp_bal_read(const char* path, gbp_bal* b) {
   return ok ? GBP_OK : GBP_ERR_IO;
 }
 
-int gbp_bal_write(const char* path, const gbp_bal* b) {
+GBP_EXPORT(gbp_bal_write, nullptr, (const char* path, const gbp_bal* b),
+           (path, b)) {
   if (!path || !b) return GBP_ERR_INVALID;
   FILE* f = std::fopen(path, "w");
   if (!f) return GBP_ERR_IO;
@@ -212,7 +215,8 @@ int gbp_bal_write(const char* path, const gbp_bal* b) {
 //     to the shared focal length f_bar = mean f, principal point (0, 0);
 //   * edges are re-sorted by (camera, landmark): the reference's SLAM mode and metric rely on camera-sorted files
 //     (util.cpp:95-99, dataio.cpp:483-486), standard BAL files are sorted by point.
-int gbp_bal_import_standard_header(const char* path, gbp_bal* h) {
+GBP_EXPORT(gbp_bal_import_standard_header, nullptr, (const char* path, gbp_bal* h),
+           (path, h)) {
   if (!path || !h) return GBP_ERR_INVALID;
   FILE* f = std::fopen(path, "r");
   if (!f) return GBP_ERR_IO;
@@ -227,7 +231,8 @@ int gbp_bal_import_standard_header(const char* path, gbp_bal* h) {
   return GBP_OK;
 }
 
-int gbp_bal_import_standard(const char* path, gbp_bal* b) {
+GBP_EXPORT(gbp_bal_import_standard, nullptr, (const char* path, gbp_bal* b),
+           (path, b)) {
   if (!path || !b || !b->cam_id || !b->lmk_id || !b->observations || !b->cameras || !b->points) return GBP_ERR_INVALID;
   FILE* f = std::fopen(path, "r");
   if (!f) return GBP_ERR_IO;
@@ -297,8 +302,8 @@ int gbp_bal_import_standard(const char* path, gbp_bal* b) {
   return GBP_OK;
 }
 
-int gbp_set_prior_lambda(const gbp_problem* p, float var, const float* cam_file, const float* lmk_file,
-                         const float* cam_mean, const float* lmk_mean, float* ce, float* cl, float* le, float* ll) {
+GBP_EXPORT(gbp_set_prior_lambda, nullptr, (const gbp_problem* p, float var, const float* cam_file, const float* lmk_file, const float* cam_mean, const float* lmk_mean, float* ce, float* cl, float* le, float* ll),
+           (p, var, cam_file, lmk_file, cam_mean, lmk_mean, ce, cl, le, ll)) {
   if (!p || !cam_file || !lmk_file || !cam_mean || !lmk_mean || !ce || !cl || !le || !ll) return GBP_ERR_INVALID;
   const uint32_t C = p->n_cams, L = p->n_lmks, E = p->n_edges;
   std::vector<float> peak_c(C, 0.f), peak_l(L, 0.f);
@@ -322,8 +327,8 @@ int gbp_set_prior_lambda(const gbp_problem* p, float var, const float* cam_file,
   return GBP_OK;
 }
 
-int gbp_prior_scalings(uint32_t C, uint32_t L, const float* cpl, float steps, float weaker, float first_std,
-                       float* cs, float* ls) {
+GBP_EXPORT(gbp_prior_scalings, nullptr, (uint32_t C, uint32_t L, const float* cpl, float steps, float weaker, float first_std, float* cs, float* ls),
+           (C, L, cpl, steps, weaker, first_std, cs, ls)) {
   if (!cpl || !cs || !ls) return GBP_ERR_INVALID;
   // ba.cpp:564: exp(-1/steps * log(lambda00 * pow(std,2))) — pow(float,int) promotes to double;
   // ba.cpp:566,571: exp(-2/steps * log(weaker)) stays in fp32.
@@ -335,8 +340,8 @@ int gbp_prior_scalings(uint32_t C, uint32_t L, const float* cpl, float steps, fl
   return GBP_OK;
 }
 
-int gbp_slam_create_flags(const gbp_problem* p, uint32_t steps, uint32_t* active, uint32_t* cwf, uint32_t* lwf,
-                          uint32_t* laf) {
+GBP_EXPORT(gbp_slam_create_flags, nullptr, (const gbp_problem* p, uint32_t steps, uint32_t* active, uint32_t* cwf, uint32_t* lwf, uint32_t* laf),
+           (p, steps, active, cwf, lwf, laf)) {
   if (!p || !active || !cwf || !lwf || !laf || p->n_cams < 2) return GBP_ERR_INVALID;
   cwf[0] = cwf[1] = steps;
   for (uint32_t e = 0; e < p->n_edges; ++e)
@@ -345,8 +350,8 @@ int gbp_slam_create_flags(const gbp_problem* p, uint32_t steps, uint32_t* active
   return GBP_OK;
 }
 
-int gbp_slam_update_flags(const gbp_problem* p, uint32_t steps, uint32_t dc, uint32_t* active, uint32_t* lwf,
-                          uint32_t* cwf, uint32_t* laf, int32_t* n_new) {
+GBP_EXPORT(gbp_slam_update_flags, nullptr, (const gbp_problem* p, uint32_t steps, uint32_t dc, uint32_t* active, uint32_t* lwf, uint32_t* cwf, uint32_t* laf, int32_t* n_new),
+           (p, steps, dc, active, lwf, cwf, laf, n_new)) {
   if (!p || !active || !cwf || !lwf || !laf || dc + 1 >= p->n_cams || steps == 0) return GBP_ERR_INVALID;
   for (uint32_t e = 0; e < p->n_edges; ++e) {
     if (p->cam_id[e] == dc + 1) active[e] = 1;
@@ -364,7 +369,8 @@ int gbp_slam_update_flags(const gbp_problem* p, uint32_t steps, uint32_t dc, uin
   return GBP_OK;
 }
 
-int gbp_slam_initialise_new_kf(uint32_t dc, const float* cbe, const float* cbl, const float* cpl, float* cpe) {
+GBP_EXPORT(gbp_slam_initialise_new_kf, nullptr, (uint32_t dc, const float* cbe, const float* cbl, const float* cpl, float* cpe),
+           (dc, cbe, cbl, cpl, cpe)) {
   if (!cbe || !cbl || !cpl || !cpe) return GBP_ERR_INVALID;
   float mu[6];
   solve_pivot(cbl + 36ull * dc, cbe + 6ull * dc, 6, mu);
@@ -376,8 +382,8 @@ int gbp_slam_initialise_new_kf(uint32_t dc, const float* cbe, const float* cbl, 
   return GBP_OK;
 }
 
-int gbp_eval_host(const gbp_problem* p, const uint32_t* active, const float* meas, const float* cbe, const float* cbl,
-                  const float* lbe, const float* lbl, double* sum_norm, double* sum_half_sq, uint64_t* n_active) {
+GBP_EXPORT(gbp_eval_host, nullptr, (const gbp_problem* p, const uint32_t* active, const float* meas, const float* cbe, const float* cbl, const float* lbe, const float* lbl, double* sum_norm, double* sum_half_sq, uint64_t* n_active),
+           (p, active, meas, cbe, cbl, lbe, lbl, sum_norm, sum_half_sq, n_active)) {
   if (!p || !active || !meas || !cbe || !cbl || !lbe || !lbl || !sum_norm || !sum_half_sq || !n_active) return GBP_ERR_INVALID;
   std::vector<float> cmu(6ull * p->n_cams), lmu(3ull * p->n_lmks);
   for (uint32_t c = 0; c < p->n_cams; ++c) solve_pivot(cbl + 36ull * c, cbe + 6ull * c, 6, &cmu[6ull * c]);
@@ -405,8 +411,8 @@ int gbp_eval_host(const gbp_problem* p, const uint32_t* active, const float* mea
 // Belief means mu = Lambda^-1 eta of every variable (the solution a caller takes away), with the solve of the metric
 // (util.cpp:103-108 uses Eigen's general inverse; here fp64 partial pivoting).  Variables without information
 // (Lambda = 0: never observed) come out non-finite, like in the reference.
-int gbp_belief_means(uint32_t C, uint32_t L, const float* cbe, const float* cbl, const float* lbe, const float* lbl,
-                     double* cameras, double* points) {
+GBP_EXPORT(gbp_belief_means, nullptr, (uint32_t C, uint32_t L, const float* cbe, const float* cbl, const float* lbe, const float* lbl, double* cameras, double* points),
+           (C, L, cbe, cbl, lbe, lbl, cameras, points)) {
   if (!cbe || !cbl || !lbe || !lbl || !cameras || !points) return GBP_ERR_INVALID;
   float mu[6];
   for (uint32_t c = 0; c < C; ++c) {
@@ -422,7 +428,8 @@ int gbp_belief_means(uint32_t C, uint32_t L, const float* cbe, const float* cbl,
 
 // Contiguous landmark ranges balanced by incident-factor count: bounds[r] = first landmark whose cumulative
 // degree reaches r/world of the factors.  A factor lives with its landmark, so this balances the sweep's work.
-int gbp_landmark_partition(const gbp_problem* p, int world, uint32_t* bounds) {
+GBP_EXPORT(gbp_landmark_partition, nullptr, (const gbp_problem* p, int world, uint32_t* bounds),
+           (p, world, bounds)) {
   if (!p || !bounds || world < 1) return GBP_ERR_INVALID;
   std::vector<uint64_t> csum((size_t)p->n_lmks + 1, 0);
   for (uint32_t e = 0; e < p->n_edges; ++e) {
@@ -443,7 +450,8 @@ int gbp_landmark_partition(const gbp_problem* p, int world, uint32_t* bounds) {
 
 // add_cam_trans_noise / add_cam_rot_noise / add_lmk_noise (dataio.cpp:330-415) with an explicit seed.  The first two
 // cameras anchor the gauge and stay exact (dataio.h:114-119, k = 2).  Draw order: translations, rotations, landmarks.
-int gbp_init_add_noise(uint32_t C, uint32_t L, float tn, float rn_deg, float ltn, uint64_t seed, float* cam, float* lmk) {
+GBP_EXPORT(gbp_init_add_noise, nullptr, (uint32_t C, uint32_t L, float tn, float rn_deg, float ltn, uint64_t seed, float* cam, float* lmk),
+           (C, L, tn, rn_deg, ltn, seed, cam, lmk)) {
   if (!cam || !lmk) return GBP_ERR_INVALID;
   NoiseGen rng(seed);
   if (tn != 0.f)
@@ -487,7 +495,8 @@ int gbp_init_add_noise(uint32_t C, uint32_t L, float tn, float rn_deg, float ltn
 // av_depth_init (dataio.cpp:417-453): every landmark starts at the point (0,0,1) of the camera frame of the LOWEST-indexed
 // keyframe observing it (the reference passes av_depth but uses the literal depth 1.0, dataio.cpp:437).  One O(E) pass:
 // the reference's camera-major visiting order picks, for each landmark, its observer with the smallest camera index.
-int gbp_init_av_depth(const gbp_problem* p, const float* cam_mean, float* lmk_mean) {
+GBP_EXPORT(gbp_init_av_depth, nullptr, (const gbp_problem* p, const float* cam_mean, float* lmk_mean),
+           (p, cam_mean, lmk_mean)) {
   if (!p || !cam_mean || !lmk_mean) return GBP_ERR_INVALID;
   std::vector<uint32_t> first(p->n_lmks, ~0u);
   for (uint32_t e = 0; e < p->n_edges; ++e) {
@@ -506,8 +515,8 @@ int gbp_init_av_depth(const gbp_problem* p, const float* cam_mean, float* lmk_me
   return GBP_OK;
 }
 
-int gbp_synth_generate(uint32_t C, uint32_t L, uint32_t obs_per_lmk, uint64_t seed, gbp_bal* out, double* gt_cams,
-                       double* gt_pts) {
+GBP_EXPORT(gbp_synth_generate, nullptr, (uint32_t C, uint32_t L, uint32_t obs_per_lmk, uint64_t seed, gbp_bal* out, double* gt_cams, double* gt_pts),
+           (C, L, obs_per_lmk, seed, out, gt_cams, gt_pts)) {
   if (!out || !out->cam_id || !out->lmk_id || !out->observations || !out->cameras || !out->points || C < 2 || L < 1)
     return GBP_ERR_INVALID;
   const uint32_t per = std::min(obs_per_lmk, C);
@@ -598,4 +607,3 @@ int gbp_synth_generate(uint32_t C, uint32_t L, uint32_t obs_per_lmk, uint64_t se
   return GBP_OK;
 }
 
-}  // extern "C"

@@ -1,4 +1,4 @@
-// gbp_kernels.h — device data layout + kernel launchers shared by gbp_kernels.hip and gbp_capi.cpp.
+// gbp_kernels.h — device data layout + kernel launchers shared by gbp_kernels.hip and the C-ABI translation units (gbp_api_*.cpp, gbp_ctx.hpp).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -101,7 +101,7 @@ struct SweepArgs {
   const uint32_t* tile_perm; // [n_tiles] or NULL: wave slot (4 * block + wave) -> tile.  The XCD-aware execution order (gbp_layout.cpp):
                              // workgroups are dealt round-robin over the 8 XCDs, the table hands every XCD the tiles of one landmark
                              // class so that its private L2 holds that slice of the gathered landmark tables
-  uint32_t policy;           // kPol* bits: cache policy of the two message streams, chosen per graph shape (gbp_capi.cpp: sweep_policy)
+  uint32_t policy;           // kPol* bits: cache policy of the two message streams, chosen per graph shape (gbp_api_ctx.cpp: sweep_policy_for)
   EvalRide ev;               // k_sweep<EV> only
 };
 // SweepArgs.policy.  The potentials (read once per sweep) and every tile STORE of the camera messages carry the non-temporal

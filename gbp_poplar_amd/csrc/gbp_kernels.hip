@@ -550,7 +550,7 @@ GBP_DEV void eval_factor(const float (&cm)[6], const float (&lmu)[3], float z0, 
 //   w_t  = the 64 lane values of tile t (0 + the factor's term) reduced by the shuffle tree below;
 //   B_b  = ((w_4b + w_4b+1) + w_4b+2) + w_4b+3      the 256 factor positions of sweep workgroup b;
 //   S_j  = B_j + B_j+N + B_j+2N + ...  (serially, from 0)   N = eval_blocks(n_tiles) <= 1 024 block sums travel to the host;
-//   sum  = S_0 + S_1 + ... (serially, on the host: sum_eval in gbp_capi.cpp).
+//   sum  = S_0 + S_1 + ... (serially, on the host: sum_eval in gbp_api_eval.cpp).
 // (lane 0 ends with the sum; what the other lanes end with is not used.  The tree is s += shfl_down(s, off) for off = 32, 16, 8,
 // 4, 2, 1; from 8 on the lanes that still matter read inside their own DPP row: a row shift — two v_mov_b32_dpp per double — instead
 // of two ds_bpermute round trips through the LDS crossbar per double and step.  Same operands, same additions.)
@@ -617,7 +617,7 @@ GBP_DEV void ride_metric(const EvalRide& ev, uint32_t done, uint32_t ws, uint32_
 // two of the five small inverses disappear from the sweep.  HOIST = false keeps the literal per-factor
 // mu/oldmu tensors (needed only if a caller uploads non-zero oldmu).
 constexpr int kWpb = 4;      // wavefronts per workgroup of the sweep (the waves of a workgroup share nothing)
-// POL: cache policy of the two message streams (SweepArgs.policy, chosen per graph shape by gbp_capi.cpp; a template parameter,
+// POL: cache policy of the two message streams (SweepArgs.policy, chosen per graph shape by gbp_api_ctx.cpp; a template parameter,
 // not a branch on the flag: with both load sequences behind a branch the non-temporal path lost 1.2 %)
 // EV: the metric of the PREVIOUS iteration rides in this sweep (EvalRide in gbp_kernels.h)
 template <bool HOIST, uint32_t POL = 0, bool EV = false>
@@ -1220,7 +1220,7 @@ GBP_DEV void grid_wait(unsigned* sync, unsigned target /* arrivals to wait for *
       // bounded wait (1.5 s by the wall clock), and once ONE workgroup has given up every other one leaves its barriers at once
       // (sync[32] is the abort word): a launch that can never complete ends in seconds with *status raised, it does not hang
       // the GPU.  The abort word stays set: later launches of the ctx return at once (k_persist prologue) until the host has
-      // restored the state the failed launch started from (gbp_capi.cpp: persist_recover).
+      // restored the state the failed launch started from (gbp_api_persist.cpp: persist_recover).
       if ((++spin & 255u) == 0u) {
         const unsigned long long now = wall_clock64();
         if (t0 == 0) t0 = now;
@@ -2154,7 +2154,7 @@ void launch_sweep(const SweepArgs& a, uint32_t n_tiles, bool hoist, hipStream_t 
   if (lab_launch_sweep(a, n_tiles, hoist, s)) return;     // a mapping experiment / an ablated sweep was asked for (SweepArgs.variant)
 #endif
   if (!hoist) { hipLaunchKernelGGL(k_sweep<false>, g, b, 0, s, a); return; }
-  switch (a.policy) {      // the instantiations gbp_capi.cpp's sweep_policy() can choose
+  switch (a.policy) {      // the instantiations sweep_policy_for() (gbp_api_ctx.cpp) can choose
     case kPolCmsgLoadCached: hipLaunchKernelGGL((k_sweep<true, kPolCmsgLoadCached>), g, b, 0, s, a); break;
     case kPolLmsgLoadNt | kPolLmsgStoreNt: hipLaunchKernelGGL((k_sweep<true, kPolLmsgLoadNt | kPolLmsgStoreNt>), g, b, 0, s, a); break;
 #ifdef GBP_BUILD_TEST_HOOKS      // the other combinations, for measurements (gbp_debug_force_sweep_policy)

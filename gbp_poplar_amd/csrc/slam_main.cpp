@@ -126,7 +126,7 @@ static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
     }
     if (pipe.on && o.eval_every == 1) {
       // the reference's default, the metric after EVERY iteration: everything up to the next keyframe / prior weakening in
-      // one call (gbp_iterate_eval_each, see ba_main.cpp)
+      // one call (gbp_ba_loop, see ba_main.cpp)
       const unsigned cap = gbp_graph_state(ctx) == 2 ? 512u : 128u;      // (see ba_main.cpp)
       unsigned nb = 1;
       while (nb < cap && i + nb < niters && (i + nb + 1) % (unsigned)o.iters_between_kfs != 0 &&
@@ -134,7 +134,7 @@ static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
         ++nb;
       if (cap == 512u && i + nb == niters && nb > 96u) nb -= 64u;      // the run ends with a burst of 64 (its lines are the ones no launch overlaps)
       series.resize(nb);
-      CLI_CHECK(ctx, gbp_iterate_eval_each(ctx, (int)nb, series.data()));
+      CLI_CHECK(ctx, gbp_ba_loop(ctx, (int)nb, iter, 0u, series.data()));      // steps = 0: the weakenings are this loop's own calls
       rep.last = series.back(); rep.have_metric = true;
       lines.post([total0 = (unsigned)o.iters_between_kfs * data_counter + iter, since0 = iter, batch = series, &write_iter] {
         for (size_t k = 0; k < batch.size(); ++k) write_iter(total0 + (unsigned)k, since0 + (unsigned)k, batch[k]);

@@ -6,6 +6,10 @@
  * ba/slam.cpp:937-948 adds READ_PRIORS and NEW_KEYFRAME).  The reference has no FFI; each
  * entry point below replaces one `engine.run(<PROG>)` call (+ its connected streams) and cites it.
  *
+ * This header is the whole single-GPU boundary: the program list, the loop body (gbp_ba_loop), the metric, timing and the host
+ * helpers of the path's callers.  gbp_mi355x_multi.h adds the landmark-sharded (multi-GPU) entry points, gbp_mi355x_compat.h keeps
+ * earlier forms of the loop for hosts written against ABI 2-5, gbp_mi355x_debug.h the test hooks (test builds of the library only).
+ *
  * Conventions: plain C, no exceptions across the ABI, every function returns 0 on success and a
  * negative gbp_status otherwise (text via gbp_last_error).  All pointers are HOST memory owned by
  * the caller unless the name ends in `_dev`.  A ctx is not thread-safe; calls are blocking unless
@@ -123,7 +127,7 @@ typedef struct {
                                   Not capturable either way: while the ctx's stream is being captured gbp_iterate uses the two-kernel path. */
 } gbp_params;
 
-/* Landmark shard of a multi-GPU run (one process per GPU).  The global problem is passed to
+/* Landmark shard of a multi-GPU run (one process per GPU; gbp_mi355x_multi.h).  The global problem is passed to
  * gbp_create on every rank; a rank owns landmarks [lmk_begin, lmk_end) and every factor incident
  * to them.  Cameras are replicated.  NULL shard == {0,1,0,L}.  Replaces `--ipus N`
  * (ba.cpp:414-417,617-623). */
@@ -227,22 +231,10 @@ GBP_API int gbp_read(gbp_ctx* ctx, gbp_state_out* out);                /* READ_P
 GBP_API int gbp_read_priors(gbp_ctx* ctx, gbp_priors_out* out);        /* READ_PRIORS     slam.cpp:913-917 */
 GBP_API int gbp_new_keyframe(gbp_ctx* ctx, const gbp_kf_update* upd);  /* NEW_KEYFRAME    slam.cpp:919-928 */
 GBP_API int gbp_eval(gbp_ctx* ctx, gbp_eval_out* out);                 /* util.cpp:74-144 on device (local shard) */
-/* gbp_eval in two halves: begin queues the metric of the CURRENT beliefs, end waits for the oldest queued one.  Up to two
- * may be in flight, so the loop of ba.cpp:1001-1028 can queue iteration i+1 before it prints the metric of iteration i. */
-GBP_API int gbp_eval_begin(gbp_ctx* ctx);
-GBP_API int gbp_eval_end(gbp_ctx* ctx, gbp_eval_out* out);
-/* gbp_iterate(n) + gbp_eval_begin() in ONE call (collect with gbp_eval_end): the loop of ba.cpp:1001-1028 prints the metric
- * after every iteration; on a graph that runs in the persistent kernel the metric then rides in the same launch (identical
- * results), elsewhere it is exactly the two calls. */
-GBP_API int gbp_iterate_eval(gbp_ctx* ctx, int n_iters);
-/* n iterations with the metric after EVERY one (what the loops of ba.cpp:1001-1028 and slam.cpp print), blocking: out[k] is
- * what gbp_iterate(ctx, 1) followed by gbp_eval would have returned for the k-th of them.  A burst between two host events
- * (prior weakening, a new keyframe) is ONE launch on a graph that runs in the persistent kernel — the metric of iteration k
- * is computed inside the sweep phase of iteration k + 1 — and the plain loop elsewhere.  No evaluation may be in flight. */
-GBP_API int gbp_iterate_eval_each(gbp_ctx* ctx, int n_iters, gbp_eval_out* out /* [n_iters] */);
 /* n passes of the BODY of the reference's iteration loop (ba.cpp:1001-1028, slam.cpp:1048-1103), blocking, from loop index iter0:
  *   if ((i + 1) % 2 == 0 && i < 2 * steps) WEAKEN_PRIORS;  GBP_PROG;  out[i - iter0] = the metric      for i = iter0 .. iter0 + n - 1
- * (steps = the reference's --steps).  Exactly the calls it stands for (gbp_weaken_priors / gbp_iterate_eval_each, identical results);
+ * (steps = the reference's --steps; steps = 0: n iterations with the metric after every one).  Exactly the calls it stands for
+ * (gbp_weaken_priors, gbp_iterate(1), gbp_eval: identical results);
  * on a graph that runs in the persistent kernel the passes are ONE launch however many weakenings lie between them (the kernel applies
  * WeakenPriorVertex itself in front of the iterations the loop weakens before) — the ten short launches of a run's, or a SLAM
  * keyframe's, weakening phase become one.  No evaluation may be in flight.
@@ -251,68 +243,9 @@ GBP_API int gbp_iterate_eval_each(gbp_ctx* ctx, int n_iters, gbp_eval_out* out /
 GBP_API int gbp_ba_loop(gbp_ctx* ctx, int n_passes, unsigned iter0, unsigned steps, gbp_eval_out* out /* [n_passes] */);
 GBP_API int gbp_sync(gbp_ctx* ctx);                                    /* wait for queued device work     */
 GBP_API int gbp_timing(gbp_ctx* ctx, gbp_timing_out* out, int reset);  /* ba.cpp:980,1056-1058            */
-
-/* ---- multi-GPU split-phase iteration (sharded ctx; exchange done by the caller, e.g.
- *      torch.distributed all_gather over RCCL).  gbp_iterate == begin + (local copy) + end
- *      when world == 1. -------------------------------------------------------------------- */
-GBP_API int gbp_set_stream(gbp_ctx* ctx, void* hip_stream /* hipStream_t; NULL = ctx-owned stream */);
-/* send_dev: [C*GBP_CAM_REC] fp32 this rank's camera partial sums; recv_dev: [world][C][GBP_CAM_REC]
- * (camera record = 44 floats: eta 6, pad 2, Lambda 36).  Caller-owned device memory (e.g. torch
- * tensors).  Must be set before begin/end on a world>1 ctx. */
-#define GBP_CAM_REC 44
-GBP_API int gbp_set_exchange_buffers(gbp_ctx* ctx, void* send_dev, void* recv_dev);
-GBP_API int gbp_iterate_begin(gbp_ctx* ctx);   /* prep + messages + local camera partial -> send_dev     */
-GBP_API int gbp_iterate_local(gbp_ctx* ctx);   /* optional: landmark beliefs now (rank-local), to overlap with the exchange */
-GBP_API int gbp_iterate_end(gbp_ctx* ctx);     /* camera beliefs = prior + sum_r recv_dev[r]; landmark beliefs unless done */
-/* Re-derive beliefs after an exchange outside an iteration (LINEARISE / NEW_KEYFRAME on world>1):
- * gbp_refresh_begin computes the local camera partials into send_dev, gbp_refresh_end combines. */
-GBP_API int gbp_refresh_begin(gbp_ctx* ctx);
-GBP_API int gbp_refresh_end(gbp_ctx* ctx);
-GBP_API int gbp_linearise_factors(gbp_ctx* ctx);  /* the factor half of LINEARISE_PROG (after a refresh) */
-
-/* ---- multi-GPU from the C++ host: the exchange owned by the library ---------------------------------------------------
- * Replaces `--ipus N` (ba.cpp:414-417,617-649) without any Python: one process per GPU, each with a sharded ctx
- * (gbp_shard).  Once a ctx has a communicator, the plain program list works on it — gbp_linearise, gbp_iterate(n)
- * (sweep -> local camera partials -> ncclAllGather on a second stream, overlapped with the rank-local landmark beliefs
- * -> camera combine; captured into a hipGraph like the single-GPU iteration), gbp_weaken_priors, gbp_new_keyframe —
- * and gbp_eval_global adds the metric sums of all shards in rank order.
- *
- * Launchers that fork their ranks (bin/ba --ipus N) share one MAP_SHARED region, created and initialised BEFORE the
- * ranks start; it carries the rendezvous (RCCL unique id, barrier) and, for ranks that share a GPU (fewer GPUs than
- * ranks — RCCL refuses duplicate GPUs), the host-staged transport that moves the same buffers through host memory.
- * transport: 0 = auto (RCCL when every rank has its own GPU, host-staged otherwise), 1 = RCCL, 2 = host-staged.
- * Launchers with their own rendezvous (torchrun, MPI) pass the 128-byte RCCL id around themselves:
- * gbp_comm_unique_id on rank 0, gbp_comm_init_rccl on every rank.  All calls are collective over the ranks.
- * Scheduling: with 4 ranks or more the camera side of the exchange (local partial sums, all-gather) runs on a second,
- * highest-priority stream beside the landmark beliefs; with 1 or 2 ranks everything stays on one stream (a second HSA
- * queue costs more per dispatch than a small all-gather gives back).  Environment GBP_COMM_SINGLE_STREAM=0|1, read by
- * gbp_comm_init*, overrides the rule (measurements, tests). */
-#define GBP_COMM_ID_BYTES 128
-GBP_API int gbp_device_count(void);                                    /* visible GPUs (initialises the HIP runtime)      */
-GBP_API int gbp_set_device(int device);                                /* the GPU later gbp_create calls of this process use */
-/* contiguous landmark ranges balanced by factor count: bounds[world + 1], shard r = [bounds[r], bounds[r+1]) */
-GBP_API int gbp_landmark_partition(const gbp_problem* problem, int world, uint32_t* bounds);
-GBP_API size_t gbp_comm_region_bytes(uint32_t n_cams, int world);
-GBP_API int gbp_comm_region_init(void* region, size_t bytes, uint32_t n_cams, int world);
-GBP_API void gbp_comm_region_abort(void* region);                      /* supervisor: a rank died, fail the waiting ones */
-/* the region's cross-process protocol alone (gathers + barriers, no device): every rank of `world` calls it; test hook */
-GBP_API int gbp_comm_region_selftest(void* region, int rank, int world, int rounds);
-GBP_API int gbp_comm_init(gbp_ctx* ctx, void* region, int transport);
-GBP_API int gbp_comm_unique_id(void* id128);
-GBP_API int gbp_comm_init_rccl(gbp_ctx* ctx, const void* id128);
-GBP_API const char* gbp_comm_transport(const gbp_ctx* ctx);            /* "rccl", "host-staged" or "none" */
-GBP_API int gbp_comm_barrier(gbp_ctx* ctx);
-/* What a first multi-GPU run puts on record next to its numbers (bench.py's preflight block): gbp_comm_describe writes one
- * JSON object (rank, world, device, PCI bus id, transport, the collective library's resolved path and version, schedule);
- * gbp_comm_probe times `reps` all-gathers of the camera partial buffers back to back (collective); gbp_comm_set_schedule
- * switches between the one-stream and the two-stream form of the sharded iteration (identical results) so that a launcher can
- * MEASURE both and keep the faster one instead of trusting the ">= 4 ranks" rule (ba.cpp:617-649 has no such choice to make:
- * Poplar compiles the exchange into the program). */
-GBP_API int gbp_comm_describe(gbp_ctx* ctx, char* json_buf, size_t cap);
-GBP_API int gbp_comm_set_schedule(gbp_ctx* ctx, int two_streams);
-GBP_API int gbp_comm_probe(gbp_ctx* ctx, int reps, double* avg_us);
-GBP_API int gbp_graph_state(const gbp_ctx* ctx);                       /* 2 = bursts run inside the persistent kernel (small graph), 1 = gbp_iterate replays a captured hipGraph, 0 = not captured (yet), -1 = capture failed: direct launches */
-GBP_API int gbp_eval_global(gbp_ctx* ctx, gbp_eval_out* out);          /* gbp_eval summed over all shards */
+/* which path gbp_iterate / gbp_ba_loop take on this ctx: 2 = bursts run inside the persistent kernel (small graph), 1 = a captured hipGraph is
+ * replayed, 0 = not captured (yet), -1 = capture failed: direct launches */
+GBP_API int gbp_graph_state(const gbp_ctx* ctx);
 
 /* ---- measurement ---------------------------------------------------------------------------- */
 /* per_stage_events != 0: gbp_iterate launches kernels directly with a hipEvent pair around the

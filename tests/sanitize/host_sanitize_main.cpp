@@ -6,6 +6,7 @@
 //   g++ -fsanitize=address,undefined -fno-sanitize-recover=all gbp_host.cpp oracle_*.c host_sanitize_main.cpp
 // Exit code 0 = every call returned what it should and the sanitizers stayed silent.
 #include "../../include/gbp_mi355x.h"
+#include "../../include/gbp_mi355x_multi.h"
 #include "../../oracle/oracle.h"
 
 #include <cmath>
@@ -31,10 +32,12 @@ struct Bal {
 };
 
 int layout_sanitize();   // layout_sanitize.cpp: the device-order builder of gbp_create (gbp_layout.cpp)
+int api_negative();      // api_negative.cpp: every export that needs no device, called with what a careless host passes
 
 int main(int argc, char** argv) {
   const std::string dir = argc > 1 ? argv[1] : "/tmp";
   REQUIRE(layout_sanitize() == 0);
+  REQUIRE(api_negative() == 0);
   // ---- synthetic graph -> file -> loader round trip ----
   Bal s;
   s.b.n_cams = 6; s.b.n_lmks = 50; s.b.n_edges = 50 * 4;

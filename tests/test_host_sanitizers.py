@@ -1,4 +1,5 @@
-"""AddressSanitizer + UBSan over the CPU-side C/C++ (host helpers of the C-ABI, the device-order builder of gbp_create and the oracle).  GPU sanitizers are
+"""AddressSanitizer + UBSan over the CPU-side C/C++ (the whole host side of the C-ABI library — gbp_api_*.cpp with the device code stubbed out, negative
+tests of every export that needs no device —, the host helpers, the device-order builder of gbp_create and the oracle).  GPU sanitizers are
 not available on this pool, so this is the memory-safety gate of everything that runs on the host; the harness is
 tests/sanitize/host_sanitize_main.cpp."""
 import os
@@ -20,14 +21,24 @@ def test_host_code_and_oracle_under_asan_ubsan(tmp_path):
         obj = str(tmp_path / (os.path.basename(src) + ".o"))
         subprocess.check_call(["gcc", "-std=c11", "-c", os.path.join(ROOT, src), "-o", obj] + san, cwd=ROOT)
         objs.append(obj)
-    # gbp_comm.cpp (transports of the multi-rank exchange) is host code too; its HIP / RCCL headers are on the image, the
-    # harness only exercises the parts that need no device (region layout, abort flag)
-    subprocess.check_call(["g++", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
-                           os.path.join(ROOT, "gbp_poplar_amd/csrc/gbp_host.cpp"), os.path.join(ROOT, "gbp_poplar_amd/csrc/gbp_comm.cpp"),
-                           os.path.join(ROOT, "gbp_poplar_amd/csrc/gbp_layout.cpp"), os.path.join(ROOT, "tests/sanitize/layout_sanitize.cpp"),
-                           os.path.join(ROOT, "tests/sanitize/comm_glue.cpp"),
-                           os.path.join(ROOT, "tests/sanitize/host_sanitize_main.cpp")] + objs + san
-                          + ["-L/opt/rocm/lib", "-lamdhip64", "-ldl", "-lm", "-Wl,-rpath,/opt/rocm/lib", "-o", exe], cwd=ROOT)
+    # The host side of the library itself — the C-ABI (gbp_api_*.cpp), the device order, the transports of the multi-rank exchange, the
+    # host helpers — compiled with g++ under the sanitizers; the device code is replaced by tests/sanitize/kernel_stubs.cpp (every
+    # launcher aborts: nothing here may reach a launch), the HIP / RCCL headers and libamdhip64 are on the image.  api_negative.cpp
+    # calls every export that needs no device with NULL / negative / out-of-order arguments.
+    csrc = os.path.join(ROOT, "gbp_poplar_amd", "csrc")
+    lib_srcs = [os.path.join(csrc, f) for f in ("gbp_api_ctx.cpp", "gbp_api_launch.cpp", "gbp_api_persist.cpp", "gbp_api_eval.cpp", "gbp_api_comm.cpp",
+                                                "gbp_api_debug.cpp", "gbp_host.cpp", "gbp_comm.cpp", "gbp_layout.cpp")]
+    harness = [os.path.join(ROOT, "tests", "sanitize", f) for f in ("layout_sanitize.cpp", "kernel_stubs.cpp", "api_negative.cpp", "host_sanitize_main.cpp")]
+    cxx = ["g++", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-DGBP_BUILD_TEST_HOOKS", "-I/opt/rocm/include", "-c"] + san
+    cxx_objs = []
+    from concurrent.futures import ThreadPoolExecutor
+    def one(src):
+        obj = str(tmp_path / (os.path.basename(src) + ".o"))
+        subprocess.check_call(cxx + [src, "-o", obj], cwd=ROOT)
+        return obj
+    with ThreadPoolExecutor(4) as ex:
+        cxx_objs = list(ex.map(one, lib_srcs + harness))
+    subprocess.check_call(["g++"] + cxx_objs + objs + san + ["-L/opt/rocm/lib", "-lamdhip64", "-ldl", "-lm", "-pthread", "-Wl,-rpath,/opt/rocm/lib", "-o", exe], cwd=ROOT)
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     p = subprocess.run([exe, str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=300)
     assert p.returncode == 0 and "sanitize: ok" in p.stdout, (p.returncode, p.stdout[-500:], p.stderr[-3000:])
