@@ -729,6 +729,16 @@ def preflight(eng, dist, torch, rank, world, device, fence, advance, max_over_ra
     return out, extra
 
 
+def failure_line(a, world, C, L, E, what, ranks):
+    """The JSON line of a run that could not be measured (N > 1: the communicator failed): same keys, value null, what failed where."""
+    return {"metric": "GBP iters/sec on the 1M-factor synthetic BAL graph (iterations/s x factors/1e6)", "value": None,
+            "unit": "1M-factor GBP iters/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": None,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "comm_error": what,
+            "config": {"workload": workload_name(a, world, C, L, E), "cams": C, "lmks": L, "factors": E,
+                       "comm_error": what, "ranks": ranks}}
+
+
 def workload_name(a, world, C, L, E):
     if world == 1:
         base = "S1 synthetic" if (a.cams, a.lmks, a.obs) == (1000, 100000, 10) else "synthetic"
@@ -743,6 +753,19 @@ def main(argv=None):
     a = parse(argv)
     if a.gpus > 1 and "RANK" not in os.environ:
         return self_launch(a, argv)                      # nothing in this process has touched the GPU
+    try:
+        return run_rank(a)
+    except Exception as exc:  # noqa: BLE001 — a rank of an N > 1 run that dies still leaves a line that says why (then the traceback)
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if world > 1 and int(os.environ.get("RANK", "0")) == 0 and not (a.launch_selftest or a.pmc_child):
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+            C, L = a.cams * world, a.lmks * world
+            print(json.dumps(failure_line(a, world, C, L, L * a.obs, "rank 0 ended with an exception: %r" % (exc,), None)), flush=True)
+        raise
+
+
+def run_rank(a):
     if a.launch_selftest:
         return launch_selftest(a)
     if a.pmc_child:
@@ -860,6 +883,12 @@ def main(argv=None):
                 sys.stderr.write("bench.py: the library's communicator could not be set up on rank %d: %s\n"
                                  "(no fallback: rerun with --comm torch for the torch.distributed exchange)\n"
                                  % (rank, comm_error or "failed on another rank"))
+                # the line is still printed — what failed, on which ranks, on which devices — with value null and a non-zero status
+                errs = [None] * world
+                dist.all_gather_object(errs, {"rank": rank, "device": device, "comm_error": comm_error})
+                if rank == 0:
+                    print(json.dumps(failure_line(a, world, C, L, E, "the library's communicator could not be set up (no fallback to the "
+                                                  "torch.distributed exchange: --comm torch asks for that one)", errs)), flush=True)
                 dist.barrier()
                 dist.destroy_process_group()
                 return 4
@@ -881,6 +910,14 @@ def main(argv=None):
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
+
+    def per_rank(x):
+        """[x of rank 0, x of rank 1, ...] on every rank (collective)"""
+        if dist is None:
+            return [x]
+        out = [None] * world
+        dist.all_gather_object(out, x)
+        return out
 
     def max_over_ranks(x):
         if dist is None:
@@ -919,8 +956,10 @@ def main(argv=None):
         fence()
         t0 = time.perf_counter()
         weak = ba_flow(run, opts, it, n)
-        fence()
-        dt = time.perf_counter() - t0
+        run.sync()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0       # this rank's K iterations are done (the ranks meet in every iteration's exchange); MAX over ranks below
+        fence()                             # ... and the barrier + synchronisation behind the region
         it += n
         each = [dt]
         if dist is not None:
@@ -985,6 +1024,9 @@ def main(argv=None):
                             if tr and tr.get("rocprof") else None),
                 "belief_kernels_avg_us": round(belief_s * 1e6, 2) if belief_s is not None else None,
                 "exchange_avg_us": round(tm.get("exchange_ms", 0.0) * 1e3 / a.profile_steps, 2) if sharded and run is eng else None,
+                "exchange_avg_us_per_rank": per_rank(round(tm.get("exchange_ms", 0.0) * 1e3 / a.profile_steps, 2)) if sharded and run is eng else None,
+                "sweep_avg_us_per_rank": per_rank(round(sweep_s * 1e6, 2)) if sharded else None,
+                "rank_step_ms": [round(x / a.steps * 1e3, 4) for x in rank_dt],
                 "exchange_note": "local camera partial sums + all-gather, on the communication stream (beside the landmark beliefs from 4 ranks on)" if sharded and run is eng else None,
                 "profiled_ms_per_step": round(tm["total_ms"] / a.profile_steps, 4) if not sharded else round(prof_wall / a.profile_steps * 1e3, 4),
                 "profiled_note": "direct launches with an event between kernels: sweep + beliefs + two dependent-launch gaps; "

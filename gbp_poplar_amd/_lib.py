@@ -15,7 +15,7 @@ _lib = None
 _test_lib = None
 _exp_lib = None
 
-# every symbol include/gbp_mi355x.h declares (tests/test_cabi_symbols.py parses the header and checks this list)
+# every symbol include/gbp_mi355x.h, gbp_mi355x_multi.h and gbp_mi355x_compat.h declare (tests/test_cabi_symbols.py parses the headers and checks this list)
 _SIGS = {
     "gbp_abi_version": (C.c_int, []),
     "gbp_default_params": (None, [C.POINTER(cabi.GbpParams)]),
@@ -97,6 +97,8 @@ _DEBUG_SIGS = {
     "gbp_debug_layout_options": (C.c_int, [C.POINTER(cabi.GbpLayoutOptions)]),
     "gbp_debug_force_sweep_policy": (C.c_int, [C.c_int]),
     "gbp_debug_persist_flow": (C.c_int, [C.c_void_p, C.c_int]),
+    "gbp_debug_persist_verify": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]),
+    "gbp_debug_flow_torture": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int, C.POINTER(C.c_uint64)]),
     "gbp_debug_persist_roles": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32]),
     "gbp_debug_layout_build": (C.c_int, [C.POINTER(cabi.GbpProblem), C.c_int, C.POINTER(cabi.GbpShard),
                                          C.POINTER(cabi.GbpLayoutOptions), C.POINTER(C.c_void_p)]),

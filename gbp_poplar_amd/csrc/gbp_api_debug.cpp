@@ -159,6 +159,61 @@ GBP_EXPORT(gbp_debug_persist_flow, c, (gbp_ctx* c, int on), (c, on)) {
   c->persist_flow = on != 0;
   return GBP_OK;
 }
+// Redundant records in the persistent kernel (k_persist_flow<EV, VER = true>): on != 0 — every tagged record of the following launches
+// is published twice (the second copy with its payload complemented) and a consumer accepts a record only when both copies carry the
+// same tag; a payload mismatch between the two is what a torn or stale 16-byte record would look like.  *mismatches (may be NULL)
+// receives the count since the last call and resets it.  A ctx that does not run in the persistent kernel: GBP_ERR_STATE.
+GBP_EXPORT(gbp_debug_persist_verify, c, (gbp_ctx* c, int on, uint64_t* mismatches), (c, on, mismatches)) {
+  if (!c) return GBP_ERR_INVALID;
+  if (!c->flow.lmsg || !c->flow_total4) return fail(c, GBP_ERR_STATE, "gbp_debug_persist_verify: this ctx does not run in the persistent kernel");
+  if (int rc = gbp_sync(c)) return rc;
+  unsigned long long* counter = reinterpret_cast<unsigned long long*>(static_cast<float4*>(c->pflow.p) + 2 * (size_t)c->flow_total4);
+  if (mismatches) {
+    unsigned long long v = 0;
+    HIPCHK(c, hipMemcpy(&v, counter, 8, hipMemcpyDeviceToHost));
+    *mismatches = v;
+  }
+  HIPCHK(c, hipMemsetAsync(counter, 0, 8, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->flow.mirror4 = on ? c->flow_total4 : 0u;
+  c->flow.verify_errors = counter;
+  return GBP_OK;
+}
+
+// The detector under the tagged records (hooks/gbp_flow_torture.hip): `rounds` rounds of K 16-byte records per lane between partner
+// workgroups bid and bid ^ mask of a grid of `blocks` (a power of two, 16 .. 256, >= 2 * mask; K = 4 or 16); out[4] = records seen torn
+// (tag of the awaited round, payload words of the slot's previous content), otherwise corrupt, waits that timed out, records checked.
+// inject != 0: the control — some records are stored tag first, payload later: the detector must report them.
+GBP_EXPORT(gbp_debug_flow_torture, nullptr, (int blocks, int K, int rounds, unsigned mask, int inject, uint64_t* out), (blocks, K, rounds, mask, inject, out)) {
+  if (!out || blocks < 16 || blocks > 256 || (blocks & (blocks - 1)) || (K != 4 && K != 16) || rounds < 1 || mask == 0 || 2 * mask > (unsigned)blocks)
+    return fail(nullptr, GBP_ERR_INVALID, "gbp_debug_flow_torture: blocks a power of two in [16, 256], K 4 or 16, rounds >= 1, 0 < 2 * mask <= blocks");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(nullptr, GBP_ERR_NO_DEVICE, "gbp_debug_flow_torture: no HIP device");
+  const size_t n4 = (size_t)2 * blocks * 4 * 64 * K;
+  float4* buf = nullptr;
+  unsigned long long* d_out = nullptr;
+  hipStream_t s = nullptr;
+  auto done = [&](int rc, const char* what, hipError_t e) {
+    if (buf) (void)hipFree(buf);
+    if (d_out) (void)hipFree(d_out);
+    if (s) (void)hipStreamDestroy(s);
+    return rc == GBP_OK ? rc : fail(nullptr, rc, std::string(what) + ": " + hipGetErrorString(e));
+  };
+  hipError_t e;
+  if ((e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking)) != hipSuccess) return done(GBP_ERR_HIP, "hipStreamCreate", e);
+  if ((e = hipMalloc(&buf, n4 * 16)) != hipSuccess) return done(GBP_ERR_HIP, "hipMalloc", e);
+  if ((e = hipMalloc(&d_out, 32)) != hipSuccess) return done(GBP_ERR_HIP, "hipMalloc", e);
+  if ((e = hipMemsetAsync(buf, 0, n4 * 16, s)) != hipSuccess) return done(GBP_ERR_HIP, "hipMemsetAsync", e);
+  if ((e = hipMemsetAsync(d_out, 0, 32, s)) != hipSuccess) return done(GBP_ERR_HIP, "hipMemsetAsync", e);
+  if (!launch_flow_torture(buf, d_out, blocks, K, rounds, mask, 0x40000000u, inject, s)) return done(GBP_ERR_INVALID, "launch_flow_torture", hipErrorInvalidValue);
+  if ((e = hipGetLastError()) != hipSuccess) return done(GBP_ERR_HIP, "k_flow_torture", e);
+  if ((e = hipStreamSynchronize(s)) != hipSuccess) return done(GBP_ERR_HIP, "hipStreamSynchronize", e);
+  unsigned long long h[4];
+  if ((e = hipMemcpy(h, d_out, 32, hipMemcpyDeviceToHost)) != hipSuccess) return done(GBP_ERR_HIP, "hipMemcpy", e);
+  for (int i = 0; i < 4; ++i) out[i] = h[i];
+  return done(GBP_OK, "", hipSuccess);
+}
+
 GBP_EXPORT(gbp_debug_layout_build, nullptr, (const gbp_problem* pr, int tile_order, const gbp_shard* sh, const gbp_layout_options* o, gbp_layout** out),
            (pr, tile_order, sh, o, out)) {
   if (!out) return GBP_ERR_INVALID;

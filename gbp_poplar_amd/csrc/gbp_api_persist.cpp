@@ -145,7 +145,13 @@ int persist_setup(gbp_ctx* c, const gbp_params* prm, bool sharded) {
                                2 * C_ * 4, 2 * L_, (size_t)kSeriesMax};      // (the last: [kSeriesMax][2] 64-bit health words = kSeriesMax float4)
         size_t total = 0;
         for (size_t n : n4) total += n;
+#ifdef GBP_BUILD_TEST_HOOKS
+        // gbp_debug_persist_verify: room for the redundant copy of every record + the mismatch counter (the product allocates neither)
+        rc = dev_alloc(c, c->pflow, 2 * total * 16 + 64);
+        c->flow_total4 = (uint32_t)total;
+#else
         rc = dev_alloc(c, c->pflow, total * 16);
+#endif
         if (rc == GBP_OK) {
           float4* q = static_cast<float4*>(c->pflow.p);
           float4** dst[9] = {&c->flow.lmsg, &c->flow.rowp, &c->flow.camb, &c->flow.cmu, &c->flow.clin, &c->flow.lmkb, &c->flow.lmu, &c->flow.emc, &c->flow.eml};

@@ -117,6 +117,7 @@ struct gbp_ctx {
   struct Burst { unsigned seq; int n; int mode; int area; unsigned w_first = 0, w_steps2 = 0; };
   DevBuf pflow;                        // tagged shadows of k_persist_flow (PersistFlow), one allocation
   gbp::PersistFlow flow{};                  // the tagged shadows of k_persist_flow
+  uint32_t flow_total4 = 0;            // test-hooks builds: float4 of the shadows (the redundant copies of gbp_debug_persist_verify follow them)
   bool persist_flow = true;            // test-hooks build: gbp_debug_persist_flow(ctx, 0) / GBP_PERSIST_FLOW=0 run the barrier kernel of rounds 3-4 instead
   std::vector<Burst> persist_log;      // launched, completion not yet validated
   unsigned persist_seq = 0;

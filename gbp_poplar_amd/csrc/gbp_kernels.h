@@ -178,6 +178,11 @@ struct PersistFlow {
   float4* eml;     // [2][L][1]          ... of a landmark
   unsigned long long* health_iter;   // [kSeriesMax][2] non-finite means / non-PD beliefs of iteration k of the launch (zero between launches)
   unsigned tag0;   // tags of this launch: tag0 (what the prologue publishes), tag0 + 1 + it (what iteration it produces)
+  // test-hooks builds (gbp_debug_persist_verify): mirror4 != 0 = every record is published a second time, payload complemented, this
+  // many float4 further on (the allocation is twice the size), and a consumer accepts a record only when both copies agree; mismatches
+  // are counted in *verify_errors.  0 in the product.
+  uint32_t mirror4;
+  unsigned long long* verify_errors;
 };
 
 // Which belief-phase role the wave (workgroup bid of nblk, wave wib of 4) of a k_persist_flow launch has, in k_persist's numbering:
@@ -273,6 +278,9 @@ void launch_eval(const uint32_t* row_cam, const uint32_t* lmk_idx, const float4*
 uint32_t eval_blocks(uint32_t n_tiles);
 // experiments build (csrc/experiments/gbp_lab_kernels.hip): timing ablations of the sweep; false = unknown ablation
 bool lab_launch_sweep_ablated(const SweepArgs& a, uint32_t n_tiles, int abl, hipStream_t s);
+// test hook (hooks/gbp_flow_torture.hip): `rounds` rounds of K tagged 16-byte records per lane exchanged between partner workgroups
+// bid and bid ^ mask; out[4] += {torn, corrupt, time-outs, records checked}; inject: the control (tag stored ahead of its record).  false: unsupported K
+bool launch_flow_torture(float4* buf, unsigned long long* out, int blocks, int K, int rounds, unsigned mask, unsigned tag0, int inject, hipStream_t s);
 bool debug_math_widths(int op, int* in_w, int* out_w);   // floats per vector of k_debug_math's op
 void launch_debug_math(int op, const float* in, float* out, int n, hipStream_t s);  // test hook
 

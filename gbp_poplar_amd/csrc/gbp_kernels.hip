@@ -1168,27 +1168,49 @@ __global__ __launch_bounds__(256) void k_beliefs_ev(const BeliefArgs b) { belief
 // buffer intrinsics give 16-byte sc1 accesses the compiler tracks (agent-scope atomics stop at 8 bytes, and 8-byte accesses
 // move at 0.54-0.70x the 16-byte rate, MI355X_MICROARCH.md).  Offsets are 32-bit: arrays below 4 GiB, which the size limit of
 // k_persist guarantees by a factor of a thousand.
-struct XwBuf {
+// VER (test-hooks builds only, gbp_debug_persist_verify): every record is published TWICE — the record itself and, `mirror4` float4
+// further on, a copy with the payload words complemented and the same tag — and a load hands a record to its consumer only once BOTH
+// copies carry the same tag (until then the record reads as "not arrived": tag 0, the consumer keeps polling); the two payloads must
+// then be bit-wise complements, or the load counts a mismatch in *verr.  A torn or stale 16-byte record, which the product's consumers
+// could not tell from a good one, shows up as such a mismatch (tests/test_gpu_parity.py: test_persistent_kernel_redundant_records).
+template <bool VER>
+struct XwBufT {
   __amdgpu_buffer_rsrc_t r;
-  GBP_DEV explicit XwBuf(const void* base) : r(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000)) {}
+  uint32_t mirror4 = 0;
+  unsigned long long* verr = nullptr;
+  GBP_DEV explicit XwBufT(const void* base, uint32_t mirror4_ = 0, unsigned long long* verr_ = nullptr)
+      : r(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000)), mirror4(mirror4_), verr(verr_) {}
   static constexpr int kSc1 = 16;        // cache-policy bit of the gfx94x / gfx950 buffer instructions
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
   GBP_DEV float4 ld4(uint32_t i4) const {   // float4 #i4 of the array
-    typedef unsigned v4u __attribute__((ext_vector_type(4)));
     const v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(i4 * 16u), 0, kSc1);
+    if (VER) {
+      if (mirror4 != 0u && i4 < kNone4) {
+        const v4u m = __builtin_amdgcn_raw_buffer_load_b128(r, (int)((i4 + mirror4) * 16u), 0, kSc1);
+        if (m.w != v.w) return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), 0.f);      // one copy has not arrived yet
+        if ((m.x != ~v.x || m.y != ~v.y || m.z != ~v.z) && v.w != 0u) atomicAdd(verr, 1ull);
+      }
+    }
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
   }
   // float4 #kNone4 lies beyond the descriptor's range (0x7fffffff bytes): the hardware returns zeros WITHOUT a memory access — what a
   // slot that is not needed loads (a clamped duplicate would be one more trip through the fabric; a conditional load a branch)
   static constexpr uint32_t kNone4 = 0x0fffffffu;
   GBP_DEV void st4(uint32_t i4, const float4 v) const {
-    typedef unsigned v4u __attribute__((ext_vector_type(4)));
     const v4u x = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
     __builtin_amdgcn_raw_buffer_store_b128(x, r, (int)(i4 * 16u), 0, kSc1);
+    if (VER) {
+      if (mirror4 != 0u) {
+        const v4u y = {~x.x, ~x.y, ~x.z, x.w};
+        __builtin_amdgcn_raw_buffer_store_b128(y, r, (int)((i4 + mirror4) * 16u), 0, kSc1);
+      }
+    }
   }
   // (the b32 intrinsics are typed unsigned: bit casts, not value conversions)
   GBP_DEV float ld1(uint32_t i) const { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)(i * 4u), 0, kSc1)); }
   GBP_DEV void st1(uint32_t i, const float v) const { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)(i * 4u), 0, kSc1); }
 };
+using XwBuf = XwBufT<false>;
 template <int G>
 GBP_DEV void load_rec_xw(const XwBuf& buf, uint32_t i4, float (&out)[G * 4]) {
   GBP_UNROLL
@@ -1304,8 +1326,9 @@ GBP_DEV uint32_t flow_camb_src(uint32_t k) {
 // EV: the launch carries the metric (A.ev, as in k_persist<true>): the metric means of iteration k are tagged records too (F.emc,
 // F.eml), the tile waves evaluate their residuals one iteration later behind their belief-phase role, the health counters are
 // per-iteration device words that block 0 hands to the host's slots behind the ONE barrier such a launch ends with.
-template <bool EV>
+template <bool EV, bool VER = false>
 __global__ __launch_bounds__(256) void k_persist_flow(const PersistArgs A) {
+  using Xw = XwBufT<VER>;
   const bool ev_on = EV && A.ev.on != 0;
   const SweepArgs& a = A.s;
   const BeliefArgs& b = A.b;
@@ -1326,8 +1349,11 @@ __global__ __launch_bounds__(256) void k_persist_flow(const PersistArgs A) {
   __shared__ float4 lm_stage[4][64 * 4];
   __shared__ float sh[4][48];
   float4* stage = lm_stage[wib];
-  const XwBuf S_lmsg(F.lmsg), S_rowp(F.rowp), S_camb(F.camb), S_cmu(F.cmu), S_clin(F.clin), S_lmkb(F.lmkb), S_lmu(F.lmu);
-  const XwBuf S_emc(F.emc), S_eml(F.eml);
+  const uint32_t mir = VER ? F.mirror4 : 0u;
+  unsigned long long* const verr = VER ? F.verify_errors : nullptr;
+  const Xw S_lmsg(F.lmsg, mir, verr), S_rowp(F.rowp, mir, verr), S_camb(F.camb, mir, verr), S_cmu(F.cmu, mir, verr), S_clin(F.clin, mir, verr),
+      S_lmkb(F.lmkb, mir, verr), S_lmu(F.lmu, mir, verr);
+  const Xw S_emc(F.emc, mir, verr), S_eml(F.eml, mir, verr);
   const uint32_t nC = b.n_cams, nL = b.n_lmks, Ep = A.n_tiles * 64u, n_rows = A.n_tiles * 4u;
 
   // ---- phase-A role: sweep tile w; the factor's potential and both of its messages stay in registers ----
@@ -2302,6 +2328,8 @@ hipError_t launch_persist(PersistArgs A, bool cooperative, hipStream_t s) {
   const void* f = A.ev.on ? reinterpret_cast<const void*>(k_persist_flow<true>) : reinterpret_cast<const void*>(k_persist_flow<false>);
 #ifdef GBP_BUILD_TEST_HOOKS
   if (!flow) f = A.ev.on ? reinterpret_cast<const void*>(k_persist<true>) : reinterpret_cast<const void*>(k_persist<false>);
+  else if (A.f.mirror4 != 0u)      // gbp_debug_persist_verify: every record published twice and compared by its consumers
+    f = A.ev.on ? reinterpret_cast<const void*>(k_persist_flow<true, true>) : reinterpret_cast<const void*>(k_persist_flow<false, true>);
 #else
   if (!flow) return hipErrorInvalidValue;
 #endif
@@ -2329,6 +2357,7 @@ void launch_eval(const uint32_t* row_cam, const uint32_t* lmk_idx, const float4*
 }
 
 #ifdef GBP_BUILD_TEST_HOOKS
+#include "hooks/gbp_flow_torture.hip"        // k_flow_torture: the detector under the tagged records' untorn-16-byte-store assumption
 #include "hooks/gbp_debug_math.hip"          // k_debug_math: the device math layer on caller-supplied vectors (tests only)
 #endif
 #ifdef GBP_BUILD_EXPERIMENTS

@@ -234,6 +234,14 @@ class GbpEngine:
         self._need_hooks()
         self._chk(self.lib.gbp_debug_persist_flow(self.h, int(bool(on))), "gbp_debug_persist_flow")
 
+    def persist_verify(self, on):
+        """redundant records in the persistent kernel (test hook): every tagged record published twice and compared by its consumers;
+        returns the mismatches counted since the last call"""
+        self._need_hooks()
+        n = C.c_uint64(0)
+        self._chk(self.lib.gbp_debug_persist_verify(self.h, int(bool(on)), C.byref(n)), "gbp_debug_persist_verify")
+        return int(n.value)
+
     def factor_potentials(self):
         return self._debug(0, 9 * self.E, 81 * self.E)
 

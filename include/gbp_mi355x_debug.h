@@ -66,6 +66,18 @@ GBP_API int gbp_debug_force_sweep_policy(int policy);
 /* bursts without the metric on a graph that runs in the persistent kernel: 1 (default) = k_persist_flow (hand-offs through tagged
  * records, no device-wide barrier), 0 = k_persist<false> (counter barriers); identical results — A/B measurements and tests */
 GBP_API int gbp_debug_persist_flow(gbp_ctx* ctx, int on);
+/* ---- the tagged records of the persistent kernel ("a 16-byte aligned store of one lane is not observed torn") ----
+ * gbp_debug_persist_verify: on != 0 — the following launches of k_persist_flow publish every record twice (the second copy with its
+ * payload complemented, same tag) and a consumer accepts a record only when both copies carry the same tag; a payload mismatch is what
+ * a torn or stale record would look like.  *mismatches (may be NULL) = the count since the last call (then reset).  Results are
+ * identical to the plain kernel's.
+ * gbp_debug_flow_torture: the detector under that assumption, no ctx involved — `rounds` rounds of K (4 or 16) 16-byte records per lane
+ * exchanged with the product's own store / load instructions between partner workgroups bid and bid ^ mask (odd mask: another XCD) of
+ * a grid of `blocks` (a power of two, 16 .. 256, >= 2 * mask), every word of a record a function of its round;
+ * out[4] = {records seen torn, otherwise corrupt, waits that timed out, records checked}.  inject != 0: the control — one record in
+ * 64 is stored tag first, payload a little later (what a tearing memory system would show): the detector must report torn records. */
+GBP_API int gbp_debug_persist_verify(gbp_ctx* ctx, int on, uint64_t* mismatches);
+GBP_API int gbp_debug_flow_torture(int blocks, int K, int rounds, unsigned mask, int inject, uint64_t* out /* [4] */);
 /* the grid and the belief-phase roles of a launch of the persistent kernel for a graph of n_tiles sweep tiles (a multiple of 4), n_cams
  * cameras, n_lmks landmarks, without / with the metric after every iteration (host evaluation of the function the kernel uses; no GPU):
  * dims[4] = workgroups, roles separated from the tiles (0 / 1), metric roles, landmark groups;  role[4 * workgroups] (may be NULL): per

@@ -127,7 +127,7 @@ def test_bench_line_describes_the_run_it_times():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_bench_with_real_ranks_sharing_one_gpu(world, oracle_mod):
     """`bench.py --gpus N --share-gpu` runs the N > 1 code path with N REAL processes on the one GPU of the
     box — self-launch through torch.distributed.run, per-rank shard build, rendezvous, preflight block, schedule choice, MAX-over-
@@ -155,6 +155,10 @@ def test_bench_with_real_ranks_sharing_one_gpu(world, oracle_mod):
     assert all(r["transport"] == "host-staged" for r in pre["ranks"]) and pre["exchange_probe_us"] > 0
     assert "host-staged" in out["config"]["exchange"] and out["config"]["comm_error"] is None
     assert out["roofline"]["rank_step_ms_max"] >= out["roofline"]["rank_step_ms_min"] > 0
+    # the line diagnoses itself — per-rank step, sweep and exchange times, who can reach whom
+    assert len(out["roofline"]["rank_step_ms"]) == world and len(out["roofline"]["sweep_avg_us_per_rank"]) == world
+    assert len(out["roofline"]["exchange_avg_us_per_rank"]) == world and all(x > 0 for x in out["roofline"]["sweep_avg_us_per_rank"])
+    assert all(len(r["peer_access_from_this_device"]) == r["visible_devices"] for r in pre["ranks"])
     n_it = out["config"]["iterations_run"]
     assert n_it == 4 + 50 + 8 and out["windows"]["n"] == 2 and out["sustained"]["iterations"] >= 8
     # the N-shard oracle through the same flow: RMSE after the timed region
@@ -206,14 +210,18 @@ def test_bench_sharded_line_is_complete_on_the_config5_shard_shape():
 
 @pytest.mark.gpu
 def test_bench_native_communicator_failure_is_fatal():
-    """No silent downgrade: with the library's RCCL unloadable, `--comm native` (the default) exits non-zero and prints no
-    result line; `--comm torch` is the explicit way to measure the torch.distributed exchange."""
+    """No silent downgrade: with the library's RCCL unloadable, `--comm native` (the default) exits non-zero; the line is still
+    printed — value null, `comm_error` and what every rank saw — so that the record of a failed multi-GPU run
+    says why; `--comm torch` is the explicit way to measure the torch.distributed exchange."""
     env = dict(os.environ, GBP_RCCL_LIB="/nonexistent/librccl-missing.so")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-sharded", "--cams", "60", "--lmks", "1500", "--steps", "4", "--warmup", "2",
                         "--cpu-seconds", "0", "--pmc", "off", "--profile-steps", "0"], env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, text=True, timeout=600)
     assert p.returncode == 4, (p.returncode, p.stderr[-2000:])
-    assert "could not be set up" in p.stderr and not [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert "could not be set up" in p.stderr
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["value"] is None and out["n_gpus"] == 1 and "could not be set up" in out["comm_error"]
+    assert len(out["config"]["ranks"]) == 1 and "librccl-missing" in out["config"]["ranks"][0]["comm_error"]
 
 
 def test_cli_metric_lines_are_parsed():

@@ -431,6 +431,75 @@ def test_persistent_kernel_equals_two_kernel_path(name, flow, oracle_mod):
     assert n_relin > 0 and engs[0].timing()["iterations"] == it
 
 
+@pytest.mark.parametrize("mask,blocks,K", [(1, 256, 16), (3, 256, 16), (7, 256, 16), (5, 64, 16), (8, 256, 16), (1, 256, 4), (127, 256, 4)])
+def test_tagged_records_are_never_seen_torn(mask, blocks, K):
+    """VERDICT r05 item 2 / ADVICE r05: the persistent kernel's hand-offs rest on ONE property no manual promises — a 16-byte aligned
+    store of one lane (buffer_store_dwordx4 sc1) is never observed torn by a wave on another XCD (buffer_load_dwordx4 sc1); a torn
+    record would carry the awaited tag with a stale payload: silently wrong beliefs, invisible to the time-out.  The detector, on the
+    box the suite runs on: up to 256 workgroups (one per CU) x 16 records per lane x 100 000 rounds, both halves (parities) of the
+    double buffer, EVERY word of a record a function of its round, partners on other XCDs (odd masks: bid ^ mask lands on another XCD
+    under round-robin placement; mask 8 = the same XCD, the control), the product's own store / load instructions
+    (csrc/hooks/gbp_flow_torture.hip).  Not one record may be torn or corrupt, no wait may time out.  If this test ever fails on a device:
+    gbp_params.persistent = -1 (or GBP_PERSIST=-1 for the CLIs) keeps every graph on the two-kernel path."""
+    import ctypes
+    from gbp_poplar_amd import _lib
+    lib = _lib.load(hooks=True)
+    rounds = 100000 if K == 16 else 200000
+    out = (ctypes.c_uint64 * 4)()
+    rc = lib.gbp_debug_flow_torture(blocks, K, rounds, mask, 0, out)
+    assert rc == 0, lib.gbp_last_error(None)
+    torn, corrupt, timeouts, checked = (int(x) for x in out)
+    assert checked == blocks * 256 * K * rounds, (checked, blocks * 256 * K * rounds)
+    assert (torn, corrupt, timeouts) == (0, 0, 0), {"torn": torn, "corrupt": corrupt, "timeouts": timeouts, "records_checked": checked}
+
+
+def test_torn_record_detector_detects():
+    """The control of the detector above: with one record in 64 stored tag first and payload a little later — what a tearing memory
+    system would show — the same kernel must REPORT torn records (and nothing else: no corrupt record, no time-out)."""
+    import ctypes
+    from gbp_poplar_amd import _lib
+    lib = _lib.load(hooks=True)
+    out = (ctypes.c_uint64 * 4)()
+    assert lib.gbp_debug_flow_torture(256, 16, 20000, 1, 1, out) == 0, lib.gbp_last_error(None)
+    torn, corrupt, timeouts, checked = (int(x) for x in out)
+    assert torn > 0 and corrupt == 0 and timeouts == 0 and checked == 256 * 256 * 16 * 20000, (torn, corrupt, timeouts, checked)
+
+
+@pytest.mark.parametrize("name", ["fr1xyz", "fr2robot2", "all_cus"])
+def test_persistent_kernel_redundant_records(name, oracle_mod):
+    """The same question asked of k_persist_flow itself (test-hooks build, gbp_debug_persist_verify): every record of every hand-off of
+    the default loop — beliefs, means, CAM_LIN, row sums, landmark messages, metric means — is published a second time with its payload
+    complemented, and a consumer accepts a record only when both copies carry the same tag and then compares them.  A whole default
+    run of the ./ba loop (gbp_ba_loop: prior weakening inside the launch, the metric after every iteration) and bursts without the
+    metric: zero mismatches, and every tensor and every metric equal to the plain kernel's, bit for bit."""
+    from gbp_poplar_amd import _cabi, driver, hostlib
+    from gbp_poplar_amd.engine import GbpEngine
+    opts = driver.Options()
+    bal = hostlib.synth_generate(100, 6400, 10, 7) if name == "all_cus" else _bal(name)
+    K, state, _ = driver.build_inputs(bal, opts, hostlib)
+    engs = [GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K, hooks=True, params=_cabi.GbpParams.defaults(persistent=0 if name == "all_cus" else 1))
+            for _ in range(2)]
+    assert all(e.graph_state() == 2 for e in engs)
+    assert engs[0].persist_verify(True) == 0
+    for e in engs:
+        e.upload(state)
+        e.linearise()
+    n_iters = 150 if name == "all_cus" else 600
+    evs = [e.ba_loop(n_iters, 0, int(opts.steps)) for e in engs]
+    assert evs[0] == evs[1]
+    it = n_iters
+    for burst in (2, 5, 64, 100):
+        for e in engs:
+            e.ba_loop(burst, it, int(opts.steps), metrics=False)
+        it += burst
+    sa, sb = _full_snapshot(engs[0]), _full_snapshot(engs[1])
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k], equal_nan=True), (name, k)
+    assert engs[0].eval() == engs[1].eval() and sum(e["n_relin"] for e in evs[0]) > 0
+    assert engs[0].persist_verify(False) == 0, "a record and its redundant copy disagreed: a torn or stale 16-byte record"
+    assert engs[0].graph_state() == 2 and "timed out" not in engs[0].last_error()
+
+
 def test_persistent_kernel_full_run_vs_oracle(oracle_mod):
     """`./ba fr1xyz --eval_every 100` as the CLI issues it (bursts of up to 100 iterations inside k_persist), 600 sweeps
     of the chaotic sequence: every belief equal to the CPU oracle's, bit for bit."""
