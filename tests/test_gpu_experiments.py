@@ -61,7 +61,8 @@ sys.path.insert(0, %(root)r)
 from gbp_poplar_amd import _cabi, driver, hostlib
 from gbp_poplar_amd.engine import GbpEngine
 bal = hostlib.bal_read(%(seq)r)
-K, state, _ = driver.build_inputs(bal, driver.Options(), hostlib)
+SLAM = %(first)r == "keyframe"
+K, state, extra = driver.build_inputs(bal, driver.Options(), hostlib, slam=SLAM)
 def make(**kw):
     e = GbpEngine(bal['cam_id'], bal['lmk_id'], bal['n_cams'], bal['n_lmks'], K, hooks='exp', params=_cabi.GbpParams.defaults(**kw))
     e.upload(state); e.linearise(); e.iterate(1)
@@ -78,6 +79,33 @@ def flow(e):
         return out, st
     if %(first)r == "loop":                         # gbp_ba_loop: the launch that times out weakens priors itself (loop indices 3, 5, 7, 9):
         out.extend(e.ba_loop(13, 1, 5))             # the snapshot holds priors and flags too, the fall-back redoes the burst call by call
+        st = e.read()
+        st.update({"prior_" + k: v for k, v in e.read_priors().items()})
+        return out, st
+    if %(first)r == "set_stream":                   # two unvalidated gbp_ba_loop launches in the log (the first one times out), then
+        e.ba_loop(14, 1, 5, metrics=False)          # gbp_set_stream: the recovery starts inside it (settle), the stream changes behind the replay
+        e.ba_loop(6, 15, 5, metrics=False)
+        e.set_stream(0)
+        out.extend(e.iterate_eval_each(13))
+        st = e.read()
+        st.update({"prior_" + k: v for k, v in e.read_priors().items()})
+        return out, st
+    if %(first)r == "weaken":                       # the recovery starts inside gbp_weaken_priors: WEAKEN_PRIORS follows the replayed burst
+        e.iterate(20)
+        e.weaken_priors()
+        out.extend(e.iterate_eval_each(13))
+        st = e.read()
+        st.update({"prior_" + k: v for k, v in e.read_priors().items()})
+        return out, st
+    if SLAM:                                        # a SLAM keyframe interval with unvalidated gbp_ba_loop launches in the log, then NEW_KEYFRAME
+        C, L, E = int(bal["n_cams"]), int(bal["n_lmks"]), int(bal["n_edges"])
+        active, cwf, lwf = state["active_flag"].copy(), state["cam_weaken_flag"].copy(), state["lmk_weaken_flag"].copy()
+        laf = extra["lmk_active_flag"].copy()
+        e.ba_loop(14, 1, 5, metrics=False)          # (the launch that times out: it weakens priors itself)
+        e.ba_loop(6, 15, 5, metrics=False)
+        hostlib.slam_update_flags(bal["cam_id"], bal["lmk_id"], C, L, 5, 1, active, lwf, cwf, laf)
+        e.new_keyframe({"damping_count": np.full(E, -15, np.int32), "active_flag": active, "cam_weaken_flag": cwf, "lmk_weaken_flag": lwf})
+        out.extend(e.ba_loop(13, 0, 5))             # the first passes of the new interval, weakenings included
         st = e.read()
         st.update({"prior_" + k: v for k, v in e.read_priors().items()})
         return out, st
@@ -106,7 +134,8 @@ print('RECOVERED %%.1f s graph_state_after_upload %%d :: %%s' %% (dt, eng.graph_
 
 
 @pytest.mark.skipif(not _exp_lib_present(), reason="experiments build absent (python -m gbp_poplar_amd.build --experiments)")
-@pytest.mark.parametrize("coop,first", [(0, "plain"), (0, "eval"), (0, "each"), (1, "plain"), (0, "read"), (0, "loop")])
+@pytest.mark.parametrize("coop,first", [(0, "plain"), (0, "eval"), (0, "each"), (1, "plain"), (0, "read"), (0, "loop"),
+                                        (0, "set_stream"), (0, "weaken"), (0, "keyframe")])
 def test_persistent_kernel_time_out_is_recovered(coop, first):
     """A k_persist launch whose workgroups can NOT all be resident (forced: every 8th dispatch slot = one XCD = 32 CUs for the
     52 workgroups of fr1xyz; experiments build) must not hang and must not lose the run:
@@ -115,7 +144,9 @@ def test_persistent_kernel_time_out_is_recovered(coop, first):
       * cooperative launch (persist_coop = 1): the runtime refuses the grid before anything runs, same fallback.
     The launch that fails is a plain burst, a burst with the metric at its end, or an every-iteration burst (`first`); "read": a
     plain burst followed by gbp_read with no synchronisation of the caller's in between; "loop": gbp_ba_loop, whose launch weakens
-    priors itself (priors and flags are restored with the rest and compared too).
+    priors itself (priors and flags are restored with the rest and compared too); "set_stream" / "weaken" / "keyframe" (VERDICT r05
+    item 3): the recovery starts inside gbp_set_stream, gbp_weaken_priors and gbp_new_keyframe — the last one a SLAM keyframe interval
+    with two unvalidated gbp_ba_loop launches in the log, NEW_KEYFRAME applied behind the replay.
     Either way: rc 0 everywhere, every belief / damping / counter and every metric equal to the two-kernel path's, a warning in
     gbp_last_error, and the persistent path back after the next gbp_upload."""
     import subprocess
