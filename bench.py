@@ -442,6 +442,10 @@ def small_config_gpu(name):
         "nonfinite_beliefs": rep.get("n_nonfinite"),
         "same_final_metric_with_eval_every_100": rep.get("final_mean_reproj_px") == rep100.get("final_mean_reproj_px"),
     }
+    st = rep.get("startup")
+    if st:      # where the process's wall time went (the CLI's own account from exec to the end of its teardown; exit_s = what follows main())
+        out["startup"] = dict(st, process_wall_s=round(rep["process_wall_s"], 4), exit_s=round(rep["process_wall_s"] - st["process_s"], 4),
+                              loop_share=round(st.get("loop_s", 0.0) / rep["process_wall_s"], 4))
     if band:
         out["converged_band_px"] = list(band)
         out["in_converged_band"] = bool(band[0] <= rep["final_mean_reproj_px"] <= band[1])

@@ -40,6 +40,43 @@
 
 namespace cli {
 
+// Where a run spends its wall time, from exec to exit (--profile: the `startup` object of gbp_profile.json; the "Total time" line):
+// for the shipped sequences the iteration loop is a few per cent of what a user of ./ba waits for (profiles/r06_configs.md).
+struct Phases {
+  using clk = std::chrono::steady_clock;
+  clk::time_point t_main = clk::now(), last = t_main;
+  double exec_to_main_s = 0;                                  // exec -> main(): the dynamic loader (libamdhip64 and what it pulls in)
+  std::vector<std::pair<std::string, double>> v;              // phase, seconds — in order
+  std::string create_info;                                    // gbp_create's own breakdown (gbp_last_error(ctx) right after it)
+  Phases() {
+    // start time of the process (clock ticks since boot, /proc/self/stat field 22) against the time since boot now: 10 ms resolution
+    double up = 0;
+    if (FILE* f = std::fopen("/proc/uptime", "r")) { if (std::fscanf(f, "%lf", &up) != 1) up = 0; std::fclose(f); }
+    if (FILE* f = std::fopen("/proc/self/stat", "r")) {
+      char buf[1024];
+      const size_t n = std::fread(buf, 1, sizeof(buf) - 1, f);
+      std::fclose(f);
+      buf[n] = 0;
+      if (const char* p = std::strrchr(buf, ')')) {          // the fields behind "(comm)": state is field 3
+        unsigned long long start = 0;
+        int field = 2;
+        for (const char* q = p + 1; *q && field < 22; ++q)
+          if (*q == ' ') { ++field; if (field == 22) start = std::strtoull(q + 1, nullptr, 10); }
+        const long hz = sysconf(_SC_CLK_TCK);
+        if (start && hz > 0 && up > 0) exec_to_main_s = std::max(0.0, up - (double)start / (double)hz);
+      }
+    }
+  }
+  void mark(const char* name) {
+    const auto n = clk::now();
+    v.emplace_back(name, std::chrono::duration<double>(n - last).count());
+    last = n;
+  }
+  double since_exec() const { return exec_to_main_s + std::chrono::duration<double>(clk::now() - t_main).count(); }
+  double get(const char* name) const { for (const auto& p : v) if (p.first == name) return p.second; return 0; }
+};
+inline Phases& phases() { static Phases p; return p; }
+
 struct Options {
   std::string bal_file;
   int n_iters = 1500;           // ba only
@@ -270,7 +307,9 @@ inline int round_up_pow2(int n) {   // ba.cpp:617-621: nIPUs is rounded up to a 
 
 // Creates the ctx of this rank on its GPU, landmark-sharded for world > 1, with the communicator attached.
 inline int create_rank_ctx(const Options& o, const Problem& P, RankCtx& rk, gbp_ctx** ctx) {
+  phases().mark("host_setup_s");                                  // (flags, fork, the lines printed so far)
   const int ndev = gbp_device_count();
+  phases().mark("runtime_init_s");                                // the HIP runtime comes up with the first call that needs it
   if (ndev <= 0) {
     std::cout << "Could not find a device\n";                      // ba.cpp:652-655
     return 255;
@@ -296,6 +335,8 @@ inline int create_rank_ctx(const Options& o, const Problem& P, RankCtx& rk, gbp_
     std::cout << "Exchange between the " << rk.world << " ranks: " << gbp_comm_transport(*ctx)
               << (ndev < rk.world ? " (fewer GPUs than ranks: ranks share a GPU)" : "") << "\n";
   }
+  if (const char* info = gbp_last_error(*ctx)) phases().create_info = info;
+  phases().mark("create_s");
   return 0;
 }
 
@@ -481,17 +522,16 @@ struct RunReport {
   gbp_eval_out last{};
 };
 
-inline void write_profile(gbp_ctx* ctx, const char* tool, const RunReport& r) {
+// (called after the ctx is gone — its teardown is one of the phases — with what was read from it before)
+inline void write_profile(const gbp_timing_out& t, int graph_state, const char* tool, const RunReport& r) {
   const char* dir = std::getenv("GC_PROFILE_LOG_DIR");
   const std::string path = std::string(dir ? dir : ".") + "/gbp_profile.json";
-  gbp_timing_out t{};
-  gbp_timing(ctx, &t, 0);
   if (FILE* f = std::fopen(path.c_str(), "w")) {
     std::fprintf(f, "{\"tool\": \"%s\", \"iterations\": %ld, \"wall_s\": %.6f, \"setup_s\": %.6f, \"loop_s\": %.6f, \"device_ms\": %.3f, "
                     "\"device_iterations\": %llu, \"iters_per_s_device\": %.3f, \"graph_state\": %d, "
                     "\"algorithmic_bytes_per_iter\": %llu, \"device_bytes_allocated\": %llu",
                  tool, r.iters, r.wall_s, r.setup_s, r.loop_s, t.total_ms, (unsigned long long)t.iterations,
-                 t.total_ms > 0 ? 1e3 * (double)t.iterations / t.total_ms : 0.0, gbp_graph_state(ctx),
+                 t.total_ms > 0 ? 1e3 * (double)t.iterations / t.total_ms : 0.0, graph_state,
                  (unsigned long long)t.algorithmic_bytes_per_iter, (unsigned long long)t.device_bytes_allocated);
     if (r.have_metric && r.last.n_active) {
       const double n = (double)r.last.n_active;
@@ -500,10 +540,43 @@ inline void write_profile(gbp_ctx* ctx, const char* tool, const RunReport& r) {
                    r.last.sum_norm / n, r.last.sum_half_sq, std::sqrt(2.0 * r.last.sum_half_sq / n), (unsigned long long)r.last.n_active,
                    (unsigned long long)r.last.n_relin, (unsigned long long)r.last.n_robust, (unsigned long long)r.last.n_nonfinite);
     }
+    {  // where the wall time of the PROCESS went
+      const Phases& ph = phases();
+      std::fprintf(f, ", \"startup\": {\"process_s\": %.6f, \"exec_to_main_s\": %.3f", ph.since_exec(), ph.exec_to_main_s);
+      for (const auto& p : ph.v) std::fprintf(f, ", \"%s\": %.6f", p.first.c_str(), p.second);
+      std::string info = ph.create_info;
+      for (char& ch : info) if (ch == '"' || ch == '\\') ch = '\'';
+      std::fprintf(f, ", \"create\": \"%s\"}", info.c_str());
+    }
     std::fprintf(f, "}\n");
     std::fclose(f);
     std::cout << "Profile written to " << path << "\n";
   }
+}
+
+// The end of a run, shared by ./ba and ./slam: the ctx is destroyed FIRST (its teardown is part of what the user waits for), then the
+// "Total time" line — which covers the process from exec to here — and the --profile report.
+inline int finish_run(const Options& o, const Problem& P, gbp_ctx* ctx, const RankCtx& rk, const char* tool, RunReport& rep, long iters) {
+  gbp_timing_out tm{};
+  gbp_timing(ctx, &tm, 0);
+  const int gs = gbp_graph_state(ctx);
+  print_warning(ctx);
+  const int wrc = write_solution(o, P, ctx, rk.region != nullptr);
+  phases().mark("loop_s");
+  gbp_destroy(ctx);
+  phases().mark("teardown_s");
+  const Phases& ph = phases();
+  rep.loop_s = ph.get("loop_s");
+  rep.setup_s = ph.get("upload_s") + ph.get("linearise_s");
+  rep.wall_s = rep.setup_s + rep.loop_s;
+  rep.iters = iters;
+  std::cout << "Total time: " << ph.since_exec() << " s from exec (loader " << ph.exec_to_main_s << " s, file + priors " << ph.get("file_parse_s")
+            << " s, runtime " << ph.get("runtime_init_s") << " s, gbp_create " << ph.get("create_s") << " s, upload " << ph.get("upload_s")
+            << " s, linearise + first metric " << ph.get("linearise_s") << " s, iteration loop " << rep.loop_s << " s, teardown " << ph.get("teardown_s")
+            << " s); device time in GBP iterations: " << tm.total_ms << " ms over " << tm.iterations
+            << " iterations (" << (tm.total_ms > 0 ? 1e3 * (double)tm.iterations / tm.total_ms : 0.0) << " iters/s)\n";
+  if (o.profile) write_profile(tm, gs, tool, rep);
+  return wrc;
 }
 
 }  // namespace cli

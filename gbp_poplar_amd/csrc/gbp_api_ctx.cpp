@@ -9,6 +9,7 @@
 #include "gbp_ctx.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 
@@ -35,7 +36,7 @@ int fail(gbp_ctx* c, int code, const std::string& msg) {
 // queued on — so no device-wide synchronisation is needed behind an allocation (a fill on the NULL stream is not ordered against a
 // non-blocking stream and may still be running when hipMemset returns; blocking copies into a fresh buffer wait for the stream first).
 int dev_alloc(gbp_ctx* c, DevBuf& b, size_t bytes) {
-  b.bytes = bytes < 256 ? 256 : bytes;   // >= one camera / landmark record: pad lanes of an empty shard read index 0
+  b.bytes = bytes < 256 ? 256 : (bytes + 15) / 16 * 16;   // >= one camera / landmark record (pad lanes of an empty shard read index 0); whole float4s (H2D)
   HIPCHK(c, hipMalloc(&b.p, b.bytes));
   c->all.push_back(&b);
   c->dev_bytes += b.bytes;
@@ -70,6 +71,79 @@ int span_begin(gbp_ctx* c, gbp_ctx::Span& sp) {
 int span_end(gbp_ctx* c, const gbp_ctx::Span& sp) {
   HIPCHK(c, hipEventRecord(sp.b, c->stream));
   c->spans.push_back(sp);
+  return GBP_OK;
+}
+
+int H2D::begin(gbp_ctx* ctx, size_t total_bytes, int pieces) {
+  c = ctx; used = 0; segs = CopySegs{};
+  const size_t need = total_bytes + 16 * (size_t)pieces;
+  direct = need > kStageMax;
+  if (direct) return GBP_OK;
+  if (c->stage_cap < need) {
+    if (c->stage_host) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipHostFree(c->stage_host); c->stage_host = nullptr; c->stage_cap = 0; }
+    const size_t cap = std::max<size_t>(need, (size_t)1 << 20);
+    HIPCHK(c, hipHostMalloc(&c->stage_host, cap, hipHostMallocMapped));
+    HIPCHK(c, hipHostGetDevicePointer(&c->stage_dev, c->stage_host, 0));
+    c->stage_cap = cap;
+  }
+  return GBP_OK;
+}
+int H2D::flush() {
+  if (segs.n == 0) return GBP_OK;
+  launch_copy_segments(segs, nullptr, c->stream);
+  HIPCHK(c, hipGetLastError());
+  segs.n = 0;
+  return GBP_OK;
+}
+int H2D::put(void* dst_dev, const void* src, size_t bytes) {
+  if (bytes == 0) return GBP_OK;
+  if (direct) { HIPCHK(c, hipMemcpy(dst_dev, src, bytes, hipMemcpyHostToDevice)); return GBP_OK; }
+  const size_t padded = (bytes + 15) / 16 * 16;
+  if (used + padded > c->stage_cap) return fail(c, GBP_ERR_INVALID, "H2D: staging buffer too small (internal)");
+  char* h = static_cast<char*>(c->stage_host) + used;
+  std::memcpy(h, src, bytes);
+  if (padded > bytes) std::memset(h + bytes, 0, padded - bytes);
+  if (segs.n == kMaxCopySegs)
+    if (int rc = flush()) return rc;
+  segs.src[segs.n] = static_cast<char*>(c->stage_dev) + used; segs.dst[segs.n] = dst_dev; segs.n4[segs.n] = padded / 16;
+  segs.n += 1;
+  used += padded;
+  return GBP_OK;
+}
+int H2D::end() {
+  if (!direct)
+    if (int rc = flush()) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));      // the staging buffer is free again, the data is on the device
+  return GBP_OK;
+}
+
+int D2H::begin(gbp_ctx* ctx, size_t total_bytes, int pieces) {
+  if (int rc = up.begin(ctx, total_bytes, pieces)) return rc;
+  pending.clear();
+  return GBP_OK;
+}
+int D2H::get(void* dst_host, const void* src_dev, size_t bytes) {
+  gbp_ctx* c = up.c;
+  if (bytes == 0) return GBP_OK;
+  if (up.direct) { HIPCHK(c, hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost)); return GBP_OK; }
+  const size_t padded = (bytes + 15) / 16 * 16;
+  if (up.used + padded > c->stage_cap) return fail(c, GBP_ERR_INVALID, "D2H: staging buffer too small (internal)");
+  if (up.segs.n == kMaxCopySegs) {
+    launch_copy_segments(up.segs, nullptr, c->stream);
+    HIPCHK(c, hipGetLastError());
+    up.segs.n = 0;
+  }
+  up.segs.src[up.segs.n] = src_dev; up.segs.dst[up.segs.n] = static_cast<char*>(c->stage_dev) + up.used; up.segs.n4[up.segs.n] = padded / 16;
+  up.segs.n += 1;
+  pending.push_back(Out{dst_host, up.used, bytes});
+  up.used += padded;
+  return GBP_OK;
+}
+int D2H::end() {
+  if (int rc = up.end()) return rc;      // launches what is queued, synchronises the stream
+  if (!up.direct)
+    for (const Out& o : pending) std::memcpy(o.dst, static_cast<const char*>(up.c->stage_host) + o.off, o.bytes);
+  pending.clear();
   return GBP_OK;
 }
 
@@ -163,6 +237,7 @@ GBP_EXPORT_VOID(gbp_destroy, (gbp_ctx* c), (c)) {
   for (DevBuf* b : c->all) if (b->p) (void)hipFree(b->p);
   for (auto& v : {&c->spans, &c->span_pool})
     for (auto& sp : *v) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+  if (c->stage_host) (void)hipHostFree(c->stage_host);
   if (c->eval_host) (void)hipHostFree(c->eval_host);
   if (c->ev_host) (void)hipHostFree(c->ev_host);
   if (c->series_host) (void)hipHostFree(c->series_host);
@@ -180,6 +255,18 @@ GBP_EXPORT_VOID(gbp_destroy, (gbp_ctx* c), (c)) {
 GBP_EXPORT(gbp_create, nullptr, (const gbp_problem* pr, const gbp_params* prm, const gbp_shard* sh, gbp_ctx** out), (pr, prm, sh, out)) {
   if (!pr || !out || !pr->cam_id || !pr->lmk_id || pr->n_cams == 0 || pr->n_lmks == 0 || pr->n_edges == 0)
     return fail(nullptr, GBP_ERR_INVALID, "gbp_create: null or empty problem");
+  // what the call spends where (left in gbp_last_error(ctx) as an `info:` line: the CLIs' --profile report quotes it)
+  using clk = std::chrono::steady_clock;
+  const auto ms_since = [](clk::time_point t) { return std::chrono::duration<double, std::milli>(clk::now() - t).count(); };
+  clk::time_point t_phase = clk::now();
+  // GBP_CREATE_TRACE=1: one line per step on stderr (what the first stream, the first allocation, the first fill, the first copy of a
+  // process cost: profiles/r06_configs.md)
+  const bool trace = std::getenv("GBP_CREATE_TRACE") != nullptr;
+  clk::time_point t_step = clk::now();
+  const auto step = [&](const char* what) {
+    if (trace) std::fprintf(stderr, "gbp_create: %-28s %8.3f ms\n", what, ms_since(t_step));
+    t_step = clk::now();
+  };
   // ---- device order: pure host code (gbp_layout.cpp), built and validated before anything touches the GPU ----
   Layout lay;
   {
@@ -188,9 +275,15 @@ GBP_EXPORT(gbp_create, nullptr, (const gbp_problem* pr, const gbp_params* prm, c
     std::string lerr;
     if (int lrc = layout_build(pr, (prm ? prm : &dflt)->tile_order, sh, g_layout_options, lay, lerr)) return fail(nullptr, lrc, lerr);
   }
+  const double layout_ms = ms_since(t_phase);
+  t_phase = clk::now();
+  step("device order");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     return fail(nullptr, GBP_ERR_NO_DEVICE, "gbp_create: no HIP device (the product has no CPU fallback)");
+  const double runtime_ms = ms_since(t_phase);      // (the HIP runtime comes up here unless the caller has touched it before)
+  t_phase = clk::now();
+  step("hipGetDeviceCount");
   gbp_ctx* c = new gbp_ctx();
   struct Owner { gbp_ctx* p; ~Owner() { if (p) gbp_destroy(p); } } owner{c};   // released on success only
   c->lay = std::move(lay);
@@ -220,47 +313,71 @@ GBP_EXPORT(gbp_create, nullptr, (const gbp_problem* pr, const gbp_params* prm, c
   CK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking), "hipStreamCreate");
   if (rc != GBP_OK) return rc;
   c->stream = c->own_stream;
+  step("hipStreamCreate");
   // ---- device allocations (zero-filled on the ctx's stream) ----
   auto A = [&](DevBuf& b, size_t bytes) { if (rc == GBP_OK) rc = dev_alloc(c, b, bytes); };
   const size_t Ep = c->Ep;
-  A(c->row_cam, (Ep / kRow) * 4); A(c->lmk_idx, Ep * 4); A(c->fac, Ep * kFacG * 16); A(c->cmsg, Ep * kCmsgG * 16);
+  // The index arrays of the device order live in ONE allocation and go up in ONE copy: a blocking hipMemcpy of a few KB costs ~1 ms on
+  // this stack whatever its size (the nine separate copies were 16 of the 37 ms of a `ba fr1xyz` gbp_create: profiles/r06_configs.md)
+  struct Piece { DevBuf* b; const void* src; size_t bytes; size_t off; };
+  Piece pieces[] = {{&c->row_cam, y.row_cam.data(), y.row_cam.size() * 4, 0}, {&c->lmk_idx, y.pos_lmk_loc.data(), Ep * 4, 0},
+                    {&c->d_lmk_fpos, y.lmk_fpos.data(), (size_t)c->E_loc * 4, 0}, {&c->d_lmk_ix, y.lmk_ix.data(), (size_t)c->L_loc * 64, 0},
+                    {&c->d_cam_row_ptr, y.cam_row_ptr.data(), (size_t)(C + 1) * 4, 0}, {&c->d_lmk_ptr, y.lmk_ptr.data(), (size_t)(c->L_loc + 1) * 4, 0},
+                    {&c->d_row_slot, y.row_slot.data(), y.row_slot.size() * 4, 0}, {&c->dK, c->K, 9 * 4, 0},
+                    {&c->tile_perm, y.tile_perm.data(), y.tile_perm.size() * 4, 0}};
+  size_t idx_bytes = 0;
+  for (Piece& pc : pieces) { pc.off = idx_bytes; idx_bytes += (std::max<size_t>(pc.bytes, 256) + 255) / 256 * 256; }      // (>= 256 B each: pad lanes of an empty shard read index 0)
+  A(c->idx_arena, idx_bytes);
+  step("first hipMalloc + fill");
+  for (Piece& pc : pieces) { pc.b->p = rc == GBP_OK ? static_cast<char*>(c->idx_arena.p) + pc.off : nullptr; pc.b->bytes = pc.bytes; }      // views: freed with the arena
+  A(c->fac, Ep * kFacG * 16); A(c->cmsg, Ep * kCmsgG * 16);
   A(c->mu, c->hoist ? 0 : Ep * kMuG * 16);   // literal mu/oldmu tensor: only with per_factor_mu
-  A(c->lmsg, Ep * 64); A(c->d_lmk_fpos, (size_t)c->E_loc * 4); A(c->d_lmk_ix, (size_t)c->L_loc * 64);
+  A(c->lmsg, Ep * 64);
   A(c->camb, (size_t)C * kCamRec * 4); A(c->camp, (size_t)C * kCamRec * 4); A(c->local, (size_t)C * kCamRec * 4);
   A(c->lmkb, (size_t)c->L_loc * 64); A(c->lmkp, (size_t)c->L_loc * 64);
   A(c->rowp, (Ep / kRow) * kCamRec * 4);
-  A(c->d_cam_row_ptr, (size_t)(C + 1) * 4); A(c->d_lmk_ptr, (size_t)(c->L_loc + 1) * 4);
-  A(c->d_row_slot, y.row_slot.size() * 4);
   A(c->cwf, (size_t)C * 4); A(c->lwf, (size_t)c->L_loc * 4); A(c->cscale, (size_t)C * 4); A(c->lscale, (size_t)c->L_loc * 4);
   A(c->cam_mu, (size_t)C * 6 * 4 * 2); A(c->lmk_mu, (size_t)c->L_loc * 3 * 4 * 2);   // metric means; k_persist alternates between the two halves
-  A(c->dK, 16 * 4);
   A(c->evalp, sizeof(DeviceEval) * 16); A(c->health, 32);
   A(c->hmu_c, (size_t)C * 4 * 16); A(c->hmu_l, (size_t)c->L_loc * 2 * 16); A(c->clin, (size_t)C * 5 * 16);
   A(c->st_a, Ep * 4); A(c->st_b, Ep * 4);
-  if (rc == GBP_OK && !y.tile_perm.empty()) A(c->tile_perm, (size_t)y.n_tiles * 4);
   if (rc != GBP_OK) { create_error() = c->err; return rc; }
+  step("the other allocations");
   CK(hipEventCreate(&c->ev0), "hipEventCreate"); CK(hipEventCreate(&c->ev1), "hipEventCreate");
   CK(hipEventCreate(&c->ev2), "hipEventCreate"); CK(hipEventCreate(&c->ev3), "hipEventCreate");
   CK(hipStreamSynchronize(c->stream), "hipStreamSynchronize");      // the fills have landed: blocking copies into the fresh buffers follow
-  CK(hipMemcpy(c->d_cam_row_ptr.p, y.cam_row_ptr.data(), (size_t)(C + 1) * 4, hipMemcpyHostToDevice), "copy cam_row_ptr");
-  CK(hipMemcpy(c->d_lmk_ptr.p, y.lmk_ptr.data(), (size_t)(c->L_loc + 1) * 4, hipMemcpyHostToDevice), "copy lmk_ptr");
-  if (!y.row_slot.empty()) CK(hipMemcpy(c->d_row_slot.p, y.row_slot.data(), y.row_slot.size() * 4, hipMemcpyHostToDevice), "copy row_slot");
-  CK(hipMemcpy(c->dK.p, c->K, 9 * 4, hipMemcpyHostToDevice), "copy K");
-  if (c->E_loc) CK(hipMemcpy(c->d_lmk_fpos.p, y.lmk_fpos.data(), (size_t)c->E_loc * 4, hipMemcpyHostToDevice), "copy lmk_fpos");
-  if (c->L_loc) CK(hipMemcpy(c->d_lmk_ix.p, y.lmk_ix.data(), (size_t)c->L_loc * 64, hipMemcpyHostToDevice), "copy lmk_ix");
-  CK(hipMemcpy(c->row_cam.p, y.row_cam.data(), y.row_cam.size() * 4, hipMemcpyHostToDevice), "copy row_cam");
-  CK(hipMemcpy(c->lmk_idx.p, y.pos_lmk_loc.data(), Ep * 4, hipMemcpyHostToDevice), "copy lmk_idx");
-  if (!y.tile_perm.empty()) {
-    // the XCD-aware execution order of the sweep: wave slot -> tile (gbp_layout.cpp); read once per wave with a scalar load
-    CK(hipMemcpy(c->tile_perm.p, y.tile_perm.data(), (size_t)y.n_tiles * 4, hipMemcpyHostToDevice), "copy tile_perm");
-    c->use_tile_perm = rc == GBP_OK;
+  const double alloc_ms = ms_since(t_phase);
+  t_phase = clk::now();
+  step("events + stream sync");
+  {
+    std::vector<char> stage(idx_bytes, 0);
+    for (const Piece& pc : pieces)
+      if (pc.bytes) std::memcpy(stage.data() + pc.off, pc.src, pc.bytes);
+    H2D up;
+    if (rc == GBP_OK) rc = up.begin(c, idx_bytes, 1);
+    if (rc == GBP_OK) rc = up.put(c->idx_arena.p, stage.data(), idx_bytes);
+    if (rc == GBP_OK) rc = up.end();
+    if (rc != GBP_OK) create_error() = c->err;
   }
+  step("the copy of the device order");
+  // the XCD-aware execution order of the sweep: wave slot -> tile (gbp_layout.cpp); read once per wave with a scalar load
+  c->use_tile_perm = rc == GBP_OK && !y.tile_perm.empty();
   if (rc != GBP_OK) return rc;
+  const double upload_ms = ms_since(t_phase);
+  t_phase = clk::now();
   // ---- persistent iteration kernel: only where every workgroup of the graph is resident at once (gbp_api_persist.cpp) ----
   rc = persist_setup(c, prm, sh != nullptr);
   if (rc != GBP_OK) { if (create_error().empty()) create_error() = c->err; return rc; }
   CK(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
   if (rc != GBP_OK) return rc;
+  step("persistent kernel set-up");
+  {
+    char info[320];
+    std::snprintf(info, sizeof(info), "info: gbp_create: device order %.3f ms, runtime %.3f ms, allocation %.3f ms, layout upload %.3f ms, "
+                                      "persistent kernel %.3f ms (probe %.3f ms)",
+                  layout_ms, runtime_ms, alloc_ms, upload_ms, ms_since(t_phase), c->probe_ms);
+    c->err = c->err.empty() ? std::string(info) : c->err + " | " + info;      // (a probe that failed has left its reason in front)
+  }
   owner.p = nullptr;
   *out = c;
   return GBP_OK;
@@ -323,9 +440,12 @@ GBP_EXPORT(gbp_upload, c, (gbp_ctx* c, const gbp_state_in* in), (c, in)) {
     }
     put_state(rec0, p, h);
   }
-  HIPCHK(c, hipMemcpy(c->lmsg.p, rec0.data(), rec0.size() * 4, hipMemcpyHostToDevice));   // zero messages + state
-  HIPCHK(c, hipMemcpy(c->fac.p, fac.data(), fac.size() * 4, hipMemcpyHostToDevice));
-  if (!c->hoist) HIPCHK(c, hipMemcpy(c->mu.p, mu.data(), mu.size() * 4, hipMemcpyHostToDevice));
+  H2D up;
+  if (int rc = up.begin(c, (rec0.size() + fac.size() + mu.size() + ((size_t)c->C + c->L_loc) * (kCamRec + 16 + 2)) * 4, 9)) return rc;
+  if (int rc = up.put(c->lmsg.p, rec0.data(), rec0.size() * 4)) return rc;   // zero messages + state
+  if (int rc = up.put(c->fac.p, fac.data(), fac.size() * 4)) return rc;
+  if (!c->hoist)
+    if (int rc = up.put(c->mu.p, mu.data(), mu.size() * 4)) return rc;
   HIPCHK(c, hipMemsetAsync(c->cmsg.p, 0, c->cmsg.bytes, c->stream));
   HIPCHK(c, hipMemsetAsync(c->rowp.p, 0, c->rowp.bytes, c->stream));
   HIPCHK(c, hipMemsetAsync(c->local.p, 0, c->local.bytes, c->stream));
@@ -336,17 +456,19 @@ GBP_EXPORT(gbp_upload, c, (gbp_ctx* c, const gbp_state_in* in), (c, in)) {
   HIPCHK(c, hipMemsetAsync(c->clin.p, 0, c->clin.bytes, c->stream));
   std::vector<float> rec;
   pack_cam(in->cam_priors_eta, in->cam_priors_lambda, c->C, rec);
-  HIPCHK(c, hipMemcpy(c->camp.p, rec.data(), rec.size() * 4, hipMemcpyHostToDevice));
+  if (int rc = up.put(c->camp.p, rec.data(), rec.size() * 4)) return rc;
   pack_lmk(in->lmk_priors_eta, in->lmk_priors_lambda, c->lmk_begin, c->L_loc, rec);
-  if (c->L_loc) HIPCHK(c, hipMemcpy(c->lmkp.p, rec.data(), rec.size() * 4, hipMemcpyHostToDevice));
+  if (c->L_loc)
+    if (int rc = up.put(c->lmkp.p, rec.data(), rec.size() * 4)) return rc;
   std::vector<float> zf(std::max(c->C, c->L), 0.f);
   std::vector<uint32_t> zu(std::max(c->C, c->L), 0u);
-  HIPCHK(c, hipMemcpy(c->cscale.p, in->cam_scaling ? in->cam_scaling : zf.data(), (size_t)c->C * 4, hipMemcpyHostToDevice));
-  HIPCHK(c, hipMemcpy(c->cwf.p, in->cam_weaken_flag ? in->cam_weaken_flag : zu.data(), (size_t)c->C * 4, hipMemcpyHostToDevice));
+  if (int rc = up.put(c->cscale.p, in->cam_scaling ? in->cam_scaling : zf.data(), (size_t)c->C * 4)) return rc;
+  if (int rc = up.put(c->cwf.p, in->cam_weaken_flag ? in->cam_weaken_flag : zu.data(), (size_t)c->C * 4)) return rc;
   if (c->L_loc) {
-    HIPCHK(c, hipMemcpy(c->lscale.p, in->lmk_scaling ? in->lmk_scaling + c->lmk_begin : zf.data(), (size_t)c->L_loc * 4, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->lwf.p, in->lmk_weaken_flag ? in->lmk_weaken_flag + c->lmk_begin : zu.data(), (size_t)c->L_loc * 4, hipMemcpyHostToDevice));
+    if (int rc = up.put(c->lscale.p, in->lmk_scaling ? in->lmk_scaling + c->lmk_begin : zf.data(), (size_t)c->L_loc * 4)) return rc;
+    if (int rc = up.put(c->lwf.p, in->lmk_weaken_flag ? in->lmk_weaken_flag + c->lmk_begin : zu.data(), (size_t)c->L_loc * 4)) return rc;
   }
+  if (int rc = up.end()) return rc;
   if (exch(c) && c->recv_dev) HIPCHK(c, hipMemsetAsync(c->recv_dev, 0, (size_t)c->world * c->C * kCamRec * 4, c->stream));
   c->uploaded = true;
   c->beliefs_valid = false;
@@ -357,31 +479,37 @@ GBP_EXPORT(gbp_upload, c, (gbp_ctx* c, const gbp_state_in* in), (c, in)) {
 GBP_EXPORT(gbp_read, c, (gbp_ctx* c, gbp_state_out* o), (c, o)) {
   if (!c || !o) return GBP_ERR_INVALID;
   if (int rc = gbp_sync(c)) return rc;
-  if (o->cam_beliefs_eta || o->cam_beliefs_lambda) {
-    std::vector<float> rec((size_t)c->C * kCamRec);
-    HIPCHK(c, hipMemcpy(rec.data(), c->camb.p, rec.size() * 4, hipMemcpyDeviceToHost));
+  const bool want_cam = o->cam_beliefs_eta || o->cam_beliefs_lambda, want_lmk = (o->lmk_beliefs_eta || o->lmk_beliefs_lambda) && c->L_loc;
+  const bool want_state = o->damping || o->damping_count || o->robust_flag;
+  std::vector<float> rec_c(want_cam ? (size_t)c->C * kCamRec : 0), rec_l(want_lmk ? (size_t)c->L_loc * 16 : 0), damp(want_state ? c->Ep : 0);
+  std::vector<int32_t> packed(want_state ? c->Ep : 0);
+  if (want_state) {
+    // per-factor scalars ride in the message records: a small kernel extracts them into two compact arrays
+    launch_state_get(P<float4>(c->lmsg), P<float>(c->st_a), P<int>(c->st_b), c->Ep, c->stream);
+    HIPCHK(c, hipGetLastError());
+  }
+  D2H down;
+  if (int rc = down.begin(c, (rec_c.size() + rec_l.size() + damp.size() + packed.size()) * 4, 4)) return rc;
+  if (int rc = down.get(rec_c.data(), c->camb.p, rec_c.size() * 4)) return rc;
+  if (int rc = down.get(rec_l.data(), c->lmkb.p, rec_l.size() * 4)) return rc;
+  if (int rc = down.get(damp.data(), c->st_a.p, damp.size() * 4)) return rc;
+  if (int rc = down.get(packed.data(), c->st_b.p, packed.size() * 4)) return rc;
+  if (int rc = down.end()) return rc;
+  if (want_cam) {
+    const std::vector<float>& rec = rec_c;
     for (uint32_t k = 0; k < c->C; ++k) {
       if (o->cam_beliefs_eta) std::memcpy(o->cam_beliefs_eta + (size_t)k * 6, &rec[(size_t)k * kCamRec], 6 * 4);
       if (o->cam_beliefs_lambda) std::memcpy(o->cam_beliefs_lambda + (size_t)k * 36, &rec[(size_t)k * kCamRec + 8], 36 * 4);
     }
   }
-  if ((o->lmk_beliefs_eta || o->lmk_beliefs_lambda) && c->L_loc) {
-    std::vector<float> rec((size_t)c->L_loc * 16);
-    HIPCHK(c, hipMemcpy(rec.data(), c->lmkb.p, rec.size() * 4, hipMemcpyDeviceToHost));
+  if (want_lmk) {
+    const std::vector<float>& rec = rec_l;
     for (uint32_t l = 0; l < c->L_loc; ++l) {
       if (o->lmk_beliefs_eta) std::memcpy(o->lmk_beliefs_eta + (size_t)(c->lmk_begin + l) * 3, &rec[(size_t)l * 16], 3 * 4);
       if (o->lmk_beliefs_lambda) std::memcpy(o->lmk_beliefs_lambda + (size_t)(c->lmk_begin + l) * 9, &rec[(size_t)l * 16 + 4], 9 * 4);
     }
   }
-  if (o->damping || o->damping_count || o->robust_flag) {
-    // per-factor scalars ride in the message records: a small kernel extracts them into two compact arrays
-    launch_state_get(P<float4>(c->lmsg), P<float>(c->st_a), P<int>(c->st_b), c->Ep, c->stream);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    std::vector<float> damp(c->Ep);
-    std::vector<int32_t> packed(c->Ep);
-    HIPCHK(c, hipMemcpy(damp.data(), c->st_a.p, (size_t)c->Ep * 4, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(packed.data(), c->st_b.p, (size_t)c->Ep * 4, hipMemcpyDeviceToHost));
+  if (want_state) {
     for (size_t p = 0; p < c->Ep; ++p) {
       const uint32_t e = c->lay.pos_edge[p];
       if (e == ~0u) continue;
@@ -397,15 +525,18 @@ GBP_EXPORT(gbp_read, c, (gbp_ctx* c, gbp_state_out* o), (c, o)) {
 GBP_EXPORT(gbp_read_priors, c, (gbp_ctx* c, gbp_priors_out* o), (c, o)) {
   if (!c || !o) return GBP_ERR_INVALID;
   if (int rc = gbp_sync(c)) return rc;
-  std::vector<float> rec((size_t)c->C * kCamRec);
-  HIPCHK(c, hipMemcpy(rec.data(), c->camp.p, rec.size() * 4, hipMemcpyDeviceToHost));
+  std::vector<float> rec((size_t)c->C * kCamRec), rec_l((size_t)c->L_loc * 16);
+  D2H down;
+  if (int rc = down.begin(c, (rec.size() + rec_l.size()) * 4, 2)) return rc;
+  if (int rc = down.get(rec.data(), c->camp.p, rec.size() * 4)) return rc;
+  if (int rc = down.get(rec_l.data(), c->lmkp.p, rec_l.size() * 4)) return rc;
+  if (int rc = down.end()) return rc;
   for (uint32_t k = 0; k < c->C; ++k) {
     if (o->cam_priors_eta) std::memcpy(o->cam_priors_eta + (size_t)k * 6, &rec[(size_t)k * kCamRec], 6 * 4);
     if (o->cam_priors_lambda) std::memcpy(o->cam_priors_lambda + (size_t)k * 36, &rec[(size_t)k * kCamRec + 8], 36 * 4);
   }
   if (c->L_loc) {
-    rec.resize((size_t)c->L_loc * 16);
-    HIPCHK(c, hipMemcpy(rec.data(), c->lmkp.p, rec.size() * 4, hipMemcpyDeviceToHost));
+    rec.swap(rec_l);
     for (uint32_t l = 0; l < c->L_loc; ++l) {
       if (o->lmk_priors_eta) std::memcpy(o->lmk_priors_eta + (size_t)(c->lmk_begin + l) * 3, &rec[(size_t)l * 16], 3 * 4);
       if (o->lmk_priors_lambda) std::memcpy(o->lmk_priors_lambda + (size_t)(c->lmk_begin + l) * 9, &rec[(size_t)l * 16 + 4], 9 * 4);
@@ -439,8 +570,11 @@ GBP_EXPORT(gbp_new_keyframe, c, (gbp_ctx* c, const gbp_kf_update* u), (c, u)) {
         ctl[p] |= 2u | (on ? 4u : 0u);
       }
     }
-    HIPCHK(c, hipMemcpy(c->st_b.p, cnt.data(), (size_t)c->Ep * 4, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->st_a.p, ctl.data(), (size_t)c->Ep * 4, hipMemcpyHostToDevice));
+    H2D up;
+    if (int rc = up.begin(c, (size_t)c->Ep * 8, 2)) return rc;
+    if (int rc = up.put(c->st_b.p, cnt.data(), (size_t)c->Ep * 4)) return rc;
+    if (int rc = up.put(c->st_a.p, ctl.data(), (size_t)c->Ep * 4)) return rc;
+    if (int rc = up.end()) return rc;
     launch_state_set(P<float4>(c->lmsg), P<int>(c->st_b), P<uint32_t>(c->st_a), c->Ep, c->stream);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -448,19 +582,23 @@ GBP_EXPORT(gbp_new_keyframe, c, (gbp_ctx* c, const gbp_kf_update* u), (c, u)) {
       for (size_t p = 0; p < c->Ep; ++p)
         if (c->lay.pos_edge[p] != ~0u) c->active_host[p] = u->active_flag[c->lay.pos_edge[p]] == 1;
   }
+  H2D up;
+  if (int rc = up.begin(c, ((size_t)c->C + c->L_loc) * (kCamRec + 16 + 1) * 4, 4)) return rc;
   if (u->cam_priors_eta && u->cam_priors_lambda) {
     std::vector<float> rec;
     pack_cam(u->cam_priors_eta, u->cam_priors_lambda, c->C, rec);
-    HIPCHK(c, hipMemcpy(c->camp.p, rec.data(), rec.size() * 4, hipMemcpyHostToDevice));
+    if (int rc = up.put(c->camp.p, rec.data(), rec.size() * 4)) return rc;
   }
   if (u->lmk_priors_eta && u->lmk_priors_lambda && c->L_loc) {
     std::vector<float> rec;
     pack_lmk(u->lmk_priors_eta, u->lmk_priors_lambda, c->lmk_begin, c->L_loc, rec);
-    HIPCHK(c, hipMemcpy(c->lmkp.p, rec.data(), rec.size() * 4, hipMemcpyHostToDevice));
+    if (int rc = up.put(c->lmkp.p, rec.data(), rec.size() * 4)) return rc;
   }
-  if (u->cam_weaken_flag) HIPCHK(c, hipMemcpy(c->cwf.p, u->cam_weaken_flag, (size_t)c->C * 4, hipMemcpyHostToDevice));
+  if (u->cam_weaken_flag)
+    if (int rc = up.put(c->cwf.p, u->cam_weaken_flag, (size_t)c->C * 4)) return rc;
   if (u->lmk_weaken_flag && c->L_loc)
-    HIPCHK(c, hipMemcpy(c->lwf.p, u->lmk_weaken_flag + c->lmk_begin, (size_t)c->L_loc * 4, hipMemcpyHostToDevice));
+    if (int rc = up.put(c->lwf.p, u->lmk_weaken_flag + c->lmk_begin, (size_t)c->L_loc * 4)) return rc;
+  if (int rc = up.end()) return rc;
   return refresh_beliefs_from_partials(c, false);
 }
 

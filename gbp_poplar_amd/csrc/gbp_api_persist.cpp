@@ -8,6 +8,7 @@
 #include "gbp_ctx.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <mutex>
 
@@ -98,6 +99,7 @@ int persist_setup(gbp_ctx* c, const gbp_params* prm, bool sharded) {
         std::lock_guard<std::mutex> lock(g_persist_mu);
         if (g_persist_event[dev & 15] && g_persist_last_ctx[dev & 15]) (void)hipStreamWaitEvent(c->stream, g_persist_event[dev & 15], 0);
         bool ok = false;
+        const auto t_probe = std::chrono::steady_clock::now();
         if (coop_mode > 0 && coop_attr) {
           ok = persist_probe(c->n_tiles, c->C, c->L_loc, P<unsigned>(c->psync), static_cast<unsigned*>(c->pstatus_dev),
                              static_cast<volatile unsigned*>(c->pstatus_host), true, c->stream);
@@ -110,6 +112,7 @@ int persist_setup(gbp_ctx* c, const gbp_params* prm, bool sharded) {
                              static_cast<volatile unsigned*>(c->pstatus_host), false, c->stream);
           if (!ok) c->err = "k_persist: the workgroups of this graph are not co-resident under the spread placement on this device (probe timed out)";
         }
+        c->probe_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_probe).count();
         if (!ok) c->err += "; iterations run on the two-kernel path";
         c->persist_ok = c->persist_eligible = ok;
         if (ok) CK(hipMemsetAsync(c->psync.p, 0, kPersistSyncWords * sizeof(unsigned), c->stream), "hipMemsetAsync");   // counter back to 0 after the probe

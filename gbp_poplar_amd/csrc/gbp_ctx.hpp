@@ -58,6 +58,11 @@ struct gbp_ctx {
   std::vector<DevBuf*> all;
   DevBuf row_cam, lmk_idx, fac, cmsg, mu, lmsg, camb, camp, lmkb, lmkp, rowp, local, d_cam_row_ptr, d_row_slot, d_lmk_ptr, cwf, lwf,
       cscale, lscale, cam_mu, lmk_mu, dK, evalp, hmu_c, hmu_l, clin, d_lmk_fpos, d_lmk_ix, health, tile_perm;
+  // host -> device copies of small graphs go through this pinned, device-mapped buffer and a copy kernel (gbp_api_ctx.cpp: H2D)
+  void* stage_host = nullptr;
+  void* stage_dev = nullptr;
+  size_t stage_cap = 0;
+  DevBuf idx_arena;                    // the index arrays of the device order (row_cam, lmk_idx, lmk_fpos, lmk_ix, the row / landmark pointers, row_slot, K, tile_perm: views into it)
   DevBuf st_a, st_b;                   // [Ep] scratch of the per-factor state get / set kernels
   std::vector<uint8_t> active_host;    // [Ep] host shadow of the active flags (hoist guard of gbp_new_keyframe)
   bool use_tile_perm = false;
@@ -125,6 +130,7 @@ struct gbp_ctx {
   gbp::CopySegs snap_save{}, snap_restore{};
   std::string warn;                    // text of the last recovered incident (also left in `err`, the call returns GBP_OK)
   uint64_t persist_recoveries = 0;
+  double probe_ms = 0;                 // gbp_create: what the co-residency probe took (the first kernel launch of the process: code-object load included)
   DevBuf psync;                        // barrier words
   void* pstatus_host = nullptr;        // pinned + device-mapped: raised by the kernel if a barrier gave up
   void* pstatus_dev = nullptr;
@@ -162,6 +168,33 @@ int dev_alloc(gbp_ctx* c, DevBuf& b, size_t bytes);         // zero-filled devic
 template <class T> inline T* P(DevBuf& b) { return static_cast<T*>(b.p); }
 // does this ctx combine camera partials through exchange buffers (sharded, or a 1-rank communicator)?
 inline bool exch(const gbp_ctx* c) { return c->world > 1 || c->comm != nullptr; }
+// The host -> device copies of ONE call (gbp_create, gbp_upload, gbp_new_keyframe).  The first small and the first medium-sized
+// hipMemcpy of a process cost 11 - 15 ms and 7 - 9 ms on this stack (set-up of two copy paths inside the runtime, profiles/exp_first_copy.hip)
+// — more than the 1 500 iterations of a `ba fr1xyz` run.  A call that moves at most kStageMax bytes therefore stages its pieces in one
+// pinned, device-mapped buffer and moves them with k_copy_segments on the ctx's stream (first launch 0.4 ms, then PCIe speed); larger
+// calls use hipMemcpy, where those milliseconds do not matter.  put() copies out of `src` before it returns; end() returns with
+// everything on the device (it synchronises the ctx's stream).
+struct H2D {
+  static constexpr size_t kStageMax = (size_t)32 << 20;
+  gbp_ctx* c = nullptr;
+  bool direct = true;
+  size_t used = 0;
+  CopySegs segs{};
+  int begin(gbp_ctx* ctx, size_t total_bytes, int pieces);
+  int put(void* dst_dev, const void* src, size_t bytes);      // dst: a whole DevBuf or a 16-byte aligned piece whose padded size is inside one
+  int end();
+  int flush();
+};
+// ... and the device -> host copies of one call (gbp_read, gbp_read_priors), the same way round: get() queues, end() returns with every
+// destination filled (the first device -> host hipMemcpy of a process pays the same set-up when no host -> device one came before it)
+struct D2H {
+  struct Out { void* dst; size_t off, bytes; };
+  H2D up;
+  std::vector<Out> pending;
+  int begin(gbp_ctx* ctx, size_t total_bytes, int pieces);
+  int get(void* dst_host, const void* src_dev, size_t bytes);
+  int end();
+};
 // timing brackets of the iterate calls (read later: gbp_timing, or when the ring is full)
 int resolve_spans(gbp_ctx* c, bool wait);
 int span_begin(gbp_ctx* c, gbp_ctx::Span& sp);

@@ -14,7 +14,9 @@
  * negative gbp_status otherwise (text via gbp_last_error).  All pointers are HOST memory owned by
  * the caller unless the name ends in `_dev`.  A ctx is not thread-safe; calls are blocking unless
  * stated.  All floating point is IEEE fp32, integers are 32-bit, layouts are the reference's
- * row-major AoS host layouts (ba/ba.cpp:690-713,778-790).
+ * row-major AoS host layouts (ba/ba.cpp:690-713,778-790).  All device work of a ctx is ordered on ITS stream (its own, or the one handed
+ * over with gbp_set_stream), copies to and from the host included: nothing goes through the NULL stream, so work a caller queues on other
+ * streams is the caller's to synchronise with.
  */
 #ifndef GBP_MI355X_H
 #define GBP_MI355X_H
@@ -218,6 +220,8 @@ GBP_API int  gbp_create(const gbp_problem* problem, const gbp_params* params /*N
                 const gbp_shard* shard /*NULL=single GPU*/, gbp_ctx** out);
 GBP_API void gbp_destroy(gbp_ctx* ctx);
 GBP_API const char* gbp_last_error(const gbp_ctx* ctx /*NULL = last create error*/);
+/* (a call that returned GBP_OK may leave a line that starts with "warning:" — a recovered incident — or, after gbp_create, with "info:":
+ *  where the call spent its time: device order, runtime, allocation, layout upload, persistent-kernel set-up; the CLIs' --profile quotes it) */
 
 /* ---- the program list ------------------------------------------------------------------- */
 GBP_API int gbp_upload(gbp_ctx* ctx, const gbp_state_in* in);          /* WRITE_PROG      ba.cpp:868-886  */

@@ -32,6 +32,7 @@ void launch_eval(const uint32_t*, const uint32_t*, const float4*, const float4*,
                  const unsigned long long*, unsigned long long*, uint32_t, hipStream_t) { no_device("launch_eval"); }
 uint32_t eval_blocks(uint32_t n_tiles) { return (n_tiles + 3) / 4; }
 bool lab_launch_sweep_ablated(const SweepArgs&, uint32_t, int, hipStream_t) { return false; }
+bool launch_flow_torture(float4*, unsigned long long*, int, int, int, unsigned, unsigned, int, hipStream_t) { no_device("launch_flow_torture"); }
 bool debug_math_widths(int, int*, int*) { return false; }
 void launch_debug_math(int, const float*, float*, int, hipStream_t) { no_device("launch_debug_math"); }
 

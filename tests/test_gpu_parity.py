@@ -2132,10 +2132,11 @@ def test_iterations_captured_into_a_callers_graph_use_the_two_kernel_path(oracle
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph, stream=stream):
         eng.iterate(4)
-    for _ in range(3):
-        graph.replay()
-    stream.synchronize()
-    eng.set_stream(0)
+    with torch.cuda.stream(stream):                    # (CUDAGraph.replay launches on torch's CURRENT stream, whatever stream captured it)
+        for _ in range(3):
+            graph.replay()
+    stream.synchronize()                               # the caller's work on the caller's stream is the caller's to wait for: gbp_read
+    eng.set_stream(0)                                  # orders against the ctx's stream only (it no longer goes through the NULL stream)
     g, o = eng.read(), ref.read()
     for k in g:
         assert np.array_equal(g[k], o[k], equal_nan=True), k
@@ -2180,7 +2181,8 @@ def test_capture_begun_with_bursts_in_flight_is_refused_not_broken(oracle_mod):
     graph2 = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph2, stream=stream):
         eng.iterate(2)
-    graph2.replay()
+    with torch.cuda.stream(stream):                    # (replay launches on torch's current stream)
+        graph2.replay()
     stream.synchronize()
     eng.set_stream(0)
     ref.iterate(2)
