@@ -96,6 +96,7 @@ _DEBUG_SIGS = {
     "gbp_debug_layout_default_options": (None, [C.POINTER(cabi.GbpLayoutOptions)]),
     "gbp_debug_layout_options": (C.c_int, [C.POINTER(cabi.GbpLayoutOptions)]),
     "gbp_debug_force_sweep_policy": (C.c_int, [C.c_int]),
+    "gbp_debug_force_seg_skip": (C.c_int, [C.c_int]),
     "gbp_debug_persist_flow": (C.c_int, [C.c_void_p, C.c_int]),
     "gbp_debug_persist_verify": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]),
     "gbp_debug_flow_torture": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int, C.POINTER(C.c_uint64)]),

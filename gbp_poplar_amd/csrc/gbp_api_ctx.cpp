@@ -21,6 +21,7 @@ namespace api {
 
 LayoutOptions g_layout_options;
 int g_force_sweep_policy = -1;
+int g_force_seg_skip = -1;
 
 std::string& create_error() {
   thread_local std::string g_create_error;
@@ -317,14 +318,31 @@ GBP_EXPORT(gbp_create, nullptr, (const gbp_problem* pr, const gbp_params* prm, c
   // ---- device allocations (zero-filled on the ctx's stream) ----
   auto A = [&](DevBuf& b, size_t bytes) { if (rc == GBP_OK) rc = dev_alloc(c, b, bytes); };
   const size_t Ep = c->Ep;
-  // The index arrays of the device order live in ONE allocation and go up in ONE copy: a blocking hipMemcpy of a few KB costs ~1 ms on
-  // this stack whatever its size (the nine separate copies were 16 of the 37 ms of a `ba fr1xyz` gbp_create: profiles/r06_configs.md)
+  // The index arrays of the device order live in ONE allocation and go up in ONE copy (H2D, gbp_ctx.hpp)
   struct Piece { DevBuf* b; const void* src; size_t bytes; size_t off; };
   Piece pieces[] = {{&c->row_cam, y.row_cam.data(), y.row_cam.size() * 4, 0}, {&c->lmk_idx, y.pos_lmk_loc.data(), Ep * 4, 0},
                     {&c->d_lmk_fpos, y.lmk_fpos.data(), (size_t)c->E_loc * 4, 0}, {&c->d_lmk_ix, y.lmk_ix.data(), (size_t)c->L_loc * 64, 0},
                     {&c->d_cam_row_ptr, y.cam_row_ptr.data(), (size_t)(C + 1) * 4, 0}, {&c->d_lmk_ptr, y.lmk_ptr.data(), (size_t)(c->L_loc + 1) * 4, 0},
                     {&c->d_row_slot, y.row_slot.data(), y.row_slot.size() * 4, 0}, {&c->dK, c->K, 9 * 4, 0},
-                    {&c->tile_perm, y.tile_perm.data(), y.tile_perm.size() * 4, 0}};
+                    {&c->tile_perm, y.tile_perm.data(), y.tile_perm.size() * 4, 0}, {&c->seg_live, nullptr, 0, 0}};
+  // Which 64-byte segments (four positions) of a tile hold a factor at all?  A camera is padded to whole rows of 16: the tail of its
+  // last row is empty — on a graph of many small cameras (BASELINE config 5: ~156 factors per camera and rank) the all-pad segments
+  // are 3.7 % of all positions, which the sweep then neither streams in nor out (k_sweep<..., SEG>).  Used where it is worth a kernel
+  // of its own: at least 1 % of the positions, a graph that runs on the two-kernel path with the default cache policy.
+  std::vector<uint32_t> seg_live(y.n_tiles, 0u);
+  size_t dead = 0;
+  for (size_t t = 0; t < y.n_tiles; ++t) {
+    uint32_t m = 0;
+    for (uint32_t sgi = 0; sgi < 16; ++sgi)
+      for (uint32_t k = 0; k < 4; ++k)
+        if (y.pos_edge[t * 64 + sgi * 4 + k] != kNoEdge) { m |= 1u << sgi; break; }
+    seg_live[t] = m;
+    dead += 16u - (uint32_t)__builtin_popcount(m);
+  }
+  const char* seg_env = std::getenv("GBP_SEG_SKIP");      // A/B measurements (bench.py, the CLIs): 0 = never, 1 = always; results are identical
+  const int seg_force = g_force_seg_skip >= 0 ? g_force_seg_skip : (seg_env ? (seg_env[0] == '1') : -1);
+  const bool use_seg = c->hoist && c->sweep_policy == 0u && (seg_force >= 0 ? seg_force == 1 : (dead * 4 * 100 >= (size_t)c->Ep && y.n_tiles >= 2048));
+  if (use_seg) { pieces[9].src = seg_live.data(); pieces[9].bytes = seg_live.size() * 4; }
   size_t idx_bytes = 0;
   for (Piece& pc : pieces) { pc.off = idx_bytes; idx_bytes += (std::max<size_t>(pc.bytes, 256) + 255) / 256 * 256; }      // (>= 256 B each: pad lanes of an empty shard read index 0)
   A(c->idx_arena, idx_bytes);
@@ -362,6 +380,7 @@ GBP_EXPORT(gbp_create, nullptr, (const gbp_problem* pr, const gbp_params* prm, c
   step("the copy of the device order");
   // the XCD-aware execution order of the sweep: wave slot -> tile (gbp_layout.cpp); read once per wave with a scalar load
   c->use_tile_perm = rc == GBP_OK && !y.tile_perm.empty();
+  c->use_seg_live = rc == GBP_OK && use_seg;
   if (rc != GBP_OK) return rc;
   const double upload_ms = ms_since(t_phase);
   t_phase = clk::now();

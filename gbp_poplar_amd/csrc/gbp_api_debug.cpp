@@ -142,6 +142,7 @@ GBP_EXPORT_VOID(gbp_debug_layout_default_options, (gbp_layout_options* o), (o)) 
 }
 GBP_EXPORT(gbp_debug_layout_options, nullptr, (const gbp_layout_options* o), (o)) { g_layout_options = to_options(o); return GBP_OK; }
 GBP_EXPORT(gbp_debug_force_sweep_policy, nullptr, (int policy), (policy)) { g_force_sweep_policy = policy; return GBP_OK; }
+GBP_EXPORT(gbp_debug_force_seg_skip, nullptr, (int mode), (mode)) { g_force_seg_skip = mode; return GBP_OK; }
 GBP_EXPORT(gbp_debug_persist_roles, nullptr, (uint32_t n_tiles, uint32_t n_cams, uint32_t n_lmks, int with_metric, uint32_t* dims, uint32_t* role, uint32_t cap),
            (n_tiles, n_cams, n_lmks, with_metric, dims, role, cap)) {
   if (!dims) return GBP_ERR_INVALID;

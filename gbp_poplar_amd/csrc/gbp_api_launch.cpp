@@ -26,6 +26,7 @@ SweepArgs sweep_args(gbp_ctx* c) {
   a.hp.nstds = c->prm.nstds; a.hp.relin_mode = c->prm.relin_mode;
   a.variant = c->prm.reserved[0];      // read by the experiments build only
   a.tile_perm = c->use_tile_perm ? P<uint32_t>(c->tile_perm) : nullptr;
+  a.seg_live = c->use_seg_live ? P<uint32_t>(c->seg_live) : nullptr;
   a.policy = c->sweep_policy;
   a.ev = EvalRide{};
   return a;

@@ -66,6 +66,8 @@ struct gbp_ctx {
   DevBuf st_a, st_b;                   // [Ep] scratch of the per-factor state get / set kernels
   std::vector<uint8_t> active_host;    // [Ep] host shadow of the active flags (hoist guard of gbp_new_keyframe)
   bool use_tile_perm = false;
+  DevBuf seg_live;                     // [n_tiles] which 64-byte segments of a tile hold a factor (view into idx_arena; SweepArgs.seg_live)
+  bool use_seg_live = false;
   uint32_t sweep_policy = 0;           // kPol* bits of SweepArgs.policy for this graph's shape (sweep_policy_for)
   bool hoist = true;  // per-variable belief means (k_sweep<true>); false = literal per-factor mu/oldmu tensors
   void* send_dev = nullptr;
@@ -206,6 +208,7 @@ int event_pair(gbp_ctx* c, hipEvent_t* a, hipEvent_t* b);
 // test-hooks build can change them (gbp_debug_layout_options / gbp_debug_force_sweep_policy: measurements and tests).
 extern LayoutOptions g_layout_options;
 extern int g_force_sweep_policy;
+extern int g_force_seg_skip;      // -1: by shape; 0 / 1: never / always skip the all-pad segments in the sweep (gbp_debug_force_seg_skip)
 
 // Per-factor scalar state lives in the pad slots of the LMSG records (gbp_kernels.h): {damping, count, flags, variance} per
 // device position, as the host code sees it.

@@ -101,6 +101,9 @@ struct SweepArgs {
   const uint32_t* tile_perm; // [n_tiles] or NULL: wave slot (4 * block + wave) -> tile.  The XCD-aware execution order (gbp_layout.cpp):
                              // workgroups are dealt round-robin over the 8 XCDs, the table hands every XCD the tiles of one landmark
                              // class so that its private L2 holds that slice of the gathered landmark tables
+  const uint32_t* seg_live;  // [n_tiles] or NULL: bit s = the 64-byte segment (lanes 4s .. 4s + 3) of the tile holds a factor; with it the sweep
+                             // neither loads nor stores the all-pad segments (k_sweep<..., SEG>): graphs of many small cameras, where the unused
+                             // tails of the cameras' last rows are a few per cent of all positions
   uint32_t policy;           // kPol* bits: cache policy of the two message streams, chosen per graph shape (gbp_api_ctx.cpp: sweep_policy_for)
   EvalRide ev;               // k_sweep<EV> only
 };

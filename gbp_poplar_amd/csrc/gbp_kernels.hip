@@ -44,6 +44,39 @@ GBP_DEV void store_tile(float4* base, uint32_t tile, uint32_t lane, const float 
     if (NT) __builtin_nontemporal_store(v, p + g * 64); else p[g * 64] = v;
   }
 }
+// SEG (k_sweep<..., SEG = true>): the same tile accesses through a buffer descriptor that covers exactly this tile's G KiB, so that
+// a lane whose 64-byte segment (four lanes) holds PAD positions only can be given an offset beyond the descriptor's range: the
+// hardware then returns zeros for a load and drops a store WITHOUT a memory access — no branch, no divergence, and the all-pad
+// segments (the unused tail of a camera's last row: 3.7 % of the positions on the config-5 shard shape) are never streamed in or
+// out.  Measured on that shape: 839 -> 813 MB per ordinary sweep (reads only drop where BOTH halves of a 128-byte line are empty,
+// writes per 64 bytes), 0.1551 -> 0.1532 ms per iteration (profiles/r06_configs.md).  aux: 2 = the non-temporal hint of the gfx94x / gfx950 buffer instructions.
+constexpr int kBufOob = 0x40000000;      // beyond every tile descriptor (<= 14 KiB), and + g KiB does not wrap
+template <int G>
+GBP_DEV __amdgpu_buffer_rsrc_t tile_rsrc(const float4* base, uint32_t tile) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(base) + (size_t)tile * G * 64, 0, G * 1024, 0x00020000);
+}
+template <int G, bool NT = true>
+GBP_DEV void load_tile_seg(const float4* base, uint32_t tile, uint32_t lane, bool live, float (&out)[G * 4]) {
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t r = tile_rsrc<G>(base, tile);
+  const int off = live ? (int)(lane * 16u) : kBufOob;
+  GBP_UNROLL
+  for (int g = 0; g < G; ++g) {
+    const v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, off + g * 1024, 0, NT ? 2 : 0);
+    out[4 * g] = __uint_as_float(v.x); out[4 * g + 1] = __uint_as_float(v.y); out[4 * g + 2] = __uint_as_float(v.z); out[4 * g + 3] = __uint_as_float(v.w);
+  }
+}
+template <int G, bool NT = true>
+GBP_DEV void store_tile_seg(float4* base, uint32_t tile, uint32_t lane, bool live, const float (&in)[G * 4]) {
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t r = tile_rsrc<G>(base, tile);
+  const int off = live ? (int)(lane * 16u) : kBufOob;
+  GBP_UNROLL
+  for (int g = 0; g < G; ++g) {
+    const v4u v = {__float_as_uint(in[4 * g]), __float_as_uint(in[4 * g + 1]), __float_as_uint(in[4 * g + 2]), __float_as_uint(in[4 * g + 3])};
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, off + g * 1024, 0, NT ? 2 : 0);
+  }
+}
 template <int G>
 GBP_DEV void load_rec(const float4* rec, float (&out)[G * 4]) {
   GBP_UNROLL
@@ -620,7 +653,8 @@ constexpr int kWpb = 4;      // wavefronts per workgroup of the sweep (the waves
 // POL: cache policy of the two message streams (SweepArgs.policy, chosen per graph shape by gbp_api_ctx.cpp; a template parameter,
 // not a branch on the flag: with both load sequences behind a branch the non-temporal path lost 1.2 %)
 // EV: the metric of the PREVIOUS iteration rides in this sweep (EvalRide in gbp_kernels.h)
-template <bool HOIST, uint32_t POL = 0, bool EV = false>
+// SEG: the tile's all-pad 64-byte segments are neither loaded nor stored (SweepArgs.seg_live, load_tile_seg above)
+template <bool HOIST, uint32_t POL = 0, bool EV = false, bool SEG = false>
 GBP_DEV void sweep_tile(const SweepArgs& a, const uint32_t wslot) {
   // (the slot is wave-uniform: as an SGPR it turns the permutation look-up into one scalar load)
   const uint32_t ws = (uint32_t)__builtin_amdgcn_readfirstlane((int)wslot);
@@ -631,12 +665,17 @@ GBP_DEV void sweep_tile(const SweepArgs& a, const uint32_t wslot) {
   const uint32_t cam_i = a.row_cam[p >> 4];
   const uint32_t lmk_i = __builtin_nontemporal_load(a.lmk_idx + p);
 
+  // SEG: bit s of the tile's mask = the 64-byte segment of lanes 4s .. 4s + 3 holds at least one factor (one scalar load)
+  const uint32_t segm = SEG ? a.seg_live[tile] : 0xffffu;
+  const bool live8 = !SEG || ((segm >> (lane >> 2)) & 1u) != 0u;
   float fac[56], cm[28], mu[12], lm[16], cb[44], lb[16];
-  load_tile<kFacG>(a.fac, tile, lane, fac);
+  if (SEG) load_tile_seg<kFacG>(a.fac, tile, lane, live8, fac);
+  else load_tile<kFacG>(a.fac, tile, lane, fac);
   // The camera messages: non-temporal like the potentials, or — SweepArgs.cmsg_cached, graphs with few cameras — with the
   // default policy like the landmark messages below (both are rewritten in place by this tile).  The potentials, which an
   // ordinary sweep only reads, keep the hint on every graph: with default-policy loads they cost 3 %.
-  load_tile<kCmsgG, !(POL & kPolCmsgLoadCached)>(a.cmsg, tile, lane, cm);
+  if (SEG) load_tile_seg<kCmsgG, !(POL & kPolCmsgLoadCached)>(a.cmsg, tile, lane, live8, cm);
+  else load_tile<kCmsgG, !(POL & kPolCmsgLoadCached)>(a.cmsg, tile, lane, cm);
   if (!HOIST) load_tile<kMuG>(a.mu, tile, lane, mu);
   // Landmark messages live as 64-byte records in DEVICE (camera-major) order: the wave's 64 records are one
   // contiguous 4 KiB block, moved with four coalesced 1 KiB accesses and transposed through a wave-private
@@ -650,15 +689,25 @@ GBP_DEV void sweep_tile(const SweepArgs& a, const uint32_t wslot) {
   const uint32_t rec_t = lane >> 2;                                   // record handled in tile order (+16k)
   const uint32_t swz_own = ((lane >> 2) & 3u) ^ (lane & 2u);          // swizzle of the lane's own record
   float4* lm_tile = a.lmsg + (size_t)tile * 256;
+  // SEG: access k moves the records 16k .. 16k + 15 (four lanes each): lanes 16j .. 16j + 15 the records of segment 4k + j
+  const __amdgpu_buffer_rsrc_t lm_rsrc = tile_rsrc<4>(a.lmsg, SEG ? tile : 0u);
   GBP_UNROLL
   for (int k = 0; k < 4; ++k) {
     // (DEFAULT policy for this one stream unless the shape says otherwise: the tile is rewritten in place ten microseconds later
     // and gathered by k_beliefs right after the sweep — measured +1.5 % iterations/s on the 1M-factor graph against the
     // non-temporal hint, with either store policy; the potentials keep the hint on every graph)
-    const v4f* src = reinterpret_cast<const v4f*>(lm_tile) + k * 64 + lane;
-    const v4f v = (POL & kPolLmsgLoadNt) ? __builtin_nontemporal_load(src) : *src;
     const uint32_t r = k * 16 + rec_t;
-    stage[r * 4 + ((lane & 3u) ^ (((r >> 2) & 3u) ^ (r & 2u)))] = make_float4(v.x, v.y, v.z, v.w);
+    if (SEG) {
+      typedef unsigned v4u __attribute__((ext_vector_type(4)));
+      const bool live_k = ((segm >> (4 * k + (int)(lane >> 4))) & 1u) != 0u;
+      const v4u v = __builtin_amdgcn_raw_buffer_load_b128(lm_rsrc, (live_k ? (int)(lane * 16u) : kBufOob) + k * 1024, 0, (POL & kPolLmsgLoadNt) ? 2 : 0);
+      stage[r * 4 + ((lane & 3u) ^ (((r >> 2) & 3u) ^ (r & 2u)))] =
+          make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    } else {
+      const v4f* src = reinterpret_cast<const v4f*>(lm_tile) + k * 64 + lane;
+      const v4f v = (POL & kPolLmsgLoadNt) ? __builtin_nontemporal_load(src) : *src;
+      stage[r * 4 + ((lane & 3u) ^ (((r >> 2) & 3u) ^ (r & 2u)))] = make_float4(v.x, v.y, v.z, v.w);
+    }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -686,6 +735,7 @@ GBP_DEV void sweep_tile(const SweepArgs& a, const uint32_t wslot) {
   }
   // per-factor scalar state rides in the pad slots of the landmark-message record (read and rewritten
   // every sweep anyway): [3] damping, [13] (damping_count << 3) | flags, [14] measurement variance
+  if (SEG && !live8) lm[13] = __int_as_float((int)kFlagPad);      // (the record that was not loaded: a pad, as in memory)
   float damping = lm[3];
   const int packed = __float_as_int(lm[13]);
   int count = packed >> 3;
@@ -748,7 +798,12 @@ GBP_DEV void sweep_tile(const SweepArgs& a, const uint32_t wslot) {
   for (int k = 0; k < 4; ++k) {
     const uint32_t r = k * 16 + rec_t;
     const float4 f = stage[r * 4 + ((lane & 3u) ^ (((r >> 2) & 3u) ^ (r & 2u)))];
-    if (POL & kPolLmsgStoreNt) {
+    if (SEG) {
+      typedef unsigned v4u __attribute__((ext_vector_type(4)));
+      const bool live_k = ((segm >> (4 * k + (int)(lane >> 4))) & 1u) != 0u;
+      const v4u v = {__float_as_uint(f.x), __float_as_uint(f.y), __float_as_uint(f.z), __float_as_uint(f.w)};
+      __builtin_amdgcn_raw_buffer_store_b128(v, lm_rsrc, (live_k ? (int)(lane * 16u) : kBufOob) + k * 1024, 0, (POL & kPolLmsgStoreNt) ? 2 : 0);
+    } else if (POL & kPolLmsgStoreNt) {
       const v4f v = {f.x, f.y, f.z, f.w};
       __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(lm_tile) + k * 64 + lane);
     } else {
@@ -765,7 +820,8 @@ GBP_DEV void sweep_tile(const SweepArgs& a, const uint32_t wslot) {
       for (int j = 0; j <= i; ++j) cmo[6 + tri(i, j)] = oc_lam[i * 6 + j];
     }
     cmo[27] = 0.f;
-    store_tile<kCmsgG>(a.cmsg, tile, lane, cmo);
+    if (SEG) store_tile_seg<kCmsgG>(a.cmsg, tile, lane, live8, cmo);
+    else store_tile<kCmsgG>(a.cmsg, tile, lane, cmo);
   }
   // camera half of the belief reduction: per-row (16 factors of one camera) tree sums
   {
@@ -784,9 +840,9 @@ GBP_DEV void sweep_tile(const SweepArgs& a, const uint32_t wslot) {
   }
 }
 
-template <bool HOIST, uint32_t POL = 0, bool EV = false>
+template <bool HOIST, uint32_t POL = 0, bool EV = false, bool SEG = false>
 __global__ __launch_bounds__(64 * kWpb) void k_sweep(const SweepArgs a) {
-  sweep_tile<HOIST, POL, EV>(a, blockIdx.x * kWpb + (threadIdx.x >> 6));
+  sweep_tile<HOIST, POL, EV, SEG>(a, blockIdx.x * kWpb + (threadIdx.x >> 6));
 }
 
 // =================================================================================================
@@ -2171,8 +2227,10 @@ bool lab_launch_sweep(const SweepArgs& a, uint32_t n_tiles, bool hoist, hipStrea
 #endif
 void launch_sweep(const SweepArgs& a, uint32_t n_tiles, bool hoist, hipStream_t s, bool ev) {
   const dim3 g(n_tiles / kWpb), b(64 * kWpb);
+  const bool seg = a.seg_live && hoist && a.policy == 0u;      // a graph of many small cameras (gbp_api_ctx.cpp decides): the all-pad segments are skipped
   if (ev && hoist) {        // the metric rides along (gbp_iterate_eval_each beyond k_persist): the policies sweep_policy_for() chooses
-    if (a.policy == kPolCmsgLoadCached) hipLaunchKernelGGL((k_sweep<true, kPolCmsgLoadCached, true>), g, b, 0, s, a);
+    if (seg) hipLaunchKernelGGL((k_sweep<true, 0, true, true>), g, b, 0, s, a);
+    else if (a.policy == kPolCmsgLoadCached) hipLaunchKernelGGL((k_sweep<true, kPolCmsgLoadCached, true>), g, b, 0, s, a);
     else hipLaunchKernelGGL((k_sweep<true, 0, true>), g, b, 0, s, a);
     return;
   }
@@ -2180,6 +2238,7 @@ void launch_sweep(const SweepArgs& a, uint32_t n_tiles, bool hoist, hipStream_t 
   if (lab_launch_sweep(a, n_tiles, hoist, s)) return;     // a mapping experiment / an ablated sweep was asked for (SweepArgs.variant)
 #endif
   if (!hoist) { hipLaunchKernelGGL(k_sweep<false>, g, b, 0, s, a); return; }
+  if (seg) { hipLaunchKernelGGL((k_sweep<true, 0, false, true>), g, b, 0, s, a); return; }
   switch (a.policy) {      // the instantiations sweep_policy_for() (gbp_api_ctx.cpp) can choose
     case kPolCmsgLoadCached: hipLaunchKernelGGL((k_sweep<true, kPolCmsgLoadCached>), g, b, 0, s, a); break;
     case kPolLmsgLoadNt | kPolLmsgStoreNt: hipLaunchKernelGGL((k_sweep<true, kPolLmsgLoadNt | kPolLmsgStoreNt>), g, b, 0, s, a); break;

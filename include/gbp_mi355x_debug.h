@@ -63,6 +63,9 @@ GBP_API int gbp_debug_layout_options(const gbp_layout_options* opt);
 /* the cache policy of the sweep's message streams (SweepArgs.policy bits: 1 = camera messages loaded cached, 2 / 4 = landmark
  * messages loaded / stored non-temporal) later gbp_create calls use instead of the choice by graph shape; -1 = by shape */
 GBP_API int gbp_debug_force_sweep_policy(int policy);
+/* the sweep of later gbp_create calls skips the all-pad 64-byte segments of its tiles (k_sweep<..., SEG>): -1 = by shape (the default:
+ * graphs of >= 2 048 tiles where they are >= 1 % of the positions), 0 = never, 1 = always; identical results — A/B measurements and tests */
+GBP_API int gbp_debug_force_seg_skip(int mode);
 /* bursts without the metric on a graph that runs in the persistent kernel: 1 (default) = k_persist_flow (hand-offs through tagged
  * records, no device-wide barrier), 0 = k_persist<false> (counter barriers); identical results — A/B measurements and tests */
 GBP_API int gbp_debug_persist_flow(gbp_ctx* ctx, int on);

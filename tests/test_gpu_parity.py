@@ -1134,6 +1134,51 @@ def test_row_placement_is_unobservable():
     assert ea["n_relin"] == eb["n_relin"] and ea["n_robust"] == eb["n_robust"] and ea["sum_norm"] == eb["sum_norm"]
 
 
+@pytest.mark.parametrize("shape", ["config5_like", "ragged_small"])
+def test_skipping_all_pad_segments_is_unobservable(shape):
+    """on graphs of many small cameras the sweep neither loads nor stores the 64-byte segments of a tile that hold
+    pad positions only (k_sweep<..., SEG>: a buffer descriptor per tile, out-of-range offsets for the lanes of an all-pad segment — the
+    hardware returns zeros / drops the store without touching memory).  Pads are inactive factors whose records never change, so
+    nothing may change: forced on against forced off (gbp_debug_force_seg_skip), every tensor incl. both message sets and the
+    potentials, bit for bit through the start of a BA run with relinearisations, the plain sweep and the one the metric rides in
+    (gbp_ba_loop with metrics), on a 4 096-camera x 40 000-landmark graph (rows placed, tiles permuted: the shape that selects it by
+    itself) and on a small ragged graph with inactive factors where most segments of the last tiles are empty."""
+    from gbp_poplar_amd import _cabi, _lib, driver, hostlib
+    from gbp_poplar_amd.engine import GbpEngine
+    lib = _lib.load(hooks=True)
+    opts = driver.Options()
+    kw = {}
+    if shape == "config5_like":
+        bal = hostlib.synth_generate(4096, 40000, 10, 7)
+    else:
+        bal, kw = _ragged_bal()
+        opts.undamped_start = 2
+    K, state, _ = driver.build_inputs(bal, opts, hostlib)
+    if shape != "config5_like":
+        state["active_flag"] = _ragged_active(bal)
+    engs = []
+    try:
+        for mode in (1, 0):
+            assert lib.gbp_debug_force_seg_skip(mode) == 0
+            engs.append(GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K, hooks=True,
+                                  params=_cabi.GbpParams.defaults(persistent=-1, **kw)))
+    finally:
+        lib.gbp_debug_force_seg_skip(-1)
+    evs = []
+    for e in engs:
+        e.upload(state)
+        e.linearise()
+        out = e.ba_loop(14, 0, int(opts.steps))                    # the metric rides in k_sweep<EV, SEG>
+        e.ba_loop(25, 14, int(opts.steps), metrics=False)           # k_sweep<SEG> from the hipGraph
+        out += e.ba_loop(6, 39, int(opts.steps))
+        evs.append(out)
+    assert evs[0] == evs[1]
+    sa, sb = _full_snapshot(engs[0]), _full_snapshot(engs[1])
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k], equal_nan=True), (shape, k)
+    assert sum(e["n_relin"] for e in evs[0]) > 0 or shape == "config5_like"
+
+
 def test_sharded_slam_keyframes_on_one_gpu(oracle_mod):
     """READ_PRIORS / NEW_KEYFRAME on landmark-shard contexts (two shards on one GPU, exchange by device copies): the
     incremental SLAM flow of slam.cpp:1018-1055 with a keyframe every 12 sweeps == the oracle in 2-shard order."""
