@@ -579,4 +579,16 @@ inline int finish_run(const Options& o, const Problem& P, gbp_ctx* ctx, const Ra
   return wrc;
 }
 
+// The last step of main(): everything is written, the ctx is destroyed.  Normally the process then leaves WITHOUT running exit handlers
+// (std::_Exit) — the HIP runtime's take 15 - 30 ms in which the user's prompt does not come back, and the driver reclaims the process's
+// resources either way.  Under an injected library (LD_PRELOAD: rocprofv3, sanitizers — their reports are written by exit handlers) or
+// with GBP_CLI_FULL_EXIT set, the ordinary return.
+inline int leave(int rc) {
+  std::cout.flush();
+  std::cerr.flush();
+  std::fflush(nullptr);
+  if (std::getenv("LD_PRELOAD") || std::getenv("GBP_CLI_FULL_EXIT") || std::getenv("ROCP_TOOL_LIBRARIES")) return rc;
+  std::_Exit(rc);
+}
+
 }  // namespace cli

@@ -1234,15 +1234,20 @@ struct XwBufT {
   __amdgpu_buffer_rsrc_t r;
   uint32_t mirror4 = 0;
   unsigned long long* verr = nullptr;
-  GBP_DEV explicit XwBufT(const void* base, uint32_t mirror4_ = 0, unsigned long long* verr_ = nullptr)
-      : r(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000)), mirror4(mirror4_), verr(verr_) {}
+  // soff: byte offset of this array inside the allocation the descriptor covers — the scalar offset operand of the buffer instructions,
+  // an add the address unit does for nothing (and which its range check ignores: kNone4 stays out of range).  k_persist_flow describes
+  // its nine shadows, which live in ONE allocation, with one descriptor + nine such offsets instead of nine descriptors: 23 fewer
+  // live SGPRs in a kernel that spills them (profiles/r06_resources.md)
+  uint32_t soff = 0;
+  GBP_DEV explicit XwBufT(const void* base, uint32_t mirror4_ = 0, unsigned long long* verr_ = nullptr, uint32_t soff_ = 0)
+      : r(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000)), mirror4(mirror4_), verr(verr_), soff(soff_) {}
   static constexpr int kSc1 = 16;        // cache-policy bit of the gfx94x / gfx950 buffer instructions
   typedef unsigned v4u __attribute__((ext_vector_type(4)));
   GBP_DEV float4 ld4(uint32_t i4) const {   // float4 #i4 of the array
-    const v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(i4 * 16u), 0, kSc1);
+    const v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(i4 * 16u), (int)soff, kSc1);
     if (VER) {
       if (mirror4 != 0u && i4 < kNone4) {
-        const v4u m = __builtin_amdgcn_raw_buffer_load_b128(r, (int)((i4 + mirror4) * 16u), 0, kSc1);
+        const v4u m = __builtin_amdgcn_raw_buffer_load_b128(r, (int)((i4 + mirror4) * 16u), (int)soff, kSc1);
         if (m.w != v.w) return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), 0.f);      // one copy has not arrived yet
         if ((m.x != ~v.x || m.y != ~v.y || m.z != ~v.z) && v.w != 0u) atomicAdd(verr, 1ull);
       }
@@ -1254,17 +1259,17 @@ struct XwBufT {
   static constexpr uint32_t kNone4 = 0x0fffffffu;
   GBP_DEV void st4(uint32_t i4, const float4 v) const {
     const v4u x = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-    __builtin_amdgcn_raw_buffer_store_b128(x, r, (int)(i4 * 16u), 0, kSc1);
+    __builtin_amdgcn_raw_buffer_store_b128(x, r, (int)(i4 * 16u), (int)soff, kSc1);
     if (VER) {
       if (mirror4 != 0u) {
         const v4u y = {~x.x, ~x.y, ~x.z, x.w};
-        __builtin_amdgcn_raw_buffer_store_b128(y, r, (int)((i4 + mirror4) * 16u), 0, kSc1);
+        __builtin_amdgcn_raw_buffer_store_b128(y, r, (int)((i4 + mirror4) * 16u), (int)soff, kSc1);
       }
     }
   }
   // (the b32 intrinsics are typed unsigned: bit casts, not value conversions)
-  GBP_DEV float ld1(uint32_t i) const { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)(i * 4u), 0, kSc1)); }
-  GBP_DEV void st1(uint32_t i, const float v) const { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)(i * 4u), 0, kSc1); }
+  GBP_DEV float ld1(uint32_t i) const { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)(i * 4u), (int)soff, kSc1)); }
+  GBP_DEV void st1(uint32_t i, const float v) const { __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)(i * 4u), (int)soff, kSc1); }
 };
 using XwBuf = XwBufT<false>;
 template <int G>
@@ -1407,9 +1412,12 @@ __global__ __launch_bounds__(256) void k_persist_flow(const PersistArgs A) {
   float4* stage = lm_stage[wib];
   const uint32_t mir = VER ? F.mirror4 : 0u;
   unsigned long long* const verr = VER ? F.verify_errors : nullptr;
-  const Xw S_lmsg(F.lmsg, mir, verr), S_rowp(F.rowp, mir, verr), S_camb(F.camb, mir, verr), S_cmu(F.cmu, mir, verr), S_clin(F.clin, mir, verr),
-      S_lmkb(F.lmkb, mir, verr), S_lmu(F.lmu, mir, verr);
-  const Xw S_emc(F.emc, mir, verr), S_eml(F.eml, mir, verr);
+  // ONE descriptor (the shadows are one allocation, F.lmsg its start) + a scalar byte offset per array
+  const auto off_of = [&](const float4* q) { return (uint32_t)(reinterpret_cast<const char*>(q) - reinterpret_cast<const char*>(F.lmsg)); };
+  const Xw S_lmsg(F.lmsg, mir, verr), S_rowp(F.lmsg, mir, verr, off_of(F.rowp)), S_camb(F.lmsg, mir, verr, off_of(F.camb)),
+      S_cmu(F.lmsg, mir, verr, off_of(F.cmu)), S_clin(F.lmsg, mir, verr, off_of(F.clin)), S_lmkb(F.lmsg, mir, verr, off_of(F.lmkb)),
+      S_lmu(F.lmsg, mir, verr, off_of(F.lmu));
+  const Xw S_emc(F.lmsg, mir, verr, off_of(F.emc)), S_eml(F.lmsg, mir, verr, off_of(F.eml));
   const uint32_t nC = b.n_cams, nL = b.n_lmks, Ep = A.n_tiles * 64u, n_rows = A.n_tiles * 4u;
 
   // ---- phase-A role: sweep tile w; the factor's potential and both of its messages stay in registers ----
@@ -1495,7 +1503,7 @@ __global__ __launch_bounds__(256) void k_persist_flow(const PersistArgs A) {
     if (weakens) { wf = b.lmk_wflag[l]; wscale = b.lmk_scale[l]; }
   }
   const uint32_t deg = (uint32_t)__shfl((int)ix.x, 0, 4);
-  uint32_t pos[15], pos2[15];
+  uint32_t pos[32];
   GBP_UNROLL
   for (int k = 0; k < 15; ++k) {
     const uint32_t e = ((k + 1) & 3) == 0 ? ix.x : ((k + 1) & 3) == 1 ? ix.y : ((k + 1) & 3) == 2 ? ix.z : ix.w;
@@ -1504,7 +1512,7 @@ __global__ __launch_bounds__(256) void k_persist_flow(const PersistArgs A) {
   GBP_UNROLL
   for (int k = 0; k < 15; ++k) {
     const uint32_t p2 = b.lmk_fpos[lp0 + (15u + (uint32_t)k < deg ? 15u + (uint32_t)k : 0u)];
-    pos2[k] = (lmk_live && 15u + (uint32_t)k < deg) ? p2 : 0u;
+    pos[15 + k] = (lmk_live && 15u + (uint32_t)k < deg) ? p2 : 0u;
   }
 
   // ---- prologue: the beliefs this launch starts from, published as "iteration -1" (half 1, tag0) ----
@@ -1885,7 +1893,7 @@ __global__ __launch_bounds__(256) void k_persist_flow(const PersistArgs A) {
               for (int k = 0; k < 15; ++k) m[k] = S_lmsg.ld4((uint32_t)k < deg ? (base + pos[k]) * 4u + q4 : XwBuf::kNone4);
               if (second) {
                 GBP_UNROLL
-                for (int k = 0; k < 15; ++k) m2[k] = S_lmsg.ld4(15u + (uint32_t)k < deg ? (base + pos2[k]) * 4u + q4 : XwBuf::kNone4);
+                for (int k = 0; k < 15; ++k) m2[k] = S_lmsg.ld4(15u + (uint32_t)k < deg ? (base + pos[15 + k]) * 4u + q4 : XwBuf::kNone4);
               }
               GBP_UNROLL
               for (int k = 0; k < 15; ++k) ok = ok && ((uint32_t)k >= deg || flow_is(m[k], t_out));

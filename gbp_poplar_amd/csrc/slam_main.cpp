@@ -181,8 +181,5 @@ int main(int argc, char** argv) {
   const int rc = cli::run_ranks(world, P.bal.n_cams, o.force_sharded, [&](cli::RankCtx& rk) { return run(o, P, rk); });
   // Everything is written and flushed, the ctx is destroyed: leave WITHOUT running the HIP runtime's exit handlers (70 - 90 ms during
   // which the user's prompt does not come back: a fifth of a `ba fr1xyz` run; the driver reclaims the process's resources either way)
-  std::cout.flush();
-  std::cerr.flush();
-  std::fflush(nullptr);
-  std::_Exit(rc);
+  return cli::leave(rc);
 }
