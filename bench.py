@@ -226,8 +226,10 @@ def pmc_shape(a, world):
 def build_stamp(a, world=1):
     """Identifies the kernels + workload a traffic figure belongs to: hash of the device sources and the shapes."""
     h = hashlib.sha256()
-    for f in ("gbp_kernels.hip", "gbp_kernels.h", "gbp_device_math.hpp"):
-        h.update(open(os.path.join(ROOT, "gbp_poplar_amd", "csrc", f), "rb").read())
+    from gbp_poplar_amd import build as _b
+    for f in _b._deps():      # every source the library is built from: kernels, device order, launch policy, headers (ADVICE r05)
+        if not f.endswith("build.py"):
+            h.update(open(f, "rb").read())
     cams, lmks = pmc_shape(a, world)
     return {"source_sha16": h.hexdigest()[:16], "workload": [cams, lmks, a.obs, a.seed], "tile_order": a.tile_order,
             "window": [a.warmup + a.steps + extra_untimed_iterations(a, world), a.profile_steps]}     # which launches the mean is over
@@ -267,6 +269,9 @@ def measure_traffic_live(a, keep_dir=None, world=1):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT",
               "TORCHELASTIC_RUN_ID"):
         env.pop(k, None)           # the child is a plain single-process run on this rank's GPU
+    for k in list(env):            # ... and not a child of an OUTER profiler: its preloaded tool library and settings stay out
+        if k == "LD_PRELOAD" or k.startswith(("ROCP_", "ROCPROF", "ROCPROFILER_", "ROCTRACER_", "HSA_TOOLS_")):
+            env.pop(k, None)
     if "LOCAL_RANK" in os.environ:
         env.setdefault("HIP_VISIBLE_DEVICES", os.environ["LOCAL_RANK"])
     cams, lmks = pmc_shape(a, world)

@@ -52,7 +52,7 @@ static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
   // the reference's default (the metric after EVERY iteration) with a whole number of --steps: the loop's body goes down as
   // gbp_ba_loop — prior weakening, iteration and metric of many passes in one call (ONE launch on a graph that runs in the persistent
   // kernel, which weakens the priors itself); the lines are written from the results, "Weakening priors" where the loop weakens
-  const bool whole_loop = pipe.on && o.eval_every == 1 && o.steps >= 0.f && o.steps == (float)(unsigned)o.steps;
+  const bool whole_loop = pipe.on && o.eval_every == 1 && cli::whole_steps(o.steps);
   for (int i = 0; i < o.n_iters; ++i) {
     if (whole_loop) {
       const int cap = gbp_graph_state(ctx) == 2 ? 512 : 128;      // (so that the lines keep coming on a large graph)
@@ -72,7 +72,7 @@ static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
       iter += (unsigned)burst;
       continue;
     }
-    if (o.eval_every > 1 && !o.verbose && o.steps >= 0.f && o.steps == (float)(unsigned)o.steps) {
+    if (o.eval_every > 1 && !o.verbose && cli::whole_steps(o.steps)) {
       // --eval_every N: everything up to the next metric in one call, the prior weakenings inside included (gbp_ba_loop without the
       // metric); the pass the metric follows goes down with it (pipe.submit: gbp_iterate_eval)
       const auto weak = [&](unsigned it_) { return (it_ + 1) % 2 == 0 && it_ < 2u * (unsigned)o.steps; };

@@ -579,6 +579,10 @@ inline int finish_run(const Options& o, const Problem& P, gbp_ctx* ctx, const Ra
   return wrc;
 }
 
+// --steps as gbp_ba_loop takes it: a whole, non-negative number below 2^30 (the loop's test is `iter < 2 * steps`: the product must not
+// wrap, and a float beyond UINT_MAX must not be cast at all) — anything else keeps the loop's own float test, call by call
+inline bool whole_steps(float steps) { return steps >= 0.f && steps < 1073741824.f && steps == (float)(unsigned)steps; }
+
 // The last step of main(): everything is written, the ctx is destroyed.  Normally the process then leaves WITHOUT running exit handlers
 // (std::_Exit) — the HIP runtime's take 15 - 30 ms in which the user's prompt does not come back, and the driver reclaims the process's
 // resources either way.  Under an injected library (LD_PRELOAD: rocprofv3, sanitizers — their reports are written by exit handlers) or

@@ -305,6 +305,7 @@ static int iterate_eval_each_impl(gbp_ctx* c, int n, gbp_eval_out* out) {
 static int ba_loop_impl(gbp_ctx* c, int n, unsigned iter0, unsigned steps, gbp_eval_out* out) {
   if (!c || !c->uploaded) return fail(c, GBP_ERR_STATE, "gbp_ba_loop: upload first");
   if (n < 0) return fail(c, GBP_ERR_INVALID, "gbp_ba_loop: n >= 0");
+  if (steps >= (1u << 30)) return fail(c, GBP_ERR_INVALID, "gbp_ba_loop: steps < 2^30 (the loop's test is iter < 2 * steps)");
   const auto weak = [&](unsigned i) { return ((i + 1u) % 2u == 0u) && i < 2u * steps; };
   if (!out) {
     // without the metric (out == NULL): not blocking, like gbp_iterate.  The weakening in front of the first pass is a launch of its

@@ -80,7 +80,7 @@ static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
       up.active_flag = P.active.data(); up.cam_weaken_flag = P.cwf.data(); up.lmk_weaken_flag = P.lwf.data();
       CLI_CHECK(ctx, gbp_new_keyframe(ctx, &up));
     }
-    if (pipe.on && o.eval_every == 1 && o.steps >= 0.f && o.steps == (float)(unsigned)o.steps) {
+    if (pipe.on && o.eval_every == 1 && cli::whole_steps(o.steps)) {
       // the loop's body up to the next keyframe as gbp_ba_loop (see ba_main.cpp): prior weakening, iteration, metric — one call
       const unsigned cap = gbp_graph_state(ctx) == 2 ? 512u : 128u;
       unsigned nb = 1;
@@ -100,7 +100,7 @@ static int run(const cli::Options& o, cli::Problem& P, cli::RankCtx& rk) {
       iter += nb;
       continue;
     }
-    if (o.eval_every > 1 && !o.verbose && o.steps >= 0.f && o.steps == (float)(unsigned)o.steps) {
+    if (o.eval_every > 1 && !o.verbose && cli::whole_steps(o.steps)) {
       // --eval_every N: everything up to the next metric / keyframe in one call, the prior weakenings inside included (see ba_main.cpp)
       const auto weak = [&](unsigned it_) { return (it_ + 1) % 2 == 0 && it_ < 2u * (unsigned)o.steps; };
       unsigned burst = 1;

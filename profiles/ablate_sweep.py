@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Timing-only ablations of k_sweep on the S1 graph (see gbp_debug_time_sweep): which stream costs what.
-The ablated instantiations are not part of the product library: rebuild first with
-    GBP_EXTRA_HIPFLAGS=-DGBP_BUILD_ABLATIONS python -m gbp_poplar_amd.build --force
-(and rebuild without the flag afterwards)."""
+The ablated instantiations live in the experiments build only (csrc/experiments/, -DGBP_BUILD_EXPERIMENTS):
+    python -m gbp_poplar_amd.build --experiments
+    GBP_LIB=gbp_poplar_amd/libgbp_mi355x_exp.so python profiles/ablate_sweep.py
+(the product and the test-hooks library answer gbp_debug_time_sweep(ablation != 0) with GBP_ERR_INVALID)."""
 import ctypes as C
 import os
 import sys

@@ -147,6 +147,7 @@ static int calls_out_of_order() {
   // pretend the upload happened: the argument checks behind it (still nothing that would touch a device)
   c->uploaded = true;
   REQUIRE(gbp_ba_loop(c, -1, 0, 5, ev) == GBP_ERR_INVALID);
+  REQUIRE(gbp_ba_loop(c, 2, 0, 1u << 30, ev) == GBP_ERR_INVALID);      // 2 * steps would wrap
   REQUIRE(gbp_iterate_eval_each(c, -2, ev) == GBP_ERR_INVALID);
   REQUIRE(gbp_iterate_eval_each(c, 2, nullptr) == GBP_ERR_INVALID);
   REQUIRE(gbp_iterate(c, 0) == GBP_OK && gbp_iterate(c, -3) == GBP_OK);      // nothing to do
