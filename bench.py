@@ -67,7 +67,14 @@ roofline (dominant kernel k_sweep; `kernels` carries the same figures for k_beli
                                 line of every N carries a measured roofline.frac; beside it exchange_avg_us (local camera
                                 partial sums + all-gather per iteration, rank 0) and the fastest / slowest rank's step time.
                                 A native-communicator failure ends the run non-zero on every rank (no silent downgrade to
-                                the torch.distributed exchange; `--comm torch` asks for that one explicitly).
+                                the torch.distributed exchange; `--comm torch` asks for that one explicitly) — and STILL prints the
+                                line: `value` null, `comm_error`, `config.ranks` = what every rank saw (a rank that dies with an
+                                exception leaves such a line too).  The line of a run that worked carries, per rank, the step time of
+                                the timed region, the sweep's and the exchange's live time (`roofline.rank_step_ms`,
+                                `sweep_avg_us_per_rank`, `exchange_avg_us_per_rank`) and in `config.preflight` the devices, who can
+                                reach whom, the collective library each rank resolved, one all-gather of the real buffers and BOTH
+                                schedules timed.  A rank's clock stops when ITS K iterations have completed (the ranks meet in every
+                                iteration's exchange); the barrier + synchronisation of the contract follow, `ms_per_step` = MAX over ranks.
 """
 import argparse
 import glob
