@@ -509,6 +509,7 @@ GBP_EXPORT(gbp_read, c, (gbp_ctx* c, gbp_state_out* o), (c, o)) {
   }
   D2H down;
   if (int rc = down.begin(c, (rec_c.size() + rec_l.size() + damp.size() + packed.size()) * 4, 4)) return rc;
+  if (want_state && down.up.direct) HIPCHK(c, hipStreamSynchronize(c->stream));      // (a large graph: the copies below are blocking hipMemcpy calls, which do not order against the ctx's stream)
   if (int rc = down.get(rec_c.data(), c->camb.p, rec_c.size() * 4)) return rc;
   if (int rc = down.get(rec_l.data(), c->lmkb.p, rec_l.size() * 4)) return rc;
   if (int rc = down.get(damp.data(), c->st_a.p, damp.size() * 4)) return rc;
