@@ -4,7 +4,8 @@
 // by profiles/*.py and tests/test_gpu_experiments.py); neither the product nor the test-hooks library contains a line of it.
 //   k_sweep_lab<LAB>   a COPY of the product sweep's shell (sweep_tile) with timing ablations — results are garbage:
 //                      1 = no landmark-message stream, 2 = no landmark-belief gather, 4 = no arithmetic (pass-through),
-//                      16 / 32 = no landmark-message load / store; "no lane / every lane relinearises" needs no code: the
+//                      16 / 32 = no landmark-message load / store; 256 = + the tail the sharded partial-sum fusion would add (write-through row sums,
+//                      acknowledged stores, one agent-scope arrival per row); "no lane / every lane relinearises" needs no code: the
 //                      launcher passes dmu_threshold = -1 / +inf (64 / 128)
 //   k_sweep_w3         the product sweep forced to three wavefronts per SIMD (<= 168 VGPRs)
 //   k_sweep_loop       the product sweep as resident waves that loop over the tiles
@@ -158,13 +159,26 @@ GBP_DEV void lab_sweep_tile(const SweepArgs& a, const uint32_t wslot) {
     store_tile<kCmsgG>(a.cmsg, tile, lane, cmo);
   }
   // camera half of the belief reduction: per-row (16 factors of one camera) tree sums
-  {
+  if (LAB & 256) {
+    // 256: what folding the sharded iteration's partial-sum launch into the sweep would add to EVERY wave: the row sums
+    // written through (sc1), the wave's stores acknowledged, one agent-scope arrival per row on its camera's counter (here: a pad word
+    // of ROWP — results are garbage) — the last arriver's sum itself (one camera in ~2.4 waves) is not emulated
+    const XwBuf R(a.rowp);
+    row16_sums_store(oc_eta, oc_lam, lane, [&](uint32_t g, float4 v) { R.st4((p >> 4) * kCamRec4 + g, v); });
+  } else {
     float4* rp = a.rowp + (size_t)(p >> 4) * kCamRec4;
     row16_sums_store(oc_eta, oc_lam, lane, [&](uint32_t g, float4 v) { rp[g] = v; });
   }
   if (active) {
     if (!true) store_tile<kMuG>(a.mu, tile, lane, mu);
     if (relin) store_tile<kFacG>(a.fac, tile, lane, fac);
+  }
+  if (LAB & 256) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned old = 0;
+    if ((lane & 15u) == 0u)
+      old = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(a.rowp) + (size_t)cam_i * kCamRec + 7, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__builtin_amdgcn_ballot_w64(old == 0xfffffff0u) != 0ull) a.rowp[0].x = 1.f;      // (the wave waits for what its arrivals return)
   }
 }
 
@@ -578,7 +592,7 @@ bool lab_launch_sweep_ablated(const SweepArgs& a0, uint32_t n_tiles, int abl, hi
   switch (abl) {
     case 0: hipLaunchKernelGGL((k_sweep<true, 0>), g, b, 0, s, a); break;
 #define GBP_LAB_CASE(N) case N: hipLaunchKernelGGL((k_sweep_lab<N>), g, b, 0, s, a); break;
-    GBP_LAB_CASE(1) GBP_LAB_CASE(2) GBP_LAB_CASE(3) GBP_LAB_CASE(4) GBP_LAB_CASE(7) GBP_LAB_CASE(16) GBP_LAB_CASE(32)
+    GBP_LAB_CASE(1) GBP_LAB_CASE(2) GBP_LAB_CASE(3) GBP_LAB_CASE(4) GBP_LAB_CASE(7) GBP_LAB_CASE(16) GBP_LAB_CASE(32) GBP_LAB_CASE(256)
 #undef GBP_LAB_CASE
     case 3000: hipLaunchKernelGGL(k_sweep_w3, g, b, 0, s, a); break;                                // the product sweep at 3 waves / SIMD
     case 3001: hipLaunchKernelGGL(k_sweep_coop16, dim3(n_tiles * 4), dim3(256), 0, s, a); break;    // 16 lanes per factor
