@@ -905,14 +905,24 @@ GBP_DEV void cam_mean(REC&& cb, float (&x0c)[6]) {
 }
 
 // EV: the belief owners also leave the METRIC RECORDS of the new beliefs (EvalRide in gbp_kernels.h): what k_means computes.
-template <bool EV>
+// CAM_ONLY: a launch without landmark blocks (the camera combine behind the exchange of a sharded iteration, prior-only refreshes of the
+// split-phase path): the landmark half is compiled out, so the kernel needs the camera half's registers only — 8 waves per SIMD instead of
+// 7, i.e. the 2 000 workgroups of an 8 000-camera graph resident in ONE generation (256 CUs x 8) instead of one and a bit
+template <bool EV, bool CAM_ONLY = false>
 GBP_DEV void beliefs_body(const BeliefArgs& b) {
   __shared__ float sh[4][48];
   __shared__ float lrec[EV ? 64 : 1][13];      // EV: the beliefs of the workgroup's 64 landmarks (eta 3, Lambda 9; 13: bank spread)
   if (EV && blockIdx.x == 0 && threadIdx.x == 0) *b.ev.counter = *b.ev.counter + 1u;     // one more iteration of the burst done (read by the NEXT sweep)
-  if (blockIdx.x < b.cam_blocks) {
+  // Which blocks are the cameras'?  The FIRST cam_blocks of the grid where a camera block ends in the serial chain of its means (long
+  // latency: started first, hidden under the landmark blocks) — the LAST ones where it only adds up rows (partial_only, before the
+  // exchange of a sharded iteration): short work that fills the slots the landmark blocks free as they drain, instead of holding the
+  // first generation of the grid (config-5 shard shape: profiles/r06_sharded_timeline.md)
+  const bool cams_last = !CAM_ONLY && b.partial_only != 0 && b.lmk_blocks != 0u;
+  const bool cam_block = cams_last ? blockIdx.x >= b.lmk_blocks : blockIdx.x < b.cam_blocks;
+  if (cam_block) {
     const uint32_t w = threadIdx.x >> 6, j = threadIdx.x & 63;
-    const uint32_t c = blockIdx.x * 4 + w;
+    const uint32_t cblk = cams_last ? blockIdx.x - b.lmk_blocks : blockIdx.x;
+    const uint32_t c = cblk * 4 + w;
     const bool live = c < b.n_cams && j < (uint32_t)kCamRec;
     float bel = 0.f;
     if (live) {
@@ -993,7 +1003,7 @@ GBP_DEV void beliefs_body(const BeliefArgs& b) {
     // single stream (lanes 0..3 of wave 0) instead of issuing it from four wavefronts: with thousands of cameras the
     // camera part is bound by exactly these issue slots (8 000 cameras: 11 -> 4 us).
     if (b.hoist && w == 0 && j < 4) {
-      const uint32_t cj = blockIdx.x * 4 + j;
+      const uint32_t cj = cblk * 4 + j;
       if (cj < b.n_cams) {
         float x0c[6];
         cam_mean(sh[j], x0c);                    // operands straight from LDS: the 44-float copy cost 14 VGPRs of occupancy
@@ -1026,7 +1036,7 @@ GBP_DEV void beliefs_body(const BeliefArgs& b) {
       // 68 to 96 VGPRs = from 7 to 5 waves per SIMD, which costs the landmark part 1.5 us; measured and worse: the occupancy
       // pinned at 7 (the tableau spills: 20.1 us against 18.3), the tableau in LDS (21.4 - 25.1 us: the camera chain then sets the
       // kernel's length) — profiles/r05_default_loop.md.
-      const uint32_t cj = blockIdx.x * 4 + j;
+      const uint32_t cj = cblk * 4 + j;
       if (cj < b.n_cams) {
         if (w == 1) {
           float xm[6], R[9];
@@ -1049,8 +1059,9 @@ GBP_DEV void beliefs_body(const BeliefArgs& b) {
     if (live) b.camb[(size_t)c * kCamRec + j] = sh[w][j];
     return;
   }
+  if (CAM_ONLY) return;
   // ---- landmark part ----
-  uint32_t lb = blockIdx.x - b.cam_blocks;
+  uint32_t lb = cams_last ? blockIdx.x : blockIdx.x - b.cam_blocks;
   if (b.lmk_xcd_order) {
     // XCD-aware order: the blocks that share an XCD (equal index mod 8 under round-robin placement) take one contiguous
     // run of landmarks.  The 64-B message records of two neighbouring factors share a 128-B line, and the partner's
@@ -1191,6 +1202,7 @@ GBP_DEV void beliefs_body(const BeliefArgs& b) {
   if (live) b.lmkb[(size_t)l * 4 + q] = acc;
 }
 __global__ __launch_bounds__(256) void k_beliefs(const BeliefArgs b) { beliefs_body<false>(b); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_beliefs_cam(const BeliefArgs b) { beliefs_body<false, true>(b); }
 __global__ __launch_bounds__(256) void k_beliefs_ev(const BeliefArgs b) { beliefs_body<true>(b); }
 
 // =================================================================================================
@@ -2269,6 +2281,7 @@ void launch_beliefs(BeliefArgs b, bool do_cam, bool do_lmk, hipStream_t s, bool 
   b.lmk_blocks = lmk_blocks;
   if (b.cam_blocks + lmk_blocks == 0) return;
   if (ev) hipLaunchKernelGGL(k_beliefs_ev, dim3(b.cam_blocks + lmk_blocks), dim3(256), 0, s, b);
+  else if (lmk_blocks == 0) hipLaunchKernelGGL(k_beliefs_cam, dim3(b.cam_blocks), dim3(256), 0, s, b);
   else hipLaunchKernelGGL(k_beliefs, dim3(b.cam_blocks + lmk_blocks), dim3(256), 0, s, b);
 }
 void launch_eval_ride(const EvalRide& ev, const uint32_t* row_cam, const uint32_t* lmk_idx, const float4* lmsg, const float4* fac, const float* K9_dev, hipStream_t s) {
