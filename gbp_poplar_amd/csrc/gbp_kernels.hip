@@ -1201,7 +1201,7 @@ GBP_DEV void beliefs_body(const BeliefArgs& b) {
   }
   if (live) b.lmkb[(size_t)l * 4 + q] = acc;
 }
-__global__ __launch_bounds__(256) void k_beliefs(const BeliefArgs b) { beliefs_body<false>(b); }      // (held at 8 waves per SIMD: S1 +0.1 %, noise — profiles/HISTORY.md)
+__global__ __launch_bounds__(256) void k_beliefs(const BeliefArgs b) { beliefs_body<false>(b); }      // (held at 8 waves per SIMD: S1 +0.1 %, config-5 shape +0.2 %: noise — profiles/HISTORY.md)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_beliefs_cam(const BeliefArgs b) { beliefs_body<false, true>(b); }
 __global__ __launch_bounds__(256) void k_beliefs_ev(const BeliefArgs b) { beliefs_body<true>(b); }
 
