@@ -299,6 +299,17 @@ struct RankCtx {
   gbp_shard shard{0, 1, 0, 0};
 };
 
+// A single-process run brings the HIP runtime up (120 - 240 ms: the first call that needs it) on a second thread WHILE the main thread
+// reads the file and builds the priors — nothing for the shipped sequences (4 ms of host work), the runtime's whole start-up for a
+// file of a million factors (1 - 2 s of parsing).  Never with --ipus N > 1: the ranks are forked before anything touches HIP.
+struct RuntimeWarmup {
+  std::thread t;
+  void start(bool on) { if (on && !std::getenv("GBP_CLI_NO_WARMUP")) t = std::thread([] { (void)gbp_device_count(); }); }      // (the switch: profiles/big_file_cli.py's A/B)
+  void wait() { if (t.joinable()) t.join(); }
+  ~RuntimeWarmup() { wait(); }
+};
+inline RuntimeWarmup& runtime_warmup() { static RuntimeWarmup w; return w; }
+
 inline int round_up_pow2(int n) {   // ba.cpp:617-621: nIPUs is rounded up to a power of two
   int p = 1;
   while (p < n) p *= 2;
@@ -308,8 +319,9 @@ inline int round_up_pow2(int n) {   // ba.cpp:617-621: nIPUs is rounded up to a 
 // Creates the ctx of this rank on its GPU, landmark-sharded for world > 1, with the communicator attached.
 inline int create_rank_ctx(const Options& o, const Problem& P, RankCtx& rk, gbp_ctx** ctx) {
   phases().mark("host_setup_s");                                  // (flags, fork, the lines printed so far)
+  runtime_warmup().wait();
   const int ndev = gbp_device_count();
-  phases().mark("runtime_init_s");                                // the HIP runtime comes up with the first call that needs it
+  phases().mark("runtime_init_s");                                // the HIP runtime comes up with the first call that needs it — what of it the file's parsing did not hide
   if (ndev <= 0) {
     std::cout << "Could not find a device\n";                      // ba.cpp:652-655
     return 255;
