@@ -405,6 +405,9 @@ def parse_iter_lines(stdout):
     return rows
 
 
+CLI_IDLE_S = 0.5
+
+
 def run_cli(tool, seq, extra=(), timeout=600):
     """One run of bin/<tool> on a shipped sequence as a fresh process; returns (its --profile report, parsed metric lines)."""
     exe = os.path.join(BIN_DIR, tool)
@@ -415,6 +418,10 @@ def run_cli(tool, seq, extra=(), timeout=600):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     try:
+        # The kernel driver tears a finished process's GPU context down in the background, and the first HIP call of a process started
+        # right behind it waits for that (50 ms of runtime start-up become 120 - 250 ms: profiles/r06_cli_pause.txt).  The CLI runs are
+        # taken the way a user starts one — not on the heels of the previous process.
+        time.sleep(CLI_IDLE_S)
         t0 = time.perf_counter()
         p = subprocess.run([exe, "--bal_file", os.path.join(SEQ_DIR, seq + ".txt"), "--profile", "1", *extra], env=env,
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
@@ -456,7 +463,7 @@ def small_config_gpu(name):
     }
     st = rep.get("startup")
     if st:      # where the process's wall time went (the CLI's own account from exec to the end of its teardown; exit_s = what follows main())
-        out["startup"] = dict(st, process_wall_s=round(rep["process_wall_s"], 4), exit_s=round(rep["process_wall_s"] - st["process_s"], 4),
+        out["startup"] = dict(st, process_wall_s=round(rep["process_wall_s"], 4), exit_s=round(rep["process_wall_s"] - st["process_s"], 4), idle_before_start_s=CLI_IDLE_S,
                               loop_share=round(st.get("loop_s", 0.0) / rep["process_wall_s"], 4))
     if band:
         out["converged_band_px"] = list(band)

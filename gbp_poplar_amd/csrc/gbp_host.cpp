@@ -21,8 +21,16 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <thread>
 #include <vector>
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 namespace {
 
@@ -154,6 +162,133 @@ struct NoiseGen {
 
 }  // namespace
 
+// ---- text files of numbers, read by every host core ------------------------------------------------------
+// Both file formats are one stream of whitespace-separated tokens whose meaning follows from the position alone:
+//   n_hdr_int integers, n_hdr_dbl doubles, E records (int int double double), n_tail doubles; whatever follows is ignored
+// (what a chain of fscanf("%d") / fscanf("%lf") calls reads: dataio.cpp:17-57).  The whole file is read into memory, cut into
+// one piece per thread at whitespace, the tokens of every piece are counted, and with the counts summed every thread knows
+// the position of its first token and converts its own — with strtol / strtod, the conversions fscanf itself makes, so the values
+// are the ones the serial reader produced.  A token that strtol / strtod does not consume whole ("12abc", "1.5.3") is where fscanf's
+// behaviour depends on what follows: such files are reported as `irregular` and the caller falls back to the fscanf chain.
+struct NumberFile {
+  int hdr_int[3] = {0, 0, 0};
+  double hdr_dbl[4] = {0, 0, 0, 0};
+  enum Status { kOk, kNoFile, kIrregular };
+};
+
+inline unsigned host_threads(uint64_t work_items, uint64_t min_items_per_thread) {
+  unsigned T = std::thread::hardware_concurrency();
+  if (const char* e = std::getenv("GBP_HOST_THREADS")) T = (unsigned)std::max(1, std::atoi(e));
+  T = std::max(1u, std::min(T, 32u));
+  return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(T, work_items / std::max<uint64_t>(1, min_items_per_thread)));
+}
+template <class F> void on_threads(unsigned T, F&& fn) {      // fn(t) for t in [0, T), fn(0) on the caller's thread
+  std::vector<std::thread> th;
+  for (unsigned t = 1; t < T; ++t) th.emplace_back(fn, t);
+  fn(0u);
+  for (auto& x : th) x.join();
+}
+
+inline bool is_space(unsigned char c) { return c == ' ' || c == '\n' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; }      // isspace(), "C" locale
+
+NumberFile::Status read_number_file(const char* path, int n_hdr_dbl, uint64_t E, uint64_t n_tail, NumberFile& h,
+                                    int* rec_a, int* rec_b, double* rec_xy /* [2E] */, double* tail) {
+  const bool trace = std::getenv("GBP_HOST_TRACE") != nullptr;
+  auto t0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!trace) return;
+    const auto t1 = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "read_number_file: %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  };
+  const int fd = ::open(path, O_RDONLY);
+  if (fd < 0) return NumberFile::kNoFile;
+  std::unique_ptr<char[]> buf;
+  size_t n = 0;
+  struct stat sb;
+  if (::fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {
+    n = (size_t)sb.st_size;
+    buf.reset(new char[n + 2]);
+    const unsigned R = host_threads(n, 4u << 20);      // every thread copies (and first touches) its own part of the buffer
+    std::vector<int> short_read(R, 0);
+    on_threads(R, [&](unsigned t) {
+      size_t lo = n / R * t;
+      const size_t hi = t + 1 == R ? n : n / R * (t + 1);
+      while (lo < hi) {
+        const ssize_t got = ::pread(fd, buf.get() + lo, hi - lo, (off_t)lo);
+        if (got <= 0) { short_read[t] = 1; return; }
+        lo += (size_t)got;
+      }
+    });
+    for (unsigned t = 0; t < R; ++t) if (short_read[t]) n = 0;
+  }
+  ::close(fd);
+  if (n == 0) return NumberFile::kIrregular;           // (not a regular file, empty, or it shrank under us: the fscanf chain decides)
+  lap("file into memory");
+  buf[n++] = ' ';                                      // every token ends at a whitespace character ...
+  buf[n] = 0;                                          // ... and strtod never runs off the end
+  const char* base = buf.get();
+  const uint64_t n_hdr = 3 + (uint64_t)n_hdr_dbl, want = n_hdr + 4 * E + n_tail;
+
+  const unsigned T = host_threads(n, 1u << 20);        // one thread per MB at most (the shipped sequences: 100 - 400 KB, one thread)
+  std::vector<size_t> cut(T + 1);
+  cut[0] = 0; cut[T] = n;
+  for (unsigned t = 1; t < T; ++t) {                   // a piece starts behind a whitespace character: no token straddles two pieces
+    size_t p = std::max(cut[t - 1], n / T * t);
+    while (p < n && !is_space((unsigned char)base[p])) ++p;
+    cut[t] = p;
+  }
+  std::vector<uint64_t> first(T + 1, 0);
+  std::vector<int> bad(T, 0);
+  auto run = [&](auto&& fn) { on_threads(T, fn); };
+  run([&](unsigned t) {                                // pass 1: tokens per piece
+    uint64_t k = 0;                                    // a token starts where a non-space follows a space (no loop-carried state: the loop vectorises)
+    const size_t lo = cut[t], hi = cut[t + 1];
+    if (lo < hi && lo == 0) k += !is_space((unsigned char)base[0]);
+    for (size_t p = std::max<size_t>(lo, 1); p < hi; ++p) {
+      const unsigned char c = (unsigned char)base[p], d = (unsigned char)base[p - 1];
+      const unsigned sc = (c == ' ') | ((unsigned char)(c - 9) < 5), sd = (d == ' ') | ((unsigned char)(d - 9) < 5);
+      k += (sc ^ 1u) & sd;
+    }
+    first[t + 1] = k;
+  });
+  for (unsigned t = 0; t < T; ++t) first[t + 1] += first[t];
+  lap("tokens counted");
+  if (first[T] < want) return NumberFile::kIrregular;      // fewer tokens than numbers: a truncated file, or glued tokens ("1.5.25") that only fscanf tells apart
+  run([&](unsigned t) {                                // pass 2: the conversions
+    uint64_t g = first[t];
+    size_t p = cut[t];
+    const size_t end = cut[t + 1];
+    while (g < want) {
+      while (p < end && is_space((unsigned char)base[p])) ++p;
+      if (p >= end) break;
+      char* q = nullptr;
+      bool is_int;
+      if (g < 3) is_int = true;
+      else if (g < n_hdr) is_int = false;
+      else if (g < n_hdr + 4 * E) is_int = ((g - n_hdr) & 3) < 2;
+      else is_int = false;
+      if (is_int) {
+        const long v = std::strtol(base + p, &q, 10);
+        const int iv = (v < -2147483647L - 1 || v > 2147483647L) ? -1 : (int)v;      // (no index of a valid file is out of int's range)
+        if (g < 3) h.hdr_int[g] = iv;
+        else { const uint64_t r = g - n_hdr; ((r & 3) == 0 ? rec_a : rec_b)[r >> 2] = iv; }
+      } else {
+        const double v = std::strtod(base + p, &q);
+        if (g < n_hdr) h.hdr_dbl[g - 3] = v;
+        else if (g < n_hdr + 4 * E) { const uint64_t r = g - n_hdr; rec_xy[2 * (r >> 2) + ((r & 3) - 2)] = v; }
+        else tail[g - n_hdr - 4 * E] = v;
+      }
+      if (q == base + p || !is_space((unsigned char)*q)) { bad[t] = 1; return; }
+      p = (size_t)(q - base);
+      ++g;
+    }
+  });
+  lap("tokens converted");
+  for (unsigned t = 0; t < T; ++t) if (bad[t]) return NumberFile::kIrregular;
+  return NumberFile::kOk;
+}
+
 GBP_EXPORT(gbp_bal_read_header, nullptr, (const char* path, gbp_bal* h),
            (path, h)) {
   if (!path || !h) return GBP_ERR_INVALID;
@@ -174,6 +309,24 @@ GBP_EXPORT(gbp_bal_read_header, nullptr, (const char* path, gbp_bal* h),
 GBP_EXPORT(gbp_bal_read, nullptr, (const char* path, gbp_bal* b),
            (path, b)) {
   if (!path || !b || !b->cam_id || !b->lmk_id || !b->observations || !b->cameras || !b->points) return GBP_ERR_INVALID;
+  {      // every host core reads its piece of the file; only a file with a token no conversion takes whole goes to the fscanf chain below
+    const uint64_t C = b->n_cams, L = b->n_lmks, E = b->n_edges;
+    std::vector<double> tail(6 * C + 3 * L);
+    static_assert(sizeof(int) == sizeof(uint32_t), "the indices are converted in place");
+    NumberFile h;
+    const NumberFile::Status st = read_number_file(path, 4, E, tail.size(), h, reinterpret_cast<int*>(b->cam_id), reinterpret_cast<int*>(b->lmk_id),
+                                                   b->observations, tail.data());
+    if (st == NumberFile::kNoFile) return GBP_ERR_IO;
+    if (st == NumberFile::kOk) {
+      if (h.hdr_int[0] < 0 || (uint64_t)h.hdr_int[0] != C || h.hdr_int[1] < 0 || (uint64_t)h.hdr_int[1] != L || h.hdr_int[2] < 0 || (uint64_t)h.hdr_int[2] != E) return GBP_ERR_IO;
+      for (uint64_t i = 0; i < E; ++i)
+        if ((int)b->cam_id[i] < 0 || b->cam_id[i] >= C || (int)b->lmk_id[i] < 0 || b->lmk_id[i] >= L) return GBP_ERR_IO;
+      b->fx = h.hdr_dbl[0]; b->fy = h.hdr_dbl[1]; b->cx = h.hdr_dbl[2]; b->cy = h.hdr_dbl[3];
+      std::copy(tail.begin(), tail.begin() + 6 * C, b->cameras);
+      std::copy(tail.begin() + 6 * C, tail.end(), b->points);
+      return GBP_OK;
+    }
+  }
   FILE* f = std::fopen(path, "r");
   if (!f) return GBP_ERR_IO;
   int c = 0, l = 0, e = 0;
@@ -241,14 +394,30 @@ GBP_EXPORT(gbp_bal_import_standard, nullptr, (const char* path, gbp_bal* b),
             static_cast<uint32_t>(l) == b->n_lmks && static_cast<uint32_t>(e) == b->n_edges;
   struct Obs { uint32_t cam, lmk; double x, y; };
   std::vector<Obs> obs(ok ? e : 0);
-  for (int i = 0; ok && i < e; ++i) {
+  std::vector<double> cam9(ok ? 9ull * c : 0);
+  bool parsed = false;
+  if (ok) {      // every host core reads its piece (read_number_file); an irregular file goes through the fscanf chain below
+    std::vector<int> ca(e), la(e);
+    std::vector<double> xy(2ull * e), tail(9ull * c + 3ull * l);
+    NumberFile h;
+    const NumberFile::Status st = read_number_file(path, 0, (uint64_t)e, tail.size(), h, ca.data(), la.data(), xy.data(), tail.data());
+    if (st == NumberFile::kOk) {
+      for (int i = 0; ok && i < e; ++i) {
+        ok = ca[i] >= 0 && ca[i] < c && la[i] >= 0 && la[i] < l;
+        obs[i] = Obs{(uint32_t)ca[i], (uint32_t)la[i], xy[2ull * i], xy[2ull * i + 1]};
+      }
+      std::copy(tail.begin(), tail.begin() + 9ull * c, cam9.begin());
+      std::copy(tail.begin() + 9ull * c, tail.end(), b->points);
+      parsed = true;
+    }
+  }
+  for (int i = 0; !parsed && ok && i < e; ++i) {
     int ci, li;
     ok = std::fscanf(f, "%d %d %lf %lf", &ci, &li, &obs[i].x, &obs[i].y) == 4 && ci >= 0 && ci < c && li >= 0 && li < l;
     if (ok) { obs[i].cam = static_cast<uint32_t>(ci); obs[i].lmk = static_cast<uint32_t>(li); }
   }
-  std::vector<double> cam9(ok ? 9ull * c : 0);
-  for (size_t i = 0; ok && i < cam9.size(); ++i) ok = std::fscanf(f, "%lf", &cam9[i]) == 1;
-  for (int i = 0; ok && i < 3 * l; ++i) ok = std::fscanf(f, "%lf", &b->points[i]) == 1;
+  for (size_t i = 0; !parsed && ok && i < cam9.size(); ++i) ok = std::fscanf(f, "%lf", &cam9[i]) == 1;
+  for (int i = 0; !parsed && ok && i < 3 * l; ++i) ok = std::fscanf(f, "%lf", &b->points[i]) == 1;
   std::fclose(f);
   if (!ok) return GBP_ERR_IO;
 
@@ -306,13 +475,28 @@ GBP_EXPORT(gbp_set_prior_lambda, nullptr, (const gbp_problem* p, float var, cons
            (p, var, cam_file, lmk_file, cam_mean, lmk_mean, ce, cl, le, ll)) {
   if (!p || !cam_file || !lmk_file || !cam_mean || !lmk_mean || !ce || !cl || !le || !ll) return GBP_ERR_INVALID;
   const uint32_t C = p->n_cams, L = p->n_lmks, E = p->n_edges;
-  std::vector<float> peak_c(C, 0.f), peak_l(L, 0.f);
-  for (uint32_t e = 0; e < E; ++e) {  // one pass: max over incident observations (dataio.cpp:78-87, 99-108)
-    const uint32_t c = p->cam_id[e], l = p->lmk_id[e];
-    if (c >= C || l >= L) return GBP_ERR_INVALID;
-    const float m = jacobian_peak(cam_file + 6ull * c, lmk_file + 3ull * l, p->K);
-    peak_c[c] = std::max(peak_c[c], m);
-    peak_l[l] = std::max(peak_l[l], m);
+  // one pass: max over incident observations (dataio.cpp:78-87, 99-108).  A maximum does not depend on the order it is taken in: large
+  // graphs are cut into one range of factors per host thread, each with its own peaks, and the peaks are merged.
+  const unsigned T = host_threads(E, 1u << 16);
+  std::vector<std::vector<float>> pc(T), pl(T);
+  std::vector<int> bad(T, 0);
+  on_threads(T, [&](unsigned t) {
+    pc[t].assign(C, 0.f); pl[t].assign(L, 0.f);
+    const uint64_t lo = (uint64_t)E * t / T, hi = (uint64_t)E * (t + 1) / T;
+    for (uint64_t e = lo; e < hi; ++e) {
+      const uint32_t c = p->cam_id[e], l = p->lmk_id[e];
+      if (c >= C || l >= L) { bad[t] = 1; return; }
+      const float m = jacobian_peak(cam_file + 6ull * c, lmk_file + 3ull * l, p->K);
+      pc[t][c] = std::max(pc[t][c], m);
+      pl[t][l] = std::max(pl[t][l], m);
+    }
+  });
+  for (unsigned t = 0; t < T; ++t) if (bad[t]) return GBP_ERR_INVALID;
+  std::vector<float>& peak_c = pc[0];
+  std::vector<float>& peak_l = pl[0];
+  for (unsigned t = 1; t < T; ++t) {
+    for (uint32_t c = 0; c < C; ++c) peak_c[c] = std::max(peak_c[c], pc[t][c]);
+    for (uint32_t l = 0; l < L; ++l) peak_l[l] = std::max(peak_l[l], pl[t][l]);
   }
   std::fill(cl, cl + 36ull * C, 0.f);
   std::fill(ll, ll + 9ull * L, 0.f);

@@ -4,7 +4,8 @@
     python profiles/big_file_cli.py [runs=3] [n_cams=1000] [n_lmks=100000]
 
 Writes the synthetic S1 graph (gbp_synth_generate, the bench's workload) as a text file in the reference's format under /tmp, then
-runs `bin/ba --n_iters 10 --profile 1` on it with and without GBP_CLI_NO_WARMUP=1, alternating, and prints each run's own phases."""
+runs `bin/ba --n_iters 10 --profile 1` on it three ways, alternating — one host thread and no overlap (GBP_HOST_THREADS=1, GBP_CLI_NO_WARMUP=1),
+the file read by every core, and that plus the runtime coming up beside it (the default) — and prints each run's own phases."""
 import json, os, subprocess, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -19,8 +20,11 @@ hostlib.bal_write(path, hostlib.synth_generate(n_cams, n_lmks))
 print("file: %d cameras, %d landmarks, %.1f MB, written in %.2f s" % (n_cams, n_lmks, os.path.getsize(path) / 1e6, time.perf_counter() - t0), flush=True)
 md5 = set()
 for r in range(runs):
-    for label, extra in (("serial", {"GBP_CLI_NO_WARMUP": "1"}), ("overlapped", {})):
+    for label, extra in (("r06-start", {"GBP_CLI_NO_WARMUP": "1", "GBP_HOST_THREADS": "1"}),      # one host thread reads the file, then the runtime comes up
+                         ("threads", {"GBP_CLI_NO_WARMUP": "1"}),                                   # every host core reads its piece of the file
+                         ("both", {})):                                                            # ... and the runtime comes up beside that
         d = tempfile.mkdtemp(dir=tmp)
+        time.sleep(0.5)      # not on the heels of the previous process (its GPU context is torn down in the background: r06_cli_pause.txt)
         t0 = time.perf_counter()
         p = subprocess.run([os.path.join(ROOT, "gbp_poplar_amd", "bin", "ba"), "--bal_file", path, "--n_iters", "10", "--profile", "1"],
                            env=dict(os.environ, GC_PROFILE_LOG_DIR=d, **extra), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
@@ -29,6 +33,9 @@ for r in range(runs):
             sys.exit("ba failed: " + p.stderr[-2000:])
         st = json.load(open(os.path.join(d, "gbp_profile.json")))["startup"]
         md5.add("\n".join(l for l in p.stdout.splitlines() if "Total time" not in l and "Profile written" not in l))
-        print("%-10s run %d: process wall %.3f s | loader %.3f, file %.3f, runtime (what was left to wait for) %.3f, create %.3f, loop %.3f"
+        print("%-9s run %d: process wall %.3f s | loader %.3f, file %.3f, runtime (what was left to wait for) %.3f, create %.3f, loop %.3f"
               % (label, r, wall, st["exec_to_main_s"], st["file_parse_s"], st["runtime_init_s"], st["create_s"], st["loop_s"]), flush=True)
 print("stdout identical across all runs: %s" % (len(md5) == 1))
+p = subprocess.run([os.path.join(ROOT, "gbp_poplar_amd", "bin", "ba"), "--bal_file", path, "--n_iters", "1"], env=dict(os.environ, GBP_HOST_TRACE="1"),
+                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+print("".join(l + "\n" for l in p.stderr.splitlines() if "read_number_file" in l), end="")

@@ -1,5 +1,7 @@
 """Product host code (csrc/gbp_host.cpp through the C-ABI) against the oracle's independent restatement
 of the same reference functions, plus the synthetic generator's contract and error behaviour."""
+import os
+
 import numpy as np
 import pytest
 
@@ -38,6 +40,69 @@ def test_bal_write_read_round_trip(tmp_path):
         assert np.array_equal(bal[k], back[k]), k                   # %.16e round-trips doubles exactly
 
 
+@pytest.mark.parametrize("threads", [1, 3, 7, 32])
+def test_big_files_are_read_by_every_core_with_the_serial_result(tmp_path, monkeypatch, threads):
+    """Files above 1 MB are cut at whitespace and converted by one thread per piece (gbp_host.cpp: read_number_file) — the same
+    strtol / strtod conversions fscanf makes (dataio.cpp:17-57), so the arrays are those of the serial reader, for any thread count
+    and any whitespace between the tokens; what follows the last number is ignored as fscanf ignores it."""
+    bal = hostlib.synth_generate(60, 9000, 8, 4)
+    p = str(tmp_path / "big.txt")
+    hostlib.bal_write(p, bal)
+    assert os.path.getsize(p) > (1 << 20)
+    monkeypatch.setenv("GBP_HOST_THREADS", str(threads))
+    back = hostlib.bal_read(p)
+    for k in ("cam_id", "lmk_id", "observations", "cameras", "points", "fx", "fy", "cx", "cy"):
+        assert np.array_equal(np.asarray(bal[k]), np.asarray(back[k])), k
+    # the same tokens with other whitespace (tabs, CRLF, blank lines, leading blanks) and a tail that no conversion is asked for
+    text = open(p).read().split("\n")
+    mixed = str(tmp_path / "mixed.txt")
+    with open(mixed, "w", newline="") as f:
+        f.write("  \n\t" + text[0].replace(" ", "\t") + "\r\n\r\n" + text[1] + "\n")
+        for i, line in enumerate(text[2:]):
+            f.write(line.replace(" ", "  \t" if i % 3 == 0 else " ") + ("\r\n" if i % 5 == 0 else "\n\n" if i % 7 == 0 else "\n"))
+        f.write("trailing words 1 2 3\n")
+    again = hostlib.bal_read(mixed)
+    for k in ("cam_id", "lmk_id", "observations", "cameras", "points", "fx", "fy", "cx", "cy"):
+        assert np.array_equal(np.asarray(bal[k]), np.asarray(again[k])), k
+
+
+@pytest.mark.parametrize("lmks", [40, 9000])      # below and above the size where the threads start
+def test_irregular_tokens_keep_fscanfs_meaning(tmp_path, monkeypatch, lmks):
+    """A token that strtod does not take whole is where fscanf's result depends on what follows: such files go through the fscanf
+    chain itself.  "1.5.25" is two numbers for fscanf (1.5 and .25); "7x" ends the file for it."""
+    monkeypatch.setenv("GBP_HOST_THREADS", "4")
+    bal = hostlib.synth_generate(60, lmks, 8, 4)
+    p = str(tmp_path / "s.txt")
+    hostlib.bal_write(p, bal)
+    lines = open(p).read().split("\n")
+    e = bal["n_edges"] // 2
+    ci, li = lines[2 + e].split()[:2]
+    lines[2 + e] = "%s %s 1.5.25" % (ci, li)
+    q = str(tmp_path / "glued.txt")
+    open(q, "w").write("\n".join(lines))
+    back = hostlib.bal_read(q)
+    want = np.array(bal["observations"], np.float64).copy()
+    want[2 * e:2 * e + 2] = (1.5, 0.25)
+    assert np.array_equal(back["observations"], want) and np.array_equal(back["points"], bal["points"])
+    lines[2 + e] = "%s %s 7x 1.0" % (ci, li)
+    open(q, "w").write("\n".join(lines))
+    with pytest.raises(IOError):
+        hostlib.bal_read(q)
+    # truncated in the middle of the landmarks; an index out of range
+    lines[2 + e] = "%s %s 1.0 2.0" % (ci, li)
+    open(q, "w").write("\n".join(lines[:len(lines) - 20]))
+    with pytest.raises(IOError):
+        hostlib.bal_read(q)
+    lines[2 + e] = "%d %s 1.0 2.0" % (bal["n_cams"], li)
+    open(q, "w").write("\n".join(lines))
+    with pytest.raises(IOError):
+        hostlib.bal_read(q)
+    lines[2 + e] = "%s -1 1.0 2.0" % ci
+    open(q, "w").write("\n".join(lines))
+    with pytest.raises(IOError):
+        hostlib.bal_read(q)
+
+
 @pytest.mark.parametrize("name", ["fr2robot2", "fr1xyz"])
 def test_priors_scalings_and_state_match_oracle(name):
     bal = hostlib.bal_read(seq_path(name))
@@ -53,6 +118,19 @@ def test_priors_scalings_and_state_match_oracle(name):
     s = sa["cam_scaling"].astype(np.float64)
     assert np.isclose(lam[0, 0, 0] * s[0] ** 5, 1 / 0.01 ** 2, rtol=1e-5)
     assert np.isclose(s[2] ** 5, 1e-4, rtol=1e-5) and np.isclose(float(sa["lmk_scaling"][0]) ** 5, 1e-4, rtol=1e-5)
+
+
+def test_prior_strengths_do_not_depend_on_the_host_thread_count(monkeypatch):
+    """gbp_set_prior_lambda cuts large graphs into one range of factors per thread; a maximum is the same in any order."""
+    bal = hostlib.synth_generate(80, 30000, 8, 11)
+    opts = driver.Options()
+    out = []
+    for threads in ("1", "3", "8"):
+        monkeypatch.setenv("GBP_HOST_THREADS", threads)
+        _, st, _ = driver.build_inputs(bal, opts, hostlib)
+        out.append(st)
+    for k in out[0]:
+        assert np.array_equal(out[0][k], out[1][k]) and np.array_equal(out[0][k], out[2][k]), k
 
 
 def test_slam_flags_and_new_kf_match_oracle():
