@@ -259,7 +259,9 @@ GBP_API int gbp_graph_state(const gbp_ctx* ctx);
 GBP_API int gbp_set_profiling(gbp_ctx* ctx, int per_stage_events);
 
 /* ---- host-side helpers of the path's callers (pure CPU, no device needed) ---------------- */
-/* BALProblem::LoadFile (dataio.cpp:17-57).  Two-call pattern: pass NULL arrays to get sizes. */
+/* BALProblem::LoadFile (dataio.cpp:17-57).  Two-call pattern: pass NULL arrays to get sizes.
+ * Files above 1 MB are converted by several host threads (at most 32; GBP_HOST_THREADS=n overrides) with the conversions fscanf makes:
+ * the values do not depend on the thread count.  A file that is not a plain stream of whole numeric tokens is read by the fscanf chain itself. */
 typedef struct {
   uint32_t n_cams, n_lmks, n_edges;
   double   fx, fy, cx, cy;
