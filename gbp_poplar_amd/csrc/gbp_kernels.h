@@ -277,7 +277,7 @@ void launch_means(const float4* camb, const float4* lmkb, float* cam_mu, float* 
                   bool count_cams, hipStream_t s);
 void launch_eval(const uint32_t* row_cam, const uint32_t* lmk_idx, const float4* lmsg, const float4* fac, const float* cam_mu,
                  const float* lmk_mu, const float* K9_dev, int num_undamped_iters, DeviceEval* partials /* may be mapped host memory */,
-                 const unsigned long long* health2, unsigned long long* health2_out, uint32_t n_tiles, hipStream_t s);
+                 unsigned long long* health2, unsigned long long* health2_out, uint32_t n_tiles, hipStream_t s);
 uint32_t eval_blocks(uint32_t n_tiles);
 // experiments build (csrc/experiments/gbp_lab_kernels.hip): timing ablations of the sweep; false = unknown ablation
 bool lab_launch_sweep_ablated(const SweepArgs& a, uint32_t n_tiles, int abl, hipStream_t s);

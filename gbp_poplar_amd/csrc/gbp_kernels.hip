@@ -2057,6 +2057,8 @@ __global__ __launch_bounds__(256) void k_persist_flow(const PersistArgs A) {
         unsigned long long* out = reinterpret_cast<unsigned long long*>(A.ev.slots);
         out[0] = __hip_atomic_load(&A.ev.health[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         out[1] = __hip_atomic_load(&A.ev.health[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&A.ev.health[0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (both areas zero behind every metric: see k_eval)
+        __hip_atomic_store(&A.ev.health[1], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         A.ev.health_next[0] = 0ull; A.ev.health_next[1] = 0ull;
       }
     }
@@ -2129,9 +2131,11 @@ uint32_t eval_blocks(uint32_t n_tiles) {
 __global__ __launch_bounds__(256) void k_eval(const uint32_t* __restrict__ row_cam, const uint32_t* __restrict__ lmk_idx,
                                               const float4* __restrict__ lmsg, const float4* __restrict__ fac, const float* __restrict__ cam_mu,
                                               const float* __restrict__ lmk_mu, const float* __restrict__ Kd,
-                                              int num_undamped, DeviceEval* partials, const unsigned long long* health,
+                                              int num_undamped, DeviceEval* partials, unsigned long long* health,
                                               unsigned long long* health_out, uint32_t n_tiles) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) { health_out[0] = health[0]; health_out[1] = health[1]; }   // k_means has finished (stream order)
+  // k_means has finished (stream order).  The words go back to zero: every user of the health areas finds them zero and leaves them so — the
+  // launches of k_persist_flow that carry a metric per iteration count into BOTH areas (words 2k, 2k + 1 for iteration k) without a reset.
+  if (blockIdx.x == 0 && threadIdx.x == 0) { health_out[0] = health[0]; health_out[1] = health[1]; health[0] = 0ull; health[1] = 0ull; }
   // block j produces S_j (see "THE ORDER OF THE METRIC'S SUMS"): one 256-factor block of the sweep at a time, wave w = tile 4b + w
   __shared__ double sh_d[2][4];
   __shared__ unsigned sh_u[3][4];
@@ -2431,7 +2435,7 @@ void launch_means(const float4* camb, const float4* lmkb, float* cam_mu, float* 
 }
 void launch_eval(const uint32_t* row_cam, const uint32_t* lmk_idx, const float4* lmsg, const float4* fac, const float* cam_mu,
                  const float* lmk_mu, const float* K9_dev, int num_undamped_iters, DeviceEval* partials,
-                 const unsigned long long* health2, unsigned long long* health2_out, uint32_t n_tiles, hipStream_t s) {
+                 unsigned long long* health2, unsigned long long* health2_out, uint32_t n_tiles, hipStream_t s) {
   hipLaunchKernelGGL(k_eval, dim3(eval_blocks(n_tiles)), dim3(256), 0, s, row_cam, lmk_idx, lmsg, fac, cam_mu, lmk_mu, K9_dev,
                      num_undamped_iters, partials, health2, health2_out, n_tiles);
 }

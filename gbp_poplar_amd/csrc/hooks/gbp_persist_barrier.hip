@@ -172,10 +172,10 @@ __global__ __launch_bounds__(256) void k_persist(const PersistArgs A) {
       unsigned long long* out = reinterpret_cast<unsigned long long*>(slots);
       out[0] = __hip_atomic_load(&h[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       out[1] = __hip_atomic_load(&h[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (A.ev.each) {   // this half counts from zero again when its turn comes (two hand-offs from now)
-        __hip_atomic_store(&h[0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&h[1], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+      // each: this half counts from zero again when its turn comes (two hand-offs from now); one metric: the area goes back to zero like
+      // every other user of the health words leaves it (k_eval in gbp_kernels.hip)
+      __hip_atomic_store(&h[0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&h[1], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   };
   auto metric_means = [&](uint32_t k, float (&cmv)[6], float (&lmu)[3]) {

@@ -29,7 +29,7 @@ void launch_state_get(const float4*, float*, int*, uint32_t, hipStream_t) { no_d
 void launch_state_set(float4*, const int*, const uint32_t*, uint32_t, hipStream_t) { no_device("launch_state_set"); }
 void launch_means(const float4*, const float4*, float*, float*, uint32_t, uint32_t, unsigned long long*, unsigned long long*, bool, hipStream_t) { no_device("launch_means"); }
 void launch_eval(const uint32_t*, const uint32_t*, const float4*, const float4*, const float*, const float*, const float*, int, DeviceEval*,
-                 const unsigned long long*, unsigned long long*, uint32_t, hipStream_t) { no_device("launch_eval"); }
+                 unsigned long long*, unsigned long long*, uint32_t, hipStream_t) { no_device("launch_eval"); }
 uint32_t eval_blocks(uint32_t n_tiles) { return (n_tiles + 3) / 4; }
 bool lab_launch_sweep_ablated(const SweepArgs&, uint32_t, int, hipStream_t) { return false; }
 bool launch_flow_torture(float4*, unsigned long long*, int, int, int, unsigned, unsigned, int, hipStream_t) { no_device("launch_flow_torture"); }

@@ -1531,6 +1531,60 @@ def test_health_counters(oracle_mod):
     assert (g["n_nonpd"], g["n_nonfinite"]) == (o["n_nonpd"], o["n_nonfinite"]) and g["n_nonpd"] >= 1
 
 
+@pytest.mark.parametrize("flow", [1, 0], ids=["tagged_records", "barriers"])
+def test_health_counters_with_metric_calls_of_every_kind_interleaved(flow, oracle_mod):
+    """Found by profiles/fuzz_parity.py (round 6, seed 19): gbp_eval between two gbp_ba_loop calls left its count in the health area it
+    had used (only the NEXT gbp_eval's k_means reset it), and the barrier variant of the persistent kernel — which counts the metrics of
+    a burst into both areas alternately — reported the first iteration of the next burst twice as unhealthy.  Now every user of the
+    health words leaves them zero.  A graph with landmarks nobody observes (zero prior -> infinite weakening scale -> NaN belief from
+    the first weakening on, by design: dataio.cpp:76-95, ba.cpp:564): gbp_eval, gbp_ba_loop, gbp_iterate_eval + gbp_eval_end and
+    gbp_iterate_eval_each in turn on the persistent kernel against one call at a time on the two-kernel path — every metric equal."""
+    from gbp_poplar_amd import _cabi, driver, hostlib
+    from gbp_poplar_amd.engine import GbpEngine
+    bal, kw = _ragged_bal()
+    opts = driver.Options()
+    opts.undamped_start = 2
+    K, state, _ = driver.build_inputs(bal, opts, hostlib)
+    steps = int(opts.steps)
+    a = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K, hooks=True, params=_cabi.GbpParams.defaults(persistent=1, **kw))
+    b = GbpEngine(bal["cam_id"], bal["lmk_id"], bal["n_cams"], bal["n_lmks"], K, hooks=True, params=_cabi.GbpParams.defaults(persistent=-1, **kw))
+    assert a.graph_state() == 2
+    a.persist_flow(flow)
+    for e in (a, b):
+        e.upload(state)
+        e.linearise()
+    it = [0]
+
+    def step_b(n):
+        out = []
+        for i in range(it[0], it[0] + n):
+            if (i + 1) % 2 == 0 and i < 2 * steps:
+                b.weaken_priors()
+            b.iterate(1)
+            out.append(b.eval())
+        return out
+
+    assert a.eval() == b.eval()
+    for n, kind in ((2, "loop"), (1, "eval"), (5, "loop"), (1, "eval"), (4, "loop"), (3, "iterate_eval"), (1, "eval"), (3, "each"), (2, "loop")):
+        if kind == "eval":
+            assert a.eval() == b.eval(), (kind, it[0])
+            continue
+        if kind == "loop":
+            ea = a.ba_loop(n, it[0], steps)
+            eb = step_b(n)
+        else:
+            assert it[0] >= 2 * steps      # (no weakening inside: these two calls know nothing of the loop's schedule)
+            eb = step_b(n)
+            if kind == "each":
+                ea = a.iterate_eval_each(n)
+            else:
+                a.iterate_eval(n)
+                ea, eb = [a.eval_end()], eb[-1:]
+        assert ea == eb, (kind, it[0], [(x["n_nonfinite"], y["n_nonfinite"]) for x, y in zip(ea, eb)])
+        it[0] += n
+    assert eb[-1]["n_nonfinite"] > 0 and eb[-1]["n_nonpd"] > 0
+
+
 # ---- BASELINE.json's full size (S1: 1 000 cams x 100 000 lmks x 1 000 000 factors) ---------------------------------
 
 @pytest.fixture(scope="module")
