@@ -15,7 +15,7 @@ Per seed (everything below drawn from the seed):
     bursts of random length by one of {gbp_iterate(k) + gbp_weaken_priors, gbp_ba_loop with the metric, gbp_ba_loop without}; the
     persistent kernel with tagged records or barriers, with or without its redundant-record check — against A after every burst:
     every tensor incl. the hoisted means, bit for bit; the metrics gbp_ba_loop returns against A's gbp_eval() after each iteration.
-Every fourth seed runs ./slam's flow instead (slam_seed below).
+Every fourth seed runs ./slam's flow instead (slam_seed below), every eighth a landmark-sharded group of contexts (shard_seed).
 The first mismatch stops the run with the seed and what differed; the summary line goes to stdout (copied to profiles/ by hand).
 test infrastructure: the oracle is the checker here, never the product.
 """
@@ -280,6 +280,97 @@ def slam_seed(seed):
     return desc, n_relin
 
 
+class GatherAll:
+    """the all-gather between shard contexts living in one process (what RCCL does between GPUs): every rank's send buffer into every
+    rank's receive buffer, by device copies"""
+
+    def __init__(self):
+        self.members = []
+
+    def __call__(self):
+        import torch
+        for m in self.members:
+            m.stream.synchronize()
+        for dst in self.members:
+            for r, src in enumerate(self.members):
+                n = src.send.numel()
+                dst.recv[r * n:(r + 1) * n].copy_(src.send)
+        torch.cuda.synchronize()
+
+
+def shard_seed(seed):
+    """`world` landmark-shard contexts (2..8, ranges balanced by factor count — ranks without a landmark included) on the one GPU, the
+    exchange by device copies: the sharded C-ABI verbs (gbp_iterate_begin / _local / _end, gbp_refresh_*, gbp_linearise_factors,
+    gbp_weaken_priors on a sharded ctx) against the oracle summing in `world`-shard device order — camera beliefs identical on every rank
+    and equal to the oracle's, every rank's own landmark beliefs and per-factor state, bit for bit."""
+    from gbp_poplar_amd.distributed import ShardedGbp, landmark_partition
+    rng = np.random.default_rng(11000 + seed)
+    bal = random_problem(rng)
+    C, L, E = bal["n_cams"], bal["n_lmks"], bal["n_edges"]
+    opts = driver.Options()
+    opts.undamped_start = int(rng.integers(1, 4))
+    K, state, _ = driver.build_inputs(bal, opts, hostlib)
+    state["active_flag"] = (rng.random(E) < 0.9).astype(np.uint32)
+    kw = dict(dmu_threshold=float(rng.choice([0.05, 0.02, 3e-3])), min_linear_iters=int(rng.integers(2, 6)), num_undamped_iters=int(rng.integers(1, 4)))
+    world = int(rng.choice([2, 3, 4, 5, 8]))
+    bounds = landmark_partition(bal["lmk_id"], L, world)
+    gather = GatherAll()
+    shards = []
+    for r in range(world):
+        eng = GbpEngine(bal["cam_id"], bal["lmk_id"], C, L, K, shard=(r, world, int(bounds[r]), int(bounds[r + 1])), params=_cabi.GbpParams.defaults(**kw))
+        sh = ShardedGbp(eng, C, r, world, dist=None, device="cuda")
+        gather.members.append(sh)
+        shards.append(sh)
+
+    def all_do(name, *a):
+        for sh in shards:
+            getattr(sh.e, name)(*a)
+
+    O = orc_mod.Oracle(bal["cam_id"], bal["lmk_id"], C, L, K, params=_cabi.GbpParams.defaults(**kw))
+    O.set_sum_order(1, bounds)
+    O.upload(state)
+    O.linearise()
+    all_do("upload", state)
+    all_do("refresh_begin"); gather(); all_do("refresh_end"); all_do("linearise_factors")
+    total = int(rng.integers(12, 40))
+    steps = int(opts.steps)
+    lmk = np.asarray(bal["lmk_id"])
+    n_relin = 0
+    for it in range(total):
+        if (it + 1) % 2 == 0 and it < 2 * steps:
+            all_do("weaken_priors")
+            O.weaken_priors()
+        all_do("iterate_begin")
+        if rng.random() < 0.5:
+            all_do("iterate_local")          # the landmark half first (what overlaps the all-gather on N GPUs)
+        gather()
+        all_do("iterate_end")
+        O.iterate(1)
+        if it < 6 or it == total - 1:
+            ro = O.read()
+            for r, sh in enumerate(shards):
+                g = sh.read()
+                same(g["cam_beliefs_eta"], ro["cam_beliefs_eta"], "world %d rank %d after iteration %d: cam_beliefs_eta" % (world, r, it))
+                same(g["cam_beliefs_lambda"], ro["cam_beliefs_lambda"], "world %d rank %d after iteration %d: cam_beliefs_lambda" % (world, r, it))
+                lo, hi = int(bounds[r]), int(bounds[r + 1])
+                same(g["lmk_beliefs_eta"][3 * lo:3 * hi], ro["lmk_beliefs_eta"][3 * lo:3 * hi], "world %d rank %d after iteration %d: lmk_beliefs_eta" % (world, r, it))
+                same(g["lmk_beliefs_lambda"][9 * lo:9 * hi], ro["lmk_beliefs_lambda"][9 * lo:9 * hi], "world %d rank %d after iteration %d: lmk_beliefs_lambda" % (world, r, it))
+                own = (lmk >= lo) & (lmk < hi)
+                for k in ("damping", "damping_count", "robust_flag"):
+                    same(g[k][own], ro[k][own], "world %d rank %d after iteration %d: %s" % (world, r, it, k))
+            evs = [sh.e.eval() for sh in shards]
+            eo = O.eval()
+            for k in ("n_active", "n_relin", "n_robust"):
+                if sum(e[k] for e in evs) != eo[k]:
+                    raise Mismatch("world %d after iteration %d: %s summed over the ranks %d vs oracle %d" % (world, it, k, sum(e[k] for e in evs), eo[k]))
+            n_relin += eo["n_relin"]
+    desc = "SHARDED world %d (landmark ranges %s) C %d L %d E %d | %d iterations | relinearisations seen %d" % (
+        world, "/".join(str(int(bounds[r + 1] - bounds[r])) for r in range(world)), C, L, E, total, n_relin)
+    for sh in shards:
+        sh.e.close()
+    return desc, n_relin
+
+
 def main():
     orc_mod.load("restatement")
     orc_mod.set_trig_mode(1)
@@ -288,13 +379,14 @@ def main():
     seed, done, relin_runs, paths = first, 0, 0, {}
     while time.time() - t0 < budget:
         try:
-            desc, nr = slam_seed(seed) if seed % 4 == 3 else one_seed(seed, lib)
+            desc, nr = slam_seed(seed) if seed % 4 == 3 else shard_seed(seed) if seed % 8 == 5 else one_seed(seed, lib)
         except Mismatch as e:
             print("seed %d: MISMATCH — %s" % (seed, e), flush=True)
             return 1
         print("seed %d ok: %s" % (seed, desc), flush=True)
         relin_runs += nr > 0
-        key = desc.split("| B: ")[1].split(" |")[0] if "| B: " in desc else "SLAM flow on " + desc.split("| path ")[1].split(" |")[0]
+        key = (desc.split("| B: ")[1].split(" |")[0] if "| B: " in desc else "sharded, world " + desc.split()[2] if desc.startswith("SHARDED")
+               else "SLAM flow on " + desc.split("| path ")[1].split(" |")[0])
         paths[key] = paths.get(key, 0) + 1
         done += 1
         seed += 1
