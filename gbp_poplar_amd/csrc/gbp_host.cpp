@@ -182,10 +182,18 @@ inline unsigned host_threads(uint64_t work_items, uint64_t min_items_per_thread)
   T = std::max(1u, std::min(T, 32u));
   return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(T, work_items / std::max<uint64_t>(1, min_items_per_thread)));
 }
-template <class F> void on_threads(unsigned T, F&& fn) {      // fn(t) for t in [0, T), fn(0) on the caller's thread
+// fn(t) for t in [0, T), fn(0) on the caller's thread.  fn must not throw (it allocates nothing: an exception inside a thread would end the
+// process); a thread the system refuses to start has its share run on the caller's thread instead.
+template <class F> void on_threads(unsigned T, F&& fn) {
   std::vector<std::thread> th;
-  for (unsigned t = 1; t < T; ++t) th.emplace_back(fn, t);
+  th.reserve(T);
+  unsigned started = 1;
+  try {
+    for (; started < T; ++started) th.emplace_back(fn, started);
+  } catch (...) {
+  }
   fn(0u);
+  for (unsigned t = started; t < T; ++t) fn(t);
   for (auto& x : th) x.join();
 }
 
@@ -201,7 +209,8 @@ NumberFile::Status read_number_file(const char* path, int n_hdr_dbl, uint64_t E,
     std::fprintf(stderr, "read_number_file: %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
     t0 = t1;
   };
-  const int fd = ::open(path, O_RDONLY);
+  struct Fd { int v; ~Fd() { if (v >= 0) ::close(v); } } file{::open(path, O_RDONLY)};      // (closed on every way out, an allocation failure included)
+  const int fd = file.v;
   if (fd < 0) return NumberFile::kNoFile;
   std::unique_ptr<char[]> buf;
   size_t n = 0;
@@ -222,7 +231,6 @@ NumberFile::Status read_number_file(const char* path, int n_hdr_dbl, uint64_t E,
     });
     for (unsigned t = 0; t < R; ++t) if (short_read[t]) n = 0;
   }
-  ::close(fd);
   if (n == 0) return NumberFile::kIrregular;           // (not a regular file, empty, or it shrank under us: the fscanf chain decides)
   lap("file into memory");
   buf[n++] = ' ';                                      // every token ends at a whitespace character ...
@@ -478,10 +486,9 @@ GBP_EXPORT(gbp_set_prior_lambda, nullptr, (const gbp_problem* p, float var, cons
   // one pass: max over incident observations (dataio.cpp:78-87, 99-108).  A maximum does not depend on the order it is taken in: large
   // graphs are cut into one range of factors per host thread, each with its own peaks, and the peaks are merged.
   const unsigned T = host_threads(E, 1u << 16);
-  std::vector<std::vector<float>> pc(T), pl(T);
+  std::vector<std::vector<float>> pc(T, std::vector<float>(C, 0.f)), pl(T, std::vector<float>(L, 0.f));      // (allocated here: nothing throws inside a thread)
   std::vector<int> bad(T, 0);
   on_threads(T, [&](unsigned t) {
-    pc[t].assign(C, 0.f); pl[t].assign(L, 0.f);
     const uint64_t lo = (uint64_t)E * t / T, hi = (uint64_t)E * (t + 1) / T;
     for (uint64_t e = lo; e < hi; ++e) {
       const uint32_t c = p->cam_id[e], l = p->lmk_id[e];

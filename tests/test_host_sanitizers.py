@@ -42,3 +42,17 @@ def test_host_code_and_oracle_under_asan_ubsan(tmp_path):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     p = subprocess.run([exe, str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=300)
     assert p.returncode == 0 and "sanitize: ok" in p.stdout, (p.returncode, p.stdout[-500:], p.stderr[-3000:])
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_threaded_host_code_under_tsan(tmp_path):
+    """The host code that runs on several threads — the file reader (one piece of the file per thread) and the prior strengths (one range
+    of factors per thread) — under ThreadSanitizer: results equal to the single-threaded ones, no report (tests/sanitize/host_threads_main.cpp)."""
+    exe = str(tmp_path / "host_threads")
+    subprocess.check_call(["g++", "-std=c++17", "-fsanitize=thread", "-O1", "-g", "-pthread", "-ffp-contract=off",
+                           os.path.join(ROOT, "gbp_poplar_amd", "csrc", "gbp_host.cpp"), os.path.join(ROOT, "tests", "sanitize", "host_threads_main.cpp"), "-o", exe], cwd=ROOT)
+    p = subprocess.run([exe, str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300,
+                       env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"))
+    if "unexpected memory mapping" in p.stderr:
+        pytest.skip("ThreadSanitizer cannot map its shadow on this kernel")
+    assert p.returncode == 0 and "tsan: ok" in p.stdout and "ThreadSanitizer" not in p.stderr, (p.returncode, p.stdout[-300:], p.stderr[-3000:])
