@@ -111,6 +111,15 @@ int H2D::put(void* dst_dev, const void* src, size_t bytes) {
   used += padded;
   return GBP_OK;
 }
+// bytes into the staging buffer for a kernel of the caller's to read (no copy segment): *dev = their device address, valid until end()
+int H2D::stage(const void* src, size_t bytes, const void** dev) {
+  const size_t padded = (bytes + 15) / 16 * 16;
+  if (direct || used + padded > c->stage_cap) return fail(c, GBP_ERR_INVALID, "H2D: staging buffer too small (internal)");
+  std::memcpy(static_cast<char*>(c->stage_host) + used, src, bytes);
+  *dev = static_cast<const char*>(c->stage_dev) + used;
+  used += padded;
+  return GBP_OK;
+}
 int H2D::end() {
   if (!direct)
     if (int rc = flush()) return rc;
@@ -441,28 +450,61 @@ GBP_EXPORT(gbp_upload, c, (gbp_ctx* c, const gbp_state_in* in), (c, in)) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (int rc = persist_reset(c)) return rc;      // a fresh start for the persistent kernel too
   const size_t Ep = c->Ep;
-  std::vector<float> rec0(Ep * 16, 0.f), fac(Ep * kFacG * 4, 0.f), mu(c->hoist ? 0 : Ep * kMuG * 4, 0.f);
+  // The per-factor streams in their compact form, in device order: {damping, count << 3 | flags, z0, z1} + the variance = 20 bytes per
+  // position.  k_upload_scatter writes them into the records they belong to (the whole 64-byte LMSG record: zero messages + state; the
+  // measurement slots of the FAC tile, the other 216 bytes per position zeroed on the device) — 288 bytes per position used to be built on
+  // the host and cross PCIe: 0.11 s of a `bin/ba` run on a file of 10^6 factors (profiles/r06_configs.md section 2).
+  struct St { float damping; int32_t packed; float z0, z1; };
+  static_assert(sizeof(St) == 16, "k_upload_scatter reads one float4 per position");
+  std::vector<St> st(Ep);
+  std::vector<float> var(Ep), mu(c->hoist ? 0 : Ep * kMuG * 4, 0.f);
   c->active_host.assign(Ep, 0);
+  const float* om = in->oldmu ? in->oldmu : in->mu;
   for (size_t p = 0; p < Ep; ++p) {
     const uint32_t e = c->lay.pos_edge[p];
-    HostState h{0.f, 0, kFlagPad, 0.f};
+    St o{0.f, (int32_t)kFlagPad, 0.f, 0.f};
+    float v = 0.f;
     if (e != ~0u) {
-      h.flags = (in->active_flag[e] == 1) ? kFlagActive : 0u;
-      c->active_host[p] = in->active_flag[e] == 1;
-      h.damping = in->damping ? in->damping[e] : 0.f;
-      h.count = in->damping_count ? in->damping_count[e] : 0;
-      h.var = in->meas_variances[e];
-      fac[tile_off((uint32_t)p, kFacG, 54)] = in->measurements[2 * (size_t)e];
-      fac[tile_off((uint32_t)p, kFacG, 55)] = in->measurements[2 * (size_t)e + 1];
-      const float* om = in->oldmu ? in->oldmu : in->mu;
+      const bool on = in->active_flag[e] == 1;
+      c->active_host[p] = on;
+      const int32_t count = in->damping_count ? in->damping_count[e] : 0;
+      o.damping = in->damping ? in->damping[e] : 0.f;
+      o.packed = (int32_t)(((uint32_t)count << 3) | (on ? kFlagActive : 0u));
+      o.z0 = in->measurements[2 * (size_t)e];
+      o.z1 = in->measurements[2 * (size_t)e + 1];
+      v = in->meas_variances[e];
       if (om && !c->hoist) for (int i = 0; i < 9; ++i) mu[tile_off((uint32_t)p, kMuG, i)] = om[(size_t)e * 9 + i];
     }
-    put_state(rec0, p, h);
+    st[p] = o;
+    var[p] = v;
   }
+  HIPCHK(c, hipMemsetAsync(c->fac.p, 0, c->fac.bytes, c->stream));
   H2D up;
-  if (int rc = up.begin(c, (rec0.size() + fac.size() + mu.size() + ((size_t)c->C + c->L_loc) * (kCamRec + 16 + 2)) * 4, 9)) return rc;
-  if (int rc = up.put(c->lmsg.p, rec0.data(), rec0.size() * 4)) return rc;   // zero messages + state
-  if (int rc = up.put(c->fac.p, fac.data(), fac.size() * 4)) return rc;
+  if (int rc = up.begin(c, (Ep * 5 + mu.size() + ((size_t)c->C + c->L_loc) * (kCamRec + 16 + 2)) * 4, 9)) return rc;
+  {
+    // the compact streams: out of the pinned staging buffer (the kernel reads host memory), or — too large for it — through a device
+    // buffer that lives for this call
+    DevBuf tmp;
+    const float4* st_dev = nullptr;
+    const float* var_dev = nullptr;
+    if (!up.direct) {
+      const void *a = nullptr, *b = nullptr;
+      if (int rc = up.stage(st.data(), Ep * 16, &a)) return rc;
+      if (int rc = up.stage(var.data(), Ep * 4, &b)) return rc;
+      st_dev = static_cast<const float4*>(a); var_dev = static_cast<const float*>(b);
+    } else {
+      HIPCHK(c, hipMalloc(&tmp.p, Ep * 20));
+      tmp.bytes = Ep * 20;
+      const hipError_t e1 = hipMemcpy(tmp.p, st.data(), Ep * 16, hipMemcpyHostToDevice);
+      const hipError_t e2 = e1 == hipSuccess ? hipMemcpy(static_cast<char*>(tmp.p) + Ep * 16, var.data(), Ep * 4, hipMemcpyHostToDevice) : e1;
+      if (e2 != hipSuccess) { (void)hipFree(tmp.p); HIPCHK(c, e2); }
+      st_dev = static_cast<const float4*>(tmp.p); var_dev = reinterpret_cast<const float*>(static_cast<char*>(tmp.p) + Ep * 16);
+    }
+    launch_upload_scatter(P<float4>(c->lmsg), P<float4>(c->fac), st_dev, var_dev, (uint32_t)Ep, c->stream);
+    const hipError_t le = hipGetLastError();
+    if (tmp.p) { (void)hipStreamSynchronize(c->stream); (void)hipFree(tmp.p); }
+    HIPCHK(c, le);
+  }
   if (!c->hoist)
     if (int rc = up.put(c->mu.p, mu.data(), mu.size() * 4)) return rc;
   HIPCHK(c, hipMemsetAsync(c->cmsg.p, 0, c->cmsg.bytes, c->stream));

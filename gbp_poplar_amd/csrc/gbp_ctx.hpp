@@ -184,6 +184,7 @@ struct H2D {
   CopySegs segs{};
   int begin(gbp_ctx* ctx, size_t total_bytes, int pieces);
   int put(void* dst_dev, const void* src, size_t bytes);      // dst: a whole DevBuf or a 16-byte aligned piece whose padded size is inside one
+  int stage(const void* src, size_t bytes, const void** dev);  // staged only (!direct): the bytes where a kernel of the caller's reads them
   int end();
   int flush();
 };

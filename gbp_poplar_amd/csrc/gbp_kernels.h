@@ -271,6 +271,10 @@ bool persist_probe(uint32_t n_tiles, uint32_t n_cams, uint32_t n_lmks, unsigned*
                    bool cooperative, hipStream_t s);
 void launch_state_get(const float4* lmsg, float* damping, int* packed, uint32_t n, hipStream_t s);
 void launch_state_set(float4* lmsg, const int* new_count, const uint32_t* ctl, uint32_t n, hipStream_t s);
+// WRITE_PROG's per-factor streams (ba.cpp:868-886) from their compact host form — st[p] = {damping, count << 3 | flags, z0, z1}, var[p], both possibly
+// host-mapped — into the records of the device order: the whole LMSG record of position p (zero messages + state) and the measurement
+// slots of its FAC tile (the rest of FAC is zeroed by the caller)
+void launch_upload_scatter(float4* lmsg, float4* fac, const float4* st, const float* var, uint32_t n, hipStream_t s);
 void launch_means(const float4* camb, const float4* lmkb, float* cam_mu, float* lmk_mu, uint32_t n_cams,
                   uint32_t n_lmks, unsigned long long* health2 /* [0] non-finite means, [1] non-PD beliefs: zero on entry */,
                   unsigned long long* health2_next /* zeroed by this launch for the next evaluation */,

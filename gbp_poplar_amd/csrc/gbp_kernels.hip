@@ -2094,6 +2094,21 @@ __global__ __launch_bounds__(256) void k_state_set(float4* __restrict__ lmsg, co
   lmsg[(size_t)p * 4 + 3] = st;
 }
 
+// gbp_upload: 20 bytes per position cross PCIe (read here straight out of the pinned staging buffer when they fit it) instead of the 288 bytes
+// of the records they go into
+__global__ __launch_bounds__(256) void k_upload_scatter(float4* __restrict__ lmsg, float4* __restrict__ fac, const float4* __restrict__ st,
+                                                        const float* __restrict__ var, uint32_t n) {
+  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  const float4 s = st[p];
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  lmsg[(size_t)p * 4] = make_float4(0.f, 0.f, 0.f, s.x);
+  lmsg[(size_t)p * 4 + 1] = z;
+  lmsg[(size_t)p * 4 + 2] = z;
+  lmsg[(size_t)p * 4 + 3] = make_float4(0.f, s.y, var[p], 0.f);
+  fac[((size_t)(p >> 6) * kFacG + 13) * 64 + (p & 63)] = make_float4(0.f, 0.f, s.z, s.w);      // floats 52..55: z = .z, .w
+}
+
 __global__ __launch_bounds__(256) void k_means(const float* __restrict__ camb, const float* __restrict__ lmkb,
                                                float* __restrict__ cam_mu, float* __restrict__ lmk_mu, uint32_t n_cams,
                                                uint32_t n_lmks, unsigned long long* health, unsigned long long* health_next,
@@ -2424,6 +2439,9 @@ hipError_t launch_persist(PersistArgs A, bool cooperative, hipStream_t s) {
 }
 void launch_state_get(const float4* lmsg, float* damping, int* packed, uint32_t n, hipStream_t s) {
   hipLaunchKernelGGL(k_state_get, dim3(blocks_for(n)), dim3(256), 0, s, lmsg, damping, packed, n);
+}
+void launch_upload_scatter(float4* lmsg, float4* fac, const float4* st, const float* var, uint32_t n, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(k_upload_scatter, dim3(blocks_for(n)), dim3(256), 0, s, lmsg, fac, st, var, n);
 }
 void launch_state_set(float4* lmsg, const int* new_count, const uint32_t* ctl, uint32_t n, hipStream_t s) {
   hipLaunchKernelGGL(k_state_set, dim3(blocks_for(n)), dim3(256), 0, s, lmsg, new_count, ctl, n);

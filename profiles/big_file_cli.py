@@ -33,8 +33,9 @@ for r in range(runs):
             sys.exit("ba failed: " + p.stderr[-2000:])
         st = json.load(open(os.path.join(d, "gbp_profile.json")))["startup"]
         md5.add("\n".join(l for l in p.stdout.splitlines() if "Total time" not in l and "Profile written" not in l))
-        print("%-9s run %d: process wall %.3f s | loader %.3f, file %.3f, runtime (what was left to wait for) %.3f, create %.3f, loop %.3f"
-              % (label, r, wall, st["exec_to_main_s"], st["file_parse_s"], st["runtime_init_s"], st["create_s"], st["loop_s"]), flush=True)
+        print("%-9s run %d: process wall %.3f s | loader %.3f, file %.3f, runtime (what was left to wait for) %.3f, create %.3f, upload %.3f, linearise + first metric %.3f, loop %.3f, teardown %.3f, after main %.3f"
+              % (label, r, wall, st["exec_to_main_s"], st["file_parse_s"], st["runtime_init_s"], st["create_s"], st.get("upload_s", 0.0), st.get("linearise_s", 0.0), st["loop_s"],
+                 st["teardown_s"], wall - st["process_s"]), flush=True)
 print("stdout identical across all runs: %s" % (len(md5) == 1))
 p = subprocess.run([os.path.join(ROOT, "gbp_poplar_amd", "bin", "ba"), "--bal_file", path, "--n_iters", "1"], env=dict(os.environ, GBP_HOST_TRACE="1"),
                    stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)

@@ -27,6 +27,7 @@ void launch_copy_segments(const CopySegs&, const unsigned*, hipStream_t) { no_de
 bool persist_probe(uint32_t, uint32_t, uint32_t, unsigned*, unsigned*, volatile unsigned*, bool, hipStream_t) { return false; }
 void launch_state_get(const float4*, float*, int*, uint32_t, hipStream_t) { no_device("launch_state_get"); }
 void launch_state_set(float4*, const int*, const uint32_t*, uint32_t, hipStream_t) { no_device("launch_state_set"); }
+void launch_upload_scatter(float4*, float4*, const float4*, const float*, uint32_t, hipStream_t) { no_device("launch_upload_scatter"); }
 void launch_means(const float4*, const float4*, float*, float*, uint32_t, uint32_t, unsigned long long*, unsigned long long*, bool, hipStream_t) { no_device("launch_means"); }
 void launch_eval(const uint32_t*, const uint32_t*, const float4*, const float4*, const float*, const float*, const float*, int, DeviceEval*,
                  unsigned long long*, unsigned long long*, uint32_t, hipStream_t) { no_device("launch_eval"); }

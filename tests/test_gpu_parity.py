@@ -1789,6 +1789,37 @@ def test_full_size_s1_properties(s1):
 
 # ---- BASELINE config 5 at size: 8 000 cams x 1 000 000 lmks x 10 000 000 factors, 8 landmark shards ------------------------
 
+def test_upload_of_a_graph_beyond_the_staging_buffer(oracle_mod):
+    """gbp_upload moves the per-factor streams in compact form (20 bytes per position) and k_upload_scatter writes the records: out of
+    the pinned staging buffer up to 32 MB (every other test), through a device buffer of the call's own beyond — 1.8 M factors here.
+    Two sweeps with a weakening, every belief and the per-factor state bit for bit against the oracle; inactive factors and non-default
+    damping state in the upload."""
+    from gbp_poplar_amd import driver, hostlib
+    bal = hostlib.synth_generate(400, 180000, 10, 31)
+    eng, orc, opts, state, _ = _setup(bal, oracle_mod, hooks=False)
+    rng = np.random.default_rng(3)
+    state = dict(state)
+    state["active_flag"] = (rng.random(bal["n_edges"]) < 0.95).astype(np.uint32)
+    state["damping"] = rng.choice(np.array([0.0, 0.4], np.float32), bal["n_edges"])
+    state["damping_count"] = rng.integers(-15, 3, bal["n_edges"]).astype(np.int32)
+    oracle_mod.set_trig_mode(1)
+    try:
+        for x in (eng, orc):
+            x.upload(state)
+            x.linearise()
+        for it in range(2):
+            if it == 1:
+                eng.weaken_priors()
+                orc.weaken_priors()
+            eng.iterate(1)
+            orc.iterate(1)
+        _assert_state_equal(eng, orc, exact=True)
+        g, o = eng.eval(), orc.eval()
+    finally:
+        oracle_mod.set_trig_mode(0)
+    assert (g["n_active"], g["n_relin"], g["n_robust"]) == (o["n_active"], o["n_relin"], o["n_robust"]) and g["n_active"] < bal["n_edges"]
+
+
 def test_config5_at_size_eight_shards_on_one_gpu(oracle_mod):
     """The graph of BASELINE config 5 through the SHARDED kernels: eight landmark-shard contexts (what the eight ranks
     of an 8-GPU run hold) on one GPU, camera partial sums exchanged by device copies (what the RCCL all-gather moves).
