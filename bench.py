@@ -1157,6 +1157,24 @@ def run_rank(a):
                 except Exception as exc:  # noqa: BLE001
                     small[name]["cpu_baseline"] = {"error": repr(exc)}
 
+    # ---- what the boundary's host buffers cost (never part of `value`: the iterations run on state resident in HBM) ----
+    transfer = None
+    if rank == 0 and not sharded and world == 1:
+        import numpy as np
+        t0 = time.perf_counter()
+        back = eng.read()                                   # READ_PROG: beliefs + damping, damping_count, robust_flag
+        read_s = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        eng.upload(state)                                   # WRITE_PROG (returns with everything on the device)
+        upload_s = time.perf_counter() - t0
+        n_ref = 1500                                        # the reference's default run (--n_iters, ba.cpp:406-409)
+        step_s = dt / a.steps
+        transfer = {"upload_ms": round(upload_s * 1e3, 2), "read_ms": round(read_s * 1e3, 2),
+                    "host_bytes_in": int(sum(np.asarray(v).nbytes for v in state.values())), "host_bytes_out": int(sum(np.asarray(v).nbytes for v in back.values())),
+                    "value_incl_transfers": round(n_ref / (upload_s + n_ref * step_s + read_s) * E / 1e6, 2),
+                    "is": "gbp_upload (WRITE_PROG) and gbp_read (READ_PROG) of this graph, host clock, once each after the timed windows; "
+                          "value_incl_transfers = a run of the reference's default %d iterations with one upload in front and one read behind, in the metric's unit" % n_ref}
+
     if rank == 0:
         ips = a.steps / dt
         m0, m1 = driver.metric(ev0), driver.metric(ev1)
@@ -1184,6 +1202,8 @@ def run_rank(a):
             out["sustained"] = sustained
         if trace_info:
             out["config"]["flow_trace"] = trace_info
+        if transfer:
+            out["host_transfer"] = transfer
         if roof:
             out["roofline"] = roof
         if cpu:

@@ -183,7 +183,7 @@ struct Problem {
   std::vector<uint32_t> cam_id, lmk_id;
   std::vector<double> obs, cams, pts;
   std::vector<float> K, meas, var, cam_file, lmk_file, cam_mean, lmk_mean;
-  std::vector<float> cpe, cpl, lpe, lpl, cscale, lscale, damping, mu;
+  std::vector<float> cpe, cpl, lpe, lpl, cscale, lscale, damping;
   std::vector<int32_t> count;
   std::vector<uint32_t> active, cwf, lwf;
   gbp_problem prob{};
@@ -236,13 +236,14 @@ inline int load_problem(const Options& o, Problem& P) {
   std::cout << "Completed loading data!\n";
   P.damping.assign(E, 0.f);
   P.count.assign(E, -o.iters_before_damping);  // ba.cpp:581
-  P.mu.assign(9 * (size_t)E, 0.f);
+  // mu / oldmu: the reference uploads 9 E zeros for each (ba.cpp:582-583); gbp_upload takes NULL for "zeros" — 72 MB per million factors
+  // that are neither allocated nor compared here
   return 0;
 }
 
 inline gbp_state_in state_in(const Problem& P) {
   gbp_state_in s{};
-  s.damping = P.damping.data(); s.damping_count = P.count.data(); s.mu = P.mu.data(); s.oldmu = P.mu.data();
+  s.damping = P.damping.data(); s.damping_count = P.count.data(); s.mu = nullptr; s.oldmu = nullptr;
   s.active_flag = P.active.data(); s.cam_scaling = P.cscale.data(); s.lmk_scaling = P.lscale.data();
   s.cam_weaken_flag = P.cwf.data(); s.lmk_weaken_flag = P.lwf.data();
   s.cam_priors_eta = P.cpe.data(); s.cam_priors_lambda = P.cpl.data(); s.lmk_priors_eta = P.lpe.data();

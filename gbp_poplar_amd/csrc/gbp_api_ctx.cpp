@@ -82,7 +82,7 @@ int H2D::begin(gbp_ctx* ctx, size_t total_bytes, int pieces) {
   if (direct) return GBP_OK;
   if (c->stage_cap < need) {
     if (c->stage_host) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipHostFree(c->stage_host); c->stage_host = nullptr; c->stage_cap = 0; }
-    const size_t cap = std::max<size_t>(need, (size_t)1 << 20);
+    const size_t cap = std::max<size_t>(std::max(need, c->stage_hint <= kStageMax ? c->stage_hint : 0), (size_t)1 << 20);
     HIPCHK(c, hipHostMalloc(&c->stage_host, cap, hipHostMallocMapped));
     HIPCHK(c, hipHostGetDevicePointer(&c->stage_dev, c->stage_host, 0));
     c->stage_cap = cap;
@@ -380,6 +380,8 @@ GBP_EXPORT(gbp_create, nullptr, (const gbp_problem* pr, const gbp_params* prm, c
     std::vector<char> stage(idx_bytes, 0);
     for (const Piece& pc : pieces)
       if (pc.bytes) std::memcpy(stage.data() + pc.off, pc.src, pc.bytes);
+    // (pinned once, large enough for the gbp_upload that follows: pinning costs ~0.5 ms per MB, a second buffer would cost that again)
+    c->stage_hint = (Ep * 5 + (size_t)(c->hoist ? 0 : Ep * kMuG * 4) + ((size_t)c->C + c->L_loc) * (kCamRec + 16 + 2)) * 4 + 16 * 9;
     H2D up;
     if (rc == GBP_OK) rc = up.begin(c, idx_bytes, 1);
     if (rc == GBP_OK) rc = up.put(c->idx_arena.p, stage.data(), idx_bytes);
@@ -438,7 +440,7 @@ GBP_EXPORT(gbp_upload, c, (gbp_ctx* c, const gbp_state_in* in), (c, in)) {
   if (!in->cam_priors_eta || !in->cam_priors_lambda || !in->lmk_priors_eta || !in->lmk_priors_lambda ||
       !in->measurements || !in->meas_variances || !in->active_flag)
     return fail(c, GBP_ERR_INVALID, "gbp_upload: priors, measurements, meas_variances and active_flag are required");
-  if (in->mu && in->oldmu && std::memcmp(in->mu, in->oldmu, (size_t)c->E * 9 * 4) != 0)
+  if (in->mu && in->oldmu && in->mu != in->oldmu && std::memcmp(in->mu, in->oldmu, (size_t)c->E * 9 * 4) != 0)
     return fail(c, GBP_ERR_INVALID, "gbp_upload: mu != oldmu is not supported (the reference uploads zeros for both, ba.cpp:582-583)");
   if (c->hoist) {
     const float* om = in->oldmu ? in->oldmu : in->mu;

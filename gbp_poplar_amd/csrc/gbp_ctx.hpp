@@ -62,6 +62,7 @@ struct gbp_ctx {
   void* stage_host = nullptr;
   void* stage_dev = nullptr;
   size_t stage_cap = 0;
+  size_t stage_hint = 0;               // what gbp_upload will stage: the buffer is pinned once, at that size (gbp_create)
   DevBuf idx_arena;                    // the index arrays of the device order (row_cam, lmk_idx, lmk_fpos, lmk_ix, the row / landmark pointers, row_slot, K, tile_perm: views into it)
   DevBuf st_a, st_b;                   // [Ep] scratch of the per-factor state get / set kernels
   std::vector<uint8_t> active_host;    // [Ep] host shadow of the active flags (hoist guard of gbp_new_keyframe)

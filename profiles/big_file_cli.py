@@ -37,6 +37,7 @@ for r in range(runs):
               % (label, r, wall, st["exec_to_main_s"], st["file_parse_s"], st["runtime_init_s"], st["create_s"], st.get("upload_s", 0.0), st.get("linearise_s", 0.0), st["loop_s"],
                  st["teardown_s"], wall - st["process_s"]), flush=True)
 print("stdout identical across all runs: %s" % (len(md5) == 1))
+print("the last run's %s" % st.get("create", "")[6:])
 p = subprocess.run([os.path.join(ROOT, "gbp_poplar_amd", "bin", "ba"), "--bal_file", path, "--n_iters", "1"], env=dict(os.environ, GBP_HOST_TRACE="1"),
                    stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
 print("".join(l + "\n" for l in p.stderr.splitlines() if "read_number_file" in l), end="")
