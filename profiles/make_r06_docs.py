@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.chdir(ROOT)
 O = "gpurun_out/round_r06/"
 for src, dst in (("r06_kernel_stats.csv", "r06_kernel_stats.csv"), ("traffic_S1.json", "traffic_S1.json"), ("cli_md5.txt", "r06_cli_md5.txt"),
-                 ("cli_summary.txt", "r06_cli_summary.txt"), ("persist_bursts.txt", "r06_persist_bursts.txt"), ("cli_startup.txt", "r06_cli_startup.txt")):
+                 ("cli_summary.txt", "r06_cli_summary.txt"), ("persist_bursts.txt", "r06_persist_bursts.txt"), ("cli_startup.txt", "r06_cli_startup.txt"), ("cli_bigfile.txt", "r06_cli_bigfile.txt")):
     shutil.copy(O + src, "profiles/" + dst)
 names = ["bench_driver_under_rocprof", "bench_driver_1", "bench_driver_2", "bench_default", "bench_c5shape_plain", "bench_c5shape_driverline",
          "bench_c5shape_native_200", "bench_share_2", "bench_share_4", "bench_share_8"]
@@ -24,6 +24,7 @@ d1, d2, dd = R["bench_driver_1"], R["bench_driver_2"], R["bench_default"]
 c5p, c5d, c5n = R["bench_c5shape_plain"], R["bench_c5shape_driverline"], R["bench_c5shape_native_200"]
 fx, sl, dl = d1["configs"]["fr1xyz"], d1["configs"]["slam_fr2robot2"], d1["configs"]["s1_default_loop"]
 cb, rep = d1["cpu_baseline"], d1["roofline"]["replay"]
+ht = d1["host_transfer"]
 ks = list(csv.DictReader(open("profiles/r06_kernel_stats.csv")))
 md5_same = open("profiles/r05_cli_md5.txt").read() == open("profiles/r06_cli_md5.txt").read()
 
@@ -50,6 +51,7 @@ def s1row(n, label):
 
 
 sw, bl, swe, ble, cp = k("void gbp::k_sweep<true, 1u, false"), k("gbp::k_beliefs("), k("void gbp::k_sweep<true, 1u, true"), k("gbp::k_beliefs_ev"), k("gbp::k_copy_segments")
+usc = k("gbp::k_upload_scatter")
 tests = open("profiles/r06_summary.md").read()
 tests = tests[tests.index("## Tests on the final tree"):] if "## Tests on the final tree" in tests else ""
 summary = """# Round 6 — measurements on one MI355X (gfx950) through `gpurun`
@@ -65,6 +67,7 @@ the driver will start, as eight processes), `r06_configs.md` (config-5 shape wit
 ## The bench line on S1 (`configs[1]`: 1 000 x 100 000 x 1 000 000 factors, f32, one GPU)
 
 The single-GPU hot path was not touched this round (VERDICT r05: closed with evidence); the line is the control that nothing moved.
+New in the line: `host_transfer` — what the boundary's host buffers cost, never part of `value`.
 
 | run (`r06_bench_lines.jsonl`) | `value` = first window (1M-factor it/s) | ms/step | weakenings timed | `windows` min / median / max | `sustained` | `k_sweep` live us | `k_beliefs` live us | `roofline.traffic` | `achieved` GB/s | `frac` | `rocprof` avg us / frac |
 |---|---|---|---|---|---|---|---|---|---|---|---|
@@ -76,9 +79,12 @@ The single-GPU hot path was not touched this round (VERDICT r05: closed with evi
   per dispatch ordinary **%.1f MB**, lock-step **%.1f MB**, mean %.1f MB = %.3f x the 591-B layout.
 * `cpu_baseline`: the oracle (16 threads) %.2f it/s over the first %d iterations of the same flow; **every belief and the per-factor state bit-identical**
   to the GPU's (`beliefs_bit_exact_vs_oracle: %s`, `max_rel_deviation: %s`).
+* `host_transfer` (driver_1): `gbp_upload` of the graph %.2f ms (%.1f MB of host buffers in; 20 B per position cross PCIe, `k_upload_scatter` writes the records),
+  `gbp_read` %.2f ms (%.1f MB out); a run of the reference's default 1 500 iterations with one upload in front and one read behind: **%.0f** 1M-factor it/s
+  against %.0f with the state resident (`value`).
 * `configs.s1_default_loop` (metric after every iteration, any graph size): steady ratio **%.3f x** of the plain iteration.
-* `configs.fr1xyz` **%.0f it/s** loop wall (%.2f ms, %.2f us per iteration on the device), process wall **%.3f s** (round 5: 0.576 s on its box; `startup` in the line says
-  where it goes: `r06_configs.md` section 2); `configs.slam_fr2robot2` **%.0f it/s** (%.1f ms, %.2f us), process %.3f s.  Finals unchanged, stdout md5s %s
+* `configs.fr1xyz` **%.0f it/s** loop wall (%.2f ms, %.2f us per iteration on the device), process wall **%.3f s** (round 5: 0.576 s on its box; started 0.5 s after the previous GPU process, beside the bench's own
+  live context — alone on the GPU 0.16 - 0.19 s, `r06_cli_idle.txt`; `startup` in the line says where it goes: `r06_configs.md` section 2); `configs.slam_fr2robot2` **%.0f it/s** (%.1f ms, %.2f us), process %.3f s.  Finals unchanged, stdout md5s %s
   (`r06_cli_md5.txt`).
 
 ## Kernel statistics (`r06_kernel_stats.csv`: the driver's command, parent process, every launch)
@@ -89,7 +95,8 @@ The single-GPU hot path was not touched this round (VERDICT r05: closed with evi
 | `k_beliefs` | %s | **%.2f** | %.1f | %.1f |
 | `k_sweep<true,1,true,false>` (the sweeps the metric rides in) | %s | %.2f | %.1f | %.1f |
 | `k_beliefs_ev` | %s | %.2f | %.1f | %.1f |
-| `k_copy_segments` (the staged index arrays of three engines: 15 MB each over PCIe; S1's 290 MB of state go through `hipMemcpy`) | %s | %.1f | | |
+| `k_copy_segments` (the staged host data of the engines: index arrays 15 MB each, priors) | %s | %.1f | | |
+| `k_upload_scatter` (`gbp_upload`: 20 MB of compact per-factor streams out of the pinned buffer into the `LMSG` / `FAC` records) | %s | %.1f | | |
 
 Round 5's table had 97.04 / 16.98 us for the first two: sweep + beliefs = %.1f us against `ms_per_step` %.1f us.
 
@@ -115,11 +122,12 @@ all-pad 64-byte segments of its tiles (`k_sweep<..., SEG>`, `r06_configs.md` sec
 
 """ % (rep["lockstep_iterations_in_window"], rep.get("child_replayed_the_same_launches"), rep["traffic_ordinary_launch"] / 1e6, rep["traffic_lockstep_launch"] / 1e6,
        d1["roofline"]["traffic"] / 1e6, d1["roofline"]["traffic_over_layout"], cb["value"], cb["iterations"], cb["beliefs_bit_exact_vs_oracle"], cb["max_rel_deviation"],
+       ht["upload_ms"], ht["host_bytes_in"] / 1e6, ht["read_ms"], ht["host_bytes_out"] / 1e6, ht["value_incl_transfers"], d1["value"],
        dl["steady"]["ratio"], fx["iters_per_sec"], fx["loop_wall_ms"], fx["us_per_iter_device"], fx["process_wall_s"], sl["iters_per_sec"], sl["loop_wall_ms"],
        sl["us_per_iter_device"], sl["process_wall_s"], "identical to rounds 1 - 5" if md5_same else "DIFFER from round 5's",
        sw["Calls"], us(sw, "AverageNs"), us(sw, "MinNs"), us(sw, "MaxNs"), bl["Calls"], us(bl, "AverageNs"), us(bl, "MinNs"), us(bl, "MaxNs"),
        swe["Calls"], us(swe, "AverageNs"), us(swe, "MinNs"), us(swe, "MaxNs"), ble["Calls"], us(ble, "AverageNs"), us(ble, "MinNs"), us(ble, "MaxNs"),
-       cp["Calls"], us(cp, "AverageNs"), us(sw, "AverageNs") + us(bl, "AverageNs"), d1["ms_per_step"] * 1e3,
+       cp["Calls"], us(cp, "AverageNs"), usc["Calls"], us(usc, "AverageNs"), us(sw, "AverageNs") + us(bl, "AverageNs"), d1["ms_per_step"] * 1e3,
        c5p["ms_per_step"], c5p["windows"]["median"], c5p["sustained"]["value"], c5p["roofline"]["avg_launch_us"], c5p["roofline"]["rocprof"]["avg_launch_us"],
        c5p["roofline"]["traffic"] / 1e6, c5p["roofline"]["traffic_over_layout"], c5p["roofline"]["frac"],
        c5d["ms_per_step"], c5d["windows"]["median"], c5d["sustained"]["value"], c5d["roofline"]["avg_launch_us"], c5d["roofline"]["rocprof"]["avg_launch_us"],
@@ -145,7 +153,8 @@ tab = """| S1 = `configs[1]`, 1000 × 100 000 × 1 M factors, N = 1 | driver's c
 | rocprofv3 `--kernel-trace --stats`, same command (`--pmc off`) | `k_sweep<true,1,false,false>` %.2f µs × %s, `k_beliefs` %.2f µs (`r06_kernel_stats.csv`) | |
 | `cpu_baseline` (oracle, 16 threads) | %.1f–%.1f it/s; beliefs bit-exact, deviation 0.0 | %.1f it/s; bit-exact |
 | metric after every iteration (`s1_default_loop`) | %.3f–%.3f × the plain iteration | |
-| `configs.fr1xyz` / `configs.slam_fr2robot2` (`bin/ba`, `bin/slam`, default flags) | %.0f / %.0f it/s loop wall (%.1f ms / %.3f s), %.2f / %.2f µs per iteration on the device; process wall %.2f / %.2f s (r05: 0.58 s), `startup` in the line | |
+| `configs.fr1xyz` / `configs.slam_fr2robot2` (`bin/ba`, `bin/slam`, default flags) | %.0f / %.0f it/s loop wall (%.1f ms / %.3f s), %.2f / %.2f µs per iteration on the device; process wall %.2f / %.2f s under the bench (r05: 0.58 s; alone on the GPU 0.16 - 0.19 / 0.29 - 0.31 s, `r06_cli_idle.txt`), `startup` in the line; a 10^6-factor text file end to end 0.57 → 0.19 s (`r06_cli_bigfile.txt`) | |
+| `host_transfer`: the boundary's host buffers (PCIe-inclusive; never `value`) | `gbp_upload` %.1f ms + `gbp_read` %.1f ms around the reference's 1 500 iterations: %.0f it/s against %.0f resident | |
 
 Config-5 shard shape (8000 × 125 000 × 1.25 M): plain ctx %.0f 1M-factor it/s = %.4f ms per iteration (windows %.0f, sustained %.0f), traffic %.1f MB per
 average launch (ordinary 813.3), traffic / layout %.3f (r05: 0.1539 ms, 868.9 MB, 1.176: the all-pad segments are no longer streamed, `profiles/r06_configs.md` §1);
@@ -167,6 +176,7 @@ all finals unchanged since round 1, stdout bit-identical (`r06_cli_md5.txt`).
        min(d1["configs"]["s1_default_loop"]["steady"]["ratio"], d2["configs"]["s1_default_loop"]["steady"]["ratio"]),
        max(d1["configs"]["s1_default_loop"]["steady"]["ratio"], d2["configs"]["s1_default_loop"]["steady"]["ratio"]),
        fx["iters_per_sec"], sl["iters_per_sec"], fx["loop_wall_ms"], sl["loop_wall_ms"] / 1e3, fx["us_per_iter_device"], sl["us_per_iter_device"], fx["process_wall_s"], sl["process_wall_s"],
+       ht["upload_ms"], ht["read_ms"], ht["value_incl_transfers"], d1["value"],
        c5p["value"], c5p["ms_per_step"], c5p["windows"]["median"], c5p["sustained"]["value"], ro(c5p)["traffic"] / 1e6, ro(c5p)["traffic_over_layout"],
        c5d["ms_per_step"], c5d["windows"]["median"], c5d["sustained"]["value"], 1.25e3 / c5d["sustained"]["value"], ro(c5d)["traffic"] / 1e6, ro(c5d)["traffic_over_layout"],
        R["bench_share_2"]["ms_per_step"], R["bench_share_4"]["ms_per_step"], R["bench_share_8"]["ms_per_step"], fx["loop_wall_ms"], sl["loop_wall_ms"] / 1e3)
@@ -182,7 +192,7 @@ tab = """| S1 (1 000 × 100 000 × 1 M factors), `python bench.py --gpus 1 --ste
 | `roofline.frac` = PMC traffic ÷ live launch time ÷ 8 TB/s | **%.2f–%.2f** (driver's window, two lock-step launches in it) – **%.2f** (200 steps); rocprofv3 durations of the same launches: %.2f–%.2f |
 | CPU oracle on the box's 16 cores, same flow | %.1f–%.1f it/s; after its 50 iterations EVERY belief and the per-factor state equal the GPU's bit for bit (in the line: `cpu_baseline.beliefs_bit_exact_vs_oracle`) |
 | the reference's default loop (metric after every iteration) on S1 | **%.3f ×** the plain iteration: the metric of iteration k rides in sweep k + 1, the burst replays from a hipGraph |
-| `bin/ba fr1xyz` (1 500 iterations, default flags) / `bin/slam fr2robot2` (13 299) | **%.1f ms** loop = %.0f it/s (%.2f µs per iteration on the device) / **%.3f s** = %.0f it/s (%.2f µs); the whole PROCESS %.2f / %.2f s (round 5: 0.58 s), of which ~0.2 s are the HIP runtime coming up and going away (`profiles/r06_configs.md` §2) |
+| `bin/ba fr1xyz` (1 500 iterations, default flags) / `bin/slam fr2robot2` (13 299) | **%.1f ms** loop = %.0f it/s (%.2f µs per iteration on the device) / **%.3f s** = %.0f it/s (%.2f µs); the whole PROCESS %.2f / %.2f s under the bench (round 5: 0.58 s), **0.16–0.19 / 0.29–0.31 s** alone on the GPU (`profiles/r06_cli_idle.txt`; ~0.1 s of it the HIP runtime coming up and going away, `profiles/r06_configs.md` §2) |
 | config-5 shard shape (8 000 × 125 000 × 1.25 M: one rank of the 8-GPU line), plain ctx | %.4f ms per iteration, %.1f MB per sweep = %.3f × layout (round 5: 0.1539 ms, 868.9 MB, 1.176: the sweep no longer streams the all-pad segments of its tiles) |
 | the same shape through the sharded code path, 1-rank communicator (what every rank of `--gpus 8` runs) | %.4f ms first window, **%.4f ms** sustained (round 5: 0.166–0.168 / 0.159–0.160: the all-gather runs in place, the camera-only belief launches at 8 waves per SIMD; kernel by kernel in `profiles/r06_sharded_timeline.md`) |
 | `bench.py --gpus 2 / 4 / 8 --share-gpu` (real ranks, one GPU, host-staged exchange; 8 = config 5 itself, 10 M factors) | run green, RMSE = the N-shard oracle's; %.2f / %.2f / %.1f ms per iteration — correctness lines (`profiles/r06_world8.md`) |

@@ -22,7 +22,8 @@ for seq in fr1xyz fr2robot2 fr1desk; do for ev in 1 100; do for rep in 1 2; do
   gbp_poplar_amd/bin/ba --bal_file data/sequences/$seq.txt --eval_every $ev > $OUT/ba_${seq}_every$ev.log 2>&1; done; done; done
 for ev in 1 100; do for rep in 1 2; do gbp_poplar_amd/bin/slam --bal_file data/sequences/fr2robot2.txt --eval_every $ev > $OUT/slam_fr2robot2_every$ev.log 2>&1; done; done
 for f in $OUT/ba_*_every1.log $OUT/slam_fr2robot2_every1.log; do echo "$(basename $f) $(grep -v 'Total time' $f | md5sum | cut -c1-32)"; done > $OUT/cli_md5.txt
-python3 profiles/time_cli.py 5 > $OUT/cli_startup.txt 2>&1
+python3 profiles/time_cli.py 5 0.5 > $OUT/cli_startup.txt 2>&1      # 0.5 s idle in front of every run (r06_cli_pause.txt)
+python3 profiles/big_file_cli.py 4 > $OUT/cli_bigfile.txt 2>&1
 # 6. the reference's default loop on the 1M-factor graph THROUGH bin/ba
 python3 - <<PY
 import sys; sys.path.insert(0, "$REPO")
