@@ -153,7 +153,7 @@ tab = """| S1 = `configs[1]`, 1000 × 100 000 × 1 M factors, N = 1 | driver's c
 | rocprofv3 `--kernel-trace --stats`, same command (`--pmc off`) | `k_sweep<true,1,false,false>` %.2f µs × %s, `k_beliefs` %.2f µs (`r06_kernel_stats.csv`) | |
 | `cpu_baseline` (oracle, 16 threads) | %.1f–%.1f it/s; beliefs bit-exact, deviation 0.0 | %.1f it/s; bit-exact |
 | metric after every iteration (`s1_default_loop`) | %.3f–%.3f × the plain iteration | |
-| `configs.fr1xyz` / `configs.slam_fr2robot2` (`bin/ba`, `bin/slam`, default flags) | %.0f / %.0f it/s loop wall (%.1f ms / %.3f s), %.2f / %.2f µs per iteration on the device; process wall %.2f / %.2f s under the bench (r05: 0.58 s; alone on the GPU 0.16 - 0.19 / 0.29 - 0.31 s, `r06_cli_idle.txt`), `startup` in the line; a 10^6-factor text file end to end 0.57 → 0.19 s (`r06_cli_bigfile.txt`) | |
+| `configs.fr1xyz` / `configs.slam_fr2robot2` (`bin/ba`, `bin/slam`, default flags) | %.0f / %.0f it/s loop wall (%.1f ms / %.3f s), %.2f / %.2f µs per iteration on the device; process wall %.2f / %.2f s under the bench (r05: 0.58 s; alone on the GPU 0.16 - 0.19 / 0.29 - 0.31 s, `r06_cli_idle.txt`), `startup` in the line; a 10^6-factor text file end to end 0.57 → 0.20 s (`r06_cli_bigfile.txt`) | |
 | `host_transfer`: the boundary's host buffers (PCIe-inclusive; never `value`) | `gbp_upload` %.1f ms + `gbp_read` %.1f ms around the reference's 1 500 iterations: %.0f it/s against %.0f resident | |
 
 Config-5 shard shape (8000 × 125 000 × 1.25 M): plain ctx %.0f 1M-factor it/s = %.4f ms per iteration (windows %.0f, sustained %.0f), traffic %.1f MB per
