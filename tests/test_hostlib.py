@@ -66,6 +66,56 @@ def test_big_files_are_read_by_every_core_with_the_serial_result(tmp_path, monke
         assert np.array_equal(np.asarray(bal[k]), np.asarray(again[k])), k
 
 
+@pytest.mark.parametrize("threads", [1, 4, 9])
+def test_number_formats_fscanf_accepts_are_read_as_strtod_reads_them(tmp_path, monkeypatch, threads):
+    """Every spelling %d / %lf take — explicit '+', leading zeros, no digit before or after the point, exponents with either case and
+    sign, 17 significant digits, hexadecimal floats, "inf" — converted by the threaded reader exactly as float() (= strtod) converts the
+    token: a 1.5 MB file of mixed spellings, 1 / 4 / 9 threads."""
+    rng = np.random.default_rng(17)
+    C, L, E = 7, 300, 40000
+
+    def spell(v):
+        k = int(rng.integers(0, 9))
+        if k == 0:
+            return repr(float(v))
+        if k == 1:
+            return "%+.17g" % v
+        if k == 2:
+            return ("%.9E" % v)
+        if k == 3:
+            return "%.6f" % v
+        if k == 4:
+            return float(v).hex()
+        if k == 5:
+            return ("%.3f" % (abs(v) % 1.0)).lstrip("0") or ".0"          # ".250"
+        if k == 6:
+            return "%d." % int(v)                                          # "12."
+        if k == 7:
+            return "%.12e" % (v * 1e-300)                                  # tiny
+        return "%de%+d" % (int(v * 1000), int(rng.integers(-3, 4)))         # "12345e-2"
+
+    vals = rng.normal(0, 300, 2 * E + 6 * C + 3 * L)
+    toks = [spell(v) for v in vals]
+    toks[5] = "inf"
+    cam = rng.integers(0, C, E)
+    lmk = rng.integers(0, L, E)
+    p = str(tmp_path / "spell.txt")
+    with open(p, "w") as f:
+        f.write("%d +%d 0%d\n500.0 5e2 .32e3 240.\n" % (C, L, E))
+        for i in range(E):
+            f.write("%s%d %s %s %s\n" % ("+" if i % 5 == 0 else "00" if i % 7 == 0 else "", cam[i], lmk[i], toks[2 * i], toks[2 * i + 1]))
+        for t in toks[2 * E:]:
+            f.write(t + "\n")
+    assert os.path.getsize(p) > (1 << 20)
+    monkeypatch.setenv("GBP_HOST_THREADS", str(threads))
+    bal = hostlib.bal_read(p)
+    want = np.array([float.fromhex(t) if "0x" in t else float(t) for t in toks])
+    assert (bal["n_cams"], bal["n_lmks"], bal["n_edges"]) == (C, L, E) and (bal["fx"], bal["fy"], bal["cx"], bal["cy"]) == (500.0, 500.0, 320.0, 240.0)
+    assert np.array_equal(bal["cam_id"], cam) and np.array_equal(bal["lmk_id"], lmk)
+    assert np.array_equal(bal["observations"], want[:2 * E]) and np.isinf(bal["observations"][5])
+    assert np.array_equal(bal["cameras"], want[2 * E:2 * E + 6 * C]) and np.array_equal(bal["points"], want[2 * E + 6 * C:])
+
+
 @pytest.mark.parametrize("lmks", [40, 9000])      # below and above the size where the threads start
 def test_irregular_tokens_keep_fscanfs_meaning(tmp_path, monkeypatch, lmks):
     """A token that strtod does not take whole is where fscanf's result depends on what follows: such files go through the fscanf
