@@ -37,7 +37,7 @@ first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 max_edges = int(sys.argv[3]) if len(sys.argv) > 3 else 300000
 
 
-def random_problem(rng, slam=False):
+def random_problem(rng, slam=False, big=False):
     if slam:      # a keyframe sequence: sorted by camera (slam.cpp relies on it), every keyframe sees a window of the landmarks that moves on
         C = int(rng.integers(3, 31))
         L = int(np.exp(rng.uniform(np.log(20), np.log(3000))))
@@ -50,7 +50,11 @@ def random_problem(rng, slam=False):
     else:
         C = int(rng.integers(2, 121))
         L = int(np.exp(rng.uniform(np.log(3), np.log(30000))))
+        if big:      # one seed in fifty: beyond 1.6 M positions (gbp_upload's device-buffer path), thousands of tiles (the shape rules of the sweep)
+            C, L = int(rng.integers(200, 3000)), int(rng.integers(150000, 220000))
         E = int(min(max_edges, rng.integers(max(C, L), max(C, L) + 11 * L + 1)))
+        if big:
+            E = int(rng.integers(1700000, 2100000))
         cam_id = rng.integers(0, C, E)
         if rng.random() < 0.5:                                   # half of the graphs: a few cameras see almost everything
             m = rng.random(E) < 0.5
@@ -136,7 +140,7 @@ class Clock:
 def one_seed(seed, lib):
     ck = Clock()
     rng = np.random.default_rng(7000 + seed)
-    bal = random_problem(rng)
+    bal = random_problem(rng, big=(seed % 50 == 49))
     C, L, E = bal["n_cams"], bal["n_lmks"], bal["n_edges"]
     opts = driver.Options()
     opts.undamped_start = int(rng.integers(1, 4))
@@ -168,7 +172,7 @@ def one_seed(seed, lib):
         x.upload(state)
         x.linearise()
     ck.lap("setup")
-    total = int(rng.integers(24, 60))
+    total = int(rng.integers(24, 60)) if E < 1000000 else int(rng.integers(12, 20))
     it = n_relin = 0
     while it < total:
         burst = int(min(total - it, rng.choice([1, 1, 2, 3, 5, 8, 13, 21])))
