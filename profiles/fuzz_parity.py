@@ -42,6 +42,9 @@ def random_problem(rng, slam=False, big=False):
         C = int(rng.integers(3, 31))
         L = int(np.exp(rng.uniform(np.log(20), np.log(3000))))
         per_cam = rng.integers(4, max(5, min(L, 250)), C)
+        if big:      # one SLAM seed in 250: beyond 4 M positions — NEW_KEYFRAME's streams and READ_PROG's state no longer fit the staging buffer
+            C, L = int(rng.integers(12, 16)), int(rng.integers(300000, 400000))
+            per_cam = rng.integers(300000, 380000, C)
         width = max(4, int(L * rng.uniform(0.1, 0.6)))
         cam_id = np.repeat(np.arange(C), per_cam)
         centre = (np.arange(C) / max(C - 1, 1) * max(L - width, 1)).astype(np.int64)
@@ -246,7 +249,8 @@ def slam_seed(seed):
     damping counts, the weakening schedule restarting at every keyframe) on a random keyframe sequence: the PRODUCT library on the path it
     chooses (or kept off the persistent kernel) against the oracle — counts of every printed line exact, the metric to 1e-5 relative + 1e-4 px, every belief and per-factor state bit for bit at the end, the priors (READ_PRIORS) too."""
     rng = np.random.default_rng(9000 + seed)
-    bal = random_problem(rng, slam=True)
+    big = seed % 1000 == 999
+    bal = random_problem(rng, slam=True, big=big)
     C, L, E = bal["n_cams"], bal["n_lmks"], bal["n_edges"]
     opts = driver.Options()
     K, state, extra = driver.build_inputs(bal, opts, hostlib, slam=True)
@@ -254,7 +258,10 @@ def slam_seed(seed):
     pf, persistent = int(rng.integers(0, 2)), int(rng.choice([0, 0, -1]))
     ibk = int(rng.integers(4, 40))
     every = int(rng.choice([1, 1, 3, 10]))
-    max_iters = int(rng.integers(40, 260))
+    max_iters = int(rng.integers(40, 260)) if not big else int(rng.integers(30, 50))
+    if big:
+        ibk = int(rng.integers(4, 9))
+        pf = (seed // 1000) % 2
     G = GbpEngine(bal["cam_id"], bal["lmk_id"], C, L, K, hooks=False, params=_cabi.GbpParams.defaults(per_factor_mu=pf, persistent=persistent, **kw))
     O = orc_mod.Oracle(bal["cam_id"], bal["lmk_id"], C, L, K, params=_cabi.GbpParams.defaults(**kw))
     O.set_sum_order(1)
