@@ -190,6 +190,14 @@ struct Problem {
 };
 
 inline int load_problem(const Options& o, Problem& P) {
+  const bool trace = std::getenv("GBP_HOST_TRACE") != nullptr;      // milliseconds of every step on stderr
+  auto t0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!trace) return;
+    const auto t1 = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "load_problem: %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  };
   if (gbp_bal_read_header(o.bal_file.c_str(), &P.bal) != GBP_OK) {
     std::cerr << "ERROR: unable to open file " << o.bal_file << "\n";  // ba.cpp:484-487
     return 1;
@@ -198,10 +206,12 @@ inline int load_problem(const Options& o, Problem& P) {
   P.cam_id.resize(E); P.lmk_id.resize(E); P.obs.resize(2 * (size_t)E); P.cams.resize(6 * (size_t)C); P.pts.resize(3 * (size_t)L);
   P.bal.cam_id = P.cam_id.data(); P.bal.lmk_id = P.lmk_id.data(); P.bal.observations = P.obs.data();
   P.bal.cameras = P.cams.data(); P.bal.points = P.pts.data();
+  lap("header + arrays");
   if (gbp_bal_read(o.bal_file.c_str(), &P.bal) != GBP_OK) {
     std::cerr << "Invalid UW data file.\nERROR: unable to read file " << o.bal_file << "\n";
     return 1;
   }
+  lap("gbp_bal_read");
   P.K = {(float)P.bal.fx, 0.f, (float)P.bal.cx, 0.f, (float)P.bal.fy, (float)P.bal.cy, 0.f, 0.f, 1.f};  // ba.cpp:494-495
   P.meas.resize(2 * (size_t)E);
   for (size_t i = 0; i < 2 * (size_t)E; ++i) P.meas[i] = (float)P.obs[i];
@@ -213,6 +223,7 @@ inline int load_problem(const Options& o, Problem& P) {
   P.prob.n_cams = C; P.prob.n_lmks = L; P.prob.n_edges = E; P.prob.cam_id = P.cam_id.data(); P.prob.lmk_id = P.lmk_id.data();
   std::memcpy(P.prob.K, P.K.data(), 9 * sizeof(float));
 
+  lap("measurements, variances, means as float");
   // ba.cpp:536-548; the reference seeds from the clock (dataio.cpp:334,349,406): --seed 0 does the same
   const unsigned long long seed = o.seed ? o.seed : (unsigned long long)std::chrono::system_clock::now().time_since_epoch().count();
   if (o.transnoise != 0.f)
@@ -228,14 +239,17 @@ inline int load_problem(const Options& o, Problem& P) {
     gbp_init_av_depth(&P.prob, P.cam_mean.data(), P.lmk_mean.data());
   }
 
+  lap("initialisation options");
   P.cpe.resize(6 * (size_t)C); P.cpl.resize(36 * (size_t)C); P.lpe.resize(3 * (size_t)L); P.lpl.resize(9 * (size_t)L);
   gbp_set_prior_lambda(&P.prob, o.reproj_meas_var, P.cam_file.data(), P.lmk_file.data(), P.cam_mean.data(), P.lmk_mean.data(),
                        P.cpe.data(), P.cpl.data(), P.lpe.data(), P.lpl.data());
+  lap("gbp_set_prior_lambda");
   P.cscale.resize(C); P.lscale.resize(L);
   gbp_prior_scalings(C, L, P.cpl.data(), o.steps, o.prior_std_weaker_factor, o.first_cam_prior_std, P.cscale.data(), P.lscale.data());
   std::cout << "Completed loading data!\n";
   P.damping.assign(E, 0.f);
   P.count.assign(E, -o.iters_before_damping);  // ba.cpp:581
+  lap("scalings, damping state");
   // mu / oldmu: the reference uploads 9 E zeros for each (ba.cpp:582-583); gbp_upload takes NULL for "zeros" — 72 MB per million factors
   // that are neither allocated nor compared here
   return 0;
