@@ -292,3 +292,35 @@ def test_two_processes_on_one_gpu_concurrently():
             warnings += "warning:" in err
     assert len(digests[0]) == 1 and len(digests[1]) == 1, digests
     print("recovered time-outs in 60 runs:", warnings)
+
+
+def _build_c_example(tmp_path):
+    """examples/ba_minimal.c: the reference's ./ba over the C-ABI alone, compiled as C11 with gcc (the product headers are plain C)"""
+    exe = str(tmp_path / "ba_minimal")
+    subprocess.check_call(["gcc", "-std=c11", "-O2", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "ba_minimal.c"), "-L" + os.path.join(ROOT, "gbp_poplar_amd"), "-lgbp_mi355x",
+                           "-Wl,-rpath," + os.path.join(ROOT, "gbp_poplar_amd"), "-o", exe])
+    return exe
+
+
+def test_plain_c_host_over_the_c_abi_builds_and_fails_loudly_without_a_device(tmp_path):
+    """A C11 translation unit that includes include/gbp_mi355x.h and nothing else of ours compiles without a warning, links against the
+    product library, reads a sequence and builds the priors on the host — and, in a container without a GPU, stops where ./ba stops."""
+    import torch
+    exe = _build_c_example(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the run itself is test_plain_c_host_prints_the_lines_of_bin_ba")
+    rc, out, _ = run([exe, "--bal_file", seq_path("fr2robot2"), "--n_iters", "3"])
+    assert rc == 255 and "Completed loading data!" in out and "Could not find a device" in out
+
+
+@pytest.mark.gpu
+def test_plain_c_host_prints_the_lines_of_bin_ba(tmp_path):
+    """... and on a GPU prints, line for line, what bin/ba prints for the same run (the initial metric, "Weakening priors", every iteration)."""
+    exe = _build_c_example(tmp_path)
+    rc, out, err = run([exe, "--bal_file", seq_path("fr1xyz"), "--n_iters", "300"])
+    assert rc == 0, err
+    rc2, ref, err2 = run([BA, "--bal_file", seq_path("fr1xyz"), "--n_iters", "300"])
+    assert rc2 == 0, err2
+    pick = lambda text: [l for l in text.splitlines() if l.startswith(("Iter ", "Weakening priors", "Initial Reprojection error"))]
+    assert len(pick(out)) == 300 + 5 + 1 and pick(out) == pick(ref)
