@@ -26,7 +26,7 @@ $(OBJDIR)/%.o: $(CSRC)/%.cpp $(HDRS)
 	$(HIPCC) -c -o $@ $(HIPFLAGS) -x c++ -D__HIP_PLATFORM_AMD__ -I$(dir $(shell readlink -f $$(which $(HIPCC))))../include $<
 
 $(LIB): $(OBJS)
-	$(HIPCC) -shared -o $@ --offload-arch=$(ARCH) $(OBJS) -ldl -Wl,--version-script=$(CSRC)/gbp_exports.map
+	$(HIPCC) -shared -o $@ --offload-arch=$(ARCH) $(OBJS) -ldl -pthread -Wl,--version-script=$(CSRC)/gbp_exports.map
 
 $(PKG)/bin/%: $(CSRC)/%_main.cpp $(CSRC)/cli_common.hpp include/gbp_mi355x.h include/gbp_mi355x_multi.h include/gbp_mi355x_compat.h $(LIB)
 	@mkdir -p $(PKG)/bin

@@ -94,7 +94,7 @@ def _build_lib(target, variant, defines, force, verbose):
                 f.result()
     if todo or force or _stale(target, objs):
         cmd = [hipcc(), "-shared", "-o", target, "--offload-arch=" + ARCH] + objs + \
-              ["-ldl", "-Wl,--version-script=" + os.path.join(CSRC, "gbp_exports.map")]
+              ["-ldl", "-pthread", "-Wl,--version-script=" + os.path.join(CSRC, "gbp_exports.map")]      # (-pthread: the host helpers' reader threads, for a libc that still keeps them in libpthread)
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
