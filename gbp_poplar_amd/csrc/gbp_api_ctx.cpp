@@ -7,6 +7,7 @@
 //   gbp_sync, gbp_set_stream, gbp_timing, gbp_set_profiling
 // gbp_create sorts the factors into device order (gbp_layout.cpp, pure host code) and only then touches the GPU.
 #include "gbp_ctx.hpp"
+#include "gbp_threads.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -462,24 +463,27 @@ GBP_EXPORT(gbp_upload, c, (gbp_ctx* c, const gbp_state_in* in), (c, in)) {
   std::vector<float> var(Ep), mu(c->hoist ? 0 : Ep * kMuG * 4, 0.f);
   c->active_host.assign(Ep, 0);
   const float* om = in->oldmu ? in->oldmu : in->mu;
-  for (size_t p = 0; p < Ep; ++p) {
-    const uint32_t e = c->lay.pos_edge[p];
-    St o{0.f, (int32_t)kFlagPad, 0.f, 0.f};
-    float v = 0.f;
-    if (e != ~0u) {
-      const bool on = in->active_flag[e] == 1;
-      c->active_host[p] = on;
-      const int32_t count = in->damping_count ? in->damping_count[e] : 0;
-      o.damping = in->damping ? in->damping[e] : 0.f;
-      o.packed = (int32_t)(((uint32_t)count << 3) | (on ? kFlagActive : 0u));
-      o.z0 = in->measurements[2 * (size_t)e];
-      o.z1 = in->measurements[2 * (size_t)e + 1];
-      v = in->meas_variances[e];
-      if (om && !c->hoist) for (int i = 0; i < 9; ++i) mu[tile_off((uint32_t)p, kMuG, i)] = om[(size_t)e * 9 + i];
+  const unsigned T = gbp::host::host_threads(Ep, 1u << 17);      // (a gather by device position: every position is written by one thread)
+  gbp::host::on_threads(T, [&](unsigned t) {
+    for (size_t p = Ep * t / T, p1 = Ep * (t + 1) / T; p < p1; ++p) {
+      const uint32_t e = c->lay.pos_edge[p];
+      St o{0.f, (int32_t)kFlagPad, 0.f, 0.f};
+      float v = 0.f;
+      if (e != ~0u) {
+        const bool on = in->active_flag[e] == 1;
+        c->active_host[p] = on;
+        const int32_t count = in->damping_count ? in->damping_count[e] : 0;
+        o.damping = in->damping ? in->damping[e] : 0.f;
+        o.packed = (int32_t)(((uint32_t)count << 3) | (on ? kFlagActive : 0u));
+        o.z0 = in->measurements[2 * (size_t)e];
+        o.z1 = in->measurements[2 * (size_t)e + 1];
+        v = in->meas_variances[e];
+        if (om && !c->hoist) for (int i = 0; i < 9; ++i) mu[tile_off((uint32_t)p, kMuG, i)] = om[(size_t)e * 9 + i];
+      }
+      st[p] = o;
+      var[p] = v;
     }
-    st[p] = o;
-    var[p] = v;
-  }
+  });
   HIPCHK(c, hipMemsetAsync(c->fac.p, 0, c->fac.bytes, c->stream));
   H2D up;
   if (int rc = up.begin(c, (Ep * 5 + mu.size() + ((size_t)c->C + c->L_loc) * (kCamRec + 16 + 2)) * 4, 9)) return rc;

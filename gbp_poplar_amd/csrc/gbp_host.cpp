@@ -17,6 +17,7 @@
 #include "../../include/gbp_mi355x.h"
 #include "../../include/gbp_mi355x_multi.h"      // gbp_landmark_partition
 #include "gbp_export.hpp"
+#include "gbp_threads.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -176,26 +177,8 @@ struct NumberFile {
   enum Status { kOk, kNoFile, kIrregular };
 };
 
-inline unsigned host_threads(uint64_t work_items, uint64_t min_items_per_thread) {
-  unsigned T = std::thread::hardware_concurrency();
-  if (const char* e = std::getenv("GBP_HOST_THREADS")) T = (unsigned)std::max(1, std::atoi(e));
-  T = std::max(1u, std::min(T, 32u));
-  return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(T, work_items / std::max<uint64_t>(1, min_items_per_thread)));
-}
-// fn(t) for t in [0, T), fn(0) on the caller's thread.  fn must not throw (it allocates nothing: an exception inside a thread would end the
-// process); a thread the system refuses to start has its share run on the caller's thread instead.
-template <class F> void on_threads(unsigned T, F&& fn) {
-  std::vector<std::thread> th;
-  th.reserve(T);
-  unsigned started = 1;
-  try {
-    for (; started < T; ++started) th.emplace_back(fn, started);
-  } catch (...) {
-  }
-  fn(0u);
-  for (unsigned t = started; t < T; ++t) fn(t);
-  for (auto& x : th) x.join();
-}
+using gbp::host::host_threads;
+using gbp::host::on_threads;
 
 inline bool is_space(unsigned char c) { return c == ' ' || c == '\n' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; }      // isspace(), "C" locale
 
