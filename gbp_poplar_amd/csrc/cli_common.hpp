@@ -325,6 +325,23 @@ struct RuntimeWarmup {
 };
 inline RuntimeWarmup& runtime_warmup() { static RuntimeWarmup w; return w; }
 
+// EMPIRICAL, measured and not explained (profiles/r06_exit_probe.txt, profiles/exit_probe.py): on this driver stack (ROCm 7.0 user space, the pool's
+// amdgpu / KFD) a process whose address space has taken page faults from SIX OR MORE threads before the HIP runtime comes up is gone 40 - 60 ms sooner
+// after its main() has ended — `ba fr1xyz --n_iters 200`: 0.15 - 0.19 s -> 0.105 - 0.12 s of process wall — than one whose memory was only ever touched by
+// one to four threads.  What it takes: threads that TOUCH fresh memory (eight threads that allocate and free without touching, or thirty-two that do
+// nothing: no effect; one thread touching 128 MB: no effect; malloc's arenas and thresholds, CPU affinity: no effect).  It showed first as the multi-threaded
+// file reader making the 10^6-factor run exit faster than the 12 908-factor one.  Eight threads write 1 MB each: < 1 ms.  GBP_CLI_NO_PRIME=1 turns it off.
+inline void prime_address_space() {
+  if (std::getenv("GBP_CLI_NO_PRIME")) return;
+  constexpr int kThreads = 8;
+  constexpr size_t kBytes = (size_t)1 << 20;
+  std::unique_ptr<char[]> buf(new char[kThreads * kBytes]);
+  std::thread th[kThreads];
+  for (int i = 0; i < kThreads; ++i) th[i] = std::thread([p = buf.get() + (size_t)i * kBytes, i] { std::memset(p, i + 1, kBytes); });
+  for (auto& t : th) t.join();
+  asm volatile("" ::"r"(buf.get()) : "memory");
+}
+
 inline int round_up_pow2(int n) {   // ba.cpp:617-621: nIPUs is rounded up to a power of two
   int p = 1;
   while (p < n) p *= 2;

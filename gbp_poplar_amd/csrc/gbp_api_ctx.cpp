@@ -222,6 +222,11 @@ void pack_lmk(const float* eta, const float* lam, uint32_t l0, uint32_t n, std::
   }
 }
 
+// what one gbp_upload stages: the compact per-factor streams (20 B per position), per_factor_mu's tensor, the packed priors, scalings and flags
+size_t upload_stage_bytes(const gbp_ctx* c) {
+  return (size_t)c->Ep * 20 + (c->hoist ? 0 : (size_t)c->Ep * kMuG * 16) + ((size_t)c->C * kCamRec + (size_t)c->L_loc * 16 + 2 * ((size_t)c->C + c->L_loc)) * 4;
+}
+
 }  // namespace
 
 GBP_EXPORT_T(int, 0, gbp_abi_version, (void), ()) { return GBP_ABI_VERSION; }
@@ -382,7 +387,7 @@ GBP_EXPORT(gbp_create, nullptr, (const gbp_problem* pr, const gbp_params* prm, c
     for (const Piece& pc : pieces)
       if (pc.bytes) std::memcpy(stage.data() + pc.off, pc.src, pc.bytes);
     // (pinned once, large enough for the gbp_upload that follows: pinning costs ~0.5 ms per MB, a second buffer would cost that again)
-    c->stage_hint = (Ep * 5 + (size_t)(c->hoist ? 0 : Ep * kMuG * 4) + ((size_t)c->C + c->L_loc) * (kCamRec + 16 + 2)) * 4 + 16 * 9;
+    c->stage_hint = upload_stage_bytes(c) + 16 * 9;
     H2D up;
     if (rc == GBP_OK) rc = up.begin(c, idx_bytes, 1);
     if (rc == GBP_OK) rc = up.put(c->idx_arena.p, stage.data(), idx_bytes);
@@ -450,8 +455,17 @@ GBP_EXPORT(gbp_upload, c, (gbp_ctx* c, const gbp_state_in* in), (c, in)) {
         if (om[i] != 0.f)
           return fail(c, GBP_ERR_INVALID, "gbp_upload: non-zero oldmu needs gbp_params.per_factor_mu = 1 (the reference uploads zeros, ba.cpp:582-583)");
   }
+  const bool trace = std::getenv("GBP_HOST_TRACE") != nullptr;      // milliseconds of every step on stderr
+  auto t0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!trace) return;
+    const auto t1 = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "gbp_upload: %s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  };
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (int rc = persist_reset(c)) return rc;      // a fresh start for the persistent kernel too
+  lap("argument checks, stream sync, persistent-kernel reset");
   const size_t Ep = c->Ep;
   // The per-factor streams in their compact form, in device order: {damping, count << 3 | flags, z0, z1} + the variance = 20 bytes per
   // position.  k_upload_scatter writes them into the records they belong to (the whole 64-byte LMSG record: zero messages + state; the
@@ -484,9 +498,12 @@ GBP_EXPORT(gbp_upload, c, (gbp_ctx* c, const gbp_state_in* in), (c, in)) {
       var[p] = v;
     }
   });
+  lap("gather by device position");
   HIPCHK(c, hipMemsetAsync(c->fac.p, 0, c->fac.bytes, c->stream));
+  lap("FAC fill queued");
   H2D up;
-  if (int rc = up.begin(c, (Ep * 5 + mu.size() + ((size_t)c->C + c->L_loc) * (kCamRec + 16 + 2)) * 4, 9)) return rc;
+  if (int rc = up.begin(c, upload_stage_bytes(c), 9)) return rc;
+  lap("staging buffer ready");
   {
     // the compact streams: out of the pinned staging buffer (the kernel reads host memory), or — too large for it — through a device
     // buffer that lives for this call
@@ -498,6 +515,7 @@ GBP_EXPORT(gbp_upload, c, (gbp_ctx* c, const gbp_state_in* in), (c, in)) {
       if (int rc = up.stage(st.data(), Ep * 16, &a)) return rc;
       if (int rc = up.stage(var.data(), Ep * 4, &b)) return rc;
       st_dev = static_cast<const float4*>(a); var_dev = static_cast<const float*>(b);
+      lap("compact streams copied into the staging buffer");
     } else {
       HIPCHK(c, hipMalloc(&tmp.p, Ep * 20));
       tmp.bytes = Ep * 20;
@@ -511,6 +529,7 @@ GBP_EXPORT(gbp_upload, c, (gbp_ctx* c, const gbp_state_in* in), (c, in)) {
     if (tmp.p) { (void)hipStreamSynchronize(c->stream); (void)hipFree(tmp.p); }
     HIPCHK(c, le);
   }
+  lap("staging + k_upload_scatter queued");
   if (!c->hoist)
     if (int rc = up.put(c->mu.p, mu.data(), mu.size() * 4)) return rc;
   HIPCHK(c, hipMemsetAsync(c->cmsg.p, 0, c->cmsg.bytes, c->stream));
@@ -535,7 +554,9 @@ GBP_EXPORT(gbp_upload, c, (gbp_ctx* c, const gbp_state_in* in), (c, in)) {
     if (int rc = up.put(c->lscale.p, in->lmk_scaling ? in->lmk_scaling + c->lmk_begin : zf.data(), (size_t)c->L_loc * 4)) return rc;
     if (int rc = up.put(c->lwf.p, in->lmk_weaken_flag ? in->lmk_weaken_flag + c->lmk_begin : zu.data(), (size_t)c->L_loc * 4)) return rc;
   }
+  lap("fills, priors, scalings queued");
   if (int rc = up.end()) return rc;
+  lap("everything on the device");
   if (exch(c) && c->recv_dev) HIPCHK(c, hipMemsetAsync(c->recv_dev, 0, (size_t)c->world * c->C * kCamRec * 4, c->stream));
   c->uploaded = true;
   c->beliefs_valid = false;

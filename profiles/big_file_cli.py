@@ -40,4 +40,4 @@ print("stdout identical across all runs: %s" % (len(md5) == 1))
 print("the last run's %s" % st.get("create", "")[6:])
 p = subprocess.run([os.path.join(ROOT, "gbp_poplar_amd", "bin", "ba"), "--bal_file", path, "--n_iters", "1"], env=dict(os.environ, GBP_HOST_TRACE="1"),
                    stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-print("".join(l + "\n" for l in p.stderr.splitlines() if "read_number_file" in l or "load_problem" in l), end="")
+print("".join(l + "\n" for l in p.stderr.splitlines() if "read_number_file" in l or "load_problem" in l or "gbp_upload" in l), end="")

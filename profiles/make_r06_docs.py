@@ -84,7 +84,7 @@ New in the line: `host_transfer` — what the boundary's host buffers cost, neve
   against %.0f with the state resident (`value`).
 * `configs.s1_default_loop` (metric after every iteration, any graph size): steady ratio **%.3f x** of the plain iteration.
 * `configs.fr1xyz` **%.0f it/s** loop wall (%.2f ms, %.2f us per iteration on the device), process wall **%.3f s** (round 5: 0.576 s on its box; started 0.5 s after the previous GPU process, beside the bench's own
-  live context — alone on the GPU 0.16 - 0.19 s, `r06_cli_idle.txt`; `startup` in the line says where it goes: `r06_configs.md` section 2); `configs.slam_fr2robot2` **%.0f it/s** (%.1f ms, %.2f us), process %.3f s.  Finals unchanged, stdout md5s %s
+  live context — alone on the GPU 0.125 - 0.136 s, `r06_exit_probe.txt`; `startup` in the line says where it goes: `r06_configs.md` section 2); `configs.slam_fr2robot2` **%.0f it/s** (%.1f ms, %.2f us), process %.3f s.  Finals unchanged, stdout md5s %s
   (`r06_cli_md5.txt`).
 
 ## Kernel statistics (`r06_kernel_stats.csv`: the driver's command, parent process, every launch)
@@ -153,7 +153,7 @@ tab = """| S1 = `configs[1]`, 1000 × 100 000 × 1 M factors, N = 1 | driver's c
 | rocprofv3 `--kernel-trace --stats`, same command (`--pmc off`) | `k_sweep<true,1,false,false>` %.2f µs × %s, `k_beliefs` %.2f µs (`r06_kernel_stats.csv`) | |
 | `cpu_baseline` (oracle, 16 threads) | %.1f–%.1f it/s; beliefs bit-exact, deviation 0.0 | %.1f it/s; bit-exact |
 | metric after every iteration (`s1_default_loop`) | %.3f–%.3f × the plain iteration | |
-| `configs.fr1xyz` / `configs.slam_fr2robot2` (`bin/ba`, `bin/slam`, default flags) | %.0f / %.0f it/s loop wall (%.1f ms / %.3f s), %.2f / %.2f µs per iteration on the device; process wall %.2f / %.2f s under the bench (r05: 0.58 s; alone on the GPU 0.16 - 0.19 / 0.29 - 0.31 s, `r06_cli_idle.txt`), `startup` in the line; a 10^6-factor text file end to end 0.57 → 0.20 s (`r06_cli_bigfile.txt`) | |
+| `configs.fr1xyz` / `configs.slam_fr2robot2` (`bin/ba`, `bin/slam`, default flags) | %.0f / %.0f it/s loop wall (%.1f ms / %.3f s), %.2f / %.2f µs per iteration on the device; process wall %.2f / %.2f s under the bench (r05: 0.58 s; alone on the GPU 0.125 - 0.136 / 0.253 - 0.260 s, `r06_exit_probe.txt`), `startup` in the line; a 10^6-factor text file end to end 0.57 → 0.17 s (`r06_cli_bigfile.txt`) | |
 | `host_transfer`: the boundary's host buffers (PCIe-inclusive; never `value`) | `gbp_upload` %.1f ms + `gbp_read` %.1f ms around the reference's 1 500 iterations: %.0f it/s against %.0f resident | |
 
 Config-5 shard shape (8000 × 125 000 × 1.25 M): plain ctx %.0f 1M-factor it/s = %.4f ms per iteration (windows %.0f, sustained %.0f), traffic %.1f MB per
@@ -192,7 +192,7 @@ tab = """| S1 (1 000 × 100 000 × 1 M factors), `python bench.py --gpus 1 --ste
 | `roofline.frac` = PMC traffic ÷ live launch time ÷ 8 TB/s | **%.2f–%.2f** (driver's window, two lock-step launches in it) – **%.2f** (200 steps); rocprofv3 durations of the same launches: %.2f–%.2f |
 | CPU oracle on the box's 16 cores, same flow | %.1f–%.1f it/s; after its 50 iterations EVERY belief and the per-factor state equal the GPU's bit for bit (in the line: `cpu_baseline.beliefs_bit_exact_vs_oracle`) |
 | the reference's default loop (metric after every iteration) on S1 | **%.3f ×** the plain iteration: the metric of iteration k rides in sweep k + 1, the burst replays from a hipGraph |
-| `bin/ba fr1xyz` (1 500 iterations, default flags) / `bin/slam fr2robot2` (13 299) | **%.1f ms** loop = %.0f it/s (%.2f µs per iteration on the device) / **%.3f s** = %.0f it/s (%.2f µs); the whole PROCESS %.2f / %.2f s under the bench (round 5: 0.58 s), **0.16–0.19 / 0.29–0.31 s** alone on the GPU (`profiles/r06_cli_idle.txt`; ~0.1 s of it the HIP runtime coming up and going away, `profiles/r06_configs.md` §2) |
+| `bin/ba fr1xyz` (1 500 iterations, default flags) / `bin/slam fr2robot2` (13 299) | **%.1f ms** loop = %.0f it/s (%.2f µs per iteration on the device) / **%.3f s** = %.0f it/s (%.2f µs); the whole PROCESS %.2f / %.2f s under the bench (round 5: 0.58 s), **0.125–0.136 / 0.253–0.260 s** alone on the GPU (`profiles/r06_exit_probe.txt`; ~0.07 s of it the HIP runtime coming up and going away, `profiles/r06_configs.md` §2) |
 | config-5 shard shape (8 000 × 125 000 × 1.25 M: one rank of the 8-GPU line), plain ctx | %.4f ms per iteration, %.1f MB per sweep = %.3f × layout (round 5: 0.1539 ms, 868.9 MB, 1.176: the sweep no longer streams the all-pad segments of its tiles) |
 | the same shape through the sharded code path, 1-rank communicator (what every rank of `--gpus 8` runs) | %.4f ms first window, **%.4f ms** sustained (round 5: 0.166–0.168 / 0.159–0.160: the all-gather runs in place, the camera-only belief launches at 8 waves per SIMD; kernel by kernel in `profiles/r06_sharded_timeline.md`) |
 | `bench.py --gpus 2 / 4 / 8 --share-gpu` (real ranks, one GPU, host-staged exchange; 8 = config 5 itself, 10 M factors) | run green, RMSE = the N-shard oracle's; %.2f / %.2f / %.1f ms per iteration — correctness lines (`profiles/r06_world8.md`) |
