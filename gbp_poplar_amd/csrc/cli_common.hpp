@@ -632,6 +632,20 @@ inline bool whole_steps(float steps) { return steps >= 0.f && steps < 1073741824
 // resources either way.  Under an injected library (LD_PRELOAD: rocprofv3, sanitizers — their reports are written by exit handlers) or
 // with GBP_CLI_FULL_EXIT set, the ordinary return.
 inline int leave(int rc) {
+  if (std::getenv("GBP_HOST_TRACE")) {      // what the kernel will have to tear down: the address space as it stands (profiles/r06_exit_probe.txt)
+    size_t vmas = 0;
+    if (FILE* f = std::fopen("/proc/self/maps", "r")) { int ch; while ((ch = std::fgetc(f)) != EOF) vmas += ch == '\n'; std::fclose(f); }
+    std::fprintf(stderr, "leave: %zu mappings;", vmas);
+    for (const char* path : {"/proc/self/status", "/proc/self/smaps_rollup"})
+      if (FILE* f = std::fopen(path, "r")) {
+        char line[256];
+        while (std::fgets(line, sizeof(line), f))
+          for (const char* key : {"VmRSS:", "VmPTE:", "RssAnon:", "RssFile:", "RssShmem:", "Threads:", "AnonHugePages:", "ShmemPmdMapped:", "FilePmdMapped:", "Locked:", "VmLck:", "VmPin:"})
+            if (!std::strncmp(line, key, std::strlen(key))) { line[std::strcspn(line, "\n")] = 0; std::fprintf(stderr, " %s", line); }
+        std::fclose(f);
+      }
+    std::fprintf(stderr, "\n");
+  }
   std::cout.flush();
   std::cerr.flush();
   std::fflush(nullptr);
