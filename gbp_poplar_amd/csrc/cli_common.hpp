@@ -319,7 +319,10 @@ struct RankCtx {
 // file of a million factors (1 - 2 s of parsing).  Never with --ipus N > 1: the ranks are forked before anything touches HIP.
 struct RuntimeWarmup {
   std::thread t;
-  void start(bool on) { if (on && !std::getenv("GBP_CLI_NO_WARMUP")) t = std::thread([] { (void)gbp_device_count(); }); }      // (the switch: profiles/big_file_cli.py's A/B)
+  void start(bool on) {      // (the switch: profiles/big_file_cli.py's A/B; a system that refuses the thread: the first HIP call stays where it was)
+    if (!on || std::getenv("GBP_CLI_NO_WARMUP")) return;
+    try { t = std::thread([] { (void)gbp_device_count(); }); } catch (...) {}
+  }
   void wait() { if (t.joinable()) t.join(); }
   ~RuntimeWarmup() { wait(); }
 };
@@ -335,10 +338,15 @@ inline void prime_address_space() {
   if (std::getenv("GBP_CLI_NO_PRIME")) return;
   constexpr int kThreads = 8;
   constexpr size_t kBytes = (size_t)1 << 20;
-  std::unique_ptr<char[]> buf(new char[kThreads * kBytes]);
+  std::unique_ptr<char[]> buf(new (std::nothrow) char[kThreads * kBytes]);
+  if (!buf) return;
   std::thread th[kThreads];
-  for (int i = 0; i < kThreads; ++i) th[i] = std::thread([p = buf.get() + (size_t)i * kBytes, i] { std::memset(p, i + 1, kBytes); });
-  for (auto& t : th) t.join();
+  try {      // (a system that refuses threads: the run goes on without them)
+    for (int i = 0; i < kThreads; ++i) th[i] = std::thread([p = buf.get() + (size_t)i * kBytes, i] { std::memset(p, i + 1, kBytes); });
+  } catch (...) {
+  }
+  for (auto& t : th)
+    if (t.joinable()) t.join();
   asm volatile("" ::"r"(buf.get()) : "memory");
 }
 
