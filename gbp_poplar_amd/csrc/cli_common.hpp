@@ -20,6 +20,7 @@
 #include <deque>
 #include <mutex>
 #include <thread>
+#include <sched.h>
 #include <chrono>
 #include <cmath>
 #include <cerrno>
@@ -342,7 +343,12 @@ inline void prime_address_space() {
   if (!buf) return;
   std::thread th[kThreads];
   try {      // (a system that refuses threads: the run goes on without them)
-    for (int i = 0; i < kThreads; ++i) th[i] = std::thread([p = buf.get() + (size_t)i * kBytes, i] { std::memset(p, i + 1, kBytes); });
+    const int pin = std::getenv("GBP_CLI_PRIME_PIN") ? sched_getcpu() : -1;      // (experiment: all eight on the caller's CPU — r06_exit_probe.txt)
+    for (int i = 0; i < kThreads; ++i)
+      th[i] = std::thread([p = buf.get() + (size_t)i * kBytes, i, pin] {
+        if (pin >= 0) { cpu_set_t set; CPU_ZERO(&set); CPU_SET(pin, &set); (void)sched_setaffinity(0, sizeof(set), &set); }
+        std::memset(p, i + 1, kBytes);
+      });
   } catch (...) {
   }
   for (auto& t : th)

@@ -1,7 +1,8 @@
 """Process wall of `bin/ba fr1xyz` with and without the address-space priming of cli_common.hpp (prime_address_space): python profiles/exit_probe.py [--n_iters N]"""
 import json, os, subprocess, sys, tempfile, time
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
-for label, extra, pre in (("GBP_CLI_NO_PRIME=1", {"GBP_CLI_NO_PRIME": "1"}, []), ("default (primed)", {}, []), ("GBP_CLI_NO_PRIME=1", {"GBP_CLI_NO_PRIME": "1"}, []), ("default (primed)", {}, [])):
+for label, extra, pre in (("GBP_CLI_NO_PRIME=1", {"GBP_CLI_NO_PRIME": "1"}, []), ("default (primed)", {}, []), ("primed, 8 threads on ONE cpu", {"GBP_CLI_PRIME_PIN": "1"}, []),
+                          ("GBP_CLI_NO_PRIME=1", {"GBP_CLI_NO_PRIME": "1"}, []), ("default (primed)", {}, []), ("primed, 8 threads on ONE cpu", {"GBP_CLI_PRIME_PIN": "1"}, [])):
     for r in range(3):
         d = tempfile.mkdtemp()
         time.sleep(0.5)
