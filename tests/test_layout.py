@@ -208,3 +208,34 @@ def test_local_tile_order_with_finer_classes():
             if window == 96 and K == 8:        # most workgroups get the class they ask for (random classes: the worst case)
                 want = (np.arange(3000) // 4) % K
                 assert np.mean(cls[perm] == want) > 0.75
+
+
+@pytest.mark.parametrize("shape", ["s1_like", "config5_like", "unsorted"])
+def test_the_device_order_does_not_depend_on_the_host_thread_count(shape, monkeypatch):
+    """Above 2^19 factors the builder cuts the file into chunks of consecutive factors, one host thread each (at most 8): every chunk counts
+    its factors per camera and per landmark, the running sums over the chunks are where a chunk continues a camera's rows and a landmark's
+    slots.  The result must be the one-thread result — every array — and keep every property above (file order of the slots among them)."""
+    rng = np.random.default_rng(5)
+    if shape == "s1_like":
+        C, L, E = 300, 220000, 2200000
+        cam, lmk = random_graph(rng, C, L, E, sort=True)
+    elif shape == "config5_like":      # many small cameras: rows placed by landmark class, tiles permuted
+        C, L, E = 12000, 150000, 2200000
+        cam, lmk = random_graph(rng, C, L, E, sort=True)
+    else:
+        C, L, E = 700, 90000, 2200000
+        cam, lmk = random_graph(rng, C, L, E, sort=False, dup=True)
+    out = {}
+    for threads in ("1", "8", "3"):
+        monkeypatch.setenv("GBP_HOST_THREADS", threads)
+        out[threads] = hostlib.layout_build(cam, lmk, C, L)
+    for k in out["1"]:
+        for threads in ("8", "3"):
+            assert np.array_equal(out["1"][k], out[threads][k]), (shape, threads, k)
+    check_layout(cam, lmk, C, L, out["8"])
+    shard = (1, 3, L // 3, 2 * L // 3)
+    a = hostlib.layout_build(cam, lmk, C, L, shard=shard)
+    monkeypatch.setenv("GBP_HOST_THREADS", "1")
+    b = hostlib.layout_build(cam, lmk, C, L, shard=shard)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), (shape, "shard", k)
